@@ -1,0 +1,108 @@
+/* llark_hip.h -- C ABI of libllark_hip.so: the MI355X (gfx950) implementation of LLark's
+ * audio-encoder -> LLM hot path.
+ *
+ * The reference (spotify-research/llark) has NO native/FFI boundary: its hot path is Python calling
+ * third-party CUDA libraries.  This header is therefore the boundary a
+ * maintainer of the reference would bind (via ctypes) underneath the
+ * reference's own Python module interfaces.  Each entry point names the reference call site it
+ * replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - every function returns LLARK_OK (0) or a negative error code, never throws, never
+ *     allocates, and enqueues its work on `stream` (a hipStream_t passed as void*);
+ *   - llark_last_error() returns a thread-local human-readable message for the last failure;
+ *   - re-entrant per stream; no global state.
+ */
+#ifndef LLARK_HIP_H
+#define LLARK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* llark_stream_t; /* hipStream_t */
+
+enum {
+    LLARK_OK = 0,
+    LLARK_ERR_INVALID = -1,     /* bad argument (shape, null pointer, alignment) */
+    LLARK_ERR_UNSUPPORTED = -2, /* shape outside what is compiled */
+    LLARK_ERR_LAUNCH = -3       /* HIP launch / runtime error */
+};
+
+enum { LLARK_F16 = 0, LLARK_BF16 = 1 };
+
+/* epilogues of llark_gemm16 */
+enum {
+    LLARK_EPI_F32 = 0,         /* C = acc + bias                              (fp32 out)        */
+    LLARK_EPI_RESID = 1,       /* C = R + (acc + bias)                        (fp32, C may alias R) */
+    LLARK_EPI_QGELU_SPLIT = 2, /* g = x*sigmoid(1.702x), x = acc+bias -> hi/lo 16-bit planes     */
+    LLARK_EPI_OUT16 = 3,       /* out = 16-bit(acc + bias)                                       */
+    LLARK_EPI_SWIGLU16 = 4,    /* out = 16-bit(silu(gate) * up), W rows interleaved [32 gate|32 up] */
+    LLARK_EPI_SPLIT16 = 5      /* acc + bias -> hi/lo 16-bit planes                              */
+};
+
+int llark_version(void);
+const char* llark_last_error(void);
+/* device properties probe: returns CU count (>0) or a negative error; arch_name receives e.g. "gfx950". */
+int llark_device_info(int device, char* arch_name, int arch_name_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * Jukebox VQ-VAE level-2 encoder: replaces `vqvae.encode(...)` at jukebox/main.py:61
+ * (upstream openai/jukebox vqvae/encdec.py EncoderConvBlock, resnet.py ResConv1DBlock,
+ * bottleneck.py BottleneckBlock.encode).  Activations: fp32 [n][C][T] (torch NCT).
+ * ------------------------------------------------------------------------------------------- */
+/* w[cout][cin][k] (torch Conv1d.weight) -> wp[k][cin][cout] (kernel layout). */
+int llark_pack_conv_weight(const float* w, float* wp, int cout, int cin, int k, llark_stream_t stream);
+/* nn.Conv1d forward; built shapes: (cin in {1,32,64}, cout 32, k4 s2) and (cin 32, cout 64, k3 s1). */
+int llark_conv1d_f32(const float* x, int n, int cin, int tin, const float* wp, const float* bias, int cout, int k,
+                     int stride, int pad, int dil, float* y, int tout, llark_stream_t stream);
+/* ResConv1DBlock: y = x + conv1x1(relu(conv3(relu(x), dilation))); c must be 32. */
+int llark_resblock_f32(const float* x, int n, int c, int t, const float* w1p, const float* b1, const float* w2p,
+                       const float* b2, int dil, float* y, llark_stream_t stream);
+/* kk[j] = sum_c k[j][c]^2 */
+int llark_codebook_norms_f32(const float* k, int bins, int emb, float* kk, llark_stream_t stream);
+/* BottleneckBlock.quantise: codes[n][t] = argmin_j |x[n][:,t] - k[j]|^2 (first minimum); min_dist optional. */
+int llark_codebook_argmin(const float* x, int n, int emb, int t, const float* k, const float* kk, int bins,
+                          int64_t* codes, float* min_dist, llark_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Jukebox top prior, only_encode: replaces `top_prior.prior.forward(...)` at jukebox/main.py:108
+ * and the pooling at jukebox/main.py:113-167.
+ * ------------------------------------------------------------------------------------------- */
+int llark_prior_embed(const int64_t* z, int n, int t, int width, int bins, const float* x_emb, const float* pos_emb,
+                      const float* x_cond, const float* y_cond, float* h, llark_stream_t stream);
+/* LayerNorm(width, eps) in fp32 -> fp16 hi/lo planes [rows][ldo] */
+int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta,
+                              float eps, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* FactoredAttention core (pattern 1 block, 2 transpose-block, 3 previous-block) on qkv [n*t][ldq]. */
+int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks, int pattern,
+                     void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* AvgPool1d(frame_len, stride=frame_len, ceil_mode=False) over time: h [n][t][width] -> out [n][frames][width] */
+int llark_pool_window(const float* h, int n, int t, int width, int frame_len, float* out, int frames,
+                      llark_stream_t stream);
+/* acts[:len].mean(0): lens is a device int[n] (NULL -> t) */
+int llark_pool_mean(const float* h, int n, int t, int width, const int* lens, float* out, llark_stream_t stream);
+int llark_zero_pad16(void* plane, int rows, int ld, int from, llark_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 16-bit MFMA GEMM with fp32 accumulation: replaces upstream Conv1D.forward (`addmm`) of the prior
+ * (split hi/lo fp16 activations, fp32-class accuracy) and nn.Linear of Llama / mm_projector
+ * (m2t/models/llamav2.py:79,133,312).  C[m,n] = (a_hi [+ a_lo])[m,k] . wt[n,k]^T (+ bias).
+ * ------------------------------------------------------------------------------------------- */
+int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt,
+                 int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid, int ldr,
+                 void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* w[k][n] (upstream Conv1D.w, 16-bit) -> wt[n][ldw] with zero K padding; also serves row-major copies
+ * (transpose=0: w is already [n][k], e.g. nn.Linear.weight). src_dtype/dst_dtype: LLARK_F16/BF16 or
+ * 2 for fp32 source. */
+int llark_pack_weight16(const void* w, int src_dtype, int transpose, int k, int n, void* wt, int dst_dtype, int ldw,
+                        llark_stream_t stream);
+/* fp32 [rows][ld_in] -> 16-bit hi/lo planes [rows][ldo] (lo may be NULL); pads [width, ldo) with zeros. */
+int llark_split16(int dtype, const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
+                  llark_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLARK_HIP_H */

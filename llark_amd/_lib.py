@@ -1,0 +1,91 @@
+"""ctypes loader for ``libllark_hip.so`` (the C-ABI declared in ``include/llark_hip.h``).
+
+The product path has NO CPU or PyTorch fallback: if the HIP library cannot be loaded this module
+raises, and every op wrapper in :mod:`llark_amd.ops` goes through it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllark_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+
+class LlarkHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``llark_amd/libllark_hip.so`` (hipcc cross-compiles
+    without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "llark_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s)
+    )
+    if force or stale:
+        cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+        res = subprocess.run(cmd, capture_output=not verbose, text=True)
+        if res.returncode != 0:
+            raise LlarkHipError(f"building libllark_hip.so failed:\n{res.stdout}\n{res.stderr}")
+    return LIB_PATH
+
+
+# name -> argtypes (all return int unless noted)
+_P = c_void_p
+_SIGS = {
+    "llark_version": [],
+    "llark_device_info": [c_int, c_char_p, c_int],
+    "llark_pack_conv_weight": [_P, _P, c_int, c_int, c_int, _P],
+    "llark_conv1d_f32": [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "llark_resblock_f32": [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P],
+    "llark_codebook_norms_f32": [_P, c_int, c_int, _P, _P],
+    "llark_codebook_argmin": [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
+    "llark_prior_embed": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P],
+    "llark_layernorm_split_f16": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_int, _P],
+    "llark_prior_attn": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P],
+    "llark_pool_window": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P],
+    "llark_pool_mean": [_P, c_int, c_int, c_int, _P, _P, _P],
+    "llark_zero_pad16": [_P, c_int, c_int, c_int, _P],
+    "llark_gemm16": [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                     _P, _P, c_int, _P],
+    "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],
+    "llark_split16": [c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P],
+}
+
+
+def declared_symbols():
+    """Every symbol ``include/llark_hip.h`` declares (kept in sync by tests/test_abi.py)."""
+    return sorted(list(_SIGS.keys()) + ["llark_last_error"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            # same image on the GPU box: hipcc is present, so a missing .so is built, never skipped
+            build()
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # fail loudly: there is no fallback path
+            raise LlarkHipError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        L.llark_last_error.argtypes = []
+        L.llark_last_error.restype = c_char_p
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().llark_last_error().decode("utf-8", "replace")
+        raise LlarkHipError(f"{what or 'llark_hip'} failed (code {rc}): {msg}")

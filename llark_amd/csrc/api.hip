@@ -1,0 +1,111 @@
+// Library plumbing of libllark_hip.so: error reporting, device probe, and the layout/precision
+// conversion kernels (weight packing, fp32 -> 16-bit hi/lo split) used at load time.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace llark {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <typename S, typename D>
+__global__ void pack_weight16_kernel(const S* __restrict__ w, D* __restrict__ wt, int k, int n, int ldw, int transpose) {
+    // one thread per destination element (n, kk), kk fastest; 32x32 LDS transpose not needed at load time
+    const size_t total = (size_t)n * ldw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % ldw);
+        const size_t nn = i / ldw;
+        float v = 0.0f;
+        if (kk < k) v = (float)(transpose ? w[(size_t)kk * n + nn] : w[nn * (size_t)k + kk]);
+        wt[i] = (D)v;
+    }
+}
+
+template <typename D>
+__global__ void split16_kernel(const float* __restrict__ x, int ldx, int rows, int width, D* __restrict__ hi,
+                               D* __restrict__ lo, int ldo) {
+    const size_t total = (size_t)rows * ldo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ldo);
+        const size_t r = i / ldo;
+        float v = c < width ? x[r * ldx + c] : 0.0f;
+        D h = (D)v;
+        hi[i] = h;
+        if (lo) lo[i] = (D)(v - (float)h);
+    }
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+extern "C" int llark_version(void) { return 100; }
+
+extern "C" const char* llark_last_error(void) { return g_err; }
+
+extern "C" int llark_device_info(int device, char* arch_name, int arch_name_len) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        set_error("device_info: %s", hipGetErrorString(e));
+        return LLARK_ERR_LAUNCH;
+    }
+    if (arch_name && arch_name_len > 0) {
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = 0;
+    }
+    return prop.multiProcessorCount;
+}
+
+template <typename S>
+static int pack_dispatch(const void* w, int transpose, int k, int n, void* wt, int dst_dtype, int ldw, hipStream_t s) {
+    const size_t total = (size_t)n * ldw;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (dst_dtype == LLARK_F16)
+        pack_weight16_kernel<S, half_t><<<grid, 256, 0, s>>>((const S*)w, (half_t*)wt, k, n, ldw, transpose);
+    else if (dst_dtype == LLARK_BF16)
+        pack_weight16_kernel<S, bf16_t><<<grid, 256, 0, s>>>((const S*)w, (bf16_t*)wt, k, n, ldw, transpose);
+    else {
+        set_error("pack_weight16: bad dst dtype %d", dst_dtype);
+        return LLARK_ERR_INVALID;
+    }
+    return check_launch("pack_weight16");
+}
+
+extern "C" int llark_pack_weight16(const void* w, int src_dtype, int transpose, int k, int n, void* wt, int dst_dtype,
+                                   int ldw, llark_stream_t stream) {
+    LLARK_REQUIRE(w && wt && k > 0 && n > 0 && ldw >= k && ldw % 8 == 0, "pack_weight16: bad arguments (k=%d n=%d ldw=%d)", k, n, ldw);
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == LLARK_F16) return pack_dispatch<half_t>(w, transpose, k, n, wt, dst_dtype, ldw, s);
+    if (src_dtype == LLARK_BF16) return pack_dispatch<bf16_t>(w, transpose, k, n, wt, dst_dtype, ldw, s);
+    if (src_dtype == 2) return pack_dispatch<float>(w, transpose, k, n, wt, dst_dtype, ldw, s);
+    set_error("pack_weight16: bad src dtype %d", src_dtype);
+    return LLARK_ERR_INVALID;
+}
+
+extern "C" int llark_split16(int dtype, const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo,
+                             int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && out_hi && rows > 0 && width > 0 && ldo >= width && ldx >= width, "split16: bad arguments");
+    const size_t total = (size_t)rows * ldo;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LLARK_F16)
+        split16_kernel<half_t><<<grid, 256, 0, s>>>(x, ldx, rows, width, (half_t*)out_hi, (half_t*)out_lo, ldo);
+    else if (dtype == LLARK_BF16)
+        split16_kernel<bf16_t><<<grid, 256, 0, s>>>(x, ldx, rows, width, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo);
+    else {
+        set_error("split16: bad dtype %d", dtype);
+        return LLARK_ERR_INVALID;
+    }
+    return check_launch("split16");
+}

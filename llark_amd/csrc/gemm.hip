@@ -1,0 +1,275 @@
+// MFMA GEMM for gfx950 (MI355X): C[M,N] = (Ahi [+ Alo])[M,K] . Wt[N,K]^T (+ bias) with fused epilogues.
+//
+// This is the dominant kernel of the hot path.  It replaces the cuBLAS `addmm` behind upstream
+// jukebox `Conv1D.forward` (4 per prior layer, reached from jukebox/main.py:108) and the
+// `nn.Linear`s of HF Llama / `mm_projector` (m2t/models/llamav2.py:79,133,224-234,312).
+//
+// Precision scheme ("split" mode, used for the Jukebox prior which the reference runs with
+// fp16=False, i.e. fp32 activations x fp16-VALUED weights): the fp32 activation a is carried as two
+// fp16 planes a = hi + lo (hi = fp16(a), lo = fp16(a - hi), 22 significant bits) produced by the
+// previous kernel's epilogue; the weight is exactly its fp16 storage.  The kernel runs TWO
+// 16-bit MFMA passes per K-step against the SAME weight fragments and accumulates in fp32, i.e.
+// fp32-class accuracy at 1/2 of the fp16 matrix rate instead of 1/16 (the f32-input MFMA rate).
+// Single-pass mode (SPLIT=false) is the plain bf16/fp16 GEMM used for Llama.
+//
+// Structure: 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x16_{f16,bf16}; operands stream HBM/L2 -> LDS with global_load_lds_dwordx4
+// (16 B/lane, no VGPR round trip) into a double-buffered LDS image whose 16-B chunks are XOR
+// swizzled on the SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128
+// fragment reads are bank-conflict free; one barrier per K-step; 48 KiB LDS -> 3 blocks/CU.
+// blockIdx is remapped XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and
+// grouped over M so that co-resident blocks share A and W panels.
+#include "common.h"
+
+namespace llark {
+
+enum { BM = 128, BN = 128, BK = 32, GEMM_THREADS = 256 };
+enum { MAT_BYTES = BM * BK * 2 };  // 8 KiB: one [128][32] 16-bit operand tile
+
+struct GemmParams {
+    const void* Ahi;
+    const void* Alo;
+    int lda;
+    const void* Wt;
+    int ldw;
+    const float* bias;
+    int M, N, Kp;
+    float* C;          // fp32 output (EPI_F32 / EPI_RESID)
+    int ldc;
+    const float* R;    // residual input (EPI_RESID); may alias C
+    int ldr;
+    void* Ohi;         // 16-bit outputs
+    void* Olo;
+    int ldo;
+    int tiles_m, tiles_n;
+};
+
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5 };
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<half_t> {
+    typedef half8_t frag;
+    static __device__ __forceinline__ f32x16_t run(frag a, frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ half_t cvt(float v) { return (half_t)v; }
+    static __device__ __forceinline__ float back(half_t v) { return (float)v; }
+};
+template <>
+struct Mfma<bf16_t> {
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ f32x16_t run(frag a, frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ bf16_t cvt(float v) { return (bf16_t)v; }
+    static __device__ __forceinline__ float back(bf16_t v) { return (float)v; }
+};
+
+// One wave-instruction of LDS-DMA: 64 lanes x 16 B -> 1 KiB (16 rows x 64 B) at `lds_dst`.
+// Lane i lands at lds_dst + 16*i = (row i>>2, slot i&3); it FETCHES chunk (i&3)^((i>>4)&3) of
+// that row so that slot p of row r holds chunk p ^ ((r>>2)&3)   [r>>2 & 3 == i>>4 & 3 here].
+template <typename T>
+__device__ __forceinline__ void dma_rows16(const T* __restrict__ g, int ld, int row0, int rows_valid, int k0,
+                                           char* lds_dst, int lane) {
+    int r = row0 + (lane >> 2);
+    r = r < rows_valid ? r : rows_valid - 1;
+    int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const T* src = g + (size_t)r * ld + k0 + chunk * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// byte offset inside an 8 KiB operand tile of (row, 16-B chunk c)
+__device__ __forceinline__ int tile_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+template <typename T, bool SPLIT, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr int NMAT = SPLIT ? 3 : 2;             // [Ahi, (Alo), W]
+    constexpr int STAGE = NMAT * MAT_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+
+    // ---- XCD-aware + M-grouped tile mapping (speed only; any mapping is correct) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    constexpr int GM = 8;
+    const int gsz = GM * p.tiles_n;
+    const int g = bid / gsz;
+    const int first_m = g * GM;
+    const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+    const int tile_m = first_m + (bid % gsz) % gm;
+    const int tile_n = (bid % gsz) / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* Ahi = (const T*)p.Ahi;
+    const T* Alo = (const T*)p.Alo;
+    const T* Wt = (const T*)p.Wt;
+
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rg = w * 2 + i;                                   // 16-row group 0..7
+            dma_rows16<T>(Ahi, p.lda, m0 + rg * 16, p.M, k0, base + rg * 1024, lane);
+            if (SPLIT) dma_rows16<T>(Alo, p.lda, m0 + rg * 16, p.M, k0, base + MAT_BYTES + rg * 1024, lane);
+            dma_rows16<T>(Wt, p.ldw, n0 + rg * 16, p.N, k0, base + (NMAT - 1) * MAT_BYTES + rg * 1024, lane);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.Kp / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* base = smem + (kt & 1) * STAGE;
+        const char* sA = base;
+        const char* sL = base + MAT_BYTES;
+        const char* sW = base + (NMAT - 1) * MAT_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int c = s * 2 + (lane >> 5);
+            frag bf[2], ah[2], al[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) bf[tn] = *(const frag*)(sW + tile_off(wn * 64 + tn * 32 + (lane & 31), c));
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                ah[tm] = *(const frag*)(sA + tile_off(wm * 64 + tm * 32 + (lane & 31), c));
+                if (SPLIT) al[tm] = *(const frag*)(sL + tile_off(wm * 64 + tm * 32 + (lane & 31), c));
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn] = Mfma<T>::run(ah[tm], bf[tn], acc[tm][tn]);
+                    if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], bf[tn], acc[tm][tn]);
+                }
+        }
+    }
+
+    // ---- epilogue ----  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            if (EPI == EPI_SWIGLU16 && tn == 1) continue;       // tn=0 holds gate, tn=1 holds up
+            const int n = n0 + wn * 64 + tn * 32 + (lane & 31);
+            // SwiGLU packing: W rows are interleaved in blocks of 32: [gate 32 | up 32] per 64 rows,
+            // so output column = (n0 + wn*64)/2 + (lane&31).
+            const int ncol = (EPI == EPI_SWIGLU16) ? ((n0 + wn * 64) >> 1) + (lane & 31) : n;
+            const int nlim = (EPI == EPI_SWIGLU16) ? (p.N >> 1) : p.N;
+            if (ncol >= nlim) continue;
+            const float bv = (p.bias != nullptr && EPI != EPI_SWIGLU16) ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M) continue;
+                float v = acc[tm][tn][r] + bv;
+                if (EPI == EPI_F32) {
+                    p.C[(size_t)m * p.ldc + n] = v;
+                } else if (EPI == EPI_RESID) {
+                    p.C[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + v;
+                } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
+                    if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
+                    T hi = Mfma<T>::cvt(v);
+                    ((T*)p.Ohi)[(size_t)m * p.ldo + n] = hi;
+                    ((T*)p.Olo)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(v - Mfma<T>::back(hi));
+                } else if (EPI == EPI_OUT16) {
+                    ((T*)p.Ohi)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(v);
+                } else if (EPI == EPI_SWIGLU16) {
+                    float gate = acc[tm][0][r], up = acc[tm][1][r];
+                    ((T*)p.Ohi)[(size_t)m * p.ldo + ncol] = Mfma<T>::cvt(silu(gate) * up);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool SPLIT, int EPI>
+static int launch_gemm(const GemmParams& p, hipStream_t s) {
+    constexpr int NMAT = SPLIT ? 3 : 2;
+    constexpr int LDS = 2 * NMAT * MAT_BYTES;
+    auto kern = gemm_kernel<T, SPLIT, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    kern<<<p.tiles_m * p.tiles_n, GEMM_THREADS, LDS, s>>>(p);
+    return check_launch("gemm");
+}
+
+template <typename T>
+static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
+#define CASE(E)                                                      \
+    case E:                                                          \
+        return split ? launch_gemm<T, true, E>(p, s) : launch_gemm<T, false, E>(p, s);
+    switch (epi) {
+        CASE(EPI_F32)
+        CASE(EPI_RESID)
+        CASE(EPI_QGELU_SPLIT)
+        CASE(EPI_OUT16)
+        CASE(EPI_SWIGLU16)
+        CASE(EPI_SPLIT16)
+    }
+#undef CASE
+    set_error("gemm: unknown epilogue %d", epi);
+    return LLARK_ERR_INVALID;
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+// dtype: LLARK_F16 / LLARK_BF16.  split != 0 -> A is given as hi/lo planes (Alo required).
+// Wt is [N][ldw] (K-contiguous rows, i.e. the transpose of upstream Conv1D.w / the native layout of
+// nn.Linear.weight); K is padded with zeros up to kp (multiple of 32) in BOTH A and Wt.  M and N
+// need no padding: out-of-range rows are clamped on load and masked on store.
+extern "C" int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                            const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                            const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                            llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
+    LLARK_REQUIRE(kp % BK == 0, "gemm16: kp=%d must be a multiple of %d (zero-pad K)", kp, BK);
+    LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16: lda/ldw must be >= kp and multiples of 8");
+    LLARK_REQUIRE(!split || a_lo, "gemm16: split mode needs the lo plane");
+    LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && (!a_lo || ((uintptr_t)a_lo & 15) == 0),
+                  "gemm16: operands must be 16-byte aligned");
+    if (epilogue == EPI_F32 || epilogue == EPI_RESID) LLARK_REQUIRE(c && ldc >= n, "gemm16: fp32 output missing");
+    if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16: residual missing");
+    if (epilogue == EPI_QGELU_SPLIT || epilogue == EPI_SPLIT16) LLARK_REQUIRE(out_hi && out_lo && ldo >= n, "gemm16: split outputs missing");
+    if (epilogue == EPI_OUT16) LLARK_REQUIRE(out_hi && ldo >= n, "gemm16: 16-bit output missing");
+    if (epilogue == EPI_SWIGLU16) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2, "gemm16: swiglu needs n%%64==0 and an output");
+    GemmParams p;
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
+    p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    p.tiles_m = cdiv(m, BM); p.tiles_n = cdiv(n, BN);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LLARK_F16) return dispatch<half_t>(p, split != 0, epilogue, s);
+    if (dtype == LLARK_BF16) return dispatch<bf16_t>(p, split != 0, epilogue, s);
+    set_error("gemm16: unknown dtype %d", dtype);
+    return LLARK_ERR_INVALID;
+}

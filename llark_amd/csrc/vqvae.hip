@@ -1,0 +1,304 @@
+// Jukebox VQ-VAE level-2 encoder + codebook search for gfx950.
+//
+// Replaces the cuDNN Conv1d stack and BottleneckBlock.quantise reached from the reference's
+// `vqvae.encode(...)` call (jukebox/main.py:61; upstream openai/jukebox vqvae/encdec.py,
+// resnet.py, bottleneck.py).  Activations are channel-major fp32 [n][C][T] like torch's NCT.
+//
+// Numerics contract (shared with oracle/jukebox_ref.c so that the integer codes are bit-exact):
+//   acc = bias; for tap: for ci: acc = fmaf(w[co][ci][tap], x[ci][t*stride+tap*dil-pad], acc)
+//   resblock: y = x + conv1x1(relu(conv3_dil(relu(x))))
+//   codebook: dist_j = (xx - 2*dot_j) + kk_j with c-ascending fmaf chains; first minimal j wins.
+// The file is built with -ffp-contract=off; every fused multiply-add is an explicit fmaf.
+//
+// Kernel shape: one thread owns TPT output time steps and ALL output channels, so the weights of
+// a (tap, ci) step are wave-uniform and arrive through the scalar cache (s_load_dwordx16) while
+// the input tile (with its dilation halo) is staged once in LDS; lanes walk consecutive time
+// steps, so LDS reads are conflict-free and HBM traffic is exactly one read + one write per layer.
+#include "common.h"
+
+namespace llark {
+
+// ------------------------------------------------------------------------------------------
+// weight re-layout: w[cout][cin][k]  ->  wp[k][cin][cout]   (scalar-load friendly)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout,
+                                        int cin, int k) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int total = cout * cin * k;
+    if (i >= total) return;
+    int co = i % cout;
+    int ci = (i / cout) % cin;
+    int tap = i / (cout * cin);
+    wp[i] = w[((size_t)co * cin + ci) * k + tap];
+}
+
+// ------------------------------------------------------------------------------------------
+// generic conv: strided down-convs (k=4,s=2,p=1) and the k=3 output convs.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int K, int STRIDE, int TT>
+__global__ __launch_bounds__(256) void conv1d_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                     const float* __restrict__ bias, float* __restrict__ y,
+                                                     int tin, int tout, int pad, int dil) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TT;                 // first output of this tile
+    const int span = (TT - 1) * STRIDE + (K - 1) * dil + 1;
+    const int in0 = t0 * STRIDE - pad;              // first input index of the tile
+    const float* xn = x + (size_t)n * CIN * tin;
+    for (int i = threadIdx.x; i < CIN * span; i += 256) {
+        int ci = i / span, j = i - ci * span;
+        int gi = in0 + j;
+        lds[ci * span + j] = (gi >= 0 && gi < tin) ? xn[(size_t)ci * tin + gi] : 0.0f;
+    }
+    __syncthreads();
+    constexpr int TPT = TT / 256;
+    float acc[TPT][COUT];
+#pragma unroll
+    for (int p = 0; p < TPT; ++p)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[p][co] = bias[co];
+    for (int tap = 0; tap < K; ++tap) {
+#pragma unroll 2
+        for (int ci = 0; ci < CIN; ++ci) {
+            const float* wrow = wp + ((size_t)tap * CIN + ci) * COUT;
+            float xv[TPT];
+#pragma unroll
+            for (int p = 0; p < TPT; ++p) xv[p] = lds[ci * span + (threadIdx.x + p * 256) * STRIDE + tap * dil];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float wv = wrow[co];
+#pragma unroll
+                for (int p = 0; p < TPT; ++p) acc[p][co] = fmaf(wv, xv[p], acc[p][co]);
+            }
+        }
+    }
+    float* yn = y + (size_t)n * COUT * tout;
+#pragma unroll
+    for (int p = 0; p < TPT; ++p) {
+        int t = t0 + threadIdx.x + p * 256;
+        if (t < tout) {
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) yn[(size_t)co * tout + t] = acc[p][co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused ResConv1DBlock: y = x + W2 * relu(W1 (*)_dil relu(x) + b1) + b2, C = 32.
+// ------------------------------------------------------------------------------------------
+template <int C, int TPT>
+__global__ __launch_bounds__(256) void resblock_kernel(const float* __restrict__ x, const float* __restrict__ w1p,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2p,
+                                                       const float* __restrict__ b2, float* __restrict__ y, int t,
+                                                       int dil) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TT = 256 * TPT;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int span = TT + 2 * dil;
+    const float* xn = x + (size_t)n * C * t;
+    for (int i = threadIdx.x; i < C * span; i += 256) {
+        int ci = i / span, j = i - ci * span;
+        int gi = t0 - dil + j;
+        lds[ci * span + j] = (gi >= 0 && gi < t) ? xn[(size_t)ci * t + gi] : 0.0f;
+    }
+    __syncthreads();
+    float acc[TPT][C];
+#pragma unroll
+    for (int p = 0; p < TPT; ++p)
+#pragma unroll
+        for (int co = 0; co < C; ++co) acc[p][co] = b1[co];
+    for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll 4
+        for (int ci = 0; ci < C; ++ci) {
+            const float* wrow = w1p + ((size_t)tap * C + ci) * C;
+            float xv[TPT];
+#pragma unroll
+            for (int p = 0; p < TPT; ++p) xv[p] = fmaxf(lds[ci * span + threadIdx.x + p * 256 + tap * dil], 0.0f);
+#pragma unroll
+            for (int co = 0; co < C; ++co) {
+                float wv = wrow[co];
+#pragma unroll
+                for (int p = 0; p < TPT; ++p) acc[p][co] = fmaf(wv, xv[p], acc[p][co]);
+            }
+        }
+    }
+    float out[TPT][C];
+#pragma unroll
+    for (int p = 0; p < TPT; ++p)
+#pragma unroll
+        for (int co = 0; co < C; ++co) out[p][co] = b2[co];
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) {
+        const float* wrow = w2p + (size_t)ci * C;
+        float hv[TPT];
+#pragma unroll
+        for (int p = 0; p < TPT; ++p) hv[p] = fmaxf(acc[p][ci], 0.0f);
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            float wv = wrow[co];
+#pragma unroll
+            for (int p = 0; p < TPT; ++p) out[p][co] = fmaf(wv, hv[p], out[p][co]);
+        }
+    }
+    float* yn = y + (size_t)n * C * t;
+#pragma unroll
+    for (int p = 0; p < TPT; ++p) {
+        int tl = threadIdx.x + p * 256;
+        int tg = t0 + tl;
+        if (tg < t) {
+#pragma unroll
+            for (int co = 0; co < C; ++co) yn[(size_t)co * t + tg] = lds[co * span + tl + dil] + out[p][co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// codebook: kk_j = sum_c k_jc^2 ;  codes = argmin_j (xx - 2 x.k_j) + kk_j
+// ------------------------------------------------------------------------------------------
+__global__ void codebook_norms_kernel(const float* __restrict__ k, float* __restrict__ kk, int bins, int emb) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= bins) return;
+    float s = 0.0f;
+    for (int c = 0; c < emb; ++c) {
+        float v = k[(size_t)j * emb + c];
+        s = fmaf(v, v, s);
+    }
+    kk[j] = s;
+}
+
+// block = 256 threads = 4 waves; 64 tokens per block; wave q scans codes [q*bins/4, (q+1)*bins/4).
+template <int EMB, int JB>
+__global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                              const float* __restrict__ kk, long long* __restrict__ codes,
+                                                              float* __restrict__ mind, int t, int bins) {
+    __shared__ float s_best[4][64];
+    __shared__ int s_idx[4][64];
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tok = blockIdx.x * 64 + lane;
+    const int tc = tok < t ? tok : t - 1;
+    const float* xn = x + (size_t)n * EMB * t;
+    float xv[EMB];
+#pragma unroll
+    for (int c = 0; c < EMB; ++c) xv[c] = xn[(size_t)c * t + tc];
+    float xx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < EMB; ++c) xx = fmaf(xv[c], xv[c], xx);
+    const int per = bins / 4;
+    const int j0 = q * per;
+    float best = INFINITY;
+    int bj = j0;
+    for (int j = j0; j < j0 + per; j += JB) {
+        float dot[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) dot[u] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < EMB; ++c) {
+#pragma unroll
+            for (int u = 0; u < JB; ++u) dot[u] = fmaf(xv[c], k[(size_t)(j + u) * EMB + c], dot[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+            float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.0f, dot[u])), kk[j + u]);
+            if (d < best) {
+                best = d;
+                bj = j + u;
+            }
+        }
+    }
+    s_best[q][lane] = best;
+    s_idx[q][lane] = bj;
+    __syncthreads();
+    if (q == 0 && tok < t) {
+        float b = s_best[0][lane];
+        int bi = s_idx[0][lane];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            float v = s_best[r][lane];
+            if (v < b) {
+                b = v;
+                bi = s_idx[r][lane];
+            }
+        }
+        codes[(size_t)n * t + tok] = bi;
+        if (mind) mind[(size_t)n * t + tok] = b;
+    }
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+extern "C" int llark_pack_conv_weight(const float* w, float* wp, int cout, int cin, int k, llark_stream_t stream) {
+    LLARK_REQUIRE(w && wp && cout > 0 && cin > 0 && k > 0, "pack_conv_weight: bad arguments");
+    int total = cout * cin * k;
+    pack_conv_weight_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wp, cout, cin, k);
+    return check_launch("pack_conv_weight");
+}
+
+template <int CIN, int COUT, int K, int STRIDE, int TT>
+static int launch_conv(const float* x, int n, int tin, const float* wp, const float* bias, int pad, int dil,
+                       float* y, int tout, hipStream_t s) {
+    int span = (TT - 1) * STRIDE + (K - 1) * dil + 1;
+    size_t lds = (size_t)CIN * span * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("conv1d: LDS tile %zu B exceeds 160 KiB", lds);
+        return LLARK_ERR_INVALID;
+    }
+    auto kern = conv1d_kernel<CIN, COUT, K, STRIDE, TT>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(cdiv(tout, TT), n);
+    kern<<<grid, 256, lds, s>>>(x, wp, bias, y, tin, tout, pad, dil);
+    return check_launch("conv1d");
+}
+
+extern "C" int llark_conv1d_f32(const float* x, int n, int cin, int tin, const float* wp, const float* bias, int cout,
+                                int k, int stride, int pad, int dil, float* y, int tout, llark_stream_t stream) {
+    LLARK_REQUIRE(x && wp && bias && y && n > 0 && tin > 0, "conv1d: null pointer or empty input");
+    int expect = (tin + 2 * pad - dil * (k - 1) - 1) / stride + 1;
+    LLARK_REQUIRE(expect == tout, "conv1d: tout=%d does not match (tin=%d,k=%d,s=%d,p=%d,d=%d) -> %d", tout, tin, k,
+                  stride, pad, dil, expect);
+    hipStream_t s = (hipStream_t)stream;
+    if (k == 4 && stride == 2 && cout == 32 && dil == 1) {
+        if (cin == 1) return launch_conv<1, 32, 4, 2, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);
+        if (cin == 32) return launch_conv<32, 32, 4, 2, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);
+        if (cin == 64) return launch_conv<64, 32, 4, 2, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);
+    }
+    if (k == 3 && stride == 1 && cin == 32 && cout == 64 && dil == 1)
+        return launch_conv<32, 64, 3, 1, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);
+    set_error("conv1d: unsupported shape cin=%d cout=%d k=%d stride=%d dil=%d", cin, cout, k, stride, dil);
+    return LLARK_ERR_UNSUPPORTED;
+}
+
+extern "C" int llark_resblock_f32(const float* x, int n, int c, int t, const float* w1p, const float* b1,
+                                  const float* w2p, const float* b2, int dil, float* y, llark_stream_t stream) {
+    LLARK_REQUIRE(x && w1p && b1 && w2p && b2 && y && n > 0 && t > 0, "resblock: null pointer or empty input");
+    LLARK_REQUIRE(c == 32, "resblock: only width 32 (Jukebox vqvae width) is built, got %d", c);
+    LLARK_REQUIRE(dil >= 1 && dil <= 81, "resblock: dilation %d out of range", dil);
+    constexpr int TPT = 2;
+    constexpr int TT = 256 * TPT;
+    size_t lds = (size_t)32 * (TT + 2 * dil) * sizeof(float);
+    auto kern = resblock_kernel<32, TPT>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(cdiv(t, TT), n);
+    kern<<<grid, 256, lds, (hipStream_t)stream>>>(x, w1p, b1, w2p, b2, y, t, dil);
+    return check_launch("resblock");
+}
+
+extern "C" int llark_codebook_norms_f32(const float* k, int bins, int emb, float* kk, llark_stream_t stream) {
+    LLARK_REQUIRE(k && kk && bins > 0 && emb > 0, "codebook_norms: bad arguments");
+    codebook_norms_kernel<<<cdiv(bins, 256), 256, 0, (hipStream_t)stream>>>(k, kk, bins, emb);
+    return check_launch("codebook_norms");
+}
+
+extern "C" int llark_codebook_argmin(const float* x, int n, int emb, int t, const float* k, const float* kk, int bins,
+                                     int64_t* codes, float* min_dist, llark_stream_t stream) {
+    LLARK_REQUIRE(x && k && kk && codes && n > 0 && t > 0, "codebook_argmin: null pointer or empty input");
+    LLARK_REQUIRE(emb == 64, "codebook_argmin: emb_width must be 64, got %d", emb);
+    LLARK_REQUIRE(bins % 32 == 0 && bins >= 32, "codebook_argmin: bins must be a multiple of 32, got %d", bins);
+    dim3 grid(cdiv(t, 64), n);
+    codebook_argmin_kernel<64, 8><<<grid, 256, 0, (hipStream_t)stream>>>(x, k, kk, (long long*)codes, min_dist, t, bins);
+    return check_launch("codebook_argmin");
+}

@@ -1,0 +1,237 @@
+"""Host-side driver of the Jukebox top prior (SimplePrior / ConditionalAutoregressive2D in
+``only_encode`` mode) on the HIP kernels.
+
+Mirrors the objects the reference touches in jukebox/main.py:71-110:
+``top_prior.raw_to_tokens``, ``top_prior.labeller.get_batch_labels``, ``top_prior.get_y``,
+``top_prior.get_cond`` and ``top_prior.prior.forward(x, x_cond=, y_cond=, encoder_kv=None,
+fp16=False)`` with ``top_prior.prior.only_encode = True``.
+
+Data layout in HBM (per batch of N clips, M = N*n_ctx rows):
+  h        fp32 [M][W]                      residual stream (updated in place by the GEMM epilogues)
+  ln_hi/lo fp16 [M][W]                      LayerNorm output as hi/lo split planes
+  qkv      fp32 [M][3S]
+  att_hi/lo fp16 [M][Sp]   (Sp = S rounded up to 32, pad columns stay zero)
+  g_hi/lo  fp16 [M][Mp]                     QuickGELU output
+  weights  fp16 [N_out][Kp]                 transposed (K-contiguous) copies of upstream Conv1D.w
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from .hparams import JukeboxHParams
+
+
+class Labeller:
+    """Upstream ``Labeller.get_batch_labels`` for the only metadata the reference ever passes
+    (artist/genre "unknown" -> id 0; jukebox/main.py:80-91)."""
+
+    def __init__(self, hps: JukeboxHParams):
+        self.hps = hps
+        self.sample_length = hps.n_ctx * hps.raw_to_tokens
+
+    def get_label(self, artist, genre, lyrics, total_length, offset):
+        del lyrics
+        if artist != "unknown" or genre != "unknown":
+            raise NotImplementedError("only artist/genre 'unknown' (ids 0) are supported; the v3 id tables are "
+                                      "not part of the reference tree")
+        y = [total_length, offset, self.sample_length, 0, 0] + [-1] * (self.hps.max_bow_genre_size - 1)
+        return dict(y=np.array(y, dtype=np.int64))
+
+    def get_batch_labels(self, metas, device="cpu"):
+        ys = [self.get_label(**m)["y"] for m in metas]
+        return dict(y=torch.from_numpy(np.stack(ys, axis=0)).to(device).long(), info=None)
+
+
+class _LayerWeights:
+    __slots__ = ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "w_attn", "b_attn", "w_proj", "b_proj", "w_fc", "b_fc", "w_proj2",
+                 "b_proj2")
+
+
+class PriorTransformer:
+    """``top_prior.prior``: the ConditionalAutoregressive2D forward in ``only_encode`` mode."""
+
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device, depth: Optional[int] = None):
+        self.hps = hps
+        self.device = torch.device(device)
+        self.only_encode = False
+        self.width = hps.prior_width
+        self.depth = hps.prior_depth if depth is None else depth
+        dev = self.device
+
+        def f32(name):
+            return weights[name].detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        def w16(name):
+            # upstream Conv1D.w is [n_in][n_out], stored fp16 (fp16_params); pack to [n_out][Kp] fp16
+            w = weights[name].detach().to(device=dev)
+            if w.dtype != torch.float16:
+                w = w.to(torch.float16)      # a real checkpoint stores fp16; fp32 inputs are rounded like upstream
+            return ops.pack_weight16(w.contiguous(), transpose=True, dst_dtype=torch.float16)
+
+        self.x_emb = f32("prior.x_emb.weight")
+        self.pos_emb = f32("prior.pos_emb.pos_emb")
+        self.layers: List[_LayerWeights] = []
+        for d in range(self.depth):
+            p = f"prior.transformer._attn_mods.{d}"
+            L = _LayerWeights()
+            L.ln0_g, L.ln0_b = f32(f"{p}.ln_0.weight"), f32(f"{p}.ln_0.bias")
+            L.ln1_g, L.ln1_b = f32(f"{p}.ln_1.weight"), f32(f"{p}.ln_1.bias")
+            L.w_attn, L.b_attn = w16(f"{p}.attn.c_attn.w"), f32(f"{p}.attn.c_attn.b")
+            L.w_proj, L.b_proj = w16(f"{p}.attn.c_proj.w"), f32(f"{p}.attn.c_proj.b")
+            L.w_fc, L.b_fc = w16(f"{p}.mlp.c_fc.w"), f32(f"{p}.mlp.c_fc.b")
+            L.w_proj2, L.b_proj2 = w16(f"{p}.mlp.c_proj.w"), f32(f"{p}.mlp.c_proj.b")
+            self.layers.append(L)
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._ws_rows = 0
+
+    # ---- workspace ---------------------------------------------------------------------------
+    def _workspace(self, rows: int):
+        if self._ws_rows != rows:
+            hps, dev = self.hps, self.device
+            W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
+            Sp, Mp, Wp = ops.round_up(S, 32), ops.round_up(Mw, 32), ops.round_up(W, 32)
+            ws = {}
+            ws["ln_hi"] = torch.zeros((rows, Wp), dtype=torch.float16, device=dev)
+            ws["ln_lo"] = torch.zeros((rows, Wp), dtype=torch.float16, device=dev)
+            ws["qkv"] = torch.empty((rows, 3 * S), dtype=torch.float32, device=dev)
+            ws["att_hi"] = torch.zeros((rows, Sp), dtype=torch.float16, device=dev)   # pad columns stay 0
+            ws["att_lo"] = torch.zeros((rows, Sp), dtype=torch.float16, device=dev)
+            ws["g_hi"] = torch.zeros((rows, Mp), dtype=torch.float16, device=dev)
+            ws["g_lo"] = torch.zeros((rows, Mp), dtype=torch.float16, device=dev)
+            self._ws, self._ws_rows = ws, rows
+        return self._ws
+
+    # ---- one ResAttnBlock --------------------------------------------------------------------
+    def layer_forward(self, h2: torch.Tensor, d: int, n: int, taps: Optional[dict] = None) -> None:
+        """h2: [M][W] fp32 residual stream, updated in place:  a = attn(ln_0(h)); h += a;
+        m = mlp(ln_1(h)); h += m   (== upstream ``x + a + m`` evaluated left to right)."""
+        hps, L = self.hps, self.layers[d]
+        rows = h2.shape[0]
+        ws = self._workspace(rows)
+        W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
+        ops.layernorm_split(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
+        ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
+        ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
+        if taps is not None:
+            taps["ln0"] = ws["ln_hi"].float() + ws["ln_lo"].float()
+            taps["qkv"] = ws["qkv"].clone()
+            taps["att"] = (ws["att_hi"].float() + ws["att_lo"].float())[:, :S]
+        ops.gemm16(ws["att_hi"], ws["att_lo"], L.w_proj, L.b_proj, W, ops.EPI_RESID, c=h2, resid=h2)
+        if taps is not None:
+            taps["xa"] = h2.clone()
+        ops.layernorm_split(h2, L.ln1_g, L.ln1_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
+        ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.b_fc, Mw, ops.EPI_QGELU_SPLIT, out_hi=ws["g_hi"], out_lo=ws["g_lo"])
+        if taps is not None:
+            taps["ln1"] = ws["ln_hi"].float() + ws["ln_lo"].float()
+            taps["g"] = (ws["g_hi"].float() + ws["g_lo"].float())[:, :Mw]
+        ops.gemm16(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
+
+    def embed(self, x: torch.Tensor, x_cond: torch.Tensor, y_cond: torch.Tensor) -> torch.Tensor:
+        n, t = x.shape
+        xc = x_cond.reshape(-1, self.width)[:t].contiguous()
+        yc = y_cond.reshape(-1)[: self.width].contiguous()
+        return ops.prior_embed(x.contiguous(), self.x_emb, self.pos_emb, xc, yc)
+
+    def forward(self, x, x_cond=None, y_cond=None, encoder_kv=None, fp16=False, depth: Optional[int] = None):
+        """``prior.forward(x, x_cond=, y_cond=, encoder_kv=None, fp16=False)`` with only_encode=True
+        (jukebox/main.py:105-108).  x: (N, n_ctx) int64 codes.  Returns (N, n_ctx, width) fp32."""
+        if not self.only_encode:
+            raise NotImplementedError("only the only_encode=True path of the prior is implemented (jukebox/main.py:105)")
+        if encoder_kv is not None or fp16:
+            raise NotImplementedError("encoder_kv / fp16=True are not used by the reference path (jukebox/main.py:108)")
+        assert x_cond is not None and y_cond is not None, "top-level prior is conditioned (x_cond=y_pos, y_cond)"
+        x = x.to(self.device)
+        n, t = x.shape
+        assert t == self.hps.n_ctx, f"expected {self.hps.n_ctx} tokens, got {t}"
+        # x_cond / y_cond are the same for every clip (the reference keeps sample 0 only, main.py:95-96)
+        h = self.embed(x, x_cond[0:1] if x_cond.dim() == 3 else x_cond, y_cond)
+        h2 = h.view(n * t, self.width)
+        for d in range(self.depth if depth is None else depth):
+            self.layer_forward(h2, d, n)
+        return h
+
+    __call__ = forward
+
+
+class TopPrior:
+    """``top_prior``: conditioning tables + the transformer (upstream SimplePrior, level = top)."""
+
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", depth: Optional[int] = None):
+        hps.check()
+        self.hps = hps
+        self.device = torch.device(device)
+        self.raw_to_tokens = hps.raw_to_tokens
+        self.n_ctx = hps.n_ctx
+        self.labeller = Labeller(hps)
+        self.prior = PriorTransformer(hps, weights, device, depth)
+        dev = self.device
+        self._y_emb = {k.split(".")[1]: v.detach().to(device=dev, dtype=torch.float32).contiguous()
+                       for k, v in weights.items() if k.startswith("y_emb.")}
+        self._cond_cache = None
+
+    def get_y(self, labels, start, get_indices=False):
+        y = labels["y"].clone()
+        # upstream: y[:, 2] = sample_length ; y[:, 1:2] += start * raw_to_tokens
+        y[:, 2] = int(self.n_ctx * self.raw_to_tokens)
+        y[:, 1:2] = y[:, 1:2] + int(start * self.raw_to_tokens)
+        return y
+
+    def _range_bins(self, n_time: int, rng, pos_start: np.ndarray, pos_end=None, clamp=False) -> np.ndarray:
+        """RangeEmbedding bin indices, evaluated in fp32 like upstream (conditioners.py)."""
+        pos_min, pos_max = np.float32(rng[0]), np.float32(rng[1])
+        pos_start = pos_start.astype(np.float32)
+        if pos_end is not None:
+            pos_end = pos_end.astype(np.float32)
+            if clamp:
+                pos_end = np.clip(pos_end, pos_min, pos_max)
+        if n_time != 1:
+            interpolation = (np.arange(0, n_time, dtype=np.float32).reshape(1, n_time) / np.float32(n_time))
+            position = pos_start + (pos_end - pos_start) * interpolation
+        else:
+            position = pos_start
+        normalised = (position - pos_min) / (pos_max - pos_min)
+        return np.floor(np.float32(self.hps.t_bins) * normalised.astype(np.float32)).astype(np.int64)
+
+    def get_cond(self, z_conds, y):
+        """``SimplePrior.get_cond`` for the top level: x_cond = y_pos, y_cond = start embedding.
+        y: (n_samples, 4 + max_bow_genre_size) int64.  Returns (x_cond, y_cond, prime=None).  The
+        tables are gathered once (they are constant for the reference's fixed metadata)."""
+        assert z_conds is None, "the top-level prior has no upsampler conditioner"
+        hps, dev = self.hps, self.device
+        yc = y.detach().cpu().numpy().astype(np.int64)
+        key = yc.tobytes()
+        if self._cond_cache is not None and self._cond_cache[0] == key:
+            return self._cond_cache[1]
+        n_all = yc.shape[0]
+        same = bool((yc == yc[0:1]).all())
+        if same:                      # the reference passes n_samples identical rows and keeps [0]
+            yc = yc[0:1]
+        total_length, offset, length, artist, genre = yc[:, 0:1], yc[:, 1:2], yc[:, 2:3], yc[:, 3:4], yc[:, 4:]
+        E = self._y_emb
+        artist_emb = E["artist_emb"][torch.from_numpy(artist).to(dev)]                     # (n,1,W)
+        mask = torch.from_numpy((genre >= 0).astype(np.float32)).to(dev).unsqueeze(2)
+        genre_emb = (E["bow_genre_emb"][torch.from_numpy(np.clip(genre, 0, None)).to(dev)] * mask).sum(dim=1, keepdim=True)
+        start_emb = genre_emb + artist_emb
+        start, end = offset, offset + length
+        tl, st, en = total_length.astype(np.float32), start.astype(np.float32), end.astype(np.float32)
+        sr = hps.sr
+        r0 = (hps.min_duration * sr, hps.max_duration * sr)
+        r1 = (0.0, hps.max_duration * sr)
+        r2 = (0.0, 1.0)
+        b0 = self._range_bins(1, r0, tl)
+        b1 = self._range_bins(hps.n_ctx, r1, st, en)
+        b2 = self._range_bins(hps.n_ctx, r2, st / tl, en / tl, clamp=True)
+        t = torch.from_numpy
+        pos_emb = (E["total_length_emb"][t(b0).to(dev)] + E["absolute_pos_emb"][t(b1).to(dev)]) + E["relative_pos_emb"][t(b2).to(dev)]
+        pos_emb, start_emb = pos_emb.contiguous(), start_emb.contiguous()
+        if same and n_all > 1:        # zero-copy views instead of n_samples x 157 MB
+            pos_emb = pos_emb.expand(n_all, -1, -1)
+            start_emb = start_emb.expand(n_all, -1, -1)
+        out = (pos_emb, start_emb, None)
+        self._cond_cache = (key, out)
+        return out

@@ -1,0 +1,99 @@
+"""Host-side driver of the Jukebox VQ-VAE level-2 encoder on the HIP kernels.
+
+Mirrors what the reference reaches through ``vqvae.encode(x)`` (jukebox/main.py:61; upstream
+``VQVAE.encode`` -> ``_encode`` -> ``encoders[level](x)[-1]`` -> ``bottleneck.encode``).  The
+reference runs all three level encoders and keeps ``zs[-1]`` (jukebox/main.py:63); the level-2
+codes do not depend on levels 0/1, so only the level-2 encoder is executed here and ``encode``
+returns ``[None, None, z_top]`` to keep the ``zs[-1]`` access pattern.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+from .hparams import JukeboxHParams
+
+
+class VQVAE:
+    """Level-2 encoder + codebook of the Jukebox VQ-VAE, weights resident in HBM in kernel layout."""
+
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda"):
+        hps.check()
+        self.hps = hps
+        self.device = torch.device(device)
+        self.sample_length = hps.sample_length
+        self.layers: List[tuple] = []          # ("conv", wp, b, stride, pad) | ("res", w1p, b1, w2p, b2, dil)
+        dev = self.device
+
+        def f32(name):
+            return weights[name].detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        p = "encoders.2"
+        for lb, (down_t, stride_t) in enumerate(zip(hps.downs_t, hps.strides_t)):
+            for i in range(down_t):
+                b = f"{p}.level_blocks.{lb}.model.{i}"
+                self.layers.append(("conv", ops.pack_conv_weight(f32(f"{b}.0.weight")), f32(f"{b}.0.bias"),
+                                    stride_t, stride_t // 2))
+                for r in range(hps.depth):
+                    rb = f"{b}.1.model.{r}.model"
+                    self.layers.append(("res", ops.pack_conv_weight(f32(f"{rb}.1.weight")), f32(f"{rb}.1.bias"),
+                                        ops.pack_conv_weight(f32(f"{rb}.3.weight")), f32(f"{rb}.3.bias"),
+                                        hps.dilation_growth_rate ** r))
+            b = f"{p}.level_blocks.{lb}.model.{down_t}"
+            self.layers.append(("conv", ops.pack_conv_weight(f32(f"{b}.weight")), f32(f"{b}.bias"), 1, 1))
+        self.set_codebook(weights["bottleneck.level_blocks.2.k"])
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+
+    def set_codebook(self, k: torch.Tensor) -> None:
+        self.k = k.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.kk = ops.codebook_norms(self.k)
+
+    def _buf(self, slot: int, shape) -> torch.Tensor:
+        """Two ping-pong activation buffers sized for the widest activation (n x 32 x T/2)."""
+        numel = 1
+        for s in shape:
+            numel *= s
+        key = slot
+        cur = self._bufs.get(key)
+        if cur is None or cur.numel() < numel:
+            cur = torch.empty((numel,), dtype=torch.float32, device=self.device)
+            self._bufs[key] = cur
+        return cur[:numel].view(*shape)
+
+    def encoder_forward(self, x: torch.Tensor, taps: Optional[list] = None) -> torch.Tensor:
+        """x: (N, 1, T) fp32 on device -> (N, emb_width, T / raw_to_tokens)."""
+        assert x.dim() == 3 and x.shape[1] == 1
+        slot = 0
+        for layer in self.layers:
+            n, c, t = x.shape
+            if layer[0] == "conv":
+                _, wp, b, stride, pad = layer
+                k, cin, cout = wp.shape
+                tout = (t + 2 * pad - (k - 1) - 1) // stride + 1
+                y = self._buf(slot, (n, cout, tout))
+                ops.conv1d(x, wp, b, stride, pad, 1, out=y)
+            else:
+                _, w1p, b1, w2p, b2, dil = layer
+                y = self._buf(slot, (n, c, t))
+                ops.resblock(x, w1p, b1, w2p, b2, dil, out=y)
+            if taps is not None:
+                taps.append(y.clone())
+            x = y
+            slot ^= 1
+        return x
+
+    def encode_top(self, audio: torch.Tensor, want_dist: bool = False):
+        """audio: (N, sample_length) fp32 device tensor -> codes (N, n_ctx) int64."""
+        assert audio.dim() == 2 and audio.shape[1] == self.sample_length, (
+            f"expected (N,{self.sample_length}) audio, got {tuple(audio.shape)}")
+        xe = self.encoder_forward(audio.contiguous().view(audio.shape[0], 1, -1))
+        return ops.codebook_argmin(xe, self.k, self.kk, want_dist=want_dist)
+
+    def encode(self, x: torch.Tensor):
+        """Upstream-shaped entry: x (N, T, 1) like ``vqvae.encode(torch.cuda.FloatTensor(audio[None,:,None]))``."""
+        assert x.dim() == 3 and x.shape[2] == 1
+        x = x.to(device=self.device, dtype=torch.float32)
+        z = self.encode_top(x[:, :, 0].contiguous())
+        return [None, None, z]

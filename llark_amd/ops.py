@@ -1,0 +1,207 @@
+"""Thin, validating Python wrappers over the C-ABI of ``libllark_hip.so``.
+
+PyTorch is used here only as a device-memory container and stream provider: every wrapper takes
+device tensors, checks dtype / shape / contiguity, and passes raw pointers plus the current HIP
+stream to the library.  There is no fallback: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+F16, BF16, F32SRC = 0, 1, 2
+EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16 = 0, 1, 2, 3, 4, 5
+
+_DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32SRC}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None, contiguous=True) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise _lib.LlarkHipError(f"{name}: tensor must live on the GPU (there is no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------
+# VQ-VAE encoder
+# ------------------------------------------------------------------------------------------------
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """torch Conv1d.weight [cout][cin][k] -> kernel layout [k][cin][cout]."""
+    cout, cin, k = w.shape
+    wp = torch.empty((k, cin, cout), dtype=torch.float32, device=w.device)
+    check(_lib.lib().llark_pack_conv_weight(_dev(w, "w", torch.float32), _dev(wp, "wp"), cout, cin, k, _stream()),
+          "pack_conv_weight")
+    return wp
+
+
+def conv1d(x: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, stride: int, pad: int, dil: int = 1,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, cin, tin = x.shape
+    k, cin2, cout = wp.shape
+    assert cin == cin2, f"conv1d: channel mismatch {cin} vs {cin2}"
+    tout = (tin + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, tout), dtype=torch.float32, device=x.device)
+    assert out.shape == (n, cout, tout)
+    check(_lib.lib().llark_conv1d_f32(_dev(x, "x", torch.float32), n, cin, tin, _dev(wp, "wp", torch.float32),
+                                      _dev(bias, "bias", torch.float32), cout, k, stride, pad, dil,
+                                      _dev(out, "out", torch.float32), tout, _stream()), "conv1d")
+    return out
+
+
+def resblock(x: torch.Tensor, w1p, b1, w2p, b2, dil: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c, t = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape and out.data_ptr() != x.data_ptr(), "resblock is out-of-place (halo reads)"
+    check(_lib.lib().llark_resblock_f32(_dev(x, "x", torch.float32), n, c, t, _dev(w1p, "w1p", torch.float32),
+                                        _dev(b1, "b1", torch.float32), _dev(w2p, "w2p", torch.float32),
+                                        _dev(b2, "b2", torch.float32), dil, _dev(out, "out", torch.float32), _stream()),
+          "resblock")
+    return out
+
+
+def codebook_norms(k: torch.Tensor) -> torch.Tensor:
+    bins, emb = k.shape
+    kk = torch.empty((bins,), dtype=torch.float32, device=k.device)
+    check(_lib.lib().llark_codebook_norms_f32(_dev(k, "k", torch.float32), bins, emb, _dev(kk, "kk"), _stream()),
+          "codebook_norms")
+    return kk
+
+
+def codebook_argmin(x: torch.Tensor, k: torch.Tensor, kk: torch.Tensor, want_dist: bool = False):
+    n, emb, t = x.shape
+    bins = k.shape[0]
+    codes = torch.empty((n, t), dtype=torch.int64, device=x.device)
+    dist = torch.empty((n, t), dtype=torch.float32, device=x.device) if want_dist else None
+    check(_lib.lib().llark_codebook_argmin(_dev(x, "x", torch.float32), n, emb, t, _dev(k, "k", torch.float32),
+                                           _dev(kk, "kk", torch.float32), bins, _dev(codes, "codes"),
+                                           dist.data_ptr() if dist is not None else None, _stream()), "codebook_argmin")
+    return (codes, dist) if want_dist else codes
+
+
+# ------------------------------------------------------------------------------------------------
+# prior
+# ------------------------------------------------------------------------------------------------
+def prior_embed(z, x_emb, pos_emb, x_cond, y_cond, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, t = z.shape
+    bins, width = x_emb.shape
+    assert pos_emb.shape == (t, width) and x_cond.numel() == t * width and y_cond.numel() == width
+    if out is None:
+        out = torch.empty((n, t, width), dtype=torch.float32, device=z.device)
+    check(_lib.lib().llark_prior_embed(_dev(z, "z", torch.int64), n, t, width, bins, _dev(x_emb, "x_emb", torch.float32),
+                                       _dev(pos_emb, "pos_emb", torch.float32), _dev(x_cond, "x_cond", torch.float32),
+                                       _dev(y_cond, "y_cond", torch.float32), _dev(out, "h", torch.float32), _stream()),
+          "prior_embed")
+    return out
+
+
+def layernorm_split(x: torch.Tensor, gamma, beta, eps: float, out_hi: torch.Tensor, out_lo: torch.Tensor) -> None:
+    """x [rows][width] fp32 -> fp16 hi/lo planes [rows][ldo]."""
+    rows, width = x.shape
+    assert out_hi.shape == out_lo.shape and out_hi.shape[0] == rows and out_hi.shape[1] >= width
+    check(_lib.lib().llark_layernorm_split_f16(_dev(x, "x", torch.float32), x.stride(0), rows, width,
+                                               _dev(gamma, "gamma", torch.float32), _dev(beta, "beta", torch.float32),
+                                               float(eps), _dev(out_hi, "out_hi", torch.float16),
+                                               _dev(out_lo, "out_lo", torch.float16), out_hi.stride(0), _stream()),
+          "layernorm_split")
+
+
+def prior_attn(qkv: torch.Tensor, n: int, t: int, n_state: int, heads: int, blocks: int, pattern: int,
+               out_hi: torch.Tensor, out_lo: torch.Tensor) -> None:
+    assert qkv.shape[0] == n * t and qkv.shape[1] >= 3 * n_state
+    check(_lib.lib().llark_prior_attn(_dev(qkv, "qkv", torch.float32), qkv.stride(0), n, t, n_state, heads, blocks,
+                                      pattern, _dev(out_hi, "out_hi", torch.float16), _dev(out_lo, "out_lo", torch.float16),
+                                      out_hi.stride(0), _stream()), "prior_attn")
+
+
+def pool_window(h: torch.Tensor, frame_len: int, frames: int) -> torch.Tensor:
+    n, t, width = h.shape
+    out = torch.empty((n, frames, width), dtype=torch.float32, device=h.device)
+    check(_lib.lib().llark_pool_window(_dev(h, "h", torch.float32), n, t, width, frame_len, _dev(out, "out"), frames,
+                                       _stream()), "pool_window")
+    return out
+
+
+def pool_mean(h: torch.Tensor, lens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, t, width = h.shape
+    out = torch.empty((n, width), dtype=torch.float32, device=h.device)
+    lp = _dev(lens, "lens", torch.int32) if lens is not None else None
+    check(_lib.lib().llark_pool_mean(_dev(h, "h", torch.float32), n, t, width, lp, _dev(out, "out"), _stream()),
+          "pool_mean")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def pack_weight16(w: torch.Tensor, transpose: bool, dst_dtype: torch.dtype, kmult: int = 32) -> torch.Tensor:
+    """Returns wt [n][kp] (K-contiguous, zero padded to a multiple of ``kmult``).
+
+    transpose=True : w is [k][n] (upstream Conv1D.w);  transpose=False: w is [n][k] (nn.Linear.weight).
+    """
+    if transpose:
+        k, n = w.shape
+    else:
+        n, k = w.shape
+    kp = round_up(k, kmult)
+    wt = torch.empty((n, kp), dtype=dst_dtype, device=w.device)
+    check(_lib.lib().llark_pack_weight16(_dev(w, "w"), _DT[w.dtype], int(transpose), k, n, _dev(wt, "wt"), _DT[dst_dtype],
+                                         kp, _stream()), "pack_weight16")
+    return wt
+
+
+def split16(x: torch.Tensor, dtype: torch.dtype, want_lo: bool = True, kmult: int = 32):
+    rows, width = x.shape
+    ldo = round_up(width, kmult)
+    hi = torch.empty((rows, ldo), dtype=dtype, device=x.device)
+    lo = torch.empty((rows, ldo), dtype=dtype, device=x.device) if want_lo else None
+    check(_lib.lib().llark_split16(_DT[dtype], _dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(hi, "hi"),
+                                   lo.data_ptr() if lo is not None else None, ldo, _stream()), "split16")
+    return hi, lo
+
+
+def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], n: int,
+           epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+           out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
+    """C[m,n] = (a_hi [+ a_lo]) . wt^T (+bias) with a fused epilogue; see include/llark_hip.h."""
+    dtype = a_hi.dtype
+    assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype
+    m = a_hi.shape[0] if m is None else m
+    kp = wt.shape[1]
+    assert a_hi.shape[1] >= kp and wt.shape[0] >= n, f"gemm16: A has {a_hi.shape[1]} cols, wt {tuple(wt.shape)}, n={n}"
+    check(_lib.lib().llark_gemm16(
+        _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
+        a_hi.stride(0), _dev(wt, "wt"), wt.stride(0), _dev(bias, "bias", torch.float32) if bias is not None else None,
+        m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
+        _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+        _dev(out_hi, "out_hi", dtype) if out_hi is not None else None,
+        _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
+        out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16")
+
+
+def device_info(device: int = 0) -> Tuple[int, str]:
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    cus = _lib.lib().llark_device_info(device, buf, 64)
+    if cus < 0:
+        check(cus, "device_info")
+    return cus, buf.value.decode()
