@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: clips/sec of LLark's audio-encoder -> LLM forward on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of B synthetic clips per GPU
+(25 s @ 44.1 kHz audio, truncated to 1 048 576 samples as jukebox/main.py:59 does, + a 128-token
+prompt):  VQ-VAE level-2 encode -> 36-layer Jukebox top prior -> 10 fps mean-pool (240 x 4800)
+-> mm_projector + splice -> Llama-2-7B causal-LM forward over S = 371 positions -> logits.
+Clips are independent units: every rank processes its own B clips (weak scaling, no data-path
+collective); the only collectives are the barrier and the max-over-ranks of the elapsed time.
+Inputs are resident in HBM when the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def _dist_setup(n_gpus: int):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    return rank, world, local
+
+
+def _barrier(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _prior_gemm_flops(hps, rows):
+    W, S, M = hps.prior_width, hps.n_state, hps.mlp_state
+    per_layer = 2.0 * rows * (W * 3 * S + S * W + W * M + M * W)
+    return per_layer * hps.prior_depth
+
+
+def build_workload(args, device):
+    from llark_amd.jukebox import extract as E
+    from llark_amd.jukebox.hparams import hparams_5b, hparams_tiny
+    from llark_amd.jukebox.synthetic import init_codebook_from_encodings, make_jukebox_weights, synthetic_clip
+
+    hps = hparams_tiny() if args.tiny else hparams_5b()
+    if args.depth:
+        hps.prior_depth = args.depth
+    weights = make_jukebox_weights(hps, seed=0, device=device)
+    enc = E.WrappedAudioEncoder(hps=hps, weights=weights, device=device)
+    seconds = 25.0 if not args.tiny else 1.6
+    rank = int(os.environ.get("RANK", "0"))
+
+    def clip(i):
+        a = E._normalize(synthetic_clip(i, seconds=seconds))
+        a = E.maybe_pad_audio_to_max_len(a, hps.sample_length)[: hps.sample_length]
+        return a.astype(np.float32)
+
+    # data-dependent codebook (upstream init_k analogue) from a calibration clip through the HIP encoder
+    cal = torch.from_numpy(clip(100000)).to(device)[None, None, :]
+    xe = enc.vqvae.encoder_forward(cal)[0]
+    enc.vqvae.set_codebook(init_codebook_from_encodings(xe, hps.l_bins))
+    weights["bottleneck.level_blocks.2.k"] = enc.vqvae.k.cpu()
+    audio = torch.from_numpy(np.stack([clip(rank * args.batch + i) for i in range(args.batch)])).to(device)
+    llm = None
+    if args.stages in ("e2e", "llama"):
+        from llark_amd.m2t import bench_support
+
+        llm = bench_support.build(args, device)
+    return hps, weights, enc, audio, llm
+
+
+def cpu_baseline(hps, weights, args):
+    """The CPU oracle on the host cores, bounded sample: 1 clip through the VQ-VAE (bit-exact C
+    restatement, OpenMP) + `cpu_layers` prior layers (torch fp32), extrapolated to 36 layers."""
+    from llark_amd.jukebox.synthetic import synthetic_clip
+    from oracle import jukebox_c as C
+    from oracle import jukebox_ref as R
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    seconds = 25.0 if not args.tiny else 1.6
+    a = R.normalize_audio(synthetic_clip(0, seconds=seconds))
+    a = np.pad(a, (0, max(0, hps.sample_length - len(a))))[: hps.sample_length].astype(np.float32)
+    wc = {k: v.detach().float().cpu() if not k.endswith(".w") else v.detach().cpu() for k, v in weights.items()
+          if not k.startswith("prior.transformer") or int(k.split(".")[3]) < args.cpu_layers}
+    t0 = time.time()
+    z = torch.from_numpy(C.encode_codes(wc, a[None], hps))
+    t_enc = time.time() - t0
+    x_cond, y_cond = R.get_cond(wc, hps)
+    h = R.prior_embed(wc, z, x_cond, y_cond, hps)
+    t0 = time.time()
+    for d in range(args.cpu_layers):
+        h = R.prior_layer(wc, h, d, hps)
+    t_layers = time.time() - t0
+    t_prior = t_layers / args.cpu_layers * hps.prior_depth
+    total = t_enc + t_prior
+    sample = (f"1 clip: VQ-VAE encode (C oracle, {t_enc:.2f}s) + {args.cpu_layers} of {hps.prior_depth} prior layers "
+              f"(torch fp32, {t_layers:.2f}s) extrapolated to {hps.prior_depth}")
+    if args.stages in ("e2e", "llama"):
+        from llark_amd.m2t import bench_support
+
+        t_llm, s_llm = bench_support.cpu_baseline(args)
+        total += t_llm
+        sample += "; " + s_llm
+    return {"value": 1.0 / total, "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step (BASELINE configs[1]: 8)")
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama"])
+    ap.add_argument("--depth", type=int, default=0, help="debug: override prior depth (result is then NOT the headline)")
+    ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-layers", type=int, default=2)
+    args = ap.parse_args()
+
+    rank, world, local = _dist_setup(args.gpus)
+    device = torch.device("cuda", local)
+    from llark_amd import ops
+
+    hps, weights, enc, audio, llm = build_workload(args, device)
+
+    def step():
+        emb = enc(audio) if args.stages != "llama" else None
+        if llm is not None:
+            return llm.forward(emb)
+        return emb
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        _barrier(world)
+        ops.start_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        _barrier(world)
+        elapsed = time.perf_counter() - t0
+        timers = ops.stop_kernel_timing()
+
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        clips = args.batch * world * args.steps
+        value = clips / elapsed
+        # dominant kernel: the split-fp16 MFMA GEMM of the prior.  Algorithmic flops (2*M*N*K of the
+        # fp32-equivalent product; the hi/lo second pass is NOT counted) / HIP-event time of its launches.
+        roof = None
+        if "gemm_split_f16" in timers and args.stages != "llama":
+            launches, ms, _ = timers["gemm_split_f16"]
+            flops = _prior_gemm_flops(hps, args.batch * hps.n_ctx) * args.steps
+            achieved = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,split>", "achieved": round(achieved, 2),
+                    "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
+                    "traffic": None, "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                    "mfma_passes": 2, "frac_of_issued_mfma": round(2 * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+        elif llm is not None:
+            roof = llm.roofline(timers, args)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(hps, weights, args)
+        workload = {"e2e": "configs[1]+llm: 8x25s clips -> Jukebox VQ-VAE+36-layer prior -> 240x4800 -> projector -> Llama-2-7B fwd (S=371) logits",
+                    "jukebox": "configs[1]: Jukebox encoder+prior forward, batch=8x25s clips -> (240,4800) embeddings",
+                    "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings"}[args.stages]
+        line = {
+            "metric": "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd",
+            "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp16x2-split(fp32-class)+bf16" if args.stages == "e2e" else (
+                "fp16x2-split(fp32-class)" if args.stages == "jukebox" else "bf16"),
+            "data": "synthetic",
+            "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": 371,
+                       "prior_depth": hps.prior_depth, "parallelism": f"dp{world} (clip-sharded, no collective)",
+                       "debug_overrides": bool(args.depth or args.tiny)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,7 +152,7 @@ def _postprocess(acts: torch.Tensor, latent_audio_len: int, meanpool: bool, pool
             frame_len = floor(acts_sample_rate / pool_frames_per_second)
             acts = windowed_average(acts, frame_len)
             acts = torch.squeeze(acts, 0)
-    acts = np.array(acts.cpu())
+    acts = acts.cpu().numpy().copy()
     logging.info(f"acts after pooling has shape {acts.shape}")
     return acts
 

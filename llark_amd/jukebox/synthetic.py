@@ -50,26 +50,33 @@ def make_vqvae_weights(hps: JukeboxHParams, seed: int = 0, codebook_std: float =
 
 
 def make_prior_weights(hps: JukeboxHParams, seed: int = 1, depth: int = None,
-                       w_std: float = None) -> Dict[str, torch.Tensor]:
+                       w_std: float = None, device="cpu") -> Dict[str, torch.Tensor]:
     """Prior weights.  ``w_std`` defaults to 1/sqrt(fan_in)-like scales instead of upstream's
     0.02*init_scale=0.002 so that attention logits / GELU inputs are O(1) with random weights."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    _randn = torch.randn
+
+    class _T:      # _T.randn(..., device=device) with the seeded generator of that device
+        @staticmethod
+        def randn(*shape, generator=None):
+            return _randn(*shape, generator=generator, device=device)
+
     W, S, M = hps.prior_width, hps.n_state, hps.mlp_state
     depth = hps.prior_depth if depth is None else depth
     w: Dict[str, torch.Tensor] = {}
     emb_std = 0.5
-    w["prior.x_emb.weight"] = (torch.randn(hps.l_bins, W, generator=g) * emb_std).float()
-    w["prior.pos_emb.pos_emb"] = (torch.randn(hps.n_ctx, W, generator=g) * 0.1).float()
+    w["prior.x_emb.weight"] = (_T.randn(hps.l_bins, W, generator=g) * emb_std).float()
+    w["prior.pos_emb.pos_emb"] = (_T.randn(hps.n_ctx, W, generator=g) * 0.1).float()
 
     def lin(n_in, n_out, std):
-        return (torch.randn(n_in, n_out, generator=g) * std).half(), (torch.randn(n_out, generator=g) * 0.02).float()
+        return (_T.randn(n_in, n_out, generator=g) * std).half(), (_T.randn(n_out, generator=g) * 0.02).float()
 
     for d in range(depth):
         p = f"prior.transformer._attn_mods.{d}"
-        w[f"{p}.ln_0.weight"] = (1.0 + 0.1 * torch.randn(W, generator=g)).float()
-        w[f"{p}.ln_0.bias"] = (0.05 * torch.randn(W, generator=g)).float()
-        w[f"{p}.ln_1.weight"] = (1.0 + 0.1 * torch.randn(W, generator=g)).float()
-        w[f"{p}.ln_1.bias"] = (0.05 * torch.randn(W, generator=g)).float()
+        w[f"{p}.ln_0.weight"] = (1.0 + 0.1 * _T.randn(W, generator=g)).float()
+        w[f"{p}.ln_0.bias"] = (0.05 * _T.randn(W, generator=g)).float()
+        w[f"{p}.ln_1.weight"] = (1.0 + 0.1 * _T.randn(W, generator=g)).float()
+        w[f"{p}.ln_1.bias"] = (0.05 * _T.randn(W, generator=g)).float()
         s_in = (1.0 / math.sqrt(W)) if w_std is None else w_std
         # q/k columns get a larger scale so that softmax is not uniform
         cw, cb = lin(W, 3 * S, s_in)
@@ -82,13 +89,14 @@ def make_prior_weights(hps: JukeboxHParams, seed: int = 1, depth: int = None,
     bow_bins, artist_bins = hps.y_bins
     for name, n in (("bow_genre_emb", bow_bins), ("artist_emb", artist_bins), ("total_length_emb", hps.t_bins),
                     ("absolute_pos_emb", hps.t_bins), ("relative_pos_emb", hps.t_bins)):
-        w[f"y_emb.{name}.emb.weight"] = (torch.randn(n, W, generator=g) * 0.1).float()
+        w[f"y_emb.{name}.emb.weight"] = (_T.randn(n, W, generator=g) * 0.1).float()
     return w
 
 
-def make_jukebox_weights(hps: JukeboxHParams, seed: int = 0, depth: int = None) -> Dict[str, torch.Tensor]:
+def make_jukebox_weights(hps: JukeboxHParams, seed: int = 0, depth: int = None, device="cpu") -> Dict[str, torch.Tensor]:
+    """``device`` places the (large) prior tensors; values depend on the device's RNG stream."""
     w = make_vqvae_weights(hps, seed)
-    w.update(make_prior_weights(hps, seed + 1, depth))
+    w.update(make_prior_weights(hps, seed + 1, depth, device=device))
     return w
 
 

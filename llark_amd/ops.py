@@ -20,6 +20,43 @@ EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16 = 0, 1
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32SRC}
 
 
+# optional per-kernel HIP-event timing (used by bench.py for the roofline line): a dict
+# name -> list[(start_event, end_event, work)] ; events are recorded on the launch stream.
+_TIMERS = None
+
+
+def start_kernel_timing() -> None:
+    global _TIMERS
+    _TIMERS = {}
+
+
+def stop_kernel_timing():
+    """Returns {name: (launches, total_ms, total_work)} and disables timing."""
+    global _TIMERS
+    torch.cuda.synchronize()
+    out = {}
+    for name, evs in (_TIMERS or {}).items():
+        out[name] = (len(evs), sum(a.elapsed_time(b) for a, b, _ in evs), sum(w for _, _, w in evs))
+    _TIMERS = None
+    return out
+
+
+class _timed:
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _TIMERS is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _TIMERS is not None:
+            self.b.record(torch.cuda.current_stream())
+            _TIMERS.setdefault(self.name, []).append((self.a, self.b, self.work))
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -188,7 +225,9 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     m = a_hi.shape[0] if m is None else m
     kp = wt.shape[1]
     assert a_hi.shape[1] >= kp and wt.shape[0] >= n, f"gemm16: A has {a_hi.shape[1]} cols, wt {tuple(wt.shape)}, n={n}"
-    check(_lib.lib().llark_gemm16(
+    name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
+    with _timed(name, 2.0 * m * n * kp):
+      check(_lib.lib().llark_gemm16(
         _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
         a_hi.stride(0), _dev(wt, "wt"), wt.stride(0), _dev(bias, "bias", torch.float32) if bias is not None else None,
         m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,

@@ -346,4 +346,4 @@ def get_acts_from_audio(audio: np.ndarray, w, spec: Spec, meanpool=True, pool_fr
             frame_len = math.floor(acts_rate / pool_frames_per_second)
             acts = windowed_average(acts, frame_len)
             acts = torch.squeeze(acts, 0)
-    return np.array(acts.cpu())
+    return acts.cpu().numpy().copy()

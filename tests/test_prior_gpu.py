@@ -1,0 +1,220 @@
+"""GPU parity: prior kernels (embed, LayerNorm-split, split-fp16 GEMM, factored attention, pooling)
+and the whole prior forward vs the fp32 CPU oracle.
+
+Tolerances (floating point): the reference runs the prior in fp32 with fp16-valued weights
+(fp16=False); the HIP path carries activations as hi+lo fp16 (22 bits) into fp32-accumulating MFMA.
+Bound used for end-to-end activations / embeddings: max|err| <= 1e-4 * max|ref| (BASELINE.json's
+1e-4), individual kernels much tighter (stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import report_close
+from llark_amd.jukebox.hparams import hparams_5b_depth, hparams_tiny
+from llark_amd.jukebox.synthetic import make_prior_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_split16_and_pack():
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 70, generator=g) * 3
+    hi, lo = ops.split16(x.cuda(), torch.float16)
+    assert hi.shape == (37, 96)
+    rh = x.half()
+    rl = (x - rh.float()).half()
+    assert torch.equal(hi[:, :70].cpu(), rh) and torch.equal(lo[:, :70].cpu(), rl)
+    assert (hi[:, 70:] == 0).all() and (lo[:, 70:] == 0).all()
+    w = (torch.randn(70, 50, generator=g)).half()
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16)
+    assert wt.shape == (50, 96) and torch.equal(wt[:, :70].cpu(), w.t()) and (wt[:, 70:] == 0).all()
+    wl = torch.randn(50, 70, generator=g)
+    wt2 = ops.pack_weight16(wl.cuda(), False, torch.bfloat16)
+    assert torch.equal(wt2[:, :70].cpu(), wl.bfloat16())
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (64, 96, 64), (200, 150, 70), (1024, 3600, 1200), (515, 4800, 4800)])
+def test_gemm_split_f16(m, n, k):
+    """C = A.W + b in split mode: fp32-class accuracy. Bound: 4e-7*(|A|.|W|) (K-ordered fp32 accumulate)."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.05).half()
+    b = torch.randn(n, generator=g)
+    hi, lo = ops.split16(a.cuda(), torch.float16)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16)
+    c = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, lo, wt, b.cuda(), n, ops.EPI_F32, c=c)
+    ref = a.double() @ w.double() + b.double()
+    bound = (a.abs().double() @ w.abs().double())
+    err = (c.cpu().double() - ref).abs()
+    assert torch.isfinite(c).all(), "non-finite or unwritten outputs"
+    worst = (err / (bound + 1e-30)).max().item()
+    assert worst < 6e-7, f"split gemm {m}x{n}x{k}: err/(|A||W|) = {worst:.3e}; max err {err.max():.3e}"
+    # single pass (hi only) must be fp16-class, and clearly worse than split (proves lo is used)
+    c1 = torch.empty((m, n), device="cuda")
+    ops.gemm16(hi, None, wt, b.cuda(), n, ops.EPI_F32, c=c1)
+    err1 = (c1.cpu().double() - ref).abs()
+    assert (err1 / (bound + 1e-30)).max().item() < 1e-3
+    if k >= 64:
+        assert err1.max() > 8 * err.max()
+
+
+def test_gemm_epilogues():
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(9)
+    m, n, k = 300, 192, 160
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    hi, lo = ops.split16(a.cuda(), torch.float16)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16)
+    ref = (a.double() @ w.double() + b.double())
+    # residual, in place
+    c = r.clone().cuda()
+    ops.gemm16(hi, lo, wt, b.cuda(), n, ops.EPI_RESID, c=c, resid=c)
+    report_close("resid", c.cpu(), (r.double() + ref), 2e-5)
+    # quick-gelu split output
+    ohi = torch.zeros((m, n), dtype=torch.float16, device="cuda")
+    olo = torch.zeros_like(ohi)
+    ops.gemm16(hi, lo, wt, b.cuda(), n, ops.EPI_QGELU_SPLIT, out_hi=ohi, out_lo=olo)
+    gref = ref * torch.sigmoid(1.702 * ref)
+    report_close("qgelu", (ohi.float() + olo.float()).cpu(), gref, 3e-6, 3e-6)
+    # plain split output
+    ops.gemm16(hi, lo, wt, b.cuda(), n, ops.EPI_SPLIT16, out_hi=ohi, out_lo=olo)
+    report_close("split16", (ohi.float() + olo.float()).cpu(), ref, 3e-6, 3e-6)
+    # bf16 single pass + OUT16 and SwiGLU (Llama shapes)
+    ab = a.bfloat16()
+    wb = (torch.randn(n, k, generator=g) * 0.1).bfloat16()         # nn.Linear layout [n][k]
+    wtb = ops.pack_weight16(wb.cuda(), False, torch.bfloat16)
+    ahi, _ = ops.split16(ab.float().cuda(), torch.bfloat16, want_lo=False)
+    o16 = torch.zeros((m, n), dtype=torch.bfloat16, device="cuda")
+    ops.gemm16(ahi, None, wtb, None, n, ops.EPI_OUT16, out_hi=o16)
+    refb = ab.double() @ wb.double().t()
+    report_close("bf16 out16", o16.float().cpu(), refb, 1e-2, 8e-3)
+    # swiglu: rows interleaved [32 gate | 32 up]
+    inter = n // 2
+    gate, up = wb[:inter], wb[inter:]
+    packed = torch.stack([gate.view(-1, 32, k), up.view(-1, 32, k)], dim=1).reshape(n, k).contiguous()
+    wts = ops.pack_weight16(packed.cuda(), False, torch.bfloat16)
+    osw = torch.zeros((m, inter), dtype=torch.bfloat16, device="cuda")
+    ops.gemm16(ahi, None, wts, None, n, ops.EPI_SWIGLU16, out_hi=osw)
+    gg, uu = ab.double() @ gate.double().t(), ab.double() @ up.double().t()
+    report_close("swiglu", osw.float().cpu(), torch.nn.functional.silu(gg) * uu, 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize("rows,width", [(5, 192), (64, 4800), (3, 1024), (9, 64)])
+def test_layernorm_split(rows, width):
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(width)
+    x = torch.randn(rows, width, generator=g) * 2 + 0.5
+    gam = 1 + 0.1 * torch.randn(width, generator=g)
+    bet = 0.1 * torch.randn(width, generator=g)
+    ld = ops.round_up(width, 32)
+    hi = torch.zeros((rows, ld), dtype=torch.float16, device="cuda")
+    lo = torch.zeros_like(hi)
+    ops.layernorm_split(x.cuda(), gam.cuda(), bet.cuda(), 1e-5, hi, lo)
+    ref = torch.nn.functional.layer_norm(x.double(), (width,), gam.double(), bet.double(), 1e-5)
+    report_close("layernorm", (hi.float() + lo.float())[:, :width].cpu(), ref, 2e-6, 2e-6)
+
+
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("cfg", ["tiny", "full"])
+def test_factored_attention(pattern, cfg):
+    """vs oracle factored_attention (fp32). Bound 2e-6 abs+rel on O(1) values (+ hi/lo output rounding)."""
+    from llark_amd import ops
+    from oracle import jukebox_ref as R
+    if cfg == "tiny":
+        n, t, heads, S, blocks = 2, 512, 2, 48, 8
+    else:
+        n, t, heads, S, blocks = 1, 8192, 8, 1200, 128
+    g = torch.Generator().manual_seed(pattern)
+    qkv = torch.randn(n, t, 3 * S, generator=g)
+    qkv[..., : 2 * S] *= 1.5
+    q, k, v = qkv.chunk(3, dim=2)
+    ref = R.factored_attention(q.contiguous(), k.contiguous(), v.contiguous(), pattern, heads, t // blocks)
+    Sp = ops.round_up(S, 32)
+    hi = torch.zeros((n * t, Sp), dtype=torch.float16, device="cuda")
+    lo = torch.zeros_like(hi)
+    ops.prior_attn(qkv.view(n * t, 3 * S).cuda(), n, t, S, heads, blocks, pattern, hi, lo)
+    got = (hi.float() + lo.float())[:, :S].cpu().view(n, t, S)
+    report_close(f"attn pattern {pattern} {cfg}", got, ref, 3e-6, 3e-6)
+    assert (hi[:, S:] == 0).all()
+    if pattern == 3:
+        assert (got[:, : t // blocks] == 0).all()
+
+
+def test_embed_and_pool():
+    from llark_amd import ops
+    from oracle import jukebox_ref as R
+    hps = hparams_tiny()
+    w = make_prior_weights(hps, 1)
+    x_cond, y_cond = R.get_cond(w, hps)
+    z = torch.randint(0, hps.l_bins, (3, hps.n_ctx), generator=torch.Generator().manual_seed(2))
+    ref = R.prior_embed(w, z, x_cond, y_cond, hps)
+    got = ops.prior_embed(z.cuda(), w["prior.x_emb.weight"].cuda(), w["prior.pos_emb.pos_emb"].cuda(),
+                          x_cond[0].contiguous().cuda(), y_cond.reshape(-1).cuda())
+    assert torch.equal(got.cpu(), ref), "embedding head must be bit-exact (same association)"
+    acts = torch.randn(2, 512, 192, generator=torch.Generator().manual_seed(3))
+    pw = ops.pool_window(acts.cuda(), 34, 512 // 34).cpu()
+    report_close("pool_window", pw[0], R.windowed_average(acts[0], 34)[0], 1e-6)
+    pm = ops.pool_mean(acts.cuda(), torch.tensor([512, 100], dtype=torch.int32).cuda()).cpu()
+    report_close("pool_mean", pm[1], acts[1, :100].mean(0), 1e-6)
+
+
+def _run_prior(hps, depth, n, seed=0):
+    from llark_amd.jukebox.prior import TopPrior
+    from llark_amd.jukebox import extract as E
+    from oracle import jukebox_ref as R
+    w = make_prior_weights(hps, seed + 1, depth=depth)
+    z = torch.randint(0, hps.l_bins, (n, hps.n_ctx), generator=torch.Generator().manual_seed(seed))
+    x_cond_r, y_cond_r = R.get_cond(w, hps)
+    tp = TopPrior(hps, w, "cuda", depth=depth)
+    x_cond, y_cond = E.get_cond(hps, tp)
+    assert torch.equal(x_cond.cpu(), x_cond_r) and torch.equal(y_cond.cpu(), y_cond_r), "conditioning tables differ"
+    # layer-by-layer taps (each HIP layer is fed the ORACLE's input so errors do not compound)
+    h_ref = R.prior_embed(w, z, x_cond_r, y_cond_r, hps)
+    tp.prior.only_encode = True
+    for d in range(depth):
+        taps_ref, taps = {}, {}
+        h_in = h_ref.clone()
+        h_ref = R.prior_layer(w, h_ref, d, hps, taps_ref)
+        h_dev = h_in.cuda().view(n * hps.n_ctx, hps.prior_width).contiguous()
+        tp.prior.layer_forward(h_dev, d, n, taps)
+        for name in ("ln0", "qkv", "att", "xa", "ln1", "g"):
+            refv = taps_ref[name].reshape(n * hps.n_ctx, -1)
+            scale = refv.abs().max().item()
+            report_close(f"layer {d} tap {name}", taps[name][:, : refv.shape[1]].cpu(), refv, 2e-5 * scale)
+        report_close(f"layer {d} out", h_dev.cpu(), h_ref.view(n * hps.n_ctx, -1), 2e-5 * h_ref.abs().max().item())
+    # end to end through the public entry point
+    acts = E.get_final_activations(z.cuda(), x_cond, y_cond, tp)
+    scale = h_ref.abs().max().item()
+    worst = report_close("prior end-to-end", acts.cpu(), h_ref, 1e-4 * scale)
+    return worst / scale
+
+
+def test_prior_tiny_layers_and_e2e():
+    rel = _run_prior(hparams_tiny(), 3, 2)
+    print(f"tiny prior rel err {rel:.3e}")
+
+
+def test_prior_full_width_depth3():
+    """5b widths (4800 / 8 heads x 150 / 8192 tokens), 3 layers = all three attention patterns."""
+    rel = _run_prior(hparams_5b_depth(3), 3, 1)
+    print(f"full-width prior (3 layers) rel err {rel:.3e}")
+
+
+def test_prior_rejects_unsupported():
+    from llark_amd.jukebox.prior import TopPrior
+    hps = hparams_tiny()
+    tp = TopPrior(hps, make_prior_weights(hps, 1, depth=1), "cuda", depth=1)
+    z = torch.zeros((1, hps.n_ctx), dtype=torch.int64, device="cuda")
+    with pytest.raises(NotImplementedError):
+        tp.prior.forward(z, x_cond=None, y_cond=None)          # only_encode not set
+    tp.prior.only_encode = True
+    with pytest.raises(NotImplementedError):
+        tp.prior.forward(z, x_cond=torch.zeros(1), y_cond=torch.zeros(1), fp16=True)
