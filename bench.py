@@ -206,7 +206,8 @@ def main():
                        "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": 371,
                        "prior_depth": hps.prior_depth, "parallelism": f"dp{world} (clip-sharded, no collective)",
                        "debug_overrides": bool(args.depth or args.tiny)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None else None),
+            "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
         print(json.dumps(line), flush=True)

@@ -102,6 +102,35 @@ int llark_pack_weight16(const void* w, int src_dtype, int transpose, int k, int 
 int llark_split16(int dtype, const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
                   llark_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Llama-2 decoder: what WrappedLlamav2Model.forward delegates to HF LlamaModel.forward
+ * (m2t/models/llamav2.py:224-234) plus the embed_tokens gather (m2t/models/llamav2.py:124).
+ * Residual stream fp32 [rows][hidden]; Linear inputs / q / k / v / probabilities bf16.
+ * ------------------------------------------------------------------------------------------- */
+/* nn.Embedding gather: out[row] = table[ids[row]] (table_dtype LLARK_F16 / LLARK_BF16 / 2 = fp32). */
+int llark_embed_gather(const int64_t* ids, int rows, const void* table, int table_dtype, int vocab, int width,
+                       float* out, int ldo, llark_stream_t stream);
+/* LlamaRMSNorm -> bf16 (out_lo optional second plane with the rounding residual). */
+int llark_rmsnorm_bf16(const float* x, int ldx, int rows, int width, const float* w, float eps, void* out_hi,
+                       void* out_lo, int ldo, llark_stream_t stream);
+/* apply_rotary_pos_emb (half-split) + split heads + KV-cache write.  qkv fp32 [batch*s][3*nh*hd];
+ * q bf16 [batch][nh][s][hd]; k_cache bf16 [batch][nh][smax][hd]; vt_cache bf16 [batch][nh][hd][smax]
+ * (V transposed); rows/columns pos0..pos0+s-1 are written; cos/sin fp32 [max_pos][hd/2]. */
+int llark_rope_split_heads(const float* qkv, int batch, int s, int nh, int hd, int pos0, const float* cos_t,
+                           const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, int smax,
+                           llark_stream_t stream);
+/* causal attention over the cache: query i sees keys j <= past + i. out bf16 [batch*s][nh*hd]. */
+int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh, int hd,
+                            int past, int smax, void* out, llark_stream_t stream);
+/* single-token attention over `total` cached keys. q bf16 [batch][nh][hd]; out bf16 [batch][nh*hd]. */
+int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int nh, int hd,
+                           int total, int smax, void* out, llark_stream_t stream);
+/* CrossEntropyLoss on shifted logits (m2t/models/llamav2.py:316-325). logits fp32 [batch*s][ldl]; labels
+ * int64 [batch][s]; row_loss scratch float[batch*s]; loss_out float[2] = {mean loss, counted rows}. */
+int llark_cross_entropy_shifted(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
+                                int64_t ignore_index, float* row_loss, float* loss_out, llark_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_char_p, c_float, c_int, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libllark_hip.so")
@@ -57,6 +57,12 @@ _SIGS = {
                      _P, _P, c_int, _P],
     "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],
     "llark_split16": [c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P],
+    "llark_embed_gather": [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P],
+    "llark_rmsnorm_bf16": [_P, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, _P],
+    "llark_rope_split_heads": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P],
+    "llark_attn_prefill_bf16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "llark_attn_decode_bf16": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "llark_cross_entropy_shifted": [_P, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P, _P],
 }
 
 

@@ -1,0 +1,488 @@
+// Llama-2 decoder support kernels for gfx950: embedding gather, RMSNorm -> bf16, RoPE + head split
+// + KV-cache write, causal flash attention (bf16 MFMA, fp32 softmax), decode attention.
+// The Linear layers (q/k/v/o, gate/up/down, lm_head, mm_projector) are gemm.hip.
+//
+// Replaces what `WrappedLlamav2Model.forward` delegates to HF `LlamaModel.forward`
+// (m2t/models/llamav2.py:224-234; transformers==4.29.2 modeling_llama.py: LlamaRMSNorm,
+// apply_rotary_pos_emb (half-split), LlamaAttention eager path with fp32 softmax, LlamaMLP) and the
+// `embed_tokens` gather at m2t/models/llamav2.py:124.
+//
+// dtype flow: residual stream fp32; every Linear input and q/k/v are bf16 (rounding points of the
+// reference's bf16 run); softmax probabilities are kept at >= 16 bits (bf16 hi+lo planes in the MFMA
+// path, fp32 in the decode path) -- finer than the reference's bf16 probabilities; accumulation fp32.
+#include "common.h"
+
+namespace llark {
+
+// ------------------------------------------------------------------------------------------
+// out[row][:] = float(table[ids[row]][:])          (nn.Embedding; table bf16 or fp32)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_gather_kernel(const long long* __restrict__ ids, const T* __restrict__ table,
+                                    float* __restrict__ out, int rows, int width, int vocab, int ldo) {
+    const int row = blockIdx.x;
+    long long id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const T* src = table + (size_t)id * width;
+    float* dst = out + (size_t)row * ldo;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) dst[c] = (float)src[c];
+}
+
+// ------------------------------------------------------------------------------------------
+// LlamaRMSNorm: y = w * (x * rsqrt(mean(x^2) + eps)) in fp32, stored as bf16 (hi) [+ lo plane].
+// One wave per row, row kept in registers.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, int ldx, int rows, int width,
+                                                      const float* __restrict__ w, float eps,
+                                                      bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int w4 = width >> 2;
+    const float4* xr = (const float4*)(x + (size_t)row * ldx);
+    float4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w4) {
+            v[k] = xr[c];
+            s += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        } else {
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float var = wave_sum(s) / (float)width;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4* w4p = (const float4*)w;
+    bf16x4_t* hr = (bf16x4_t*)(hi + (size_t)row * ldo);
+    bf16x4_t* lr = lo ? (bf16x4_t*)(lo + (size_t)row * ldo) : nullptr;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w4) {
+            const float4 g = w4p[c];
+            float y[4] = {g.x * (v[k].x * rstd), g.y * (v[k].y * rstd), g.z * (v[k].z * rstd), g.w * (v[k].w * rstd)};
+            bf16x4_t h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = (bf16_t)y[e];
+                l[e] = (bf16_t)(y[e] - (float)h[e]);
+            }
+            hr[c] = h;
+            if (lr) lr[c] = l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE (half-split convention) + head split + KV-cache write.
+//   qkv : fp32 [B*S][3*H]  (q | k | v column blocks)
+//   q   : bf16 [B][nh][S][128]
+//   kc  : bf16 [B][nh][smax][128]      rows pos0 .. pos0+S-1 are written
+//   vtc : bf16 [B][nh][128][smax]      (V transposed: keys contiguous) columns pos0 .. pos0+S-1
+//   cos/sin tables: fp32 [max_pos][64]
+// grid (ceil(S/64), nh, B), block 256.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, int S, int nh, int pos0,
+                                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                         bf16_t* __restrict__ q, bf16_t* __restrict__ kc,
+                                                         bf16_t* __restrict__ vtc, int smax) {
+    __shared__ float sv[64][129];
+    const int hd = 128, H = nh * hd;
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int ns = (S - s0) < 64 ? (S - s0) : 64;
+    // q/k: 64 tokens x 64 rotation pairs
+    for (int i = threadIdx.x; i < ns * 64; i += 256) {
+        const int t = i >> 6, d = i & 63;
+        const int s = s0 + t, pos = pos0 + s;
+        const float* row = qkv + ((size_t)b * S + s) * 3 * H + h * hd;
+        const float c = cos_t[(size_t)pos * 64 + d], sn = sin_t[(size_t)pos * 64 + d];
+        const float q1 = row[d], q2 = row[d + 64], k1 = row[H + d], k2 = row[H + d + 64];
+        // x*cos + rotate_half(x)*sin ; rotate_half = cat(-x2, x1)
+        const float qa = __fadd_rn(__fmul_rn(q1, c), __fmul_rn(-q2, sn));
+        const float qb = __fadd_rn(__fmul_rn(q2, c), __fmul_rn(q1, sn));
+        const float ka = __fadd_rn(__fmul_rn(k1, c), __fmul_rn(-k2, sn));
+        const float kb = __fadd_rn(__fmul_rn(k2, c), __fmul_rn(k1, sn));
+        bf16_t* qo = q + (((size_t)b * nh + h) * S + s) * hd;
+        bf16_t* ko = kc + (((size_t)b * nh + h) * smax + pos) * hd;
+        qo[d] = (bf16_t)qa;
+        qo[d + 64] = (bf16_t)qb;
+        ko[d] = (bf16_t)ka;
+        ko[d + 64] = (bf16_t)kb;
+    }
+    // v: transpose the [ns tokens][128] tile through LDS -> [128][ns] runs along the key axis
+    for (int i = threadIdx.x; i < ns * hd; i += 256) {
+        const int t = i >> 7, d = i & 127;
+        sv[t][d] = qkv[((size_t)b * S + s0 + t) * 3 * H + 2 * H + h * hd + d];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hd * 64; i += 256) {
+        const int d = i >> 6, t = i & 63;
+        if (t < ns) vtc[(((size_t)b * nh + h) * hd + d) * smax + pos0 + s0 + t] = (bf16_t)sv[t][d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Causal flash attention, bf16 MFMA 16x16x32, fp32 online softmax, head_dim 128.
+// Block = 4 waves x 16 query rows = 64 queries of one (batch, head); KV tiles of 64 keys staged in
+// LDS (K row-major, V already transposed in HBM), both XOR-swizzled for conflict-free b128 reads.
+// key j is visible to query i  iff  j <= past + i.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }        // [64][128] bf16
+__device__ __forceinline__ int v_off(int d, int chunk) { return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4); }       // [128][64] bf16
+__device__ __forceinline__ int p_off(int q, int key) {                                                              // [16][64] bf16
+    return q * 128 + ((((key >> 3) ^ ((q >> 1) & 7))) << 4) + ((key & 7) << 1);
+}
+
+__global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                           const bf16_t* __restrict__ vtc, bf16_t* __restrict__ out,
+                                                           int S, int nh, int past, int smax, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;                 // 16 KiB
+    char* sV = smem + 16384;         // 16 KiB
+    char* sP = smem + 32768;         // 4 waves x (2 KiB hi + 2 KiB lo): probabilities as bf16 hi+lo planes
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 64;
+    const int total = past + S;                                     // keys available
+    const size_t bh = (size_t)b * nh + h;
+    const bf16_t* qb = q + bh * S * 128;
+    const bf16_t* kb = kc + bh * (size_t)smax * 128;
+    const bf16_t* vb = vtc + bh * (size_t)128 * smax;
+
+    // Q fragments (A operand): row = wave's 16 rows, lane (g,c): row c, d = ks*32 + g*8 .. +8
+    bf16x8_t qf[4];
+    {
+        int qr = q0 + wv * 16 + c;
+        qr = qr < S ? qr : S - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+    }
+    f32x4_t o[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.0f; }
+
+    int last_key = past + q0 + 63;                                  // last key any query of this block may see
+    if (last_key > total - 1) last_key = total - 1;
+    const int ntiles = last_key / 64 + 1;
+    char* myP = sP + wv * 4096;      // hi plane; lo plane at +2048
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 64;
+        __syncthreads();                                            // previous tile fully consumed
+        // ---- stage K [64][128] and V^T [128][64] (zero beyond `total`) ----
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
+            {
+                const int key = idx >> 4, ch = idx & 15;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (key0 + key < total) val = *(const uint4*)(kb + (size_t)(key0 + key) * 128 + ch * 8);
+                *(uint4*)(sK + k_off(key, ch)) = val;
+            }
+            {
+                const int d = idx >> 3, ch = idx & 7;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                const int kk = key0 + ch * 8;
+                if (kk + 7 < total) {
+                    val = *(const uint4*)(vb + (size_t)d * smax + kk);
+                } else if (kk < total) {
+                    const bf16_t* src = vb + (size_t)d * smax + kk;
+                    unsigned short tmp[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tmp[e] = (kk + e < total) ? ((const unsigned short*)src)[e] : (unsigned short)0;
+                    val = *(uint4*)tmp;
+                }
+                *(uint4*)(sV + v_off(d, ch)) = val;
+            }
+        }
+        __syncthreads();
+        // ---- S = Q K^T : 4 key sub-tiles x 4 k-steps ----
+        f32x4_t sacc[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            sacc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub * 16 + c, ks * 4 + g));
+                sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sacc[sub], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (rows 4g+r, cols sub*16+c) ----
+        float mx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + wv * 16 + g * 4 + r;
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int key = key0 + sub * 16 + c;
+                float sv = sacc[sub][r] * scale;
+                if (key > past + qi || key >= total) sv = -INFINITY;
+                sacc[sub][r] = sv;
+                mloc = fmaxf(mloc, sv);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
+            mx[r] = mloc;
+        }
+        float alpha[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mn = fmaxf(m_run[r], mx[r]);
+            alpha[r] = (mn == -INFINITY) ? 1.0f : expf(m_run[r] - mn);
+            float rs = 0.0f;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const float pv = (mn == -INFINITY) ? 0.0f : expf(sacc[sub][r] - mn);
+                const bf16_t pb = (bf16_t)pv;                         // p = hi + lo: 16 significant bits enter PV
+                rs += pv;
+                *(bf16_t*)(myP + p_off(g * 4 + r, sub * 16 + c)) = pb;
+                *(bf16_t*)(myP + 2048 + p_off(g * 4 + r, sub * 16 + c)) = (bf16_t)(pv - (float)pb);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off, 64);
+            l_run[r] = l_run[r] * alpha[r] + rs;
+            m_run[r] = mn;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
+        __syncthreads();                                            // P visible to the whole wave (and block)
+        // ---- O += P V : 2 k-steps (32 keys) x 8 d-tiles ----
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int poff = c * 128 + (((ks * 4 + g) ^ ((c >> 1) & 7)) << 4);
+            const bf16x8_t pf = *(const bf16x8_t*)(myP + poff);
+            const bf16x8_t pl = *(const bf16x8_t*)(myP + 2048 + poff);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const bf16x8_t vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, ks * 4 + g));
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store: out[(b*S + q)][h*128 + d] ----
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = q0 + wv * 16 + g * 4 + r;
+        if (qi >= S) continue;
+        const float inv = l_run[r] > 0.0f ? 1.0f / l_run[r] : 0.0f;
+        bf16_t* dst = out + ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) dst[dt * 16 + c] = (bf16_t)(o[dt][r] * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Decode attention (one new token per sequence): one block per (batch, head).
+//   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ vtc, bf16_t* __restrict__ out,
+                                                          int nh, int total, int smax, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sp = (float*)smem;                    // [total] scores / probabilities
+    __shared__ float sq[128];
+    __shared__ float red[8];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const size_t bh = (size_t)b * nh + h;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 128) sq[tid] = (float)q[bh * 128 + tid];
+    __syncthreads();
+    const bf16_t* kb = kc + bh * (size_t)smax * 128;
+    float lmax = -INFINITY;
+    for (int j = tid; j < total; j += 256) {
+        const bf16x8_t* kr = (const bf16x8_t*)(kb + (size_t)j * 128);
+        float s = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) {
+            const bf16x8_t kv = kr[ch];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e], s);
+        }
+        s *= scale;
+        sp[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wv] = lmax;
+    __syncthreads();
+    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.0f;
+    for (int j = tid; j < total; j += 256) {
+        const float p = expf(sp[j] - mx);                     // fp32 probabilities (PV below is an fp32 fma chain)
+        sp[j] = p;
+        lsum += p;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if (lane == 0) red[4 + wv] = lsum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    // O[d] = sum_j p_j V[j][d]; V^T rows are contiguous in j. 2 threads per d.
+    const int d = tid >> 1, half = tid & 1;
+    const bf16_t* vr = vtc + (bh * 128 + d) * (size_t)smax;
+    float acc = 0.0f;
+    for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j], acc);
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) out[(size_t)b * (nh * 128) + h * 128 + d] = (bf16_t)(acc * inv);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Shifted cross-entropy (m2t/models/llamav2.py:316-325): row (b,s), s < S-1, predicts labels[b][s+1];
+// ignore_index rows are skipped; loss = mean over the counted rows.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, int ldl, int S, int vocab,
+                                                      const long long* __restrict__ labels, long long ignore_index,
+                                                      float* __restrict__ row_loss) {
+    __shared__ float red[8];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int row = b * S + s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long tgt = (s + 1 < S) ? labels[(size_t)b * S + s + 1] : ignore_index;
+    if (tgt == ignore_index || tgt < 0 || tgt >= vocab) {
+        if (threadIdx.x == 0) row_loss[row] = -1.0f;             // marker: not counted
+        return;
+    }
+    const float* lr = logits + (size_t)row * ldl;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < vocab; c += 256) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int c = threadIdx.x; c < vocab; c += 256) sum += expf(lr[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (red[4] + red[5]) + (red[6] + red[7]);
+        row_loss[row] = (logf(tot) + mx) - lr[tgt];
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ row_loss, int rows, float* __restrict__ out) {
+    __shared__ float ssum[256];
+    __shared__ int scnt[256];
+    float s = 0.0f;
+    int n = 0;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        const float v = row_loss[i];
+        if (v >= 0.0f) { s += v; ++n; }
+    }
+    ssum[threadIdx.x] = s;
+    scnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = scnt[0] > 0 ? ssum[0] / (float)scnt[0] : NAN; out[1] = (float)scnt[0]; }
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+extern "C" int llark_cross_entropy_shifted(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
+                                           int64_t ignore_index, float* row_loss, float* loss_out, llark_stream_t stream) {
+    LLARK_REQUIRE(logits && labels && row_loss && loss_out && batch > 0 && s > 0 && vocab > 0 && ldl >= vocab,
+                  "cross_entropy_shifted: bad arguments");
+    dim3 grid(s, batch);
+    ce_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ldl, s, vocab, (const long long*)labels,
+                                                          (long long)ignore_index, row_loss);
+    ce_reduce_kernel<<<1, 256, 0, (hipStream_t)stream>>>(row_loss, batch * s, loss_out);
+    return check_launch("cross_entropy_shifted");
+}
+
+extern "C" int llark_embed_gather(const int64_t* ids, int rows, const void* table, int table_dtype, int vocab,
+                                  int width, float* out, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(ids && table && out && rows > 0 && width > 0 && ldo >= width, "embed_gather: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (table_dtype == LLARK_BF16)
+        embed_gather_kernel<bf16_t><<<rows, 256, 0, s>>>((const long long*)ids, (const bf16_t*)table, out, rows, width, vocab, ldo);
+    else if (table_dtype == LLARK_F16)
+        embed_gather_kernel<half_t><<<rows, 256, 0, s>>>((const long long*)ids, (const half_t*)table, out, rows, width, vocab, ldo);
+    else if (table_dtype == 2)
+        embed_gather_kernel<float><<<rows, 256, 0, s>>>((const long long*)ids, (const float*)table, out, rows, width, vocab, ldo);
+    else {
+        set_error("embed_gather: bad table dtype %d", table_dtype);
+        return LLARK_ERR_INVALID;
+    }
+    return check_launch("embed_gather");
+}
+
+extern "C" int llark_rmsnorm_bf16(const float* x, int ldx, int rows, int width, const float* w, float eps, void* out_hi,
+                                  void* out_lo, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && w && out_hi && rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 &&
+                      ldo >= width && ldx >= width, "rmsnorm: bad shape rows=%d width=%d ldx=%d ldo=%d", rows, width, ldx, ldo);
+    const int w4 = width / 4;
+    dim3 grid(cdiv(rows, 4));
+    hipStream_t s = (hipStream_t)stream;
+#define RN_CASE(NV) rmsnorm_kernel<NV><<<grid, 256, 0, s>>>(x, ldx, rows, width, w, eps, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo)
+    if (w4 <= 64) RN_CASE(1);
+    else if (w4 <= 256) RN_CASE(4);
+    else if (w4 <= 1024) RN_CASE(16);
+    else if (w4 <= 2048) RN_CASE(32);
+    else {
+        set_error("rmsnorm: width %d too large (max 8192)", width);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+#undef RN_CASE
+    return check_launch("rmsnorm");
+}
+
+extern "C" int llark_rope_split_heads(const float* qkv, int batch, int s, int nh, int hd, int pos0, const float* cos_t,
+                                      const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, int smax,
+                                      llark_stream_t stream) {
+    LLARK_REQUIRE(qkv && cos_t && sin_t && q && k_cache && vt_cache, "rope_split_heads: null pointer");
+    LLARK_REQUIRE(hd == 128, "rope_split_heads: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && pos0 >= 0 && pos0 + s <= smax && pos0 + s <= max_pos && smax % 8 == 0,
+                  "rope_split_heads: bad shape batch=%d s=%d pos0=%d smax=%d max_pos=%d", batch, s, pos0, smax, max_pos);
+    dim3 grid(cdiv(s, 64), nh, batch);
+    rope_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, s, nh, pos0, cos_t, sin_t, (bf16_t*)q, (bf16_t*)k_cache,
+                                                              (bf16_t*)vt_cache, smax);
+    return check_launch("rope_split_heads");
+}
+
+extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh,
+                                       int hd, int past, int smax, void* out, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_prefill: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_prefill: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && past >= 0 && past + s <= smax && smax % 8 == 0, "attn_prefill: bad shape");
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    const int lds = 16384 + 16384 + 4 * 4096;
+    dim3 grid(cdiv(s, 64), nh, batch);
+    attn_prefill_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
+                                                                 (const bf16_t*)vt_cache, (bf16_t*)out, s, nh, past, smax,
+                                                                 scale);
+    return check_launch("attn_prefill");
+}
+
+extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int nh, int hd,
+                                      int total, int smax, void* out, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_decode: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_decode: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && nh > 0 && total > 0 && total <= smax, "attn_decode: bad shape total=%d smax=%d", total, smax);
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    const size_t lds = (size_t)total * sizeof(float);
+    LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode: context %d too long for the LDS score buffer", total);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(nh, batch);
+    attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
+                                                                (const bf16_t*)vt_cache, (bf16_t*)out, nh, total, smax, scale);
+    return check_launch("attn_decode");
+}

@@ -1,0 +1,206 @@
+"""Native Llama-2 execution engine on the HIP kernels (weights in kernel layout, KV cache, workspaces).
+
+This is what runs underneath :class:`llark_amd.m2t.llamav2.WrappedLlamav2ForCausalLM`; it replaces
+the arithmetic the reference delegates to HF ``LlamaModel.forward`` + ``lm_head`` + ``mm_projector``
+(m2t/models/llamav2.py:124,133,224-234,312).
+
+HBM layout:
+  embed      bf16 [V][H]                      lm_head  bf16 [V][H]
+  per layer  wqkv bf16 [3H][H] (q|k|v rows)   wo bf16 [H][H]
+             wgu  bf16 [2I][H]  rows interleaved in blocks of 32: [gate 32 | up 32] (SwiGLU epilogue)
+             wdown bf16 [H][I]                norms fp32 [H]
+  projector  bf16 [H][mm] + fp32 bias
+  h          fp32 [B*S][H] residual stream (updated in place by GEMM epilogues)
+  k_cache    bf16 [L][B][nh][Smax][128]       vt_cache bf16 [L][B][nh][128][Smax]  (V transposed)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+
+
+@dataclass
+class LlamaDims:
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    mm_hidden_size: int = 4800
+    max_position_embeddings: int = 4096
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[I][H] gate, up -> [2I][H] with rows [gate 0..31 | up 0..31 | gate 32..63 | up 32..63 | ...]."""
+    I, H = gate.shape
+    assert I % 32 == 0, "intermediate_size must be a multiple of 32"
+    return torch.stack((gate.view(I // 32, 32, H), up.view(I // 32, 32, H)), dim=1).reshape(2 * I, H).contiguous()
+
+
+class _Layer:
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2")
+
+
+class HipLlamaEngine:
+    def __init__(self, dims: LlamaDims, device="cuda", max_batch: int = 8, max_seq: int = 512):
+        if dims.head_dim != 128:
+            raise NotImplementedError(f"the HIP attention kernels are built for head_dim 128 (Llama-2); got {dims.head_dim}")
+        if dims.intermediate_size % 32 or dims.hidden_size % 32 or dims.mm_hidden_size % 32:
+            raise NotImplementedError("hidden / intermediate / mm_hidden sizes must be multiples of 32")
+        self.dims = dims
+        self.device = torch.device(device)
+        self.max_batch = max_batch
+        self.smax = ops.round_up(max_seq, 8)
+        self.layers: List[Optional[_Layer]] = [None] * dims.num_hidden_layers
+        self.embed = self.lm_head = self.norm = self.proj_w = self.proj_b = None
+        # RoPE tables exactly as HF computes them (fp32, inv_freq = theta^(-2i/d), emb = cat(freqs, freqs))
+        hd = dims.head_dim
+        inv_freq = 1.0 / (dims.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+        freqs = torch.arange(self.smax, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        self.cos = freqs.cos().contiguous().to(self.device)
+        self.sin = freqs.sin().contiguous().to(self.device)
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._ws_key = None
+        self.k_cache = self.vt_cache = None
+        self.cur_len = 0
+        self.cur_batch = 0
+
+    # ---- weights -------------------------------------------------------------------------------
+    def _bf16(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.bfloat16).contiguous()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def set_layer(self, i: int, q, k, v, o, gate, up, down, ln1, ln2) -> None:
+        L = _Layer()
+        L.wqkv = torch.cat((self._bf16(q), self._bf16(k), self._bf16(v)), dim=0).contiguous()
+        L.wo = self._bf16(o)
+        L.wgu = interleave_gate_up(self._bf16(gate), self._bf16(up))
+        L.wdown = self._bf16(down)
+        L.ln1, L.ln2 = self._f32(ln1), self._f32(ln2)
+        self.layers[i] = L
+
+    def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
+        self.embed, self.norm, self.lm_head = self._bf16(embed), self._f32(norm), self._bf16(lm_head)
+        if proj_w is not None:
+            self.proj_w, self.proj_b = self._bf16(proj_w), self._f32(proj_b)
+
+    def load_state_dict(self, sd) -> None:
+        """HF / reference state-dict names (model.layers.N.self_attn.q_proj.weight, ..., model.mm_projector.*)."""
+        d = self.dims
+        for i in range(d.num_hidden_layers):
+            p = f"model.layers.{i}"
+            self.set_layer(i, sd[f"{p}.self_attn.q_proj.weight"], sd[f"{p}.self_attn.k_proj.weight"],
+                           sd[f"{p}.self_attn.v_proj.weight"], sd[f"{p}.self_attn.o_proj.weight"],
+                           sd[f"{p}.mlp.gate_proj.weight"], sd[f"{p}.mlp.up_proj.weight"], sd[f"{p}.mlp.down_proj.weight"],
+                           sd[f"{p}.input_layernorm.weight"], sd[f"{p}.post_attention_layernorm.weight"])
+        self.set_globals(sd["model.embed_tokens.weight"], sd["model.norm.weight"], sd["lm_head.weight"],
+                         sd.get("model.mm_projector.weight"), sd.get("model.mm_projector.bias"))
+
+    # ---- workspaces ----------------------------------------------------------------------------
+    def _workspace(self, batch: int, s: int):
+        key = (batch, s)
+        if self._ws_key != key:
+            d, dev = self.dims, self.device
+            rows = batch * s
+            H, I = d.hidden_size, d.intermediate_size
+            ws = {
+                "h": torch.empty((rows, H), dtype=torch.float32, device=dev),
+                "x16": torch.empty((rows, H), dtype=torch.bfloat16, device=dev),
+                "qkv": torch.empty((rows, 3 * H), dtype=torch.float32, device=dev),
+                "q": torch.empty((batch, d.num_attention_heads, s, d.head_dim), dtype=torch.bfloat16, device=dev),
+                "att": torch.empty((rows, H), dtype=torch.bfloat16, device=dev),
+                "act": torch.empty((rows, I), dtype=torch.bfloat16, device=dev),
+            }
+            self._ws, self._ws_key = ws, key
+        return self._ws
+
+    def _ensure_cache(self, batch: int):
+        d = self.dims
+        if self.k_cache is None or self.k_cache.shape[1] < batch:
+            shape_k = (d.num_hidden_layers, batch, d.num_attention_heads, self.smax, d.head_dim)
+            shape_v = (d.num_hidden_layers, batch, d.num_attention_heads, d.head_dim, self.smax)
+            self.k_cache = torch.zeros(shape_k, dtype=torch.bfloat16, device=self.device)
+            self.vt_cache = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None):
+        d = self.dims
+        H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
+        h = ws["h"]
+        n_layers = d.num_hidden_layers if num_layers is None else num_layers
+        for i in range(n_layers):
+            L = self.layers[i]
+            kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
+            if not kc.is_contiguous():            # batch smaller than the allocated cache
+                raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
+            ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"])
+            ops.gemm16(ws["x16"], None, L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
+            ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc)
+            if s == 1:
+                ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"])
+            else:
+                ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"])
+            ops.gemm16(ws["att"], None, L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+            ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"])
+            ops.gemm16(ws["x16"], None, L.wgu, None, 2 * I, ops.EPI_SWIGLU16, out_hi=ws["act"])
+            ops.gemm16(ws["act"], None, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+
+    def reset(self, batch: int) -> None:
+        if self.k_cache is not None and self.k_cache.shape[1] != batch:
+            self.k_cache = self.vt_cache = None
+        self._ensure_cache(batch)
+        self.cur_len, self.cur_batch = 0, batch
+
+    def forward_tokens(self, input_ids: torch.Tensor, audio_segments: Sequence[Tuple[int, int, torch.Tensor]] = (),
+                       pos0: int = 0, last_only: bool = False, num_layers: Optional[int] = None,
+                       return_hidden: bool = False) -> torch.Tensor:
+        """input_ids (B,S) int64 on device.  audio_segments: (batch index, position of <audio_start>,
+        frames fp32 (F, mm) on device): projected frames overwrite rows start+1 .. start+F of the
+        embedded sequence (the splice of m2t/models/llamav2.py:141-222).  Returns fp32 logits
+        (B,S,V) (or (B,1,V) if last_only).  Positions pos0..pos0+S-1 of the KV cache are written."""
+        d = self.dims
+        assert self.embed is not None and all(L is not None for L in self.layers[: (num_layers or d.num_hidden_layers)]), \
+            "weights not loaded"
+        B, S = input_ids.shape
+        if pos0 == 0:
+            self.reset(B)
+        assert B == self.cur_batch and pos0 == self.cur_len, "KV cache is out of sync with the requested positions"
+        if pos0 + S > self.smax:
+            raise ValueError(f"sequence of {pos0 + S} exceeds the engine's max_seq {self.smax}")
+        ws = self._workspace(B, S)
+        h = ws["h"]
+        ops.embed_gather(input_ids.reshape(-1).contiguous(), self.embed, h)
+        for (b, start, frames) in audio_segments:
+            assert self.proj_w is not None, "mm_projector weights not loaded"
+            F = frames.shape[0]
+            a16, _ = ops.split16(frames.contiguous(), torch.bfloat16, want_lo=False)
+            r0 = b * S + start + 1
+            ops.gemm16(a16, None, self.proj_w, self.proj_b, d.hidden_size, ops.EPI_F32, c=h[r0: r0 + F])
+        self._layers_forward(ws, B, S, pos0, num_layers)
+        self.cur_len = pos0 + S
+        if return_hidden:
+            return h.view(B, S, d.hidden_size)
+        if last_only and S > 1:
+            hl = h.view(B, S, d.hidden_size)[:, -1].contiguous()
+            x16 = torch.empty((B, d.hidden_size), dtype=torch.bfloat16, device=self.device)
+            ops.rmsnorm_bf16(hl, self.norm, d.rms_norm_eps, x16)
+            logits = torch.empty((B, d.vocab_size), dtype=torch.float32, device=self.device)
+            ops.gemm16(x16, None, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
+            return logits.view(B, 1, d.vocab_size)
+        ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"])
+        logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
+        ops.gemm16(ws["x16"], None, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
+        return logits.view(B, S, d.vocab_size)

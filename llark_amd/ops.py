@@ -237,6 +237,64 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16")
 
 
+# ------------------------------------------------------------------------------------------------
+# Llama
+# ------------------------------------------------------------------------------------------------
+def embed_gather(ids: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> None:
+    """out[row] = table[ids[row]] ; ids flat int64 [rows]; out fp32 [rows][>=width]."""
+    rows = ids.numel()
+    vocab, width = table.shape
+    assert out.shape[0] == rows and out.shape[1] >= width
+    check(_lib.lib().llark_embed_gather(_dev(ids, "ids", torch.int64), rows, _dev(table, "table"), _DT[table.dtype], vocab,
+                                        width, _dev(out, "out", torch.float32), out.stride(0), _stream()), "embed_gather")
+
+
+def rmsnorm_bf16(x: torch.Tensor, w: torch.Tensor, eps: float, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None):
+    rows, width = x.shape
+    check(_lib.lib().llark_rmsnorm_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(w, "w", torch.float32),
+                                        float(eps), _dev(out_hi, "out_hi", torch.bfloat16),
+                                        _dev(out_lo, "out_lo", torch.bfloat16) if out_lo is not None else None,
+                                        out_hi.stride(0), _stream()), "rmsnorm_bf16")
+
+
+def rope_split_heads(qkv: torch.Tensor, batch: int, s: int, nh: int, hd: int, pos0: int, cos_t: torch.Tensor,
+                     sin_t: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor) -> None:
+    smax = k_cache.shape[-2]
+    assert qkv.shape == (batch * s, 3 * nh * hd) and k_cache.shape[-1] == hd and vt_cache.shape[-1] == smax
+    check(_lib.lib().llark_rope_split_heads(_dev(qkv, "qkv", torch.float32), batch, s, nh, hd, pos0,
+                                            _dev(cos_t, "cos", torch.float32), _dev(sin_t, "sin", torch.float32),
+                                            cos_t.shape[0], _dev(q, "q", torch.bfloat16),
+                                            _dev(k_cache, "k_cache", torch.bfloat16),
+                                            _dev(vt_cache, "vt_cache", torch.bfloat16), smax, _stream()), "rope_split_heads")
+
+
+def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, past: int, out: torch.Tensor) -> None:
+    smax = k_cache.shape[-2]
+    check(_lib.lib().llark_attn_prefill_bf16(_dev(q, "q", torch.bfloat16), _dev(k_cache, "k_cache", torch.bfloat16),
+                                             _dev(vt_cache, "vt_cache", torch.bfloat16), batch, s, nh, hd, past, smax,
+                                             _dev(out, "out", torch.bfloat16), _stream()), "attn_prefill")
+
+
+def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, out: torch.Tensor) -> None:
+    smax = k_cache.shape[-2]
+    check(_lib.lib().llark_attn_decode_bf16(_dev(q, "q", torch.bfloat16), _dev(k_cache, "k_cache", torch.bfloat16),
+                                            _dev(vt_cache, "vt_cache", torch.bfloat16), batch, nh, hd, total, smax,
+                                            _dev(out, "out", torch.bfloat16), _stream()), "attn_decode")
+
+
+def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """Mean NLL of logits[:, :-1] against labels[:, 1:] ignoring ``ignore_index`` (scalar device tensor)."""
+    B, S, V = logits.shape
+    assert labels.shape == (B, S)
+    row_loss = torch.empty((B * S,), dtype=torch.float32, device=logits.device)
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    check(_lib.lib().llark_cross_entropy_shifted(_dev(logits, "logits", torch.float32), logits.stride(1), B, S, V,
+                                                 _dev(labels.contiguous(), "labels", torch.int64), ignore_index,
+                                                 _dev(row_loss, "row_loss"), _dev(out, "loss"), _stream()),
+          "cross_entropy_shifted")
+    return out[0]
+
+
 def device_info(device: int = 0) -> Tuple[int, str]:
     import ctypes
     buf = ctypes.create_string_buffer(64)

@@ -18,8 +18,9 @@ restatement against them (<= 2e-5 abs on logits, exact on errors raised).
 ``act_dtype=torch.bfloat16`` mirrors the reduced-precision points of the reference's GPU dtype flow
 (bf16 autocast / bf16 weights: inputs of every Linear, q/k/v after RoPE, and the softmax
 probabilities are rounded to bf16 -- each of these is also a rounding point in HF's bf16 run) while
-all accumulation stays fp32; this is the dtype flow of the HIP path.  ``act_dtype=None`` is the
-pure-fp32 CPU path of the reference.
+all accumulation stays fp32.  The HIP path computes in this flow except that it keeps the softmax
+probabilities at >= 16 bits (``round_probs=False``).  ``act_dtype=None`` is the pure-fp32 CPU path
+of the reference.
 """
 from __future__ import annotations
 
@@ -99,7 +100,7 @@ def splice_audio(input_ids: torch.Tensor, inputs_embeds: torch.Tensor, audio_fea
 
 
 def decoder_layer(h: torch.Tensor, w: Dict[str, torch.Tensor], i: int, spec: LlamaSpec, cos, sin, mask, act_dtype,
-                  past_kv=None):
+                  past_kv=None, round_probs: bool = True):
     """One LlamaDecoderLayer (pre-norm residual x2).  h: (B,S,H) fp32."""
     B, S, H = h.shape
     nh, hd = spec.num_attention_heads, spec.head_dim
@@ -116,7 +117,9 @@ def decoder_layer(h: torch.Tensor, w: Dict[str, torch.Tensor], i: int, spec: Lla
         v = torch.cat((past_kv[1], v), dim=2)
     att = torch.matmul(q, k.transpose(2, 3)) * (hd ** -0.5)
     att = att + mask
-    att = _rnd(F.softmax(att, dim=-1, dtype=torch.float32), act_dtype)
+    att = F.softmax(att, dim=-1, dtype=torch.float32)
+    if round_probs:                      # HF casts the probabilities to the activation dtype before P.V
+        att = _rnd(att, act_dtype)
     o = torch.matmul(att, v).transpose(1, 2).reshape(B, S, H)
     h = h + F.linear(_rnd(o, act_dtype), w[f"{p}.self_attn.o_proj.weight"].float())
     x = _rnd(rmsnorm(h, w[f"{p}.post_attention_layernorm.weight"], spec.rms_norm_eps), act_dtype)
@@ -129,7 +132,7 @@ def decoder_layer(h: torch.Tensor, w: Dict[str, torch.Tensor], i: int, spec: Lla
 def forward(w: Dict[str, torch.Tensor], spec: LlamaSpec, input_ids: torch.Tensor,
             audio_encodings: Union[None, torch.Tensor, Sequence[torch.Tensor]] = None,
             labels: Optional[torch.Tensor] = None, act_dtype=None, past_key_values=None, num_layers: Optional[int] = None,
-            return_hidden: bool = False):
+            return_hidden: bool = False, round_probs: bool = True):
     """``WrappedLlamav2ForCausalLM.forward`` (no padding mask: full-length right-aligned batches).
 
     Returns dict(logits (B,S,V) fp32, loss or None, past_key_values, [hidden]).
@@ -154,7 +157,7 @@ def forward(w: Dict[str, torch.Tensor], spec: LlamaSpec, input_ids: torch.Tensor
     L = spec.num_hidden_layers if num_layers is None else num_layers
     for i in range(L):
         h, kv = decoder_layer(h, w, i, spec, cos, sin, mask, act_dtype,
-                              None if past_key_values is None else past_key_values[i])
+                              None if past_key_values is None else past_key_values[i], round_probs)
         new_past.append(kv)
     hn = _rnd(rmsnorm(h, w["model.norm.weight"], spec.rms_norm_eps), act_dtype)
     logits = F.linear(hn, w["lm_head.weight"].float())
@@ -170,11 +173,11 @@ def forward(w: Dict[str, torch.Tensor], spec: LlamaSpec, input_ids: torch.Tensor
 
 
 def greedy_generate(w, spec: LlamaSpec, input_ids: torch.Tensor, audio_encodings, max_new_tokens: int,
-                    act_dtype=None, eos_token_id: Optional[int] = None):
+                    act_dtype=None, eos_token_id: Optional[int] = None, round_probs: bool = True):
     """HF ``generate(do_sample=False)`` through ``prepare_inputs_for_generation``
     (m2t/models/llamav2.py:339-365): full prompt once, then one token per step with the KV cache;
     audio_encodings are only spliced on the first step (later steps contain no <audio_start>)."""
-    out = forward(w, spec, input_ids, audio_encodings, act_dtype=act_dtype)
+    out = forward(w, spec, input_ids, audio_encodings, act_dtype=act_dtype, round_probs=round_probs)
     past = out["past_key_values"]
     ids = input_ids
     for _ in range(max_new_tokens):
@@ -182,7 +185,7 @@ def greedy_generate(w, spec: LlamaSpec, input_ids: torch.Tensor, audio_encodings
         ids = torch.cat((ids, nxt), dim=1)
         if eos_token_id is not None and bool((nxt == eos_token_id).all()):
             break
-        out = forward(w, spec, nxt, None, act_dtype=act_dtype, past_key_values=past)
+        out = forward(w, spec, nxt, None, act_dtype=act_dtype, past_key_values=past, round_probs=round_probs)
         past = out["past_key_values"]
     return ids
 

@@ -39,9 +39,18 @@ def build(spec: LR.LlamaSpec, w):
 
 
 def main():
-    spec = LR.LlamaSpec(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, vocab_size=100,
-                        mm_hidden_size=48, audio_start_token=98, audio_end_token=99, audio_patch_token=97)
-    w = LR.make_weights(spec, seed=0, std=0.2)
+    # fixture 1: tiny heads (head_dim 16) -- pins the oracle's generic arithmetic
+    make(LR.LlamaSpec(hidden_size=64, intermediate_size=176, num_hidden_layers=2, num_attention_heads=4, vocab_size=100,
+                      mm_hidden_size=48, audio_start_token=98, audio_end_token=99, audio_patch_token=97),
+         "llama_tiny.npz", std=0.2, mm=48)
+    # fixture 2: Llama-2's head_dim 128 (what the HIP attention kernels are built for)
+    make(LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=100,
+                      mm_hidden_size=96, audio_start_token=98, audio_end_token=99, audio_patch_token=97),
+         "llama_hd128.npz", std=0.08, mm=96)
+
+
+def make(spec, fname, std, mm):
+    w = LR.make_weights(spec, seed=0, std=std)
     m = build(spec, w)
     g = torch.Generator().manual_seed(1)
     F_ = 5
@@ -55,7 +64,7 @@ def main():
                             spec.vocab_size, spec.mm_hidden_size, 98, 99, 97])
     # case 1: batch of 2, tensor audio, labels
     ids = torch.tensor([ids_with_audio(3, 8), ids_with_audio(5, 6)])
-    aud = torch.randn(2, F_, 48, generator=g)
+    aud = torch.randn(2, F_, mm, generator=g)
     labels = ids.clone()
     labels[:, :12] = -100
     with torch.no_grad():
@@ -78,7 +87,7 @@ def main():
     # greedy_search does with that hook: full prompt (+audio) once, then the last token with the
     # cache, audio_encodings forwarded every step -- all through the reference's own forward().
     ids4 = torch.tensor([ids_with_audio(2, 4)])
-    aud4 = torch.randn(1, F_, 48, generator=g)
+    aud4 = torch.randn(1, F_, mm, generator=g)
     gen = ids4.clone()
     with torch.no_grad():
         r4 = m(input_ids=ids4, audio_encodings=aud4, use_cache=True)
@@ -109,8 +118,8 @@ def main():
     out["c5_follow_msg"] = np.array(msg2)
     out["c5_bad_ids"] = bad.numpy()
     out["c5_bad2_ids"] = bad2.numpy()
-    np.savez_compressed(os.path.join(HERE, "llama_tiny.npz"), **out)
-    print("wrote llama_tiny.npz", {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("w::")})
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print("wrote", fname, {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("w::")})
 
 
 if __name__ == "__main__":

@@ -1,0 +1,229 @@
+"""GPU parity: Llama-2 kernels, the HIP engine and the drop-in WrappedLlamav2ForCausalLM.
+
+Tolerances.  The HIP path computes in the reference's GPU dtype flow (bf16 Linear inputs / q / k / v /
+probabilities, fp32 accumulation and residual stream).  It is compared
+  (a) with the oracle evaluated in the SAME flow (oracle/llama_ref.py act_dtype=bf16, round_probs=False,
+      bf16-valued weights; the HIP kernels keep softmax probabilities at >= 16 bits):
+      logits within 2e-3 * max|logits|  (accumulation order + bf16 rounding flips only), and
+  (b) with golden logits of the REAL reference wrapper in fp32 (tests/golden/llama_hd128.npz):
+      within 2e-2 * max|logits| (bf16-vs-fp32 distance of the flow itself, reported by the test)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import report_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+def test_rmsnorm_embed_ce():
+    from llark_amd import ops
+    from oracle import llama_ref as LR
+    g = torch.Generator().manual_seed(0)
+    for rows, width in [(7, 256), (33, 4096)]:
+        x = torch.randn(rows, width, generator=g) * 3
+        w = 1 + 0.1 * torch.randn(width, generator=g)
+        hi = torch.empty((rows, width), dtype=torch.bfloat16, device="cuda")
+        lo = torch.empty_like(hi)
+        ops.rmsnorm_bf16(x.cuda(), w.cuda(), 1e-5, hi, lo)
+        ref = LR.rmsnorm(x, w, 1e-5)
+        report_close("rmsnorm hi+lo", (hi.float() + lo.float()).cpu(), ref, 3e-5, 3e-5)
+        assert (hi.cpu().float() - ref).abs().max() <= 2 ** -8 * ref.abs().max()
+    table = torch.randn(50, 256, generator=g).bfloat16()
+    ids = torch.tensor([3, 49, 0, 7], dtype=torch.int64)
+    out = torch.empty((4, 256), device="cuda")
+    ops.embed_gather(ids.cuda(), table.cuda(), out)
+    assert torch.equal(out.cpu(), table[ids].float())
+    logits = torch.randn(2, 9, 300, generator=g) * 2
+    labels = torch.randint(0, 300, (2, 9), generator=g)
+    labels[0, :4] = -100
+    loss = ops.cross_entropy_shifted(logits.cuda(), labels.cuda())
+    ref = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, 300), labels[:, 1:].reshape(-1), ignore_index=-100)
+    assert abs(loss.item() - ref.item()) < 1e-5
+
+
+def _ref_attention(q, k, v, past):
+    """q (B,nh,S,hd), k/v (B,nh,T,hd) fp32 holding bf16 values; query i sees keys j <= past+i."""
+    B, nh, S, hd = q.shape
+    T = k.shape[2]
+    att = torch.matmul(q, k.transpose(2, 3)) * hd ** -0.5
+    mask = torch.full((S, T), float("-inf")).triu(diagonal=past + 1)
+    p = torch.softmax(att + mask, dim=-1, dtype=torch.float32)      # HIP keeps probabilities at >= 16 bits
+    return torch.matmul(p, v).transpose(1, 2).reshape(B, S, nh * hd)
+
+
+@pytest.mark.parametrize("B,nh,S,past", [(1, 2, 64, 0), (2, 3, 371, 0), (1, 2, 100, 37), (1, 1, 1, 0), (2, 2, 5, 200)])
+def test_rope_and_attention(B, nh, S, past):
+    from llark_amd import ops
+    from oracle import llama_ref as LR
+    hd, H = 128, nh * 128
+    g = torch.Generator().manual_seed(S + past)
+    smax = ops.round_up(past + S + 3, 8)
+    qkv = torch.randn(B * S, 3 * H, generator=g)
+    cos, sin = LR.rope_cos_sin(torch.arange(smax), hd, 10000.0)
+    kc = torch.zeros((B, nh, smax, hd), dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros((B, nh, hd, smax), dtype=torch.bfloat16, device="cuda")
+    # pre-existing cache content for the `past` positions
+    kpast = _bf(torch.randn(B, nh, past, hd, generator=g))
+    vpast = _bf(torch.randn(B, nh, past, hd, generator=g))
+    kc[:, :, :past] = kpast.bfloat16().cuda()
+    vc[:, :, :, :past] = vpast.transpose(2, 3).bfloat16().cuda()
+    qd = torch.empty((B, nh, S, hd), dtype=torch.bfloat16, device="cuda")
+    ops.rope_split_heads(qkv.cuda(), B, S, nh, hd, past, cos[:, :64].contiguous().cuda(), sin[:, :64].contiguous().cuda(),
+                         qd, kc, vc)
+    q, k, v = [t.view(B, S, nh, hd).transpose(1, 2) for t in qkv.view(B, S, 3 * H).chunk(3, dim=-1)]
+    c, s_ = cos[past: past + S], sin[past: past + S]
+    qr = _bf(q * c + LR._rotate_half(q) * s_)
+    kr = _bf(k * c + LR._rotate_half(k) * s_)
+    assert torch.equal(qd.float().cpu(), qr), "RoPE(q) must be bit-exact (same fp32 association, one bf16 rounding)"
+    assert torch.equal(kc[:, :, past: past + S].float().cpu(), kr)
+    assert torch.equal(vc[:, :, :, past: past + S].float().cpu(), _bf(v).transpose(2, 3))
+    kfull = torch.cat((kpast, kr), dim=2)
+    vfull = torch.cat((vpast, _bf(v)), dim=2)
+    ref = _ref_attention(qr, kfull, vfull, past)
+    out = torch.empty((B * S, H), dtype=torch.bfloat16, device="cuda")
+    if S == 1:
+        ops.attn_decode(qd, kc, vc, B, nh, hd, past + 1, out)
+    else:
+        ops.attn_prefill(qd, kc, vc, B, S, nh, hd, past, out)
+    report_close(f"attention S={S} past={past}", out.float().cpu().view(B, S, H), _bf(ref), 4e-3, 4e-3)
+    if S > 1 and past + S <= 256:          # decode kernel on the last position must agree too
+        outd = torch.empty((B, H), dtype=torch.bfloat16, device="cuda")
+        ops.attn_decode(qd[:, :, -1:].contiguous(), kc, vc, B, nh, hd, past + S, outd)
+        report_close("decode attention", outd.float().cpu(), _bf(ref[:, -1]), 4e-3, 4e-3)
+
+
+def _engine_from(spec, w, max_seq=64, max_batch=4):
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    dims = LlamaDims(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                     num_hidden_layers=spec.num_hidden_layers, num_attention_heads=spec.num_attention_heads,
+                     vocab_size=spec.vocab_size, rms_norm_eps=spec.rms_norm_eps, rope_theta=spec.rope_theta,
+                     mm_hidden_size=spec.mm_hidden_size)
+    eng = HipLlamaEngine(dims, "cuda", max_batch, max_seq)
+    eng.load_state_dict(w)
+    return eng
+
+
+def test_engine_vs_oracle_and_reference_golden():
+    from test_oracle_llama import load_gold
+    from oracle import llama_ref as LR
+    z, spec, w = load_gold("llama_hd128.npz")
+    wb = {k: _bf(v) for k, v in w.items()}
+    eng = _engine_from(spec, w)
+    ids = torch.from_numpy(z["c1_ids"])
+    aud = torch.from_numpy(z["c1_audio"])
+    segs = [(b, int((ids[b] == spec.audio_start_token).nonzero()[0, 0]), aud[b].cuda()) for b in range(ids.shape[0])]
+    logits = eng.forward_tokens(ids.cuda(), segs).cpu()
+    ref_flow = LR.forward(wb, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
+    scale = ref_flow.abs().max().item()
+    e_flow = report_close("logits vs oracle (bf16 flow)", logits, ref_flow, 2e-3 * scale)
+    gold = torch.from_numpy(z["c1_logits"])
+    e_gold = report_close("logits vs REFERENCE fp32 golden", logits, gold, 2e-2 * gold.abs().max().item())
+    print(f"logits rel err: vs oracle-bf16-flow {e_flow/scale:.2e}, vs reference fp32 {e_gold/gold.abs().max().item():.2e}")
+    # KV-cache decode step == oracle's cached step
+    out = LR.forward(wb, spec, ids[:1], aud[:1], act_dtype=torch.bfloat16, round_probs=False)
+    nxt = out["logits"][:, -1].argmax(-1, keepdim=True)
+    ref2 = LR.forward(wb, spec, nxt, None, act_dtype=torch.bfloat16, past_key_values=out["past_key_values"], round_probs=False)["logits"]
+    eng.forward_tokens(ids[:1].cuda(), segs[:1])
+    got2 = eng.forward_tokens(nxt.cuda(), (), pos0=ids.shape[1]).cpu()
+    report_close("decode-step logits", got2, ref2, 2e-3 * ref2.abs().max().item())
+    # last_only path agrees with the full-logits path
+    lo = eng.forward_tokens(ids.cuda(), segs, last_only=True).cpu()
+    assert torch.equal(lo[:, 0], logits[:, -1])
+
+
+def test_wrapped_model_api_loss_generate_errors():
+    from test_oracle_llama import load_gold
+    from llark_amd import _lib
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    from oracle import llama_ref as LR
+    z, spec, w = load_gold("llama_hd128.npz")
+    wb = {k: _bf(v) for k, v in w.items()}
+    cfg = WrappedLlamav2Config(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
+                               num_hidden_layers=spec.num_hidden_layers, num_attention_heads=spec.num_attention_heads,
+                               num_key_value_heads=spec.num_attention_heads, vocab_size=spec.vocab_size,
+                               max_position_embeddings=512, rms_norm_eps=spec.rms_norm_eps, tie_word_embeddings=False)
+    cfg.mm_hidden_size = spec.mm_hidden_size
+    m = WrappedLlamav2ForCausalLM(cfg).eval()
+    m.get_model().initialize_adapter_modules()
+    missing, unexpected = m.load_state_dict(w, strict=False)
+    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing)
+    ac = m.get_model().audio_encoder_config
+    ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = 98, 99, 97
+    ids, aud, labels = torch.from_numpy(z["c1_ids"]), torch.from_numpy(z["c1_audio"]), torch.from_numpy(z["c1_labels"])
+    with pytest.raises(_lib.LlarkHipError):
+        with torch.no_grad():
+            m(input_ids=ids, audio_encodings=aud)                     # CPU module: no fallback
+    m.cuda()
+    m.configure_engine(max_batch=4, max_seq=64)
+    with torch.no_grad():
+        r = m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), labels=labels.cuda())
+        r_list = m(input_ids=ids.cuda(), audio_encodings=[aud[0].cuda(), aud[1].cuda()])
+    ref = LR.forward(wb, spec, ids, aud, labels=labels, act_dtype=torch.bfloat16, round_probs=False)
+    report_close("wrapped logits", r.logits.cpu(), ref["logits"], 2e-3 * ref["logits"].abs().max().item())
+    assert abs(r.loss.item() - ref["loss"].item()) < 5e-3 * max(1.0, abs(ref["loss"].item()))
+    assert abs(r.loss.item() - float(z["c1_loss"])) < 5e-2 * max(1.0, float(z["c1_loss"]))
+    assert torch.equal(r_list.logits, r.logits)
+    # state-dict keys are the reference's
+    keys = set(m.state_dict().keys())
+    assert {"model.mm_projector.weight", "model.mm_projector.bias", "model.embed_tokens.weight", "lm_head.weight"} <= keys
+    # error behaviour identical to the reference (messages pinned in the golden file)
+    with pytest.raises(ValueError) as e:
+        with torch.no_grad():
+            m(input_ids=torch.from_numpy(z["c5_bad_ids"]).cuda(), audio_encodings=aud.cuda())
+    assert str(e.value) == str(z["c5_count_msg"])
+    with pytest.raises(ValueError) as e:
+        with torch.no_grad():
+            m(input_ids=torch.from_numpy(z["c5_bad2_ids"]).cuda(), audio_encodings=aud.cuda())
+    assert str(e.value) == str(z["c5_follow_msg"])
+    # greedy generation through prepare_inputs_for_generation + KV cache
+    ids4, aud4 = torch.from_numpy(z["c4_ids"]), torch.from_numpy(z["c4_audio"])
+    gen = m.generate(input_ids=ids4.cuda(), audio_encodings=aud4.cuda(), max_new_tokens=6, do_sample=False).cpu()
+    ref_gen = LR.greedy_generate(wb, spec, ids4, aud4, 6, act_dtype=torch.bfloat16, round_probs=False)
+    assert gen.shape == ref_gen.shape
+    assert torch.equal(gen, ref_gen), f"generated {gen.tolist()} vs oracle {ref_gen.tolist()} (reference fp32: {z['c4_generated'].tolist()})"
+
+    class Stop:
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, output_ids, scores, **kw):
+            self.calls += 1
+            return self.calls >= 2
+
+    st = Stop()
+    gen2 = m.generate(input_ids=ids4.cuda(), audio_encodings=aud4.cuda(), max_new_tokens=6, stopping_criteria=[st]).cpu()
+    assert gen2.shape[1] == ids4.shape[1] + 2 and torch.equal(gen2, ref_gen[:, : gen2.shape[1]])
+    # training is the next row: must fail loudly, not silently fall back
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), labels=labels.cuda())
+
+
+def test_llama7b_width_two_layers():
+    """Llama-2-7B widths (4096 / 11008 / 32 heads), S=371 (BOS + start + 240 patches + end + 128 prompt ids),
+    2 layers, small vocab: engine vs oracle in the same bf16 flow."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from oracle import llama_ref as LR
+    V = 1024
+    spec = LR.LlamaSpec(hidden_size=4096, intermediate_size=11008, num_hidden_layers=2, num_attention_heads=32,
+                        vocab_size=V, mm_hidden_size=4800, audio_start_token=V - 2, audio_end_token=V - 1,
+                        audio_patch_token=V - 3)
+    w = LR.make_weights(spec, seed=0, std=0.02, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(7)
+    B, F = 2, 240
+    ids = torch.stack([torch.tensor([1, V - 2] + [V - 3] * F + [V - 1] + torch.randint(3, V - 3, (128,), generator=g).tolist())
+                       for _ in range(B)])
+    assert ids.shape[1] == 371
+    aud = torch.randn(B, F, 4800, generator=g)
+    eng = _engine_from(spec, w, max_seq=384, max_batch=B)
+    segs = [(b, 1, aud[b].cuda()) for b in range(B)]
+    logits = eng.forward_tokens(ids.cuda(), segs).cpu()
+    ref = LR.forward({k: v.float() for k, v in w.items()}, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
+    scale = ref.abs().max().item()
+    err = report_close("7B-width logits (2 layers)", logits, ref, 2e-3 * scale)
+    print(f"7B-width 2-layer logits rel err {err/scale:.2e}")

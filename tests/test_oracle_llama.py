@@ -9,12 +9,26 @@ import torch
 
 from oracle import llama_ref as LR
 
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "llama_tiny.npz")
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.fixture(scope="module")
-def gold():
-    z = np.load(GOLD)
+def load_gold(name):
+    z = np.load(os.path.join(GOLD_DIR, name))
+    s = z["spec"]
+    spec = LR.LlamaSpec(hidden_size=int(s[0]), intermediate_size=int(s[1]), num_hidden_layers=int(s[2]),
+                        num_attention_heads=int(s[3]), vocab_size=int(s[4]), mm_hidden_size=int(s[5]),
+                        audio_start_token=int(s[6]), audio_end_token=int(s[7]), audio_patch_token=int(s[8]))
+    w = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    return z, spec, w
+
+
+@pytest.fixture(scope="module", params=["llama_tiny.npz", "llama_hd128.npz"])
+def gold(request):
+    return load_gold(request.param)
+
+
+def _unused():
+    z = None
     s = z["spec"]
     spec = LR.LlamaSpec(hidden_size=int(s[0]), intermediate_size=int(s[1]), num_hidden_layers=int(s[2]),
                         num_attention_heads=int(s[3]), vocab_size=int(s[4]), mm_hidden_size=int(s[5]),
