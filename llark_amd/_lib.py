@@ -55,6 +55,8 @@ _SIGS = {
     "llark_zero_pad16": [_P, c_int, c_int, c_int, _P],
     "llark_gemm16": [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                      _P, _P, c_int, _P],
+    "llark_gemm16_ex": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                        _P, _P, c_int, _P],
     "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],
     "llark_split16": [c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P],
     "llark_embed_gather": [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P],

@@ -23,8 +23,23 @@
 
 namespace llark {
 
-enum { BM = 128, BN = 128, BK = 32, GEMM_THREADS = 256 };
-enum { MAT_BYTES = BM * BK * 2 };  // 8 KiB: one [128][32] 16-bit operand tile
+// Tile configuration: WM x WN waves, each owning TM x TN MFMA tiles of 32x32; K-step BK (32 or 64).
+template <int WM_, int WN_, int TM_, int TN_, int BK_, int MINW_>
+struct Cfg {
+    static constexpr int MINW = MINW_;             // __launch_bounds__ waves/SIMD the register allocator must allow
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
+    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static constexpr int NW = WM * WN, THREADS = NW * 64;
+    static constexpr int ROWB = BK * 2;            // bytes per tile row (16-bit elements)
+    static constexpr int CH = ROWB / 16;           // 16-B chunks per row
+    static constexpr int RPI = 64 / CH;            // rows covered by one wave-wide 1 KiB DMA instruction
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
+    static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "DMA instructions must divide evenly over the waves");
+    // XOR swizzle of the 16-B chunk index so that ds_read_b128 fragment reads are conflict free
+    static __device__ __forceinline__ int swz(int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+    static __device__ __forceinline__ int off(int row, int c) { return row * ROWB + ((c ^ swz(row)) << 4); }
+};
 
 struct GemmParams {
     const void* Ahi;
@@ -67,36 +82,34 @@ struct Mfma<bf16_t> {
     static __device__ __forceinline__ float back(bf16_t v) { return (float)v; }
 };
 
-// One wave-instruction of LDS-DMA: 64 lanes x 16 B -> 1 KiB (16 rows x 64 B) at `lds_dst`.
-// Lane i lands at lds_dst + 16*i = (row i>>2, slot i&3); it FETCHES chunk (i&3)^((i>>4)&3) of
-// that row so that slot p of row r holds chunk p ^ ((r>>2)&3)   [r>>2 & 3 == i>>4 & 3 here].
-template <typename T>
-__device__ __forceinline__ void dma_rows16(const T* __restrict__ g, int ld, int row0, int rows_valid, int k0,
-                                           char* lds_dst, int lane) {
-    int r = row0 + (lane >> 2);
+// One wave-instruction of LDS-DMA: 64 lanes x 16 B -> 1 KiB = RPI tile rows at `lds_dst` (lane-linear
+// destination).  Lane i lands on (row i/CH, slot i%CH) and FETCHES chunk slot ^ swz(row), so that the
+// LDS image is the swizzled one the fragment reads expect (swizzle on the SOURCE address).
+template <typename T, typename C>
+__device__ __forceinline__ void dma_rows(const T* __restrict__ g, int ld, int grow0, int rows_valid, int k0, int trow0,
+                                         char* lds_dst, int lane) {
+    const int rl = lane / C::CH, p = lane % C::CH;
+    int r = grow0 + rl;
     r = r < rows_valid ? r : rows_valid - 1;
-    int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const int chunk = p ^ C::swz(trow0 + rl);
     const T* src = g + (size_t)r * ld + k0 + chunk * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// byte offset inside an 8 KiB operand tile of (row, 16-B chunk c)
-__device__ __forceinline__ int tile_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
-
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-template <typename T, bool SPLIT, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) {
+template <typename T, bool SPLIT, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
-    constexpr int NMAT = SPLIT ? 3 : 2;             // [Ahi, (Alo), W]
-    constexpr int STAGE = NMAT * MAT_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages
+    constexpr int STAGE = (SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES;     // [Ahi, (Alo), W]
+    constexpr int OFF_L = C::A_BYTES, OFF_W = (SPLIT ? 2 : 1) * C::A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / C::WN, wn = w % C::WN;
 
     // ---- XCD-aware + M-grouped tile mapping (speed only; any mapping is correct) ----
     const int nwg = p.tiles_m * p.tiles_n;
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
     const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
     const int tile_m = first_m + (bid % gsz) % gm;
     const int tile_n = (bid % gsz) / gm;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
 
     const T* Ahi = (const T*)p.Ahi;
     const T* Alo = (const T*)p.Alo;
@@ -120,25 +133,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
-        const int k0 = kt * BK;
+        const int k0 = kt * C::BK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rg = w * 2 + i;                                   // 16-row group 0..7
-            dma_rows16<T>(Ahi, p.lda, m0 + rg * 16, p.M, k0, base + rg * 1024, lane);
-            if (SPLIT) dma_rows16<T>(Alo, p.lda, m0 + rg * 16, p.M, k0, base + MAT_BYTES + rg * 1024, lane);
-            dma_rows16<T>(Wt, p.ldw, n0 + rg * 16, p.N, k0, base + (NMAT - 1) * MAT_BYTES + rg * 1024, lane);
+        for (int i = 0; i < (C::BM / C::RPI) / C::NW; ++i) {
+            const int j = w + i * C::NW;                                   // DMA instruction index in the A tile
+            dma_rows<T, C>(Ahi, p.lda, m0 + j * C::RPI, p.M, k0, j * C::RPI, base + j * 1024, lane);
+            if (SPLIT) dma_rows<T, C>(Alo, p.lda, m0 + j * C::RPI, p.M, k0, j * C::RPI, base + OFF_L + j * 1024, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < (C::BN / C::RPI) / C::NW; ++i) {
+            const int j = w + i * C::NW;
+            dma_rows<T, C>(Wt, p.ldw, n0 + j * C::RPI, p.N, k0, j * C::RPI, base + OFF_W + j * 1024, lane);
         }
     };
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[C::TM][C::TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < C::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nk = p.Kp / BK;
+    const int nk = p.Kp / C::BK;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -146,23 +163,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * STAGE;
         const char* sA = base;
-        const char* sL = base + MAT_BYTES;
-        const char* sW = base + (NMAT - 1) * MAT_BYTES;
+        const char* sL = base + OFF_L;
+        const char* sW = base + OFF_W;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < C::BK / 16; ++s) {
             const int c = s * 2 + (lane >> 5);
-            frag bf[2], ah[2], al[2];
+            frag bf[C::TN], ah[C::TM], al[C::TM];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) bf[tn] = *(const frag*)(sW + tile_off(wn * 64 + tn * 32 + (lane & 31), c));
+            for (int tn = 0; tn < C::TN; ++tn) bf[tn] = *(const frag*)(sW + C::off((wn * C::TN + tn) * 32 + (lane & 31), c));
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
-                ah[tm] = *(const frag*)(sA + tile_off(wm * 64 + tm * 32 + (lane & 31), c));
-                if (SPLIT) al[tm] = *(const frag*)(sL + tile_off(wm * 64 + tm * 32 + (lane & 31), c));
+            for (int tm = 0; tm < C::TM; ++tm) {
+                ah[tm] = *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
+                if (SPLIT) al[tm] = *(const frag*)(sL + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
             }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
+                for (int tn = 0; tn < C::TN; ++tn) {
                     acc[tm][tn] = Mfma<T>::run(ah[tm], bf[tn], acc[tm][tn]);
                     if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], bf[tn], acc[tm][tn]);
                 }
@@ -171,20 +188,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
 
     // ---- epilogue ----  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tm = 0; tm < C::TM; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            if (EPI == EPI_SWIGLU16 && tn == 1) continue;       // tn=0 holds gate, tn=1 holds up
-            const int n = n0 + wn * 64 + tn * 32 + (lane & 31);
-            // SwiGLU packing: W rows are interleaved in blocks of 32: [gate 32 | up 32] per 64 rows,
-            // so output column = (n0 + wn*64)/2 + (lane&31).
-            const int ncol = (EPI == EPI_SWIGLU16) ? ((n0 + wn * 64) >> 1) + (lane & 31) : n;
+        for (int tn = 0; tn < C::TN; ++tn) {
+            if (EPI == EPI_SWIGLU16 && (tn & 1)) continue;       // even tn holds gate, tn+1 holds up
+            const int n = n0 + (wn * C::TN + tn) * 32 + (lane & 31);
+            // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so the
+            // output column of the (tn, tn+1) pair is (its 64-aligned base)/2 + (lane&31).
+            const int ncol = (EPI == EPI_SWIGLU16) ? ((n0 + (wn * C::TN + tn) * 32) >> 1) + (lane & 31) : n;
             const int nlim = (EPI == EPI_SWIGLU16) ? (p.N >> 1) : p.N;
             if (ncol >= nlim) continue;
             const float bv = (p.bias != nullptr && EPI != EPI_SWIGLU16) ? p.bias[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + (wm * C::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M) continue;
                 float v = acc[tm][tn][r] + bv;
                 if (EPI == EPI_F32) {
@@ -199,7 +216,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
                 } else if (EPI == EPI_OUT16) {
                     ((T*)p.Ohi)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(v);
                 } else if (EPI == EPI_SWIGLU16) {
-                    float gate = acc[tm][0][r], up = acc[tm][1][r];
+                    constexpr int tu = (C::TN > 1) ? 1 : 0;
+                    float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
                     ((T*)p.Ohi)[(size_t)m * p.ldo + ncol] = Mfma<T>::cvt(silu(gate) * up);
                 }
             }
@@ -207,25 +225,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmParams p) 
     }
 }
 
-template <typename T, bool SPLIT, int EPI>
-static int launch_gemm(const GemmParams& p, hipStream_t s) {
-    constexpr int NMAT = SPLIT ? 3 : 2;
-    constexpr int LDS = 2 * NMAT * MAT_BYTES;
-    auto kern = gemm_kernel<T, SPLIT, EPI>;
+template <typename T, bool SPLIT, int EPI, typename C>
+static int launch_gemm(GemmParams p, hipStream_t s) {
+    constexpr int LDS = 2 * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
+    static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
+    auto kern = gemm_kernel<T, SPLIT, EPI, C>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    kern<<<p.tiles_m * p.tiles_n, GEMM_THREADS, LDS, s>>>(p);
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    kern<<<p.tiles_m * p.tiles_n, C::THREADS, LDS, s>>>(p);
     return check_launch("gemm");
 }
 
-template <typename T>
+template <typename T, typename C>
 static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 #define CASE(E)                                                      \
     case E:                                                          \
-        return split ? launch_gemm<T, true, E>(p, s) : launch_gemm<T, false, E>(p, s);
+        return split ? launch_gemm<T, true, E, C>(p, s) : launch_gemm<T, false, E, C>(p, s);
     switch (epi) {
         CASE(EPI_F32)
         CASE(EPI_RESID)
@@ -239,6 +259,28 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
     return LLARK_ERR_INVALID;
 }
 
+// Tile variants (tuning knob; every variant computes the same result).
+typedef Cfg<2, 2, 2, 2, 32, 3> Cfg0;   // 128x128x32, 4 waves, 48 KiB (split)      : 3 blocks/CU
+typedef Cfg<4, 2, 2, 2, 32, 4> Cfg1;   // 256x128x32, 8 waves, 80 KiB               : 2 blocks/CU
+typedef Cfg<2, 2, 2, 4, 32, 2> Cfg2;   // 128x256x32, 4 waves (64x128 per wave), 64 KiB : 2 blocks/CU
+typedef Cfg<4, 2, 2, 4, 32, 2> Cfg3;   // 256x256x32, 8 waves (64x128 per wave), 96 KiB : 1 block/CU
+typedef Cfg<2, 2, 2, 2, 64, 1> Cfg4;   // 128x128x64, 4 waves, 96 KiB               : 1 block/CU
+typedef Cfg<2, 2, 4, 2, 32, 2> Cfg5;   // 256x128x32, 4 waves (128x64 per wave), 80 KiB : 2 blocks/CU
+
+template <typename T>
+static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
+    switch (variant) {
+        case 0: return dispatch<T, Cfg0>(p, split, epi, s);
+        case 1: return dispatch<T, Cfg1>(p, split, epi, s);
+        case 2: return dispatch<T, Cfg2>(p, split, epi, s);
+        case 3: return dispatch<T, Cfg3>(p, split, epi, s);
+        case 4: return dispatch<T, Cfg4>(p, split, epi, s);
+        case 5: return dispatch<T, Cfg5>(p, split, epi, s);
+    }
+    set_error("gemm: unknown tile variant %d", variant);
+    return LLARK_ERR_INVALID;
+}
+
 }  // namespace llark
 
 using namespace llark;
@@ -247,12 +289,22 @@ using namespace llark;
 // Wt is [N][ldw] (K-contiguous rows, i.e. the transpose of upstream Conv1D.w / the native layout of
 // nn.Linear.weight); K is padded with zeros up to kp (multiple of 32) in BOTH A and Wt.  M and N
 // need no padding: out-of-range rows are clamped on load and masked on store.
-extern "C" int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
-                            const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
-                            const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
-                            llark_stream_t stream) {
+// Default tile choice, from the MI355X sweep in profiles/r01_gemm_variants.txt: wide per-wave tiles
+// (64x128 per wave, 128x256 per block) win when K is deep; the 8-wave 256x128 block wins for shallow K
+// (more blocks in flight per K-loop); tiny M keeps the small tile so that enough blocks exist.
+static int pick_variant(int split, int m, int n, int kp) {
+    (void)split;
+    if (m <= 128 || n < 256) return 0;
+    if (kp < 2048) return 1;
+    return 2;
+}
+
+extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                               const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                               const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                               llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
-    LLARK_REQUIRE(kp % BK == 0, "gemm16: kp=%d must be a multiple of %d (zero-pad K)", kp, BK);
+    LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant != 4), "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
     LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16: lda/ldw must be >= kp and multiples of 8");
     LLARK_REQUIRE(!split || a_lo, "gemm16: split mode needs the lo plane");
     LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && (!a_lo || ((uintptr_t)a_lo & 15) == 0),
@@ -266,10 +318,18 @@ extern "C" int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
     p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
-    p.tiles_m = cdiv(m, BM); p.tiles_n = cdiv(n, BN);
+    p.tiles_m = p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == LLARK_F16) return dispatch<half_t>(p, split != 0, epilogue, s);
-    if (dtype == LLARK_BF16) return dispatch<bf16_t>(p, split != 0, epilogue, s);
+    if (variant < 0) variant = pick_variant(split, m, n, kp);
+    if (dtype == LLARK_F16) return dispatch_variant<half_t>(variant, p, split != 0, epilogue, s);
+    if (dtype == LLARK_BF16) return dispatch_variant<bf16_t>(variant, p, split != 0, epilogue, s);
     set_error("gemm16: unknown dtype %d", dtype);
     return LLARK_ERR_INVALID;
+}
+
+extern "C" int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                            const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                            const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    return llark_gemm16_ex(-1, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
+                           out_lo, ldo, stream);
 }

@@ -218,7 +218,8 @@ def split16(x: torch.Tensor, dtype: torch.dtype, want_lo: bool = True, kmult: in
 
 def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], n: int,
            epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
-           out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
+           out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
+           variant: int = -1) -> None:
     """C[m,n] = (a_hi [+ a_lo]) . wt^T (+bias) with a fused epilogue; see include/llark_hip.h."""
     dtype = a_hi.dtype
     assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype
@@ -227,8 +228,8 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     assert a_hi.shape[1] >= kp and wt.shape[0] >= n, f"gemm16: A has {a_hi.shape[1]} cols, wt {tuple(wt.shape)}, n={n}"
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
     with _timed(name, 2.0 * m * n * kp):
-      check(_lib.lib().llark_gemm16(
-        _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
+      check(_lib.lib().llark_gemm16_ex(
+        variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
         a_hi.stride(0), _dev(wt, "wt"), wt.stride(0), _dev(bias, "bias", torch.float32) if bias is not None else None,
         m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
         _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,

@@ -112,8 +112,8 @@ def test_engine_vs_oracle_and_reference_golden():
     from test_oracle_llama import load_gold
     from oracle import llama_ref as LR
     z, spec, w = load_gold("llama_hd128.npz")
-    wb = {k: _bf(v) for k, v in w.items()}
-    eng = _engine_from(spec, w)
+    wb = {k: _bf(v) for k, v in w.items()}          # the reference's model.to(bf16): EVERY parameter is bf16-valued
+    eng = _engine_from(spec, wb)
     ids = torch.from_numpy(z["c1_ids"])
     aud = torch.from_numpy(z["c1_audio"])
     segs = [(b, int((ids[b] == spec.audio_start_token).nonzero()[0, 0]), aud[b].cuda()) for b in range(ids.shape[0])]
@@ -150,7 +150,7 @@ def test_wrapped_model_api_loss_generate_errors():
     cfg.mm_hidden_size = spec.mm_hidden_size
     m = WrappedLlamav2ForCausalLM(cfg).eval()
     m.get_model().initialize_adapter_modules()
-    missing, unexpected = m.load_state_dict(w, strict=False)
+    missing, unexpected = m.load_state_dict(wb, strict=False)
     assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing)
     ac = m.get_model().audio_encoder_config
     ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = 98, 99, 97

@@ -63,6 +63,24 @@ def test_gemm_split_f16(m, n, k):
         assert err1.max() > 8 * err.max()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+def test_gemm_tile_variants(variant):
+    """Every tile variant computes the same product (ragged M/N, K padded to 64)."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(variant)
+    m, n, k = 333, 450, 200
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g)
+    hi, lo = ops.split16(a.cuda(), torch.float16, kmult=64)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16, kmult=64)
+    c = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, lo, wt, b.cuda(), n, ops.EPI_F32, c=c, variant=variant)
+    ref = a.double() @ w.double() + b.double()
+    worst = ((c.cpu().double() - ref).abs() / (a.abs().double() @ w.abs().double())).max().item()
+    assert worst < 6e-7, worst
+
+
 def test_gemm_epilogues():
     from llark_amd import ops
     g = torch.Generator().manual_seed(9)
