@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------
 // Factored attention (block / transpose-block / previous-block), fp32, one workgroup per
-// (query group, head, clip).  Q, K/V tiles and the score tile live in LDS; scores, softmax and PV
-// are fp32 fma chains (d / key ascending).  Output is written as fp16 hi/lo for the c_proj GEMM.
+// (64-query group, head, clip).  Q K^T and P V run on the fp32-input matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 fma chains at the fp32 vector rate, no precision trade), the
+// softmax is fp32 in LDS.  K / V^T tiles of 64 keys and the score tile live in LDS (65-82 KiB).
+// Output is written as fp16 hi/lo for the c_proj GEMM.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
     const float* qkv;   // [n*T][ldq]: q | k | v column blocks of n_state each
@@ -128,16 +130,68 @@ struct AttnParams {
     int nk_max;         // LDS rows reserved for K/V
 };
 
-__global__ __launch_bounds__(256) void prior_attn_kernel(const AttnParams p) {
+// LDS geometry (floats): one [64][ATT_KP] tile that holds Q, then each K tile, then each V tile
+// (all row-major, staged with coalesced 8-byte row loads); scores [64][SP].  ATT_KP = 188 and
+// SP = 68 / 132 keep the ds_read_b128 operand reads at <= 2-way bank conflicts.
+enum { ATT_KP = 188 };
+
+// 16 token rows (this wave's quarter of a 64-row tile) of `hd` floats, HBM -> registers -> LDS.
+// All 32 global loads of the quarter are issued back to back (addresses are clamped so the loads are
+// unconditional; invalid elements are zeroed by a select on the way to LDS), so the wave keeps 16 KiB in
+// flight and the NEXT tile's loads can be issued before the current tile's MFMA phase (issue-early /
+// write-late), which is what hides the HBM latency in this kernel.
+struct RowRegs {
+    float2 v[16][2];
+};
+__device__ __forceinline__ void load_rows16(RowRegs& R, int row0, const float* __restrict__ base, size_t tok0,
+                                            int tok_stride, int ldq, int nvalid, int hd, int lane) {
+    const int rlast = nvalid > 0 ? nvalid - 1 : 0;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = row0 + rr;
+        const int re = r < rlast ? r : rlast;
+        const float* src = base + (tok0 + (size_t)re * tok_stride) * ldq;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int d = 2 * (lane + 64 * it);
+            const int de = d < hd ? d : hd - 2;
+            R.v[rr][it] = *(const float2*)(src + de);
+        }
+    }
+}
+__device__ __forceinline__ void store_rows16(const RowRegs& R, float* __restrict__ tile, int row0, int nvalid, int hd,
+                                             int wcols, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = row0 + rr;
+        const bool live = r < nvalid;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int d = 2 * (lane + 64 * it);
+            if (d < wcols) {
+                const bool ok = live && d < hd;
+                *(float2*)(tile + r * ATT_KP + d) = ok ? R.v[rr][it] : make_float2(0.f, 0.f);
+            }
+        }
+    }
+}
+
+// MFMA k-slot convention used below (any consistent A/B assignment is valid): in the j-th of four
+// consecutive v_mfma_f32_16x16x4_f32, lane group g = lane>>4 supplies reduction index 16*ks + 4*g + j,
+// so a row-major operand is fetched as ONE float4 per lane.
+template <int NKS>      // NKS = compile-time number of 16-wide head-dim steps (>= ceil(hd/16)); pad columns are zero
+__global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
     const int head = blockIdx.y;
     const int clip = blockIdx.z;
-    const int hd = p.hd, hdp = p.hdp;
-    const int sp = p.nk_max + 1;                 // score pitch
-    float* sQ = sm;                               // [64][hdp]
-    float* sK = sQ + 64 * hdp;                    // [nk_max][hdp]
-    float* sS = sK + p.nk_max * hdp;              // [64][sp]
+    const int hd = p.hd;
+    constexpr int nks = NKS;
+    constexpr int wcols = 16 * NKS;
+    const int sp = p.nk_max + 4;                  // score pitch (68 or 132)
+    float* sT = sm;                               // [64][ATT_KP]: K tiles, then V tiles
+    float* sS = sm + 64 * ATT_KP;                 // [64][sp]: rows of wave w are written and read by wave w only
 
     int nq, q0, qs, nkeys, k0, ks, coff;
     bool causal = true, zero_out = false;
@@ -169,105 +223,131 @@ __global__ __launch_bounds__(256) void prior_attn_kernel(const AttnParams p) {
         }
         return;
     }
+    const int ntile = (nkeys + 63) >> 6;
+    const float* kbase = p.qkv + p.n_state + hcol;
+    const float* vbase = p.qkv + 2 * p.n_state + hcol;
 
-    // ---- stage Q and K ----
-    for (int i = tid; i < nq * hd; i += 256) {
-        const int r = i / hd, d = i - r * hd;
-        sQ[r * hdp + d] = p.qkv[(rowbase + q0 + (size_t)r * qs) * p.ldq + hcol + d];
-    }
-    for (int i = tid; i < nkeys * hd; i += 256) {
-        const int r = i / hd, d = i - r * hd;
-        sK[r * hdp + d] = p.qkv[(rowbase + k0 + (size_t)r * ks) * p.ldq + p.n_state + hcol + d];
-    }
-    __syncthreads();
-
-    // ---- S = scale2 * Q K^T (4 rows x 8 strided columns per thread) ----
-    const int ti = tid >> 4, tj = tid & 15;
+    // ---- first K tile in flight, then the Q fragments straight from HBM (lane (c,g) keeps
+    //      Q[row c][16s+4g .. +3]; each row is consumed in 64-B pieces, the lines stay in L2) ----
+    RowRegs R;
+    load_rows16(R, wv * 16, kbase, rowbase + k0, ks, p.ldq, nkeys, hd, lane);
+    f32x4_t qf[NKS];
     {
-        float s[4][8];
+        int qr = wv * 16 + c;
+        qr = qr < nq ? qr : nq - 1;
+        const float* qrow = p.qkv + (rowbase + q0 + (size_t)qr * qs) * p.ldq + hcol;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) s[a][c] = 0.0f;
-        const int nc = (nkeys + 15) >> 4;            // uniform
-        for (int d = 0; d < hd; ++d) {
-            float qv[4], kv[8];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) qv[a] = sQ[(ti * 4 + a) * hdp + d];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) kv[c] = (c < nc) ? sK[(tj + 16 * c) * hdp + d] : 0.0f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) s[a][c] = fmaf(qv[a], kv[c], s[a][c]);
+        for (int s = 0; s < NKS; ++s) {
+            int d = 16 * s + 4 * g;
+            const bool in0 = d < hd, in1 = d + 2 < hd;
+            const float2 a = *(const float2*)(qrow + (in0 ? d : 0));
+            const float2 b = *(const float2*)(qrow + (in1 ? d + 2 : 0));
+            qf[s][0] = in0 ? a.x : 0.0f;
+            qf[s][1] = in0 ? a.y : 0.0f;
+            qf[s][2] = in1 ? b.x : 0.0f;
+            qf[s][3] = in1 ? b.y : 0.0f;
         }
+    }
+
+    // ---- scores: S = scale2 * Q K^T, one 64-key tile at a time; the next tile (K, then V) is
+    //      already being fetched while the MFMAs of the current one run ----
+    for (int kt = 0; kt < ntile; ++kt) {
+        if (kt) __syncthreads();                  // previous K tile fully consumed
+        store_rows16(R, sT, wv * 16, nkeys - kt * 64, hd, wcols, lane);
+        __syncthreads();
+        if (kt + 1 < ntile) load_rows16(R, wv * 16, kbase, rowbase + k0 + (size_t)(kt + 1) * 64 * ks, ks, p.ldq, nkeys - (kt + 1) * 64, hd, lane);
+        else load_rows16(R, wv * 16, vbase, rowbase + k0, ks, p.ldq, nkeys, hd, lane);
+        f32x4_t acc[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = ti * 4 + a;
+        for (int sub = 0; sub < 4; ++sub) acc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int j = tj + 16 * c;
-                if (c < nc && i < nq && j < nkeys) {
-                    const bool ok = !causal || (j <= i + coff);
-                    sS[i * sp + j] = ok ? s[a][c] * p.scale2 : -INFINITY;
-                }
+        for (int s = 0; s < NKS; ++s) {
+            {
+                f32x4_t kf[4];
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) kf[sub] = *(const f32x4_t*)(sT + (sub * 16 + c) * ATT_KP + 16 * s + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)      // 4 independent accumulators between dependent MFMAs
+                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s][j], kf[sub][j], acc[sub], 0, 0, 0);
+            }
+        }
+        // C layout: col = c (key), rows = 4g + r (query within the wave's 16)
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = wv * 16 + 4 * g + r;
+                const int j = kt * 64 + sub * 16 + c;
+                const bool ok = (j < nkeys) && (!causal || (j <= i + coff));
+                sS[i * sp + j] = ok ? acc[sub][r] * p.scale2 : -INFINITY;
+            }
+    }
+
+    // ---- fp32 softmax over the wave's own 16 rows (no block barrier needed) ----
+    const int ncol = ntile * 64;
+    for (int r = wv * 16; r < wv * 16 + 16; ++r) {
+        float v0 = lane < ncol ? sS[r * sp + lane] : -INFINITY;
+        float v1 = (lane + 64) < ncol ? sS[r * sp + lane + 64] : -INFINITY;
+        const float mx = wave_max(fmaxf(v0, v1));
+        const float e0 = (lane < ncol && mx > -INFINITY) ? expf(v0 - mx) : 0.0f;
+        const float e1 = ((lane + 64) < ncol && mx > -INFINITY) ? expf(v1 - mx) : 0.0f;
+        const float sum = wave_sum(e0 + e1);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+        if (lane < ncol) sS[r * sp + lane] = e0 * inv;
+        if (lane + 64 < ncol) sS[r * sp + lane + 64] = e1 * inv;
+    }
+
+    // ---- O^T = V^T P^T per 64-key tile: A operand = V^T[d][key] read column-wise from the row-major V
+    //      tile, B operand = P^T[key][q] = one float4 of the score row; O^T acc: col = q, rows = d ----
+    f32x4_t o[NKS];
+#pragma unroll
+    for (int dt = 0; dt < NKS; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ntile; ++kt) {
+        __syncthreads();                          // K (or previous V) tile fully consumed by every wave
+        store_rows16(R, sT, wv * 16, nkeys - kt * 64, hd, wcols, lane);
+        __syncthreads();
+        if (kt + 1 < ntile) load_rows16(R, wv * 16, vbase, rowbase + k0 + (size_t)(kt + 1) * 64 * ks, ks, p.ldq, nkeys - (kt + 1) * 64, hd, lane);
+        const float* prow = sS + (wv * 16 + c) * sp + kt * 64 + 4 * g;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4_t pf = *(const f32x4_t*)(prow + 16 * s);
+            const float* vcol = sT + (16 * s + 4 * g) * ATT_KP + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float vv[NKS];
+#pragma unroll
+                for (int dt = 0; dt < NKS; ++dt) vv[dt] = vcol[j * ATT_KP + dt * 16];
+#pragma unroll
+                for (int dt = 0; dt < NKS; ++dt)        // NKS independent accumulators
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[dt], pf[j], o[dt], 0, 0, 0);
             }
         }
     }
-    __syncthreads();
-
-    // ---- stage V over K (all K reads are done) while the softmax runs on sS ----
-    for (int i = tid; i < nkeys * hd; i += 256) {
-        const int r = i / hd, d = i - r * hd;
-        sK[r * hdp + d] = p.qkv[(rowbase + k0 + (size_t)r * ks) * p.ldq + 2 * p.n_state + hcol + d];
-    }
+    // ---- store hi/lo fp16 (two 4-byte stores per 4 head-dim values): O^T layout col = c (query of this
+    //      wave), rows d = dt*16 + 4g + r ----
     {
-        const int lane = tid & 63, wv = tid >> 6;
-        for (int r = wv; r < nq; r += 4) {
-            float v0 = lane < nkeys ? sS[r * sp + lane] : -INFINITY;
-            float v1 = (lane + 64) < nkeys ? sS[r * sp + lane + 64] : -INFINITY;
-            const float mx = wave_max(fmaxf(v0, v1));
-            const float e0 = lane < nkeys ? expf(v0 - mx) : 0.0f;
-            const float e1 = (lane + 64) < nkeys ? expf(v1 - mx) : 0.0f;
-            const float sum = wave_sum(e0 + e1);
-            if (lane < nkeys) sS[r * sp + lane] = e0 / sum;
-            if (lane + 64 < nkeys) sS[r * sp + lane + 64] = e1 / sum;
-        }
-    }
-    __syncthreads();
-
-    // ---- O = P V (4 rows x 10 strided head-dim columns per thread) ----
-    {
-        constexpr int NE = 10;                        // 16*10 = 160 >= head_dim (150)
-        float o[4][NE];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int e = 0; e < NE; ++e) o[a][e] = 0.0f;
-        const int ne = (hd + 15) >> 4;
-        for (int j = 0; j < nkeys; ++j) {
-            float pv[4], vv[NE];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) pv[a] = sS[(ti * 4 + a) * sp + j];
-#pragma unroll
-            for (int e = 0; e < NE; ++e) vv[e] = (e < ne && tj + 16 * e < hd) ? sK[j * hdp + tj + 16 * e] : 0.0f;
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int e = 0; e < NE; ++e) o[a][e] = fmaf(pv[a], vv[e], o[a][e]);
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int i = ti * 4 + a;
-            if (i >= nq) continue;
+        const int i = wv * 16 + c;
+        if (i < nq) {
             const size_t ob = (rowbase + q0 + (size_t)i * qs) * p.ldo + hcol;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int d = tj + 16 * e;
-                if (e < ne && d < hd) {
-                    const half_t h = (half_t)o[a][e];
-                    p.ohi[ob + d] = h;
-                    p.olo[ob + d] = (half_t)(o[a][e] - (float)h);
+            for (int dt = 0; dt < NKS; ++dt) {
+                {
+                    const int d = dt * 16 + 4 * g;
+                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (d + 2 * e < hd) {          // hd is even: a pair is either fully in or fully out
+                            half2_t h, l;
+                            h[0] = (half_t)o[dt][2 * e];
+                            h[1] = (half_t)o[dt][2 * e + 1];
+                            l[0] = (half_t)(o[dt][2 * e] - (float)h[0]);
+                            l[1] = (half_t)(o[dt][2 * e + 1] - (float)h[1]);
+                            *(half2_t*)(p.ohi + ob + d + 2 * e) = h;
+                            *(half2_t*)(p.olo + ob + d + 2 * e) = l;
+                        }
+                    }
                 }
             }
         }
@@ -376,15 +456,25 @@ extern "C" int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_s
         double sc = 1.0 / sqrt(sqrt((double)hd));
         p.scale2 = (float)(sc * sc);
     }
-    p.hdp = hd | 1;
-    p.nk_max = (pattern == 2) ? blocks : bc;
-    if (p.nk_max < 16) p.nk_max = 16;
+    p.hdp = 0;
+    p.nk_max = (pattern == 2 && blocks > 64) ? 128 : 64;      // score columns: one or two 64-key tiles
     int gx = (pattern == 2) ? bc * (blocks / p.qc) : blocks;
-    size_t lds = ((size_t)64 * p.hdp + (size_t)p.nk_max * p.hdp + (size_t)64 * (p.nk_max + 1)) * sizeof(float);
+    size_t lds = ((size_t)64 * ATT_KP + (size_t)64 * (p.nk_max + 4)) * sizeof(float);
+    LLARK_REQUIRE(hd % 2 == 0 && n_state % 2 == 0 && ldq % 2 == 0 && ldo % 2 == 0,
+                  "prior_attn: head_dim, n_state, ldq and ldo must be even (8-byte row loads, 4-byte stores)");
     LLARK_REQUIRE(lds <= 160 * 1024, "prior_attn: LDS %zu B exceeds 160 KiB", lds);
-    (void)hipFuncSetAttribute((const void*)prior_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(gx, heads, n);
-    prior_attn_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(p);
+    const int need = (hd + 15) / 16;
+#define ATT_LAUNCH(NKS)                                                                                              \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)prior_attn_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        prior_attn_kernel<NKS><<<grid, 256, lds, (hipStream_t)stream>>>(p);                                           \
+    } while (0)
+    if (need <= 2) ATT_LAUNCH(2);
+    else if (need <= 4) ATT_LAUNCH(4);
+    else if (need <= 8) ATT_LAUNCH(8);
+    else ATT_LAUNCH(10);
+#undef ATT_LAUNCH
     return check_launch("prior_attn");
 }
 

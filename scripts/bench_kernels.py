@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the non-GEMM kernels at the BASELINE shapes (run on the GPU box)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from llark_amd import ops
+
+dev = "cuda"
+which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["attn", "ln", "res"]
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+B, T, W, S, heads, blocks = 8, 8192, 4800, 1200, 8, 128
+g = torch.Generator(device=dev).manual_seed(0)
+if "attn" in which:
+    qkv = torch.randn(B * T, 3 * S, generator=g, device=dev)
+    hi = torch.zeros(B * T, 1216, dtype=torch.float16, device=dev)
+    lo = torch.zeros_like(hi)
+    for pat in (1, 2, 3):
+        ms = timeit(lambda: ops.prior_attn(qkv, B, T, S, heads, blocks, pat, hi, lo))
+        gb = (qkv.numel() * 4 + 2 * B * T * S * 2) / 1e9
+        print(f"prior_attn pattern {pat}: {ms*1e3:8.1f} us  ({gb/ms*1e3/1e3:.2f} TB/s of qkv-read-once + out bytes)", flush=True)
+if "ln" in which:
+    x = torch.randn(B * T, W, generator=g, device=dev)
+    gam = torch.ones(W, device=dev)
+    bet = torch.zeros(W, device=dev)
+    hi = torch.zeros(B * T, W, dtype=torch.float16, device=dev)
+    lo = torch.zeros_like(hi)
+    ms = timeit(lambda: ops.layernorm_split(x, gam, bet, 1e-5, hi, lo))
+    print(f"layernorm_split: {ms*1e3:8.1f} us  ({x.numel()*8/1e9/ms:.2f} TB/s)", flush=True)
+if "res" in which:
+    for (t, dil) in [(524288, 1), (524288, 27), (262144, 3), (131072, 9)]:
+        x = torch.randn(B, 32, t, generator=g, device=dev)
+        w1 = ops.pack_conv_weight(torch.randn(32, 32, 3, generator=g, device=dev) * 0.1)
+        w2 = ops.pack_conv_weight(torch.randn(32, 32, 1, generator=g, device=dev) * 0.1)
+        b1 = torch.zeros(32, device=dev)
+        y = torch.empty_like(x)
+        ms = timeit(lambda: ops.resblock(x, w1, b1, w2, b1, dil, out=y))
+        print(f"resblock T={t} dil={dil}: {ms*1e3:8.1f} us  ({x.numel()*8/1e9/ms:.2f} TB/s algorithmic, {B*t*8192/1e9/ms:.1f} TFLOP/s)", flush=True)

@@ -143,7 +143,7 @@ def test_layernorm_split(rows, width):
 @pytest.mark.parametrize("pattern", [1, 2, 3])
 @pytest.mark.parametrize("cfg", ["tiny", "full"])
 def test_factored_attention(pattern, cfg):
-    """vs oracle factored_attention (fp32). Bound 2e-6 abs+rel on O(1) values (+ hi/lo output rounding)."""
+    """vs oracle factored_attention (fp32). Bound 6e-6 abs+rel on O(1) values: fp32 MFMA chains + hi/lo (22-bit) output."""
     from llark_amd import ops
     from oracle import jukebox_ref as R
     if cfg == "tiny":
@@ -160,7 +160,7 @@ def test_factored_attention(pattern, cfg):
     lo = torch.zeros_like(hi)
     ops.prior_attn(qkv.view(n * t, 3 * S).cuda(), n, t, S, heads, blocks, pattern, hi, lo)
     got = (hi.float() + lo.float())[:, :S].cpu().view(n, t, S)
-    report_close(f"attn pattern {pattern} {cfg}", got, ref, 3e-6, 3e-6)
+    report_close(f"attn pattern {pattern} {cfg}", got, ref, 6e-6, 6e-6)
     assert (hi[:, S:] == 0).all()
     if pattern == 3:
         assert (got[:, : t // blocks] == 0).all()
