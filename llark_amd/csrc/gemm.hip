@@ -19,14 +19,17 @@
 // fragment reads are bank-conflict free; one barrier per K-step; 48 KiB LDS -> 3 blocks/CU.
 // blockIdx is remapped XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and
 // grouped over M so that co-resident blocks share A and W panels.
+#include <type_traits>
+
 #include "common.h"
 
 namespace llark {
 
 // Tile configuration: WM x WN waves, each owning TM x TN MFMA tiles of 32x32; K-step BK (32 or 64).
-template <int WM_, int WN_, int TM_, int TN_, int BK_, int MINW_>
+template <int WM_, int WN_, int TM_, int TN_, int BK_, int MINW_, int NSTAGE_ = 2>
 struct Cfg {
     static constexpr int MINW = MINW_;             // __launch_bounds__ waves/SIMD the register allocator must allow
+    static constexpr int NSTAGE = NSTAGE_;         // LDS ring depth (2 = double buffer; 3 keeps one tile in flight across the barrier)
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NW = WM * WN, THREADS = NW * 64;
@@ -97,15 +100,24 @@ __device__ __forceinline__ void dma_rows(const T* __restrict__ g, int ld, int gr
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + expf(-1.702f * x)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(a x) with the hardware exp2 / rcp (each <= 1 ulp): ~1e-7 relative, far inside the tolerance
+// of activations whose reference (cuDNN/ATen on another GPU) is not bit-defined either; keeps the epilogue
+// at a handful of VALU ops per element instead of IEEE division + range-reduced expf.
+__device__ __forceinline__ float fast_sigmoid_mul(float x, float a) {
+    const float e = __builtin_amdgcn_exp2f(-a * 1.44269504088896341f * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float quick_gelu(float x) { return fast_sigmoid_mul(x, 1.702f); }
+__device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
 
 template <typename T, bool SPLIT, int EPI, typename C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
     constexpr int STAGE = (SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES;     // [Ahi, (Alo), W]
     constexpr int OFF_L = C::A_BYTES, OFF_W = (SPLIT ? 2 : 1) * C::A_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // NSTAGE stages
+    constexpr int NS = C::NSTAGE;
+    constexpr int LOADS_PER_STAGE = ((SPLIT ? 2 : 1) * (C::BM / C::RPI) + (C::BN / C::RPI)) / C::NW;   // DMA instrs per wave
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -157,11 +169,22 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
 
     const int nk = p.Kp / C::BK;
     stage(0, 0);
+    if (NS == 3 && nk > 1) stage(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* base = smem + (kt & 1) * STAGE;
+        if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        } else {
+            // 3-deep ring: tile kt must have landed, tile kt+1 may stay in flight across the barrier
+            // (counted vmcnt + raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
+        }
+        const char* base = smem + (NS == 2 ? (kt & 1) : (kt % 3)) * STAGE;
         const char* sA = base;
         const char* sL = base + OFF_L;
         const char* sW = base + OFF_W;
@@ -176,6 +199,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
                 ah[tm] = *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
                 if (SPLIT) al[tm] = *(const frag*)(sL + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
             }
+            // (measured: hoisting all fragment reads of a K-tile ahead of the MFMAs, or s_setprio around the MFMA
+            //  cluster, is 5-8 % SLOWER on this 1-barrier structure; the compiler's own interleave is kept)
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
@@ -187,47 +212,82 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     }
 
     // ---- epilogue ----  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
+    // `buffer_store v, voff, rsrc, soff` with ONE per-lane byte offset (same for all tiles/registers) and a
+    // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
+    const int nlim = (EPI == EPI_SWIGLU16) ? (p.N >> 1) : p.N;
+    const int mrow0 = m0 + wm * C::TM * 32;                      // uniform
+    const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
+    const int ocol0 = (EPI == EPI_SWIGLU16) ? (ncol0 >> 1) : ncol0;
+    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+    const int lr = 4 * (lane >> 5), lc = lane & 31;
+    constexpr unsigned RSRC_FLAGS = 0x00020000u;
+    __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
+    int vC = 0, vR = 0, vO = 0;
+    if (EPI == EPI_F32 || EPI == EPI_RESID) {
+        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vC = (lr * p.ldc + lc) * 4;
+    }
+    if (EPI == EPI_RESID) {
+        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vR = (lr * p.ldr + lc) * 4;
+    }
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || EPI == EPI_SWIGLU16) {
+        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vO = (lr * p.ldo + lc) * 2;
+    }
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16)
+        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
+        for (int tm = 0; tm < C::TM; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            if (EPI == EPI_SWIGLU16 && (tn & 1)) continue;       // even tn holds gate, tn+1 holds up
-            const int n = n0 + (wn * C::TN + tn) * 32 + (lane & 31);
-            // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so the
-            // output column of the (tn, tn+1) pair is (its 64-aligned base)/2 + (lane&31).
-            const int ncol = (EPI == EPI_SWIGLU16) ? ((n0 + (wn * C::TN + tn) * 32) >> 1) + (lane & 31) : n;
-            const int nlim = (EPI == EPI_SWIGLU16) ? (p.N >> 1) : p.N;
-            if (ncol >= nlim) continue;
-            const float bv = (p.bias != nullptr && EPI != EPI_SWIGLU16) ? p.bias[n] : 0.0f;
+            for (int tn = 0; tn < C::TN; ++tn) {
+                if (EPI == EPI_SWIGLU16 && (tn & 1)) continue;       // even tn holds gate, tn+1 holds up
+                // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
+                // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
+                const int ocl = (EPI == EPI_SWIGLU16) ? (tn >> 1) * 32 : tn * 32;           // compile-time
+                if (!FULL && ocol0 + ocl + lc >= nlim) continue;
+                const float bv = (p.bias != nullptr && EPI != EPI_SWIGLU16) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * C::TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M) continue;
-                float v = acc[tm][tn][r] + bv;
-                if (EPI == EPI_F32) {
-                    p.C[(size_t)m * p.ldc + n] = v;
-                } else if (EPI == EPI_RESID) {
-                    p.C[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + v;
-                } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
-                    if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
-                    T hi = Mfma<T>::cvt(v);
-                    ((T*)p.Ohi)[(size_t)m * p.ldo + n] = hi;
-                    ((T*)p.Olo)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(v - Mfma<T>::back(hi));
-                } else if (EPI == EPI_OUT16) {
-                    ((T*)p.Ohi)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(v);
-                } else if (EPI == EPI_SWIGLU16) {
-                    constexpr int tu = (C::TN > 1) ? 1 : 0;
-                    float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
-                    ((T*)p.Ohi)[(size_t)m * p.ldo + ncol] = Mfma<T>::cvt(silu(gate) * up);
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
+                    if (!FULL && mrow0 + ml + lr >= p.M) continue;
+                    float v = acc[tm][tn][r] + bv;
+                    if (EPI == EPI_F32) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
+                    } else if (EPI == EPI_RESID) {
+                        const float res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + ocl) * 4, 0));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
+                    } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
+                        if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
+                        const T hi = Mfma<T>::cvt(v);
+                        const T lo = Mfma<T>::cvt(v - Mfma<T>::back(hi));
+                        const int so = (ml * p.ldo + ocl) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
+                    } else if (EPI == EPI_OUT16) {
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
+                                                              (ml * p.ldo + ocl) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU16) {
+                        constexpr int tu = (C::TN > 1) ? 1 : 0;
+                        const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
+                                                              vO, (ml * p.ldo + ocl) * 2, 0);
+                    }
                 }
             }
         }
-    }
+    };
+    if (full) epilogue(std::true_type{});      // interior tile: no per-element bounds checks
+    else epilogue(std::false_type{});
 }
 
 template <typename T, bool SPLIT, int EPI, typename C>
 static int launch_gemm(GemmParams p, hipStream_t s) {
-    constexpr int LDS = 2 * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
+    constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     auto kern = gemm_kernel<T, SPLIT, EPI, C>;
     static bool attr_set = false;
@@ -266,6 +326,10 @@ typedef Cfg<2, 2, 2, 4, 32, 2> Cfg2;   // 128x256x32, 4 waves (64x128 per wave),
 typedef Cfg<4, 2, 2, 4, 32, 2> Cfg3;   // 256x256x32, 8 waves (64x128 per wave), 96 KiB : 1 block/CU
 typedef Cfg<2, 2, 2, 2, 64, 1> Cfg4;   // 128x128x64, 4 waves, 96 KiB               : 1 block/CU
 typedef Cfg<2, 2, 4, 2, 32, 2> Cfg5;   // 256x128x32, 4 waves (128x64 per wave), 80 KiB : 2 blocks/CU
+typedef Cfg<4, 2, 2, 4, 32, 2, 3> Cfg6;   // 256x256x32, 8 waves, 3-stage ring, 144 KiB      : 1 block/CU
+typedef Cfg<2, 2, 2, 2, 32, 2, 3> Cfg7;   // 128x128x32, 4 waves, 3-stage ring, 72 KiB       : 2 blocks/CU
+typedef Cfg<4, 2, 2, 2, 32, 2, 3> Cfg8;   // 256x128x32, 8 waves, 3-stage ring, 120 KiB      : 1 block/CU
+typedef Cfg<2, 2, 2, 4, 32, 1, 3> Cfg9;   // 128x256x32, 4 waves, 3-stage ring, 96 KiB       : 1 block/CU
 
 template <typename T>
 static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
@@ -276,6 +340,10 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 3: return dispatch<T, Cfg3>(p, split, epi, s);
         case 4: return dispatch<T, Cfg4>(p, split, epi, s);
         case 5: return dispatch<T, Cfg5>(p, split, epi, s);
+        case 6: return dispatch<T, Cfg6>(p, split, epi, s);
+        case 7: return dispatch<T, Cfg7>(p, split, epi, s);
+        case 8: return dispatch<T, Cfg8>(p, split, epi, s);
+        case 9: return dispatch<T, Cfg9>(p, split, epi, s);
     }
     set_error("gemm: unknown tile variant %d", variant);
     return LLARK_ERR_INVALID;
