@@ -33,26 +33,19 @@ PEAK_HBM_GBS = 8000.0
 
 
 def _dist_setup(n_gpus: int):
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
-        import torch.distributed as dist
+    from llark_amd import dist as D
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rank, world, local = D.env_rank_world()
+    torch.cuda.set_device(local)
+    D.init(backend="nccl", device=torch.device("cuda", local))      # "nccl" IS RCCL on ROCm; only barrier + max-reduce use it
     assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
     return rank, world, local
 
 
 def _barrier(world):
-    torch.cuda.synchronize()
-    if world > 1:
-        import torch.distributed as dist
+    from llark_amd import dist as D
 
-        dist.barrier()
-    torch.cuda.synchronize()
+    D.barrier(world, cuda=True)
 
 
 def _prior_gemm_flops(hps, rows):
@@ -84,7 +77,9 @@ def build_workload(args, device):
     xe = enc.vqvae.encoder_forward(cal)[0]
     enc.vqvae.set_codebook(init_codebook_from_encodings(xe, hps.l_bins))
     weights["bottleneck.level_blocks.2.k"] = enc.vqvae.k.cpu()
-    audio = torch.from_numpy(np.stack([clip(rank * args.batch + i) for i in range(args.batch)])).to(device)
+    from llark_amd.dist import clip_indices
+
+    audio = torch.from_numpy(np.stack([clip(i) for i in clip_indices(rank, args.batch)])).to(device)
     llm = None
     if args.stages in ("e2e", "llama"):
         from llark_amd.m2t import bench_support
@@ -140,6 +135,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2)
+    ap.add_argument("--llm-precision", default="split", choices=["split", "bf16"],
+                    help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
 
     rank, world, local = _dist_setup(args.gpus)
@@ -166,12 +163,9 @@ def main():
         elapsed = time.perf_counter() - t0
         timers = ops.stop_kernel_timing()
 
-    if world > 1:
-        import torch.distributed as dist
+    from llark_amd import dist as D
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, world, device=device)
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -199,8 +193,9 @@ def main():
             "metric": "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp16x2-split(fp32-class)+bf16" if args.stages == "e2e" else (
-                "fp16x2-split(fp32-class)" if args.stages == "jukebox" else "bf16"),
+            "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
+                                           "jukebox": "fp16x2-split(fp32-class)",
+                                           "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16"}[args.stages],
             "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
                        "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": 371,
@@ -211,10 +206,7 @@ def main():
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    D.shutdown(world)
 
 
 if __name__ == "__main__":

@@ -39,7 +39,8 @@ enum {
     LLARK_EPI_QGELU_SPLIT = 2, /* g = x*sigmoid(1.702x), x = acc+bias -> hi/lo 16-bit planes     */
     LLARK_EPI_OUT16 = 3,       /* out = 16-bit(acc + bias)                                       */
     LLARK_EPI_SWIGLU16 = 4,    /* out = 16-bit(silu(gate) * up), W rows interleaved [32 gate|32 up] */
-    LLARK_EPI_SPLIT16 = 5      /* acc + bias -> hi/lo 16-bit planes                              */
+    LLARK_EPI_SPLIT16 = 5,     /* acc + bias -> hi/lo 16-bit planes                              */
+    LLARK_EPI_SWIGLU_SPLIT = 6 /* silu(gate)*up -> hi/lo 16-bit planes (fp32-class Llama mode)        */
 };
 
 int llark_version(void);
@@ -122,15 +123,19 @@ int llark_rmsnorm_bf16(const float* x, int ldx, int rows, int width, const float
 /* apply_rotary_pos_emb (half-split) + split heads + KV-cache write.  qkv fp32 [batch*s][3*nh*hd];
  * q bf16 [batch][nh][s][hd]; k_cache bf16 [batch][nh][smax][hd]; vt_cache bf16 [batch][nh][hd][smax]
  * (V transposed); rows/columns pos0..pos0+s-1 are written; cos/sin fp32 [max_pos][hd/2]. */
+/* q_lo / k_cache_lo / vt_cache_lo: optional second planes holding the bf16 rounding residual (all three or
+ * none): the "fp32-class" mode in which q, k, v keep 16 significant bits. */
 int llark_rope_split_heads(const float* qkv, int batch, int s, int nh, int hd, int pos0, const float* cos_t,
-                           const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, int smax,
-                           llark_stream_t stream);
+                           const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, void* q_lo,
+                           void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream);
 /* causal attention over the cache: query i sees keys j <= past + i. out bf16 [batch*s][nh*hd]. */
-int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh, int hd,
-                            int past, int smax, void* out, llark_stream_t stream);
+int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                            const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd, int past,
+                            int smax, void* out, void* out_lo, llark_stream_t stream);
 /* single-token attention over `total` cached keys. q bf16 [batch][nh][hd]; out bf16 [batch][nh*hd]. */
-int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int nh, int hd,
-                           int total, int smax, void* out, llark_stream_t stream);
+int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                           const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
+                           void* out, void* out_lo, llark_stream_t stream);
 /* CrossEntropyLoss on shifted logits (m2t/models/llamav2.py:316-325). logits fp32 [batch*s][ldl]; labels
  * int64 [batch][s]; row_loss scratch float[batch*s]; loss_out float[2] = {mean loss, counted rows}. */
 int llark_cross_entropy_shifted(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,

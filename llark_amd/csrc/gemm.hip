@@ -62,7 +62,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
 };
 
-enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5 };
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
+#define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
 
 template <typename T>
 struct Mfma;
@@ -215,10 +216,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
     // `buffer_store v, voff, rsrc, soff` with ONE per-lane byte offset (same for all tiles/registers) and a
     // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
-    const int nlim = (EPI == EPI_SWIGLU16) ? (p.N >> 1) : p.N;
+    const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
     const int mrow0 = m0 + wm * C::TM * 32;                      // uniform
     const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
-    const int ocol0 = (EPI == EPI_SWIGLU16) ? (ncol0 >> 1) : ncol0;
+    const int ocol0 = IS_SWIGLU(EPI) ? (ncol0 >> 1) : ncol0;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
     const int lr = 4 * (lane >> 5), lc = lane & 31;
     constexpr unsigned RSRC_FLAGS = 0x00020000u;
@@ -232,11 +233,11 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
         rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vR = (lr * p.ldr + lc) * 4;
     }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || EPI == EPI_SWIGLU16) {
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
         rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vO = (lr * p.ldo + lc) * 2;
     }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16)
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
         rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
 
     auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
@@ -245,12 +246,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
         for (int tm = 0; tm < C::TM; ++tm) {
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn) {
-                if (EPI == EPI_SWIGLU16 && (tn & 1)) continue;       // even tn holds gate, tn+1 holds up
+                if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
                 // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
                 // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
-                const int ocl = (EPI == EPI_SWIGLU16) ? (tn >> 1) * 32 : tn * 32;           // compile-time
+                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : tn * 32;                 // compile-time
                 if (!FULL && ocol0 + ocl + lc >= nlim) continue;
-                const float bv = (p.bias != nullptr && EPI != EPI_SWIGLU16) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
+                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
@@ -276,6 +277,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
                         const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
                                                               vO, (ml * p.ldo + ocl) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU_SPLIT) {
+                        constexpr int tu = (C::TN > 1) ? 1 : 0;
+                        const float a = silu(acc[tm][tn][r]) * acc[tm][(tn + tu) % C::TN][r];
+                        const T hi = Mfma<T>::cvt(a);
+                        const T lo = Mfma<T>::cvt(a - Mfma<T>::back(hi));
+                        const int so = (ml * p.ldo + ocl) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
                     }
                 }
             }
@@ -313,6 +322,7 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
         CASE(EPI_OUT16)
         CASE(EPI_SWIGLU16)
         CASE(EPI_SPLIT16)
+        CASE(EPI_SWIGLU_SPLIT)
     }
 #undef CASE
     set_error("gemm: unknown epilogue %d", epi);
@@ -381,7 +391,8 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
     if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16: residual missing");
     if (epilogue == EPI_QGELU_SPLIT || epilogue == EPI_SPLIT16) LLARK_REQUIRE(out_hi && out_lo && ldo >= n, "gemm16: split outputs missing");
     if (epilogue == EPI_OUT16) LLARK_REQUIRE(out_hi && ldo >= n, "gemm16: 16-bit output missing");
-    if (epilogue == EPI_SWIGLU16) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2, "gemm16: swiglu needs n%%64==0 and an output");
+    if (IS_SWIGLU(epilogue)) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2, "gemm16: swiglu needs n%%64==0 and an output");
+    if (epilogue == EPI_SWIGLU_SPLIT) LLARK_REQUIRE(out_lo, "gemm16: swiglu-split needs the lo output");
     GemmParams p;
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;

@@ -85,10 +85,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
 //   cos/sin tables: fp32 [max_pos][64]
 // grid (ceil(S/64), nh, B), block 256.
 // ------------------------------------------------------------------------------------------
+// hi/lo split store: plane `hi` gets bf16(v); if `lo` is given it gets bf16(v - hi) (fp32-class mode).
+__device__ __forceinline__ void store_split(bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, size_t idx, float v) {
+    const bf16_t h = (bf16_t)v;
+    hi[idx] = h;
+    if (lo) lo[idx] = (bf16_t)(v - (float)h);
+}
+
 __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict__ qkv, int S, int nh, int pos0,
                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                          bf16_t* __restrict__ q, bf16_t* __restrict__ kc,
-                                                         bf16_t* __restrict__ vtc, int smax) {
+                                                         bf16_t* __restrict__ vtc, bf16_t* __restrict__ q_lo,
+                                                         bf16_t* __restrict__ kc_lo, bf16_t* __restrict__ vtc_lo, int smax) {
     __shared__ float sv[64][129];
     const int hd = 128, H = nh * hd;
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
@@ -105,12 +113,12 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
         const float qb = __fadd_rn(__fmul_rn(q2, c), __fmul_rn(q1, sn));
         const float ka = __fadd_rn(__fmul_rn(k1, c), __fmul_rn(-k2, sn));
         const float kb = __fadd_rn(__fmul_rn(k2, c), __fmul_rn(k1, sn));
-        bf16_t* qo = q + (((size_t)b * nh + h) * S + s) * hd;
-        bf16_t* ko = kc + (((size_t)b * nh + h) * smax + pos) * hd;
-        qo[d] = (bf16_t)qa;
-        qo[d + 64] = (bf16_t)qb;
-        ko[d] = (bf16_t)ka;
-        ko[d + 64] = (bf16_t)kb;
+        const size_t qo = (((size_t)b * nh + h) * S + s) * hd;
+        const size_t ko = (((size_t)b * nh + h) * smax + pos) * hd;
+        store_split(q, q_lo, qo + d, qa);
+        store_split(q, q_lo, qo + d + 64, qb);
+        store_split(kc, kc_lo, ko + d, ka);
+        store_split(kc, kc_lo, ko + d + 64, kb);
     }
     // v: transpose the [ns tokens][128] tile through LDS -> [128][ns] runs along the key axis
     for (int i = threadIdx.x; i < ns * hd; i += 256) {
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
     __syncthreads();
     for (int i = threadIdx.x; i < hd * 64; i += 256) {
         const int d = i >> 6, t = i & 63;
-        if (t < ns) vtc[(((size_t)b * nh + h) * hd + d) * smax + pos0 + s0 + t] = (bf16_t)sv[t][d];
+        if (t < ns) store_split(vtc, vtc_lo, (((size_t)b * nh + h) * hd + d) * smax + pos0 + s0 + t, sv[t][d]);
     }
 }
 
@@ -136,13 +144,20 @@ __device__ __forceinline__ int p_off(int q, int key) {                          
     return q * 128 + ((((key >> 3) ^ ((q >> 1) & 7))) << 4) + ((key & 7) << 1);
 }
 
+// SPLIT = fp32-class mode: q, k, v arrive as bf16 hi+lo planes (16 significant bits each);
+//   S = qh.kh + qh.kl + ql.kh   and   O = ph.vh + pl.vh + ph.vl   (the lo.lo terms are < 2^-16 relative).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                           const bf16_t* __restrict__ vtc, bf16_t* __restrict__ out,
+                                                           const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
+                                                           const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
+                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                            int S, int nh, int past, int smax, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 16 KiB
     char* sV = smem + 16384;         // 16 KiB
     char* sP = smem + 32768;         // 4 waves x (2 KiB hi + 2 KiB lo): probabilities as bf16 hi+lo planes
+    char* sKl = smem + 49152;        // SPLIT only: lo planes of K and V^T
+    char* sVl = smem + 65536;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -153,14 +168,19 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = vtc + bh * (size_t)128 * smax;
+    const bf16_t* kbl = SPLIT ? kc_lo + bh * (size_t)smax * 128 : nullptr;
+    const bf16_t* vbl = SPLIT ? vtc_lo + bh * (size_t)128 * smax : nullptr;
 
     // Q fragments (A operand): row = wave's 16 rows, lane (g,c): row c, d = ks*32 + g*8 .. +8
-    bf16x8_t qf[4];
+    bf16x8_t qf[4], ql[4];
     {
         int qr = q0 + wv * 16 + c;
         qr = qr < S ? qr : S - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+            if (SPLIT) ql[ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
+        }
     }
     f32x4_t o[8];
 #pragma unroll
@@ -177,32 +197,36 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
         __syncthreads();                                            // previous tile fully consumed
-        // ---- stage K [64][128] and V^T [128][64] (zero beyond `total`) ----
+        // ---- stage K [64][128] and V^T [128][64] (zero beyond `total`); SPLIT: also the lo planes ----
+        auto stage_kv = [&](const bf16_t* kbase, const bf16_t* vbase, char* dK, char* dV) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
-            {
-                const int key = idx >> 4, ch = idx & 15;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (key0 + key < total) val = *(const uint4*)(kb + (size_t)(key0 + key) * 128 + ch * 8);
-                *(uint4*)(sK + k_off(key, ch)) = val;
-            }
-            {
-                const int d = idx >> 3, ch = idx & 7;
-                uint4 val = make_uint4(0, 0, 0, 0);
-                const int kk = key0 + ch * 8;
-                if (kk + 7 < total) {
-                    val = *(const uint4*)(vb + (size_t)d * smax + kk);
-                } else if (kk < total) {
-                    const bf16_t* src = vb + (size_t)d * smax + kk;
-                    unsigned short tmp[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) tmp[e] = (kk + e < total) ? ((const unsigned short*)src)[e] : (unsigned short)0;
-                    val = *(uint4*)tmp;
+            for (int i = 0; i < 4; ++i) {
+                const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
+                {
+                    const int key = idx >> 4, ch = idx & 15;
+                    uint4 val = make_uint4(0, 0, 0, 0);
+                    if (key0 + key < total) val = *(const uint4*)(kbase + (size_t)(key0 + key) * 128 + ch * 8);
+                    *(uint4*)(dK + k_off(key, ch)) = val;
                 }
-                *(uint4*)(sV + v_off(d, ch)) = val;
+                {
+                    const int d = idx >> 3, ch = idx & 7;
+                    uint4 val = make_uint4(0, 0, 0, 0);
+                    const int kk = key0 + ch * 8;
+                    if (kk + 7 < total) {
+                        val = *(const uint4*)(vbase + (size_t)d * smax + kk);
+                    } else if (kk < total) {
+                        const bf16_t* src = vbase + (size_t)d * smax + kk;
+                        unsigned short tmp[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) tmp[e] = (kk + e < total) ? ((const unsigned short*)src)[e] : (unsigned short)0;
+                        val = *(uint4*)tmp;
+                    }
+                    *(uint4*)(dV + v_off(d, ch)) = val;
+                }
             }
-        }
+        };
+        stage_kv(kb, vb, sK, sV);
+        if (SPLIT) stage_kv(kbl, vbl, sKl, sVl);
         __syncthreads();
         // ---- S = Q K^T : 4 key sub-tiles x 4 k-steps ----
         f32x4_t sacc[4];
@@ -213,6 +237,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub * 16 + c, ks * 4 + g));
                 sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sacc[sub], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16x8_t kfl = *(const bf16x8_t*)(sKl + k_off(sub * 16 + c, ks * 4 + g));
+                    sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kfl, sacc[sub], 0, 0, 0);
+                    sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[ks], kf, sacc[sub], 0, 0, 0);
+                }
             }
         }
         // ---- mask + online softmax (rows 4g+r, cols sub*16+c) ----
@@ -268,6 +297,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
                 const bf16x8_t vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, ks * 4 + g));
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[dt], 0, 0, 0);
+                if (SPLIT) {
+                    const bf16x8_t vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, ks * 4 + g));
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vfl, o[dt], 0, 0, 0);
+                }
             }
         }
     }
@@ -277,9 +310,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
         const int qi = q0 + wv * 16 + g * 4 + r;
         if (qi >= S) continue;
         const float inv = l_run[r] > 0.0f ? 1.0f / l_run[r] : 0.0f;
-        bf16_t* dst = out + ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
+        const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) dst[dt * 16 + c] = (bf16_t)(o[dt][r] * inv);
+        for (int dt = 0; dt < 8; ++dt) store_split(out, SPLIT ? out_lo : nullptr, dst + dt * 16 + c, o[dt][r] * inv);
     }
 }
 
@@ -288,7 +321,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 //   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ vtc, bf16_t* __restrict__ out,
+                                                          const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
+                                                          const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
+                                                          bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                           int nh, int total, int smax, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sp = (float*)smem;                    // [total] scores / probabilities
@@ -297,18 +332,25 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * nh + h;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 128) sq[tid] = (float)q[bh * 128 + tid];
+    if (tid < 128) sq[tid] = (float)q[bh * 128 + tid] + (q_lo ? (float)q_lo[bh * 128 + tid] : 0.0f);
     __syncthreads();
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     float lmax = -INFINITY;
     for (int j = tid; j < total; j += 256) {
         const bf16x8_t* kr = (const bf16x8_t*)(kb + (size_t)j * 128);
+        const bf16x8_t* krl = kc_lo ? (const bf16x8_t*)(kc_lo + bh * (size_t)smax * 128 + (size_t)j * 128) : nullptr;
         float s = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) {
             const bf16x8_t kv = kr[ch];
+            if (krl) {
+                const bf16x8_t kl = krl[ch];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e], s);
+                for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e] + (float)kl[e], s);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e], s);
+            }
         }
         s *= scale;
         sp[j] = s;
@@ -332,10 +374,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     // O[d] = sum_j p_j V[j][d]; V^T rows are contiguous in j. 2 threads per d.
     const int d = tid >> 1, half = tid & 1;
     const bf16_t* vr = vtc + (bh * 128 + d) * (size_t)smax;
+    const bf16_t* vrl = vtc_lo ? vtc_lo + (bh * 128 + d) * (size_t)smax : nullptr;
     float acc = 0.0f;
-    for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j], acc);
+    if (vrl) for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j] + (float)vrl[j], acc);
+    else for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j], acc);
     acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) out[(size_t)b * (nh * 128) + h * 128 + d] = (bf16_t)(acc * inv);
+    if (half == 0) store_split(out, out_lo, (size_t)b * (nh * 128) + h * 128 + d, acc * inv);
 }
 
 
@@ -445,34 +489,48 @@ extern "C" int llark_rmsnorm_bf16(const float* x, int ldx, int rows, int width, 
 }
 
 extern "C" int llark_rope_split_heads(const float* qkv, int batch, int s, int nh, int hd, int pos0, const float* cos_t,
-                                      const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, int smax,
-                                      llark_stream_t stream) {
+                                      const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, void* q_lo,
+                                      void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream) {
     LLARK_REQUIRE(qkv && cos_t && sin_t && q && k_cache && vt_cache, "rope_split_heads: null pointer");
     LLARK_REQUIRE(hd == 128, "rope_split_heads: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && pos0 >= 0 && pos0 + s <= smax && pos0 + s <= max_pos && smax % 8 == 0,
                   "rope_split_heads: bad shape batch=%d s=%d pos0=%d smax=%d max_pos=%d", batch, s, pos0, smax, max_pos);
     dim3 grid(cdiv(s, 64), nh, batch);
+    LLARK_REQUIRE((q_lo == nullptr) == (k_cache_lo == nullptr) && (q_lo == nullptr) == (vt_cache_lo == nullptr),
+                  "rope_split_heads: give all three lo planes (fp32-class mode) or none");
     rope_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, s, nh, pos0, cos_t, sin_t, (bf16_t*)q, (bf16_t*)k_cache,
-                                                              (bf16_t*)vt_cache, smax);
+                                                              (bf16_t*)vt_cache, (bf16_t*)q_lo, (bf16_t*)k_cache_lo,
+                                                              (bf16_t*)vt_cache_lo, smax);
     return check_launch("rope_split_heads");
 }
 
-extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh,
-                                       int hd, int past, int smax, void* out, llark_stream_t stream) {
+extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                       const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd,
+                                       int past, int smax, void* out, void* out_lo, llark_stream_t stream) {
     LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_prefill: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_prefill: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && past >= 0 && past + s <= smax && smax % 8 == 0, "attn_prefill: bad shape");
     const float scale = (float)(1.0 / sqrt((double)hd));
-    const int lds = 16384 + 16384 + 4 * 4096;
+    const bool split = q_lo != nullptr;
+    LLARK_REQUIRE(!split || (k_cache_lo && vt_cache_lo && out_lo), "attn_prefill: fp32-class mode needs every lo plane");
+    const int lds = 16384 + 16384 + 4 * 4096 + (split ? 32768 : 0);
     dim3 grid(cdiv(s, 64), nh, batch);
-    attn_prefill_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
-                                                                 (const bf16_t*)vt_cache, (bf16_t*)out, s, nh, past, smax,
-                                                                 scale);
+    if (split) {
+        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_prefill_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(
+            (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo,
+            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale);
+    } else {
+        attn_prefill_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(
+            (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr,
+            s, nh, past, smax, scale);
+    }
     return check_launch("attn_prefill");
 }
 
-extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, int batch, int nh, int hd,
-                                      int total, int smax, void* out, llark_stream_t stream) {
+extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                      const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total,
+                                      int smax, void* out, void* out_lo, llark_stream_t stream) {
     LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_decode: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_decode: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && nh > 0 && total > 0 && total <= smax, "attn_decode: bad shape total=%d smax=%d", total, smax);
@@ -483,6 +541,8 @@ extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const 
         (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(nh, batch);
     attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
-                                                                (const bf16_t*)vt_cache, (bf16_t*)out, nh, total, smax, scale);
+                                                                (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
+                                                                (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
+                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale);
     return check_launch("attn_decode");
 }

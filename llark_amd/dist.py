@@ -1,0 +1,83 @@
+"""Multi-GPU plumbing of the hot path: one process per GPU, clips sharded by rank, no data-path
+collective (clips are independent units -- the reference itself shards its sorted file list with
+``--batch_size/--batch_idx``, jukebox/main.py:227-232).  The only collectives are the barrier and the
+max-over-ranks of the elapsed time; the backend is RCCL ("nccl") on GPUs and gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torch.distributed.run environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init(backend: str = "nccl", device: torch.device = None) -> Tuple[int, int, int]:
+    rank, world, local = env_rank_world()
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not dist.is_initialized():
+            kw = {}
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = device
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous shard of ``n_items`` for ``rank`` (sizes differ by at most one; covers every item once)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def clip_indices(rank: int, clips_per_rank: int) -> List[int]:
+    """Weak-scaling assignment used by bench.py: rank r processes clips [r*B, (r+1)*B)."""
+    return list(range(rank * clips_per_rank, (rank + 1) * clips_per_rank))
+
+
+def barrier(world: int, cuda: bool = True) -> None:
+    if cuda:
+        torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    if cuda:
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(value: float, world: int, device="cpu") -> float:
+    if world <= 1:
+        return float(value)
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_objects(obj, world: int):
+    """Optional final gather of per-rank results on rank 0 (host side; not part of the timed path)."""
+    if world <= 1:
+        return [obj]
+    import torch.distributed as dist
+
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def shutdown(world: int) -> None:
+    if world > 1:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()

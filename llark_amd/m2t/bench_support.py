@@ -29,7 +29,7 @@ class LLMWorkload:
             dims.num_hidden_layers = layers
         self.dims = dims
         self.batch = args.batch
-        eng = HipLlamaEngine(dims, device, max_batch=args.batch, max_seq=448)
+        eng = HipLlamaEngine(dims, device, max_batch=args.batch, max_seq=448, precision=args.llm_precision)
         g = torch.Generator(device=device).manual_seed(0)
         H, I = dims.hidden_size, dims.intermediate_size
 
@@ -62,11 +62,13 @@ class LLMWorkload:
         return per_layer * d.num_hidden_layers + 2.0 * rows * d.hidden_size * d.vocab_size
 
     def roofline(self, timers, args):
-        if "gemm_bf16" not in timers:
+        key = "gemm_split_bf16" if self.engine.split else "gemm_bf16"
+        if key not in timers:
             return None
-        launches, ms, _ = timers["gemm_bf16"]
+        launches, ms, _ = timers[key]
         achieved = self.flops_per_step() * args.steps / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "gemm_kernel<bf16>", "achieved": round(achieved, 2), "peak": 2500.0,
+        return {"bound": "mfma", "kernel": "gemm_kernel<bf16%s>" % (",split" if self.engine.split else ""),
+                "mfma_passes": 2 if self.engine.split else 1, "achieved": round(achieved, 2), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None, "launches": launches,
                 "avg_launch_ms": round(ms / launches, 4)}
 

@@ -53,7 +53,16 @@ class _Layer:
 
 
 class HipLlamaEngine:
-    def __init__(self, dims: LlamaDims, device="cuda", max_batch: int = 8, max_seq: int = 512):
+    """precision: "split" (default) = fp32-class: every Linear input, q/k/v and the attention output are
+    carried as bf16 hi+lo planes (16 significant bits) and every GEMM / attention product runs the extra
+    MFMA passes -- logits then match the reference's fp32 CPU path (bf16-valued weights) to ~1e-5;
+    "bf16" = the reference's GPU dtype flow (single bf16 rounding at those points), ~2x fewer MFMAs."""
+
+    def __init__(self, dims: LlamaDims, device="cuda", max_batch: int = 8, max_seq: int = 512, precision: str = "split"):
+        if precision not in ("split", "bf16"):
+            raise ValueError(f"precision must be 'split' or 'bf16', got {precision!r}")
+        self.precision = precision
+        self.split = precision == "split"
         if dims.head_dim != 128:
             raise NotImplementedError(f"the HIP attention kernels are built for head_dim 128 (Llama-2); got {dims.head_dim}")
         if dims.intermediate_size % 32 or dims.hidden_size % 32 or dims.mm_hidden_size % 32:
@@ -72,7 +81,7 @@ class HipLlamaEngine:
         self.sin = freqs.sin().contiguous().to(self.device)
         self._ws: Dict[str, torch.Tensor] = {}
         self._ws_key = None
-        self.k_cache = self.vt_cache = None
+        self.k_cache = self.vt_cache = self.k_cache_lo = self.vt_cache_lo = None
         self.cur_len = 0
         self.cur_batch = 0
 
@@ -124,6 +133,12 @@ class HipLlamaEngine:
                 "att": torch.empty((rows, H), dtype=torch.bfloat16, device=dev),
                 "act": torch.empty((rows, I), dtype=torch.bfloat16, device=dev),
             }
+            if self.split:
+                for name in ("x16", "q", "att", "act"):
+                    ws[name + "_lo"] = torch.empty_like(ws[name])
+            else:
+                for name in ("x16", "q", "att", "act"):
+                    ws[name + "_lo"] = None
             self._ws, self._ws_key = ws, key
         return self._ws
 
@@ -134,6 +149,8 @@ class HipLlamaEngine:
             shape_v = (d.num_hidden_layers, batch, d.num_attention_heads, d.head_dim, self.smax)
             self.k_cache = torch.zeros(shape_k, dtype=torch.bfloat16, device=self.device)
             self.vt_cache = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device)
+            self.k_cache_lo = torch.zeros(shape_k, dtype=torch.bfloat16, device=self.device) if self.split else None
+            self.vt_cache_lo = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device) if self.split else None
 
     # ---- forward -------------------------------------------------------------------------------
     def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None):
@@ -141,26 +158,31 @@ class HipLlamaEngine:
         H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
         h = ws["h"]
         n_layers = d.num_hidden_layers if num_layers is None else num_layers
+        sp = self.split
         for i in range(n_layers):
             L = self.layers[i]
             kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
+            kcl = self.k_cache_lo[i, :batch] if sp else None
+            vcl = self.vt_cache_lo[i, :batch] if sp else None
             if not kc.is_contiguous():            # batch smaller than the allocated cache
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
-            ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"])
-            ops.gemm16(ws["x16"], None, L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
-            ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc)
+            ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
+            ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc,
+                                 ws["q_lo"], kcl, vcl)
             if s == 1:
-                ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"])
+                ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
             else:
-                ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"])
-            ops.gemm16(ws["att"], None, L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
-            ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"])
-            ops.gemm16(ws["x16"], None, L.wgu, None, 2 * I, ops.EPI_SWIGLU16, out_hi=ws["act"])
-            ops.gemm16(ws["act"], None, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+                ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+            ops.gemm16(ws["att"], ws["att_lo"], L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+            ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            ops.gemm16(ws["x16"], ws["x16_lo"], L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16,
+                       out_hi=ws["act"], out_lo=ws["act_lo"])
+            ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
 
     def reset(self, batch: int) -> None:
         if self.k_cache is not None and self.k_cache.shape[1] != batch:
-            self.k_cache = self.vt_cache = None
+            self.k_cache = self.vt_cache = self.k_cache_lo = self.vt_cache_lo = None
         self._ensure_cache(batch)
         self.cur_len, self.cur_batch = 0, batch
 
@@ -186,9 +208,9 @@ class HipLlamaEngine:
         for (b, start, frames) in audio_segments:
             assert self.proj_w is not None, "mm_projector weights not loaded"
             F = frames.shape[0]
-            a16, _ = ops.split16(frames.contiguous(), torch.bfloat16, want_lo=False)
+            a16, a16_lo = ops.split16(frames.contiguous(), torch.bfloat16, want_lo=self.split)
             r0 = b * S + start + 1
-            ops.gemm16(a16, None, self.proj_w, self.proj_b, d.hidden_size, ops.EPI_F32, c=h[r0: r0 + F])
+            ops.gemm16(a16, a16_lo, self.proj_w, self.proj_b, d.hidden_size, ops.EPI_F32, c=h[r0: r0 + F])
         self._layers_forward(ws, B, S, pos0, num_layers)
         self.cur_len = pos0 + S
         if return_hidden:
@@ -196,11 +218,12 @@ class HipLlamaEngine:
         if last_only and S > 1:
             hl = h.view(B, S, d.hidden_size)[:, -1].contiguous()
             x16 = torch.empty((B, d.hidden_size), dtype=torch.bfloat16, device=self.device)
-            ops.rmsnorm_bf16(hl, self.norm, d.rms_norm_eps, x16)
+            x16_lo = torch.empty_like(x16) if self.split else None
+            ops.rmsnorm_bf16(hl, self.norm, d.rms_norm_eps, x16, x16_lo)
             logits = torch.empty((B, d.vocab_size), dtype=torch.float32, device=self.device)
-            ops.gemm16(x16, None, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
+            ops.gemm16(x16, x16_lo, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
             return logits.view(B, 1, d.vocab_size)
-        ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"])
+        ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
-        ops.gemm16(ws["x16"], None, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
+        ops.gemm16(ws["x16"], ws["x16_lo"], self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
         return logits.view(B, S, d.vocab_size)

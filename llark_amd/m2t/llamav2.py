@@ -14,6 +14,7 @@ all-reduce) is the next row of SURVEY section 8 and raises ``NotImplementedError
 from __future__ import annotations
 
 import logging
+import os
 from typing import List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -125,13 +126,17 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
         self.post_init()
         self._engine: Optional[HipLlamaEngine] = None
         self._engine_max = (8, 512)
+        self._engine_precision = os.environ.get("LLARK_LLM_PRECISION", "split")
 
     def get_model(self):
         return self.model
 
     # ---- engine management -------------------------------------------------------------------
-    def configure_engine(self, max_batch: int = 8, max_seq: int = 512) -> None:
+    def configure_engine(self, max_batch: int = 8, max_seq: int = 512, precision: Optional[str] = None) -> None:
+        """precision: "split" (fp32-class, default; env LLARK_LLM_PRECISION) or "bf16" (reference's GPU dtype flow)."""
         self._engine_max = (max_batch, max_seq)
+        if precision is not None:
+            self._engine_precision = precision
         self._engine = None
 
     def sync_engine(self) -> HipLlamaEngine:
@@ -148,7 +153,7 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
                          mm_hidden_size=getattr(cfg, "mm_hidden_size", 4800))
         if getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) != cfg.num_attention_heads:
             raise NotImplementedError("grouped-query attention is not used by Llama-2-7B and is not built")
-        eng = HipLlamaEngine(dims, dev, *self._engine_max)
+        eng = HipLlamaEngine(dims, dev, *self._engine_max, precision=self._engine_precision)
         sd = {k: v for k, v in self.state_dict().items()}
         eng.load_state_dict(sd)
         self._engine = eng

@@ -15,7 +15,7 @@ from . import _lib
 from ._lib import check
 
 F16, BF16, F32SRC = 0, 1, 2
-EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16 = 0, 1, 2, 3, 4, 5
+EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16, EPI_SWIGLU_SPLIT = 0, 1, 2, 3, 4, 5, 6
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32SRC}
 
@@ -227,6 +227,8 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     kp = wt.shape[1]
     assert a_hi.shape[1] >= kp and wt.shape[0] >= n, f"gemm16: A has {a_hi.shape[1]} cols, wt {tuple(wt.shape)}, n={n}"
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
+    if epilogue == EPI_SWIGLU_SPLIT and out_lo is None:
+        raise ValueError("gemm16: EPI_SWIGLU_SPLIT needs out_lo")
     with _timed(name, 2.0 * m * n * kp):
       check(_lib.lib().llark_gemm16_ex(
         variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
@@ -258,29 +260,42 @@ def rmsnorm_bf16(x: torch.Tensor, w: torch.Tensor, eps: float, out_hi: torch.Ten
                                         out_hi.stride(0), _stream()), "rmsnorm_bf16")
 
 
+def _opt(t, name, dtype):
+    return _dev(t, name, dtype) if t is not None else None
+
+
 def rope_split_heads(qkv: torch.Tensor, batch: int, s: int, nh: int, hd: int, pos0: int, cos_t: torch.Tensor,
-                     sin_t: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor) -> None:
+                     sin_t: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor,
+                     q_lo=None, k_cache_lo=None, vt_cache_lo=None) -> None:
     smax = k_cache.shape[-2]
     assert qkv.shape == (batch * s, 3 * nh * hd) and k_cache.shape[-1] == hd and vt_cache.shape[-1] == smax
+    bf = torch.bfloat16
     check(_lib.lib().llark_rope_split_heads(_dev(qkv, "qkv", torch.float32), batch, s, nh, hd, pos0,
                                             _dev(cos_t, "cos", torch.float32), _dev(sin_t, "sin", torch.float32),
-                                            cos_t.shape[0], _dev(q, "q", torch.bfloat16),
-                                            _dev(k_cache, "k_cache", torch.bfloat16),
-                                            _dev(vt_cache, "vt_cache", torch.bfloat16), smax, _stream()), "rope_split_heads")
+                                            cos_t.shape[0], _dev(q, "q", bf), _dev(k_cache, "k_cache", bf),
+                                            _dev(vt_cache, "vt_cache", bf), _opt(q_lo, "q_lo", bf),
+                                            _opt(k_cache_lo, "k_cache_lo", bf), _opt(vt_cache_lo, "vt_cache_lo", bf), smax,
+                                            _stream()), "rope_split_heads")
 
 
-def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, past: int, out: torch.Tensor) -> None:
+def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, past: int, out: torch.Tensor,
+                 q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None) -> None:
     smax = k_cache.shape[-2]
-    check(_lib.lib().llark_attn_prefill_bf16(_dev(q, "q", torch.bfloat16), _dev(k_cache, "k_cache", torch.bfloat16),
-                                             _dev(vt_cache, "vt_cache", torch.bfloat16), batch, s, nh, hd, past, smax,
-                                             _dev(out, "out", torch.bfloat16), _stream()), "attn_prefill")
+    bf = torch.bfloat16
+    check(_lib.lib().llark_attn_prefill_bf16(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                             _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                             _opt(vt_cache_lo, "vt_cache_lo", bf), batch, s, nh, hd, past, smax,
+                                             _dev(out, "out", bf), _opt(out_lo, "out_lo", bf), _stream()), "attn_prefill")
 
 
-def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, out: torch.Tensor) -> None:
+def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, out: torch.Tensor,
+                q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None) -> None:
     smax = k_cache.shape[-2]
-    check(_lib.lib().llark_attn_decode_bf16(_dev(q, "q", torch.bfloat16), _dev(k_cache, "k_cache", torch.bfloat16),
-                                            _dev(vt_cache, "vt_cache", torch.bfloat16), batch, nh, hd, total, smax,
-                                            _dev(out, "out", torch.bfloat16), _stream()), "attn_decode")
+    bf = torch.bfloat16
+    check(_lib.lib().llark_attn_decode_bf16(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                            _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                            _opt(vt_cache_lo, "vt_cache_lo", bf), batch, nh, hd, total, smax,
+                                            _dev(out, "out", bf), _opt(out_lo, "out_lo", bf), _stream()), "attn_decode")
 
 
 def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:

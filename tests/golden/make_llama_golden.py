@@ -46,11 +46,13 @@ def main():
     # fixture 2: Llama-2's head_dim 128 (what the HIP attention kernels are built for)
     make(LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=100,
                       mm_hidden_size=96, audio_start_token=98, audio_end_token=99, audio_patch_token=97),
-         "llama_hd128.npz", std=0.08, mm=96)
+         "llama_hd128.npz", std=0.08, mm=96, bf16_valued=True)
 
 
-def make(spec, fname, std, mm):
+def make(spec, fname, std, mm, bf16_valued=False):
     w = LR.make_weights(spec, seed=0, std=std)
+    if bf16_valued:      # what the reference's `model.to(bf16)` holds: every parameter exactly representable in bf16
+        w = {k: v.bfloat16().float() for k, v in w.items()}
     m = build(spec, w)
     g = torch.Generator().manual_seed(1)
     F_ = 5

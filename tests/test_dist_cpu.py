@@ -1,0 +1,68 @@
+"""CPU: the N>1 path (rank sharding, barrier, max-over-ranks timing, result gather) with world_size 2 over gloo."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from llark_amd import dist as D
+
+    r, w, _ = D.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    clips = D.clip_indices(r, 4)                      # weak scaling: 4 clips per rank
+    shard = list(D.shard_range(11, r, w))             # strong split of an 11-file list
+    D.barrier(w, cuda=False)
+    elapsed = D.max_over_ranks(1.0 + 0.5 * r, w)      # slowest rank defines the step time
+    # every rank computes a checksum of "its" clips; rank 0 gathers them (host side, off the timed path)
+    local = {i: float(i * i) for i in clips}
+    gathered = D.gather_objects(local, w)
+    q.put((rank, clips, shard, elapsed, gathered if rank == 0 else None))
+    D.shutdown(w)
+
+
+def test_two_rank_sharding_and_timing():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, clips0, shard0, e0, g0), (r1, clips1, shard1, e1, _) = res
+    assert clips0 == [0, 1, 2, 3] and clips1 == [4, 5, 6, 7]           # disjoint, rank-ordered
+    assert sorted(shard0 + shard1) == list(range(11)) and abs(len(shard0) - len(shard1)) <= 1
+    assert e0 == e1 == 1.5                                               # MAX over ranks on every rank
+    merged = {}
+    for d in g0:
+        merged.update(d)
+    assert merged == {i: float(i * i) for i in range(8)}                # all 8 clips exactly once
+
+
+def test_shard_range_properties():
+    from llark_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 100):
+        for w in (1, 2, 3, 8):
+            parts = [list(shard_range(n, r, w)) for r in range(w)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1

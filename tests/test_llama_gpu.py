@@ -1,7 +1,12 @@
 """GPU parity: Llama-2 kernels, the HIP engine and the drop-in WrappedLlamav2ForCausalLM.
 
-Tolerances.  The HIP path computes in the reference's GPU dtype flow (bf16 Linear inputs / q / k / v /
-probabilities, fp32 accumulation and residual stream).  It is compared
+Tolerances.  Default precision "split" (fp32-class: bf16 hi+lo activations, fp32 accumulation): logits are
+compared DIRECTLY with the golden logits of the REAL reference wrapper run in fp32 with bf16-valued weights
+(tests/golden/llama_hd128.npz) and with the fp32 oracle: bound 1e-3 * max|logits| (BASELINE.json's 1e-3;
+measured ~1e-5), greedy tokens exact.
+
+Precision "bf16" computes in the reference's GPU dtype flow (bf16 Linear inputs / q / k / v, fp32
+accumulation and residual stream).  It is compared
   (a) with the oracle evaluated in the SAME flow (oracle/llama_ref.py act_dtype=bf16, round_probs=False,
       bf16-valued weights; the HIP kernels keep softmax probabilities at >= 16 bits):
       max error <= 1.5e-2 * max|logits| and mean error <= 2e-3 * max|logits|.  (Two CORRECT bf16-flow
@@ -60,6 +65,55 @@ def _ref_attention(q, k, v, past):
 
 
 @pytest.mark.parametrize("B,nh,S,past", [(1, 2, 64, 0), (2, 3, 371, 0), (1, 2, 100, 37), (1, 1, 1, 0), (2, 2, 5, 200)])
+def test_rope_and_attention_split(B, nh, S, past):
+    """fp32-class mode: q/k/v as bf16 hi+lo planes; output hi+lo vs fp32 attention, bound 3e-5."""
+    from llark_amd import ops
+    from oracle import llama_ref as LR
+    hd, H = 128, nh * 128
+    g = torch.Generator().manual_seed(S + past + 1)
+    smax = ops.round_up(past + S + 3, 8)
+    qkv = torch.randn(B * S, 3 * H, generator=g)
+    cos, sin = LR.rope_cos_sin(torch.arange(smax), hd, 10000.0)
+    bf = dict(dtype=torch.bfloat16, device="cuda")
+    kc, kcl = torch.zeros((B, nh, smax, hd), **bf), torch.zeros((B, nh, smax, hd), **bf)
+    vc, vcl = torch.zeros((B, nh, hd, smax), **bf), torch.zeros((B, nh, hd, smax), **bf)
+    kpast = torch.randn(B, nh, past, hd, generator=g)
+    vpast = torch.randn(B, nh, past, hd, generator=g)
+
+    def split(x):
+        h = x.bfloat16()
+        return h, (x - h.float()).bfloat16()
+
+    kh, kl = split(kpast)
+    vh, vl = split(vpast.transpose(2, 3).contiguous())
+    kc[:, :, :past], kcl[:, :, :past] = kh.cuda(), kl.cuda()
+    vc[:, :, :, :past], vcl[:, :, :, :past] = vh.cuda(), vl.cuda()
+    kpast16 = kh.float() + kl.float()
+    vpast16 = (vh.float() + vl.float()).transpose(2, 3)
+    qd, qdl = torch.empty((B, nh, S, hd), **bf), torch.empty((B, nh, S, hd), **bf)
+    ops.rope_split_heads(qkv.cuda(), B, S, nh, hd, past, cos[:, :64].contiguous().cuda(), sin[:, :64].contiguous().cuda(),
+                         qd, kc, vc, qdl, kcl, vcl)
+    q, k, v = [t.view(B, S, nh, hd).transpose(1, 2) for t in qkv.view(B, S, 3 * H).chunk(3, dim=-1)]
+    c, s_ = cos[past: past + S], sin[past: past + S]
+    qr = q * c + LR._rotate_half(q) * s_
+    kr = k * c + LR._rotate_half(k) * s_
+    report_close("q hi+lo", (qd.float() + qdl.float()).cpu(), qr, 2e-5, 2e-5)
+    report_close("k hi+lo", (kc.float() + kcl.float())[:, :, past: past + S].cpu(), kr, 2e-5, 2e-5)
+    q16 = (qd.float() + qdl.float()).cpu()
+    k16 = torch.cat((kpast16, (kc.float() + kcl.float())[:, :, past: past + S].cpu()), dim=2)
+    v16 = torch.cat((vpast16, (vc.float() + vcl.float())[:, :, :, past: past + S].cpu().transpose(2, 3)), dim=2)
+    att = torch.matmul(q16, k16.transpose(2, 3)) * hd ** -0.5
+    mask = torch.full((S, past + S), float("-inf")).triu(diagonal=past + 1)
+    ref = torch.matmul(torch.softmax(att + mask, dim=-1), v16).transpose(1, 2).reshape(B, S, H)
+    out, outl = torch.empty((B * S, H), **bf), torch.empty((B * S, H), **bf)
+    if S == 1:
+        ops.attn_decode(qd, kc, vc, B, nh, hd, past + 1, out, qdl, kcl, vcl, outl)
+    else:
+        ops.attn_prefill(qd, kc, vc, B, S, nh, hd, past, out, qdl, kcl, vcl, outl)
+    report_close(f"split attention S={S} past={past}", (out.float() + outl.float()).cpu().view(B, S, H), ref, 3e-5, 3e-5)
+
+
+@pytest.mark.parametrize("B,nh,S,past", [(1, 2, 64, 0), (2, 3, 371, 0), (1, 2, 100, 37), (1, 1, 1, 0), (2, 2, 5, 200)])
 def test_rope_and_attention(B, nh, S, past):
     from llark_amd import ops
     from oracle import llama_ref as LR
@@ -100,42 +154,61 @@ def test_rope_and_attention(B, nh, S, past):
         report_close("decode attention", outd.float().cpu(), _bf(ref[:, -1]), 4e-3, 4e-3)
 
 
-def _engine_from(spec, w, max_seq=64, max_batch=4):
+def _engine_from(spec, w, max_seq=64, max_batch=4, precision="split"):
     from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
     dims = LlamaDims(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                      num_hidden_layers=spec.num_hidden_layers, num_attention_heads=spec.num_attention_heads,
                      vocab_size=spec.vocab_size, rms_norm_eps=spec.rms_norm_eps, rope_theta=spec.rope_theta,
                      mm_hidden_size=spec.mm_hidden_size)
-    eng = HipLlamaEngine(dims, "cuda", max_batch, max_seq)
+    eng = HipLlamaEngine(dims, "cuda", max_batch, max_seq, precision=precision)
     eng.load_state_dict(w)
     return eng
 
 
-def test_engine_vs_oracle_and_reference_golden():
+def test_engine_split_vs_reference_golden():
+    """fp32-class mode vs the REAL reference wrapper's fp32 logits (bf16-valued weights): 1e-3 bound."""
     from test_oracle_llama import load_gold
     from oracle import llama_ref as LR
     z, spec, w = load_gold("llama_hd128.npz")
-    wb = {k: _bf(v) for k, v in w.items()}          # the reference's model.to(bf16): EVERY parameter is bf16-valued
-    eng = _engine_from(spec, wb)
+    assert all(torch.equal(v, _bf(v)) for v in w.values()), "fixture weights must be bf16-valued"
+    eng = _engine_from(spec, w, precision="split")
     ids = torch.from_numpy(z["c1_ids"])
     aud = torch.from_numpy(z["c1_audio"])
     segs = [(b, int((ids[b] == spec.audio_start_token).nonzero()[0, 0]), aud[b].cuda()) for b in range(ids.shape[0])]
     logits = eng.forward_tokens(ids.cuda(), segs).cpu()
-    ref_flow = LR.forward(wb, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
+    gold = torch.from_numpy(z["c1_logits"])
+    scale = gold.abs().max().item()
+    e_gold = report_close("split logits vs REFERENCE fp32 golden", logits, gold, 1e-3 * scale)
+    print(f"split-mode logits rel err vs reference golden {e_gold/scale:.2e}")
+    # cached decode steps vs the reference's own per-step logits
+    ids4, aud4 = torch.from_numpy(z["c4_ids"]), torch.from_numpy(z["c4_audio"])
+    seg4 = [(0, int((ids4[0] == spec.audio_start_token).nonzero()[0, 0]), aud4[0].cuda())]
+    step = eng.forward_tokens(ids4.cuda(), seg4, last_only=True).cpu()
+    gs = torch.from_numpy(z["c4_step_logits"])
+    report_close("prefill last-token logits", step[:, 0], gs[0], 1e-3 * gs.abs().max().item())
+    gen = torch.from_numpy(z["c4_generated"])
+    for t in range(1, 4):
+        nxt = gen[:, ids4.shape[1] + t - 1: ids4.shape[1] + t]
+        step = eng.forward_tokens(nxt.cuda(), (), pos0=ids4.shape[1] + t - 1).cpu()
+        report_close(f"decode step {t} logits", step[:, 0], gs[t], 1e-3 * gs.abs().max().item())
+
+
+def test_engine_bf16_vs_oracle_flow():
+    from test_oracle_llama import load_gold
+    from oracle import llama_ref as LR
+    z, spec, w = load_gold("llama_hd128.npz")
+    eng = _engine_from(spec, w, precision="bf16")
+    ids = torch.from_numpy(z["c1_ids"])
+    aud = torch.from_numpy(z["c1_audio"])
+    segs = [(b, int((ids[b] == spec.audio_start_token).nonzero()[0, 0]), aud[b].cuda()) for b in range(ids.shape[0])]
+    logits = eng.forward_tokens(ids.cuda(), segs).cpu()
+    ref_flow = LR.forward(w, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
     scale = ref_flow.abs().max().item()
     e_flow = report_close("logits vs oracle (bf16 flow)", logits, ref_flow, 1.5e-2 * scale)
     assert (logits - ref_flow).abs().mean().item() <= 2e-3 * scale
     gold = torch.from_numpy(z["c1_logits"])
-    e_gold = report_close("logits vs REFERENCE fp32 golden", logits, gold, 2e-2 * gold.abs().max().item())
-    print(f"logits rel err: vs oracle-bf16-flow {e_flow/scale:.2e}, vs reference fp32 {e_gold/gold.abs().max().item():.2e}")
-    # KV-cache decode step == oracle's cached step
-    out = LR.forward(wb, spec, ids[:1], aud[:1], act_dtype=torch.bfloat16, round_probs=False)
-    nxt = out["logits"][:, -1].argmax(-1, keepdim=True)
-    ref2 = LR.forward(wb, spec, nxt, None, act_dtype=torch.bfloat16, past_key_values=out["past_key_values"], round_probs=False)["logits"]
-    eng.forward_tokens(ids[:1].cuda(), segs[:1])
-    got2 = eng.forward_tokens(nxt.cuda(), (), pos0=ids.shape[1]).cpu()
-    report_close("decode-step logits", got2, ref2, 1.5e-2 * ref2.abs().max().item())
-    # last_only path agrees with the full-logits path
+    e_gold = report_close("bf16 logits vs REFERENCE fp32 golden", logits, gold, 3e-2 * gold.abs().max().item())
+    print(f"bf16-mode logits rel err: vs oracle-bf16-flow {e_flow/scale:.2e}, vs reference fp32 {e_gold/gold.abs().max().item():.2e}")
     lo = eng.forward_tokens(ids.cuda(), segs, last_only=True).cpu()
     assert torch.equal(lo[:, 0], logits[:, -1])
 
@@ -146,7 +219,7 @@ def test_wrapped_model_api_loss_generate_errors():
     from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
     from oracle import llama_ref as LR
     z, spec, w = load_gold("llama_hd128.npz")
-    wb = {k: _bf(v) for k, v in w.items()}
+    wb = w                                       # fixture weights are bf16-valued already
     cfg = WrappedLlamav2Config(hidden_size=spec.hidden_size, intermediate_size=spec.intermediate_size,
                                num_hidden_layers=spec.num_hidden_layers, num_attention_heads=spec.num_attention_heads,
                                num_key_value_heads=spec.num_attention_heads, vocab_size=spec.vocab_size,
@@ -167,10 +240,9 @@ def test_wrapped_model_api_loss_generate_errors():
     with torch.no_grad():
         r = m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), labels=labels.cuda())
         r_list = m(input_ids=ids.cuda(), audio_encodings=[aud[0].cuda(), aud[1].cuda()])
-    ref = LR.forward(wb, spec, ids, aud, labels=labels, act_dtype=torch.bfloat16, round_probs=False)
-    report_close("wrapped logits", r.logits.cpu(), ref["logits"], 1.5e-2 * ref["logits"].abs().max().item())
-    assert abs(r.loss.item() - ref["loss"].item()) < 5e-3 * max(1.0, abs(ref["loss"].item()))
-    assert abs(r.loss.item() - float(z["c1_loss"])) < 5e-2 * max(1.0, float(z["c1_loss"]))
+    gold = torch.from_numpy(z["c1_logits"])              # the REAL reference wrapper, fp32
+    report_close("wrapped logits vs reference golden", r.logits.cpu(), gold, 1e-3 * gold.abs().max().item())
+    assert abs(r.loss.item() - float(z["c1_loss"])) < 1e-3 * max(1.0, float(z["c1_loss"]))
     assert torch.equal(r_list.logits, r.logits)
     # state-dict keys are the reference's
     keys = set(m.state_dict().keys())
@@ -187,9 +259,9 @@ def test_wrapped_model_api_loss_generate_errors():
     # greedy generation through prepare_inputs_for_generation + KV cache
     ids4, aud4 = torch.from_numpy(z["c4_ids"]), torch.from_numpy(z["c4_audio"])
     gen = m.generate(input_ids=ids4.cuda(), audio_encodings=aud4.cuda(), max_new_tokens=6, do_sample=False).cpu()
-    ref_gen = LR.greedy_generate(wb, spec, ids4, aud4, 6, act_dtype=torch.bfloat16, round_probs=False)
+    ref_gen = torch.from_numpy(z["c4_generated"])        # greedy tokens of the reference itself
     assert gen.shape == ref_gen.shape
-    assert torch.equal(gen, ref_gen), f"generated {gen.tolist()} vs oracle {ref_gen.tolist()} (reference fp32: {z['c4_generated'].tolist()})"
+    assert torch.equal(gen, ref_gen), f"generated {gen.tolist()} vs reference {ref_gen.tolist()}"
 
     class Stop:
         def __init__(self):
@@ -224,11 +296,18 @@ def test_llama7b_width_two_layers():
                        for _ in range(B)])
     assert ids.shape[1] == 371
     aud = torch.randn(B, F, 4800, generator=g)
-    eng = _engine_from(spec, w, max_seq=384, max_batch=B)
     segs = [(b, 1, aud[b].cuda()) for b in range(B)]
+    wf = {k: v.float() for k, v in w.items()}
+    eng = _engine_from(spec, w, max_seq=384, max_batch=B, precision="split")
     logits = eng.forward_tokens(ids.cuda(), segs).cpu()
-    ref = LR.forward({k: v.float() for k, v in w.items()}, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
-    scale = ref.abs().max().item()
-    err = report_close("7B-width logits (2 layers)", logits, ref, 1.5e-2 * scale)
+    ref32 = LR.forward(wf, spec, ids, aud)["logits"]                       # pure fp32 path, bf16-valued weights
+    scale = ref32.abs().max().item()
+    err = report_close("7B-width split logits vs fp32 oracle (2 layers)", logits, ref32, 1e-3 * scale)
+    print(f"7B-width 2-layer split-mode logits rel err {err/scale:.2e}")
+    del eng
+    eng = _engine_from(spec, w, max_seq=384, max_batch=B, precision="bf16")
+    logits = eng.forward_tokens(ids.cuda(), segs).cpu()
+    ref = LR.forward(wf, spec, ids, aud, act_dtype=torch.bfloat16, round_probs=False)["logits"]
+    err = report_close("7B-width bf16 logits vs bf16-flow oracle (2 layers)", logits, ref, 1.5e-2 * scale)
     assert (logits - ref).abs().mean().item() <= 2e-3 * scale
-    print(f"7B-width 2-layer logits rel err {err/scale:.2e}")
+    print(f"7B-width 2-layer bf16-mode logits rel err {err/scale:.2e}")
