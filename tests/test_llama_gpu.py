@@ -311,3 +311,72 @@ def test_llama7b_width_two_layers():
     err = report_close("7B-width bf16 logits vs bf16-flow oracle (2 layers)", logits, ref, 1.5e-2 * scale)
     assert (logits - ref).abs().mean().item() <= 2e-3 * scale
     print(f"7B-width 2-layer bf16-mode logits rel err {err/scale:.2e}")
+
+
+def test_audio_tokenizer_init_and_infer_with_prompt():
+    """a13 + a14: initialize_audio_tokenizer (m2t/models/llamav2.py:367-419) and infer_with_prompt
+    (m2t/infer.py:99-152) on the HIP engine, checked against the oracle's greedy decode on the same weights."""
+    from toy_tokenizer import ToyTokenizer
+    from llark_amd.m2t.infer import infer_with_prompt
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    from llark_amd.m2t.prompting import DEFAULT_CONVERSATION_HEADER
+    from oracle import llama_ref as LR
+    tok = ToyTokenizer()
+    # pre-populate the vocabulary with everything the prompt will contain
+    for text in (DEFAULT_CONVERSATION_HEADER, "### Human: Assistant: <empty> \n Describe the tempo of this clip ."):
+        tok.encode(text)
+    base_vocab = len(tok)
+    torch.manual_seed(0)
+    cfg = WrappedLlamav2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=2, vocab_size=base_vocab, max_position_embeddings=512, rms_norm_eps=1e-5,
+                               tie_word_embeddings=False)
+    cfg.mm_hidden_size = 96
+    m = WrappedLlamav2ForCausalLM(cfg).eval()
+    m.get_model().initialize_adapter_modules()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_((p * 4).bfloat16().float())          # bf16-valued, livelier than init_range 0.02
+    emb_before = m.get_input_embeddings().weight.data.clone()
+    m.initialize_audio_tokenizer(mm_use_audio_start_end=True, tokenizer=tok, device="cpu", tune_mm_mlp_adapter=True)
+    ac = m.get_model().audio_encoder_config
+    assert len(tok) == base_vocab + 3 and m.get_input_embeddings().weight.shape[0] == base_vocab + 3
+    assert (ac.audio_patch_token, ac.audio_start_token, ac.audio_end_token) == tuple(
+        tok.convert_tokens_to_ids(["<audio_patch>", "<audio_start>", "<audio_end>"]))
+    emb = m.get_input_embeddings().weight.data
+    # rule (7) of SURVEY 8c: the two start/end rows are the mean of all earlier rows
+    assert torch.allclose(emb[-2:], emb[:-2].mean(dim=0, keepdim=True).expand(2, -1), atol=1e-6)
+    assert torch.equal(emb[:base_vocab], emb_before)
+    assert m.get_model().orig_embeds_params[0].shape == emb.shape
+    assert all(not p.requires_grad for p in m.get_output_embeddings().parameters())
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.bfloat16().float())
+    m.cuda()
+    m.configure_engine(max_batch=1, max_seq=128)
+    enc = torch.randn(5, 96, generator=torch.Generator().manual_seed(4))
+    end_seq = tok("\n### Assistant:").input_ids[1:]
+    mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    out = infer_with_prompt("Describe the tempo of this clip .", model=m, audio_encoding=enc, end_seq=end_seq,
+                            multimodal_cfg=mm_cfg, tokenizer=tok, audio_first=True, max_new_tokens=8).cpu()
+    # oracle: same prompt ids, fp32, greedy, stop on the "###" token like KeywordsStoppingCriteria
+    sd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                        vocab_size=base_vocab + 3, mm_hidden_size=96, audio_start_token=ac.audio_start_token,
+                        audio_end_token=ac.audio_end_token, audio_patch_token=ac.audio_patch_token)
+    n_prompt = out.shape[1] - 8 if out.shape[1] - 8 > 0 else None
+    hash_id = tok("###").input_ids[1]
+    prompt_ids = out[:, : (out[0] == tok.vocab["Assistant:"]).nonzero()[-1, 0] + 1] if "Assistant:" in tok.vocab else None
+    # rebuild the prompt exactly as infer_with_prompt does
+    from llark_amd.m2t import prompting as P
+    elem = {"audio_encoding": enc, "audio_encoding_shape": list(enc.shape), "example_id": None, "id": None,
+            "conversations": [{"from": "human", "value": P.concat_audio_token_and_prompt("Describe the tempo of this clip .", True)},
+                              {"from": "gpt", "value": "<empty>"}]}
+    elem = P.preprocess_for_lm_mappable(P.preprocess_multimodal_mappable(elem, mm_cfg), tokenizer=tok)
+    pids = P.extract_prompt_tokens(elem["input_ids"], end_seq)[None]
+    ref = LR.greedy_generate(sd, spec, pids, enc[None], 8)
+    cut = ref.shape[1]
+    for t in range(pids.shape[1], ref.shape[1]):
+        if ref[0, t].item() == hash_id:
+            cut = t + 1
+            break
+    assert torch.equal(out, ref[:, :cut]), f"{out.tolist()} vs oracle {ref[:, :cut].tolist()}"
