@@ -177,9 +177,17 @@ def main():
             launches, ms, _ = timers["gemm_split_f16"]
             flops = _prior_gemm_flops(hps, args.batch * hps.n_ctx) * args.steps
             achieved = flops / (ms * 1e-3) / 1e12
+            traffic, traffic_note = None, None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")      # separate --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+            if os.path.exists(pmc):
+                d = json.load(open(pmc))
+                traffic = d["traffic_bytes_per_launch"]
+                traffic_note = ("memory-side bytes of ONE launch of %s (algorithmic %.2f GB; includes Infinity-Cache hits, see %s)"
+                                % (d["kernel"], d["algorithmic_bytes_per_launch"] / 1e9, "profiles/r01_pmc_gemm.json"))
             roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,split>", "achieved": round(achieved, 2),
                     "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                    "traffic": None, "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                    "traffic": traffic, "traffic_note": traffic_note, "launches": launches,
+                    "avg_launch_ms": round(ms / launches, 4),
                     "mfma_passes": 2, "frac_of_issued_mfma": round(2 * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
         elif llm is not None:
             roof = llm.roofline(timers, args)
