@@ -329,6 +329,139 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
     return LLARK_ERR_INVALID;
 }
 
+// ------------------------------------------------------------------------------------------
+// Skinny GEMM for decode (M <= 16 rows: one new token per sequence): HBM-bound weight streaming.
+// Block = 4 waves owning 16 output columns (x NT tiles); wave w streams the K-slice [w*K/4, (w+1)*K/4) of
+// the weight rows straight from HBM into MFMA B fragments (no LDS: nothing is shared between waves), the
+// 16 x K activation slab comes from L2; partial 16x16 tiles are reduced through LDS by wave 0, which also
+// applies the epilogue.  v_mfma_f32_16x16x32 keeps the fp32 accumulation / hi+lo semantics of the big kernel.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<half_t> {
+    static __device__ __forceinline__ f32x4_t run(half8_t a, half8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mfma16<bf16_t> {
+    static __device__ __forceinline__ f32x4_t run(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename T, bool SPLIT, int EPI>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr int NT = IS_SWIGLU(EPI) ? 2 : 1;
+    __shared__ float red[4][NT][16][17];
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // column tiles: plain: rows n0..n0+15 of W.  SwiGLU: gate rows 64q+16t.., up rows 64q+32+16t.. (t = 0,1)
+    int wrow[NT];
+    int ocol;
+    if (IS_SWIGLU(EPI)) {
+        const int q = blockIdx.x >> 1, t = blockIdx.x & 1;
+        wrow[0] = 64 * q + 16 * t;
+        wrow[NT - 1] = 64 * q + 32 + 16 * t;
+        ocol = 32 * q + 16 * t;
+    } else {
+        wrow[0] = blockIdx.x * 16;
+        ocol = wrow[0];
+    }
+    const int ksteps = p.Kp / 32;
+    const int per = (ksteps + 3) / 4;
+    const int ks0 = w * per, ks1 = (ks0 + per) < ksteps ? (ks0 + per) : ksteps;
+    const T* Ahi = (const T*)p.Ahi;
+    const T* Alo = (const T*)p.Alo;
+    const T* Wt = (const T*)p.Wt;
+    const int arow = c < p.M ? c : p.M - 1;
+    const T* ah_p = Ahi + (size_t)arow * p.lda + g * 8;
+    const T* al_p = SPLIT ? Alo + (size_t)arow * p.lda + g * 8 : nullptr;
+    const T* w_p[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int r = wrow[t] + c;
+        r = r < p.N ? r : p.N - 1;
+        w_p[t] = Wt + (size_t)r * p.ldw + g * 8;
+    }
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int ks = ks0;
+    for (; ks + 4 <= ks1; ks += 4) {            // 4 k-steps in flight: 256 contiguous bytes per weight row
+        frag bw[NT][4], ah[4], al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bw[t][u] = *(const frag*)(w_p[t] + (ks + u) * 32);
+            ah[u] = *(const frag*)(ah_p + (ks + u) * 32);
+            if (SPLIT) al[u] = *(const frag*)(al_p + (ks + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = Mfma16<T>::run(ah[u], bw[t][u], acc[t]);
+                if (SPLIT) acc[t] = Mfma16<T>::run(al[u], bw[t][u], acc[t]);
+            }
+    }
+    for (; ks < ks1; ++ks) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const frag bw = *(const frag*)(w_p[t] + ks * 32);
+            acc[t] = Mfma16<T>::run(*(const frag*)(ah_p + ks * 32), bw, acc[t]);
+            if (SPLIT) acc[t] = Mfma16<T>::run(*(const frag*)(al_p + ks * 32), bw, acc[t]);
+        }
+    }
+    // C layout of 16x16 MFMA: col = c (weight row within the tile), rows m = 4g + r
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][t][4 * g + r][c] = acc[t][r];
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * g + r;
+        float v[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) v[t] = (red[0][t][m][c] + red[1][t][m][c]) + (red[2][t][m][c] + red[3][t][m][c]);
+        const int n = ocol + c;
+        const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
+        if (m >= p.M || n >= nlim) continue;
+        if (EPI == EPI_F32) {
+            p.C[(size_t)m * p.ldc + n] = v[0] + (p.bias ? p.bias[n] : 0.0f);
+        } else if (EPI == EPI_RESID) {
+            p.C[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
+        } else if (IS_SWIGLU(EPI)) {
+            const float a = silu(v[0]) * v[NT - 1];
+            const T hi = Mfma<T>::cvt(a);
+            ((T*)p.Ohi)[(size_t)m * p.ldo + n] = hi;
+            if (EPI == EPI_SWIGLU_SPLIT) ((T*)p.Olo)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(a - Mfma<T>::back(hi));
+        }
+    }
+}
+
+template <typename T, bool SPLIT, int EPI>
+static int launch_skinny(const GemmParams& p, hipStream_t s) {
+    const int blocks = IS_SWIGLU(EPI) ? (p.N / 64) * 2 : cdiv(p.N, 16);
+    gemm_skinny_kernel<T, SPLIT, EPI><<<blocks, 256, 0, s>>>(p);
+    return check_launch("gemm_skinny");
+}
+
+template <typename T>
+static int dispatch_skinny(const GemmParams& p, bool split, int epi, hipStream_t s) {
+#define SK(E)                                                                                             \
+    case E:                                                                                               \
+        return split ? launch_skinny<T, true, E>(p, s) : launch_skinny<T, false, E>(p, s);
+    switch (epi) {
+        SK(EPI_F32)
+        SK(EPI_RESID)
+        SK(EPI_SWIGLU16)
+        SK(EPI_SWIGLU_SPLIT)
+    }
+#undef SK
+    return 1;      // not a skinny epilogue: caller falls back to the tiled kernel
+}
+
 // Tile variants (tuning knob; every variant computes the same result).
 typedef Cfg<2, 2, 2, 2, 32, 3> Cfg0;   // 128x128x32, 4 waves, 48 KiB (split)      : 3 blocks/CU
 typedef Cfg<4, 2, 2, 2, 32, 4> Cfg1;   // 256x128x32, 8 waves, 80 KiB               : 2 blocks/CU
@@ -399,6 +532,12 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
     p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
     p.tiles_m = p.tiles_n = 0;
     hipStream_t s = (hipStream_t)stream;
+    if (variant < 0 && m <= 16) {                 // decode: HBM-bound skinny kernel
+        int rc = 1;
+        if (dtype == LLARK_F16) rc = dispatch_skinny<half_t>(p, split != 0, epilogue, s);
+        else if (dtype == LLARK_BF16) rc = dispatch_skinny<bf16_t>(p, split != 0, epilogue, s);
+        if (rc != 1) return rc;
+    }
     if (variant < 0) variant = pick_variant(split, m, n, kp);
     if (dtype == LLARK_F16) return dispatch_variant<half_t>(variant, p, split != 0, epilogue, s);
     if (dtype == LLARK_BF16) return dispatch_variant<bf16_t>(variant, p, split != 0, epilogue, s);

@@ -49,3 +49,24 @@ if "res" in which:
         y = torch.empty_like(x)
         ms = timeit(lambda: ops.resblock(x, w1, b1, w2, b1, dil, out=y))
         print(f"resblock T={t} dil={dil}: {ms*1e3:8.1f} us  ({x.numel()*8/1e9/ms:.2f} TB/s algorithmic, {B*t*8192/1e9/ms:.1f} TFLOP/s)", flush=True)
+if "decode" in which:
+    import types
+    from llark_amd.m2t import bench_support as BS
+    for prec in ("split", "bf16"):
+        args = types.SimpleNamespace(batch=8, llm_precision=prec)
+        wl = BS.LLMWorkload(args, torch.device("cuda"))
+        eng = wl.engine
+        wl.forward(None)                                    # prefill (fills the KV cache up to 371)
+        tok = torch.randint(3, 32000, (8, 1), device=dev)
+        torch.cuda.synchronize()
+        import time
+        n = 16
+        t0 = time.perf_counter()
+        for i in range(n):
+            eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        wbytes = 32 * (4 * 4096 * 4096 + 3 * 4096 * 11008) * 2 + 32004 * 4096 * 2
+        print(f"decode step B=8 ({prec}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
+        del wl, eng
+        torch.cuda.empty_cache()

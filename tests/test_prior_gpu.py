@@ -236,3 +236,40 @@ def test_prior_rejects_unsupported():
     tp.prior.only_encode = True
     with pytest.raises(NotImplementedError):
         tp.prior.forward(z, x_cond=torch.zeros(1), y_cond=torch.zeros(1), fp16=True)
+
+
+@pytest.mark.parametrize("m", [1, 8, 16])
+def test_gemm_skinny_decode_shapes(m):
+    """M <= 16 goes to the HBM-bound skinny kernel (decode): F32, RESID, SwiGLU (plain and split), both modes."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(100 + m)
+    n, k = 448, 800                                  # n: 7 SwiGLU groups of 64; k: 25 k-steps (uneven 4-way split)
+    a = torch.randn(m, k, generator=g)
+    wb = (torch.randn(n, k, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(n, generator=g)
+    wt = ops.pack_weight16(wb.cuda(), False, torch.bfloat16)
+    hi, lo = ops.split16(a.cuda(), torch.bfloat16)
+    a16 = hi.float().cpu()[:, :k] + lo.float().cpu()[:, :k]
+    ref = a16.double() @ wb.double().t() + bias.double()
+    c = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, lo, wt, bias.cuda(), n, ops.EPI_F32, c=c)
+    report_close("skinny split f32", c.cpu(), ref, 2e-5, 2e-5)
+    c1 = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, None, wt, None, n, ops.EPI_F32, c=c1)
+    report_close("skinny plain f32", c1.cpu(), hi.float().cpu()[:, :k].double() @ wb.double().t(), 2e-5, 2e-5)
+    r = torch.randn(m, n, generator=g)
+    cr = r.clone().cuda()
+    ops.gemm16(hi, lo, wt, bias.cuda(), n, ops.EPI_RESID, c=cr, resid=cr)
+    report_close("skinny resid", cr.cpu(), r.double() + ref, 2e-5, 2e-5)
+    inter = n // 2
+    gate, up = wb[:inter], wb[inter:]
+    packed = torch.stack([gate.view(-1, 32, k), up.view(-1, 32, k)], dim=1).reshape(n, k).contiguous()
+    wts = ops.pack_weight16(packed.cuda(), False, torch.bfloat16)
+    oh = torch.zeros((m, inter), dtype=torch.bfloat16, device="cuda")
+    ol = torch.zeros_like(oh)
+    ops.gemm16(hi, lo, wts, None, n, ops.EPI_SWIGLU_SPLIT, out_hi=oh, out_lo=ol)
+    sref = torch.nn.functional.silu(a16.double() @ gate.double().t()) * (a16.double() @ up.double().t())
+    report_close("skinny swiglu split", (oh.float() + ol.float()).cpu(), sref, 3e-5, 3e-5)
+    ops.gemm16(hi, None, wts, None, n, ops.EPI_SWIGLU16, out_hi=oh)
+    h16 = hi.float().cpu()[:, :k].double()
+    report_close("skinny swiglu16", oh.float().cpu(), torch.nn.functional.silu(h16 @ gate.double().t()) * (h16 @ up.double().t()), 1e-2, 1e-2)
