@@ -14,6 +14,8 @@
 // a (tap, ci) step are wave-uniform and arrive through the scalar cache (s_load_dwordx16) while
 // the input tile (with its dilation halo) is staged once in LDS; lanes walk consecutive time
 // steps, so LDS reads are conflict-free and HBM traffic is exactly one read + one write per layer.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace llark {
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(256) void resblock_kernel(const float* __restrict__
 #pragma unroll
         for (int co = 0; co < C; ++co) out[p][co] = b2[co];
 #pragma unroll
-    for (int ci = 0; ci < C; ++ci) {
+    for (int cs = 0; cs < C; ++cs) {
+        const int ci = ((cs >> 1) & 3) + 8 * (cs >> 3) + 4 * (cs & 1);   // shared 1x1 accumulation order (see oracle)
         const float* wrow = w2p + (size_t)ci * C;
         float hv[TPT];
 #pragma unroll
@@ -149,6 +152,93 @@ __global__ __launch_bounds__(256) void resblock_kernel(const float* __restrict__
         if (tg < t) {
 #pragma unroll
             for (int co = 0; co < C; ++co) yn[(size_t)co * t + tg] = lds[co * span + tl + dil] + out[p][co];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ResConv1DBlock on the fp32-input matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf
+// chain (D = fma(a_k1,b_k1, fma(a_k0,b_k0,C))), so chaining it over (tap, ci) reproduces the oracle's
+// evaluation order exactly while running at the fp32 vector peak with the VALU free.
+//   A operand  = weights [co = lane&31][k = lane>>5]   (all 64 A values live in registers for the whole block)
+//   B operand  = relu(x)[ci = 2j + (lane>>5)][t = lane&31 (+ tap*dil)]   (one ds_read_b32 per MFMA)
+//   D layout   = col t = lane&31, row co = (r&3) + 8*(r>>2) + 4*(lane>>5): the hidden activations of the
+//   conv3 are consumed by the 1x1 conv straight from these registers -- register r of the lower/upper
+//   half-wave IS the B operand of the r-th 1x1 MFMA (channels a_r and a_r + 4): no cross-lane traffic.
+// ------------------------------------------------------------------------------------------
+template <int NTILE>
+__global__ __launch_bounds__(256, 3) void resblock_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w1p,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2p,
+                                                               const float* __restrict__ b2, float* __restrict__ y, int t,
+                                                               int dil) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int C = 32;
+    constexpr int TT = 4 * NTILE * 32;
+    constexpr int MAXSPAN = TT + 2 * 27;                     // dilation <= 27 on this path
+    constexpr int NIT = (MAXSPAN + 63) / 64;
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int span = TT + 2 * dil;
+    const float* xn = x + (size_t)n * C * t;
+    {   // stage the [32][span] input tile: wave w owns channels 8w..8w+7, lanes walk time; all loads of a
+        // channel row are issued before the LDS writes (addresses clamped, zero halo by select)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int ci = wv * 8 + rr;
+            const float* src = xn + (size_t)ci * t;
+            float v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int gi = t0 - dil + lane + 64 * it;
+                gi = gi < 0 ? 0 : (gi >= t ? t - 1 : gi);
+                v[it] = src[gi];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int j = lane + 64 * it;
+                const int gi = t0 - dil + j;
+                if (j < span) lds[ci * span + j] = (gi >= 0 && gi < t) ? v[it] : 0.0f;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int co = lane & 31, h = lane >> 5;
+    float wa[48], wb[16];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wa[tap * 16 + j] = w1p[((size_t)tap * C + 2 * j + h) * C + co];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wb[j] = w2p[(size_t)((j & 3) + 8 * (j >> 2) + 4 * h) * C + co];
+    __syncthreads();
+    float* yn = y + (size_t)n * C * t;
+    for (int tile = 0; tile < NTILE; ++tile) {
+        const int tl = (wv * NTILE + tile) * 32 + (lane & 31);       // this lane's time step within the block tile
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b1[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap) {
+            const float* col = lds + tl + tap * dil + h * span;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float b = fmaxf(col[2 * j * span], 0.0f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[tap * 16 + j], b, acc, 0, 0, 0);
+            }
+        }
+        f32x16_t out;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], fmaxf(acc[j], 0.0f), out, 0, 0, 0);
+        const int tg = t0 + tl;
+        if (tg < t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cr = (r & 3) + 8 * (r >> 2) + 4 * h;
+                yn[(size_t)cr * t + tg] = lds[cr * span + tl + dil] + out[r];
+            }
         }
     }
 }
@@ -277,14 +367,27 @@ extern "C" int llark_resblock_f32(const float* x, int n, int c, int t, const flo
     LLARK_REQUIRE(x && w1p && b1 && w2p && b2 && y && n > 0 && t > 0, "resblock: null pointer or empty input");
     LLARK_REQUIRE(c == 32, "resblock: only width 32 (Jukebox vqvae width) is built, got %d", c);
     LLARK_REQUIRE(dil >= 1 && dil <= 81, "resblock: dilation %d out of range", dil);
-    constexpr int TPT = 2;
-    constexpr int TT = 256 * TPT;
+    LLARK_REQUIRE(t >= 1, "resblock: empty time axis");
+    static const bool use_valu = getenv("LLARK_RESBLOCK_VALU") != nullptr;      // A/B knob: the fp32 VALU version
+    if (use_valu) {
+        constexpr int TPT = 2;
+        constexpr int TT = 256 * TPT;
+        size_t lds = (size_t)32 * (TT + 2 * dil) * sizeof(float);
+        auto kern = resblock_kernel<32, TPT>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        dim3 grid(cdiv(t, TT), n);
+        kern<<<grid, 256, lds, (hipStream_t)stream>>>(x, w1p, b1, w2p, b2, y, t, dil);
+        return check_launch("resblock");
+    }
+    LLARK_REQUIRE(dil <= 27, "resblock: the matrix-core path is built for dilation <= 27 (Jukebox: 1,3,9,27), got %d", dil);
+    constexpr int NTILE = 2;
+    constexpr int TT = 4 * NTILE * 32;
     size_t lds = (size_t)32 * (TT + 2 * dil) * sizeof(float);
-    auto kern = resblock_kernel<32, TPT>;
+    auto kern = resblock_mfma_kernel<NTILE>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(cdiv(t, TT), n);
     kern<<<grid, 256, lds, (hipStream_t)stream>>>(x, w1p, b1, w2p, b2, y, t, dil);
-    return check_launch("resblock");
+    return check_launch("resblock_mfma");
 }
 
 extern "C" int llark_codebook_norms_f32(const float* k, int bins, int emb, float* kk, llark_stream_t stream) {

@@ -12,7 +12,11 @@
  *   conv:     acc = bias[co];  for tap in 0..K-1:  for ci in 0..Cin-1:
  *                 acc = fmaf(w[co][ci][tap], x[ci][t*stride + tap*dil - pad], acc)   (zero padding
  *                 taps are skipped: fmaf(w, 0, acc) == acc)
- *   resblock: y = x + conv1x1(relu(conv3_dil(relu(x))))          (one rounding for the final add)
+ *   resblock: y = x + conv1x1(relu(conv3_dil(relu(x))))          (one rounding for the final add);
+ *             the 1x1 conv accumulates its 32 input channels in the order JB_ORDER_1X1 below
+ *             (0,4,1,5,2,6,3,7, 8,12,9,13,...): this is the order in which the fp32 matrix cores
+ *             (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) see the hidden activations when they
+ *             are consumed straight from the previous MFMA's accumulator registers.
  *   codebook: xx = sum_c fmaf(x_c,x_c,.), dot_j = sum_c fmaf(x_c,k_jc,.), kk_j = sum_c fmaf(k_jc,k_jc,.)
  *             (c ascending), dist_j = (xx - 2*dot_j) + kk_j, code = first j attaining the minimum.
  *
@@ -27,8 +31,20 @@
 
 /* y[co][t] for one clip. x: [cin][tin], w: [cout][cin][k], y: [cout][tout]. relu_in applies
  * max(x,0) to the input on the fly (ResConv1DBlock's leading ReLU). */
+/* accumulation order of the 1x1 conv inside ResConv1DBlock (width 32): pairs (a, a+4) with
+ * a = (j&3) + 8*(j>>2), j = 0..15 */
+static int jb_order_1x1(int i) { int j = i >> 1; return (j & 3) + 8 * (j >> 2) + 4 * (i & 1); }
+
+static void jbref_conv1d_ord(const float* x, int cin, int tin, const float* w, const float* b, int cout, int k,
+                             int stride, int pad, int dil, int relu_in, float* y, int tout, int use_order);
+
 void jbref_conv1d(const float* x, int cin, int tin, const float* w, const float* b, int cout, int k,
                   int stride, int pad, int dil, int relu_in, float* y, int tout) {
+    jbref_conv1d_ord(x, cin, tin, w, b, cout, k, stride, pad, dil, relu_in, y, tout, 0);
+}
+
+static void jbref_conv1d_ord(const float* x, int cin, int tin, const float* w, const float* b, int cout, int k,
+                             int stride, int pad, int dil, int relu_in, float* y, int tout, int use_order) {
     const float* xin = x;
     float* xr = NULL;
     if (relu_in) {
@@ -48,7 +64,8 @@ void jbref_conv1d(const float* x, int cin, int tin, const float* w, const float*
                 int lo = t0, hi = t1;
                 if (off < 0) { int need = (-off + stride - 1) / stride; if (lo < need) lo = need; }
                 { long maxt = ((long)tin - 1 - off) / stride; if (tin - 1 - off < 0) maxt = -1; if (hi > maxt + 1) hi = (int)(maxt + 1); }
-                for (int ci = 0; ci < cin; ++ci) {
+                for (int cs = 0; cs < cin; ++cs) {
+                    const int ci = use_order ? jb_order_1x1(cs) : cs;
                     float wv = w[((size_t)co * cin + ci) * k + tap];
                     const float* xi = xin + (size_t)ci * tin + off;
                     if (stride == 1) {
@@ -69,7 +86,7 @@ void jbref_resblock(const float* x, int c, int t, const float* w1, const float* 
     float* h = (float*)malloc((size_t)c * t * sizeof(float));
     float* m = (float*)malloc((size_t)c * t * sizeof(float));
     jbref_conv1d(x, c, t, w1, b1, c, 3, 1, dil, dil, 1, h, t);
-    jbref_conv1d(h, c, t, w2, b2, c, 1, 1, 0, 1, 1, m, t);
+    jbref_conv1d_ord(h, c, t, w2, b2, c, 1, 1, 0, 1, 1, m, t, c == 32);
     for (size_t i = 0; i < (size_t)c * t; ++i) y[i] = x[i] + m[i];
     free(h);
     free(m);
