@@ -157,6 +157,79 @@ __global__ __launch_bounds__(256) void resblock_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Strided / output convs on the fp32-input matrix cores (same chain order as the oracle: tap-major, ci
+// ascending, two channels per v_mfma_f32_32x32x2_f32).  Wave = 32 output steps x COUT channels
+// (COUT/32 accumulators); weights live in registers; the input tile (with stride and taps) in LDS.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int K, int STRIDE, int NTILE>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int tin,
+                                                           int tout, int pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TT = 4 * NTILE * 32;
+    constexpr int SPAN = (TT - 1) * STRIDE + K;              // dilation 1
+    constexpr int NIT = (SPAN + 63) / 64;
+    constexpr int COT = COUT / 32;
+    constexpr int NJ = CIN / 2;                              // MFMAs per tap
+    const int n = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int in0 = t0 * STRIDE - pad;
+    const float* xn = x + (size_t)n * CIN * tin;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int ci = wv; ci < CIN; ci += 4) {                   // wave w stages channels w, w+4, ...
+        const float* src = xn + (size_t)ci * tin;
+        float v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int gi = in0 + lane + 64 * it;
+            gi = gi < 0 ? 0 : (gi >= tin ? tin - 1 : gi);
+            v[it] = src[gi];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int j = lane + 64 * it;
+            const int gi = in0 + j;
+            if (j < SPAN) lds[ci * SPAN + j] = (gi >= 0 && gi < tin) ? v[it] : 0.0f;
+        }
+    }
+    const int co = lane & 31, h = lane >> 5;
+    float wa[COT][K * NJ];
+#pragma unroll
+    for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) wa[ct][tap * NJ + j] = wp[((size_t)tap * CIN + 2 * j + h) * COUT + ct * 32 + co];
+    __syncthreads();
+    float* yn = y + (size_t)n * COUT * tout;
+    for (int tile = 0; tile < NTILE; ++tile) {
+        const int tl = (wv * NTILE + tile) * 32 + (lane & 31);
+        f32x16_t acc[COT];
+#pragma unroll
+        for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ct][r] = bias[ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+            const float* col = lds + tl * STRIDE + tap + h * SPAN;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float b = col[2 * j * SPAN];
+#pragma unroll
+                for (int ct = 0; ct < COT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[ct][tap * NJ + j], b, acc[ct], 0, 0, 0);
+            }
+        }
+        const int tg = t0 + tl;
+        if (tg < tout) {
+#pragma unroll
+            for (int ct = 0; ct < COT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yn[(size_t)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * tout + tg] = acc[ct][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // ResConv1DBlock on the fp32-input matrix cores.  v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf
 // chain (D = fma(a_k1,b_k1, fma(a_k0,b_k0,C))), so chaining it over (tap, ci) reproduces the oracle's
 // evaluation order exactly while running at the fp32 vector peak with the VALU free.
@@ -351,6 +424,23 @@ extern "C" int llark_conv1d_f32(const float* x, int n, int cin, int tin, const f
     LLARK_REQUIRE(expect == tout, "conv1d: tout=%d does not match (tin=%d,k=%d,s=%d,p=%d,d=%d) -> %d", tout, tin, k,
                   stride, pad, dil, expect);
     hipStream_t s = (hipStream_t)stream;
+    static const bool conv_valu = getenv("LLARK_CONV_VALU") != nullptr;         // A/B knob: the fp32 VALU kernels
+    if (!conv_valu && dil == 1) {
+#define CONV_MFMA(CIN, COUT, K, STRIDE, NTILE)                                                                          \
+    do {                                                                                                                \
+        constexpr int TT_ = 4 * NTILE * 32;                                                                             \
+        constexpr int LDS_ = CIN * ((TT_ - 1) * STRIDE + K) * 4;                                                        \
+        auto kern = conv_mfma_kernel<CIN, COUT, K, STRIDE, NTILE>;                                                      \
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                 \
+        dim3 grid(cdiv(tout, TT_), n);                                                                                  \
+        kern<<<grid, 256, LDS_, s>>>(x, wp, bias, y, tin, tout, pad);                                                   \
+        return check_launch("conv_mfma");                                                                               \
+    } while (0)
+        if (k == 4 && stride == 2 && cout == 32 && cin == 32) CONV_MFMA(32, 32, 4, 2, 2);
+        if (k == 4 && stride == 2 && cout == 32 && cin == 64) CONV_MFMA(64, 32, 4, 2, 1);
+        if (k == 3 && stride == 1 && cout == 64 && cin == 32) CONV_MFMA(32, 64, 3, 1, 2);
+#undef CONV_MFMA
+    }
     if (k == 4 && stride == 2 && cout == 32 && dil == 1) {
         if (cin == 1) return launch_conv<1, 32, 4, 2, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);
         if (cin == 32) return launch_conv<32, 32, 4, 2, 256>(x, n, tin, wp, bias, pad, dil, y, tout, s);

@@ -70,3 +70,15 @@ if "decode" in which:
         print(f"decode step B=8 ({prec}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
         del wl, eng
         torch.cuda.empty_cache()
+if "vqvae" in which:
+    import numpy as np
+    from llark_amd.jukebox.hparams import hparams_5b
+    from llark_amd.jukebox.synthetic import make_vqvae_weights
+    from llark_amd.jukebox.vqvae import VQVAE
+    hps = hparams_5b()
+    vq = VQVAE(hps, make_vqvae_weights(hps, 0), dev)
+    audio = torch.randn(8, hps.sample_length, generator=g, device=dev)
+    ms = timeit(lambda: vq.encode_top(audio), iters=3)
+    per_clip = ms / 8
+    print(f"VQ-VAE level-2 encode B=8: {ms:.2f} ms  -> {per_clip*1e3:.0f} us/clip; algorithmic 1.42 GB/clip -> {1.42/per_clip:.2f} TB/s "
+          f"= {1.42/per_clip/8*100:.1f}% of the 8 TB/s HBM roofline; 41 GFLOP/clip -> {41/per_clip:.1f} TFLOP/s", flush=True)

@@ -1,0 +1,6 @@
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_vqvae_gpu.py tests/test_extract_gpu.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/tests15.log 2>&1; echo "tests exit $?"
+timeout 300 python scripts/bench_kernels.py vqvae > gpurun_out/bench_vq_mfma.log 2>&1
+LLARK_CONV_VALU=1 LLARK_RESBLOCK_VALU=1 timeout 300 python scripts/bench_kernels.py vqvae > gpurun_out/bench_vq_valu.log 2>&1
+grep -E "passed|failed" gpurun_out/tests15.log | tail -2; grep -E "^E  " gpurun_out/tests15.log | cut -c1-300 | head -6; echo MFMA; grep VQ-VAE gpurun_out/bench_vq_mfma.log; echo VALU; grep VQ-VAE gpurun_out/bench_vq_valu.log
