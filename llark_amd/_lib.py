@@ -11,7 +11,7 @@ import subprocess
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libllark_hip.so")
+LIB_PATH = os.environ.get("LLARK_HIP_LIB") or os.path.join(_HERE, "libllark_hip.so")   # override: profiling builds only
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None

@@ -21,6 +21,12 @@
 // grouped over M so that co-resident blocks share A and W panels.
 #include <type_traits>
 
+// Profiling-only compile-time ablations (results invalid): 1 = no DMA in the K loop, 2 = no LDS fragment
+// reads, 3 = no MFMA.  Built into separate libraries by scripts/build_ablations.sh; never set in the product.
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0
+#endif
+
 #include "common.h"
 
 namespace llark {
@@ -169,13 +175,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.Kp / C::BK;
-    stage(0, 0);
+    if (NS >= 2) stage(0, 0);
     if (NS == 3 && nk > 1) stage(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        if (NS == 2) {
+        if (NS == 1) {
+            // single LDS stage, two barriers per K-step: overlap comes from the other blocks resident on the CU
+            if (kt) __syncthreads();
+            stage(0, kt);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        } else if (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk && GEMM_ABLATE != 1) stage((kt + 1) & 1, kt + 1);
         } else {
             // 3-deep ring: tile kt must have landed, tile kt+1 may stay in flight across the barrier
             // (counted vmcnt + raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
             asm volatile("" ::: "memory");
             if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
         }
-        const char* base = smem + (NS == 2 ? (kt & 1) : (kt % 3)) * STAGE;
+        const char* base = smem + (NS == 1 ? 0 : (NS == 2 ? (kt & 1) : (kt % 3))) * STAGE;
         const char* sA = base;
         const char* sL = base + OFF_L;
         const char* sW = base + OFF_W;
@@ -193,6 +205,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
         for (int s = 0; s < C::BK / 16; ++s) {
             const int c = s * 2 + (lane >> 5);
             frag bf[C::TN], ah[C::TM], al[C::TM];
+#if GEMM_ABLATE == 2
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) asm volatile("" : "=v"(bf[tn]));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" : "=v"(ah[tm])); asm volatile("" : "=v"(al[tm])); }
+#else
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn) bf[tn] = *(const frag*)(sW + C::off((wn * C::TN + tn) * 32 + (lane & 31), c));
 #pragma unroll
@@ -200,6 +218,14 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
                 ah[tm] = *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
                 if (SPLIT) al[tm] = *(const frag*)(sL + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
             }
+#endif
+#if GEMM_ABLATE == 3
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) asm volatile("" ::"v"(bf[tn]));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" ::"v"(ah[tm])); if (SPLIT) asm volatile("" ::"v"(al[tm])); }
+            continue;
+#endif
             // (measured: hoisting all fragment reads of a K-tile ahead of the MFMAs, or s_setprio around the MFMA
             //  cluster, is 5-8 % SLOWER on this 1-barrier structure; the compiler's own interleave is kept)
 #pragma unroll
@@ -468,11 +494,11 @@ typedef Cfg<4, 2, 2, 2, 32, 4> Cfg1;   // 256x128x32, 8 waves, 80 KiB           
 typedef Cfg<2, 2, 2, 4, 32, 2> Cfg2;   // 128x256x32, 4 waves (64x128 per wave), 64 KiB : 2 blocks/CU
 typedef Cfg<4, 2, 2, 4, 32, 2> Cfg3;   // 256x256x32, 8 waves (64x128 per wave), 96 KiB : 1 block/CU
 typedef Cfg<2, 2, 2, 2, 64, 1> Cfg4;   // 128x128x64, 4 waves, 96 KiB               : 1 block/CU
-typedef Cfg<2, 2, 4, 2, 32, 2> Cfg5;   // 256x128x32, 4 waves (128x64 per wave), 80 KiB : 2 blocks/CU
 typedef Cfg<4, 2, 2, 4, 32, 2, 3> Cfg6;   // 256x256x32, 8 waves, 3-stage ring, 144 KiB      : 1 block/CU
-typedef Cfg<2, 2, 2, 2, 32, 2, 3> Cfg7;   // 128x128x32, 4 waves, 3-stage ring, 72 KiB       : 2 blocks/CU
-typedef Cfg<4, 2, 2, 2, 32, 2, 3> Cfg8;   // 256x128x32, 8 waves, 3-stage ring, 120 KiB      : 1 block/CU
-typedef Cfg<2, 2, 2, 4, 32, 1, 3> Cfg9;   // 128x256x32, 4 waves, 3-stage ring, 96 KiB       : 1 block/CU
+// BK = 64: every DMA instruction moves 8 rows x 128 B (full cache lines) instead of 16 rows x 64 B
+typedef Cfg<2, 4, 2, 2, 64, 2, 2> Cfg10;  // 128x256x64, 8 waves (64x64 per wave), double buffer 128 KiB : 1 block/CU
+typedef Cfg<2, 2, 2, 2, 64, 3, 1> Cfg11;  // 128x128x64, 4 waves, single stage 48 KiB                    : 3 blocks/CU
+typedef Cfg<2, 2, 2, 4, 64, 2, 1> Cfg12;  // 128x256x64, 4 waves (64x128 per wave), single stage 64 KiB  : 2 blocks/CU
 
 template <typename T>
 static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
@@ -482,11 +508,10 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 2: return dispatch<T, Cfg2>(p, split, epi, s);
         case 3: return dispatch<T, Cfg3>(p, split, epi, s);
         case 4: return dispatch<T, Cfg4>(p, split, epi, s);
-        case 5: return dispatch<T, Cfg5>(p, split, epi, s);
         case 6: return dispatch<T, Cfg6>(p, split, epi, s);
-        case 7: return dispatch<T, Cfg7>(p, split, epi, s);
-        case 8: return dispatch<T, Cfg8>(p, split, epi, s);
-        case 9: return dispatch<T, Cfg9>(p, split, epi, s);
+        case 10: return dispatch<T, Cfg10>(p, split, epi, s);
+        case 11: return dispatch<T, Cfg11>(p, split, epi, s);
+        case 12: return dispatch<T, Cfg12>(p, split, epi, s);
     }
     set_error("gemm: unknown tile variant %d", variant);
     return LLARK_ERR_INVALID;
@@ -500,14 +525,16 @@ using namespace llark;
 // Wt is [N][ldw] (K-contiguous rows, i.e. the transpose of upstream Conv1D.w / the native layout of
 // nn.Linear.weight); K is padded with zeros up to kp (multiple of 32) in BOTH A and Wt.  M and N
 // need no padding: out-of-range rows are clamped on load and masked on store.
-// Default tile choice, from the MI355X sweep in profiles/r01_gemm_variants.txt: wide per-wave tiles
-// (64x128 per wave, 128x256 per block) win when K is deep; the 8-wave 256x128 block wins for shallow K
-// (more blocks in flight per K-loop); tiny M keeps the small tile so that enough blocks exist.
+// Default tile choice, from the MI355X sweeps in profiles/r01_gemm_variants*.txt.  An ablation of the main
+// loop (profiles/r01_gemm_ablation.txt) shows the L2->LDS DMA stream, not the MFMAs, is the long pole, so the
+// winners are the shapes that move the fewest bytes per flop in FULL 128-B lines: BK = 64 (8 rows x 128 B per
+// DMA instruction), 64x128 per wave, single LDS stage with 2 blocks per CU overlapping each other.
 static int pick_variant(int split, int m, int n, int kp) {
-    (void)split;
     if (m <= 128 || n < 256) return 0;
-    if (kp < 2048) return 1;
-    return 2;
+    if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
+    if (kp < 2048) return 1;                      // shallow K (attention c_proj, K = 1216): 8-wave 256x128 block
+    if (!split && n < 16384) return 11;           // plain 16-bit, mid-size N (Llama q/k/v/o, down): 128x128x64, 3 blocks/CU
+    return 12;                                    // 128x256x64
 }
 
 extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
@@ -515,7 +542,8 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
                                const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
                                llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
-    LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant != 4), "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
+    LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant != 4 && variant < 10),
+                  "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
     LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16: lda/ldw must be >= kp and multiples of 8");
     LLARK_REQUIRE(!split || a_lo, "gemm16: split mode needs the lo plane");
     LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && (!a_lo || ((uintptr_t)a_lo & 15) == 0),

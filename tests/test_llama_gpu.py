@@ -209,8 +209,10 @@ def test_engine_bf16_vs_oracle_flow():
     gold = torch.from_numpy(z["c1_logits"])
     e_gold = report_close("bf16 logits vs REFERENCE fp32 golden", logits, gold, 3e-2 * gold.abs().max().item())
     print(f"bf16-mode logits rel err: vs oracle-bf16-flow {e_flow/scale:.2e}, vs reference fp32 {e_gold/gold.abs().max().item():.2e}")
+    # last_only routes the final norm + lm_head through the skinny (M <= 16) kernel: same math, different
+    # accumulation order -> fp32 rounding-level agreement
     lo = eng.forward_tokens(ids.cuda(), segs, last_only=True).cpu()
-    assert torch.equal(lo[:, 0], logits[:, -1])
+    report_close("last_only logits", lo[:, 0], logits[:, -1], 1e-4 * scale)
 
 
 def test_wrapped_model_api_loss_generate_errors():
