@@ -99,6 +99,12 @@ int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const voi
 int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* Batched form (grid.y = batch): per-batch element strides for A, wt, c and the 16-bit outputs (no bias / residual).
+ * Used by the attention backward of the training step (one product per (sequence, head)). */
+int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, long long stride_a,
+                         const void* wt, int ldw, long long stride_w, int m, int n, int kp, float* c, int ldc,
+                         long long stride_c, void* out_hi, void* out_lo, int ldo, long long stride_o, int batch,
+                         llark_stream_t stream);
 /* w[k][n] (upstream Conv1D.w, 16-bit) -> wt[n][ldw] with zero K padding; also serves row-major copies
  * (transpose=0: w is already [n][k], e.g. nn.Linear.weight). src_dtype/dst_dtype: LLARK_F16/BF16 or
  * 2 for fp32 source. */
@@ -140,6 +146,41 @@ int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_ca
  * int64 [batch][s]; row_loss scratch float[batch*s]; loss_out float[2] = {mean loss, counted rows}. */
 int llark_cross_entropy_shifted(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
                                 int64_t ignore_index, float* row_loss, float* loss_out, llark_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step of the LLM half: backward / optimizer pieces around the GEMMs (m2t/train.py:53-277 -> HF Trainer:
+ * WrappedLlamav2ForCausalLM.forward(labels), loss.backward(), AdamW; scripts/training/train_llark.sh:20-49).
+ * ------------------------------------------------------------------------------------------- */
+/* dst[b][c][r] = src[b][r][c] (16-bit), dst columns [rows, ld_dst) zero-filled. */
+int llark_transpose16(const void* src, int ld_src, int rows, int cols, void* dst, int ld_dst, int batch,
+                      long long stride_src, long long stride_dst, llark_stream_t stream);
+/* x [batch*s][nh*hd] (16-bit) -> y [batch][nh][s][hd] */
+int llark_split_heads16(const void* x, int batch, int s, int nh, int hd, void* y, llark_stream_t stream);
+/* P[b][i][j] = softmax_j(scale*scores[b][i][j]), j <= i (bf16, pitch ldp, zero elsewhere). scores fp32 [batch][s][s]. */
+int llark_causal_softmax_rows(const float* scores, int batch, int s, float scale, void* p_out, int ldp, llark_stream_t stream);
+/* softmax backward: dS = P o (dP - rowsum(P o dP)) * scale  (bf16, pitch ldp) */
+int llark_attn_ds(const void* p, const float* dp, int batch, int s, float scale, void* ds_out, int ldp, llark_stream_t stream);
+/* RoPE backward + merge heads: dq/dk/dv fp32 [batch][nh][s][hd] -> dqkv bf16 [batch*s][3*nh*hd] */
+int llark_rope_merge_bwd(const float* dq, const float* dk, const float* dv, const float* cos_t, const float* sin_t, int batch,
+                         int s, int nh, int hd, int pos0, void* dqkv, llark_stream_t stream);
+/* LlamaRMSNorm backward: dx (=|+=) ..., dw += ... (fp32 atomics) */
+int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx, int accumulate,
+                      float* dw, llark_stream_t stream);
+/* SwiGLU on the interleaved [32 gate | 32 up] layout: gu fp32 [rows][2*inter] */
+int llark_swiglu_fwd(const float* gu, int rows, int inter, void* act, llark_stream_t stream);
+int llark_swiglu_bwd(const float* gu, const float* dact, int rows, int inter, void* dgu, llark_stream_t stream);
+/* d(mean shifted CE)/dlogits * loss_scale as bf16 [batch*s][ldd]; row_loss / loss_cnt come from llark_cross_entropy_shifted */
+int llark_cross_entropy_bwd(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
+                            const float* row_loss, const float* loss_cnt, float loss_scale, void* dlogits, int ldd,
+                            llark_stream_t stream);
+int llark_colsum_f32(const float* x, int ld, int rows, int cols, float* out, llark_stream_t stream);
+int llark_gather_rows_f32(const float* src, int ld_src, const int64_t* idx, int n, int cols, float* dst, int ld_dst,
+                          llark_stream_t stream);
+int llark_scatter_add_rows_f32(const float* src, int ld_src, const int64_t* idx, int n, int cols, float* dst, int ld_dst,
+                               llark_stream_t stream);
+/* torch.optim.AdamW step on bf16 (param_dtype 1) or fp32 (2) parameters with fp32 gradients (scaled by grad_scale) and moments */
+int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int step, float grad_scale, llark_stream_t stream);
 
 #ifdef __cplusplus
 }

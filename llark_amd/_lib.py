@@ -57,6 +57,8 @@ _SIGS = {
                      _P, _P, c_int, _P],
     "llark_gemm16_ex": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                         _P, _P, c_int, _P],
+    "llark_gemm16_batched": [c_int, c_int, c_int, _P, _P, c_int, c_int64, _P, c_int, c_int64, c_int, c_int, c_int, _P, c_int,
+                             c_int64, _P, _P, c_int, c_int64, c_int, _P],
     "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],
     "llark_split16": [c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P],
     "llark_embed_gather": [_P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P],
@@ -65,6 +67,19 @@ _SIGS = {
     "llark_attn_prefill_bf16": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "llark_attn_decode_bf16": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "llark_cross_entropy_shifted": [_P, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P, _P],
+    "llark_transpose16": [_P, c_int, c_int, c_int, _P, c_int, c_int, c_int64, c_int64, _P],
+    "llark_split_heads16": [_P, c_int, c_int, c_int, c_int, _P, _P],
+    "llark_causal_softmax_rows": [_P, c_int, c_int, c_float, _P, c_int, _P],
+    "llark_attn_ds": [_P, _P, c_int, c_int, c_float, _P, c_int, _P],
+    "llark_rope_merge_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "llark_rmsnorm_bwd": [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P],
+    "llark_swiglu_fwd": [_P, c_int, c_int, _P, _P],
+    "llark_swiglu_bwd": [_P, _P, c_int, c_int, _P, _P],
+    "llark_cross_entropy_bwd": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, c_int, _P],
+    "llark_colsum_f32": [_P, c_int, c_int, c_int, _P, _P],
+    "llark_gather_rows_f32": [_P, c_int, _P, c_int, c_int, _P, c_int, _P],
+    "llark_scatter_add_rows_f32": [_P, c_int, _P, c_int, c_int, _P, c_int, _P],
+    "llark_adamw": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P],
 }
 
 

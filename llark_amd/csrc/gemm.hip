@@ -66,6 +66,9 @@ struct GemmParams {
     void* Olo;
     int ldo;
     int tiles_m, tiles_n;
+    // batched mode (grid.y = batch): element strides added per batch index; 0 = operand shared by all batches
+    int batch;
+    long long sA, sW, sC, sR, sO;
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
@@ -146,9 +149,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     const int tile_n = (bid % gsz) / gm;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
 
-    const T* Ahi = (const T*)p.Ahi;
-    const T* Alo = (const T*)p.Alo;
-    const T* Wt = (const T*)p.Wt;
+    const long long bz = blockIdx.y;                              // batch index (0 when not batched)
+    const T* Ahi = (const T*)p.Ahi + bz * p.sA;
+    const T* Alo = SPLIT ? (const T*)p.Alo + bz * p.sA : nullptr;
+    const T* Wt = (const T*)p.Wt + bz * p.sW;
 
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE;
@@ -252,19 +256,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
     int vC = 0, vR = 0, vO = 0;
     if (EPI == EPI_F32 || EPI == EPI_RESID) {
-        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + bz * p.sC + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vC = (lr * p.ldc + lc) * 4;
     }
     if (EPI == EPI_RESID) {
-        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + bz * p.sR + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vR = (lr * p.ldr + lc) * 4;
     }
     if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
-        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vO = (lr * p.ldo + lc) * 2;
     }
     if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
-        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
 
     auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -332,7 +336,7 @@ static int launch_gemm(GemmParams p, hipStream_t s) {
     }
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
-    kern<<<p.tiles_m * p.tiles_n, C::THREADS, LDS, s>>>(p);
+    kern<<<dim3(p.tiles_m * p.tiles_n, p.batch > 0 ? p.batch : 1), C::THREADS, LDS, s>>>(p);
     return check_launch("gemm");
 }
 
@@ -537,10 +541,10 @@ static int pick_variant(int split, int m, int n, int kp) {
     return 12;                                    // 128x256x64
 }
 
-extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
-                               const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
-                               const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
-                               llark_stream_t stream) {
+static int gemm16_impl(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                       const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                       const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, int batch, long long sa,
+                       long long sw, long long sc, long long sr, long long so, llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
     LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant != 4 && variant < 10),
                   "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
@@ -559,8 +563,9 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
     p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
     p.tiles_m = p.tiles_n = 0;
+    p.batch = batch; p.sA = sa; p.sW = sw; p.sC = sc; p.sR = sr; p.sO = so;
     hipStream_t s = (hipStream_t)stream;
-    if (variant < 0 && m <= 16) {                 // decode: HBM-bound skinny kernel
+    if (variant < 0 && m <= 16 && batch <= 1) {   // decode: HBM-bound skinny kernel
         int rc = 1;
         if (dtype == LLARK_F16) rc = dispatch_skinny<half_t>(p, split != 0, epilogue, s);
         else if (dtype == LLARK_BF16) rc = dispatch_skinny<bf16_t>(p, split != 0, epilogue, s);
@@ -571,6 +576,23 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
     if (dtype == LLARK_BF16) return dispatch_variant<bf16_t>(variant, p, split != 0, epilogue, s);
     set_error("gemm16: unknown dtype %d", dtype);
     return LLARK_ERR_INVALID;
+}
+
+extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                               const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                               const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                               llark_stream_t stream) {
+    return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
+                       out_lo, ldo, 0, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                                    long long stride_a, const void* wt, int ldw, long long stride_w, int m, int n, int kp,
+                                    float* c, int ldc, long long stride_c, void* out_hi, void* out_lo, int ldo,
+                                    long long stride_o, int batch, llark_stream_t stream) {
+    LLARK_REQUIRE(batch >= 1 && batch <= 65535, "gemm16_batched: batch %d out of range", batch);
+    return gemm16_impl(-1, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, nullptr, m, n, kp, c, ldc, nullptr, 0, out_hi, out_lo,
+                       ldo, batch, stride_a, stride_w, stride_c, 0, stride_o, stream);
 }
 
 extern "C" int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,

@@ -1,0 +1,410 @@
+// Backward / optimizer support kernels of the instruction-tuning step (m2t/train.py:53-277 -> HF Trainer ->
+// WrappedLlamav2ForCausalLM.forward(labels) + loss.backward() + AdamW; scripts/training/train_llark.sh:20-49).
+// Every matrix product of the backward pass is the MFMA GEMM of gemm.hip (dX = dY.W, dW = dY^T.X, and the
+// attention backward as batched products over materialised [S][S] score tiles -- 288 GB of HBM make the
+// O(S^2) buffers of S <= 2048 affordable); this file holds the transposes and the element-wise / row-wise
+// pieces between them.  dtype flow = the reference's bf16 training run: bf16 matrix operands, fp32
+// accumulation, fp32 residual-stream gradients.
+#include "common.h"
+
+namespace llark {
+
+// ------------------------------------------------------------------------------------------
+// batched 16-bit transpose: dst[b][c][r] = src[b][r][c], columns [rows, ld_dst) of dst zero-filled
+// (K padding of the following GEMM).  64x64 tiles through LDS, both sides coalesced.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ src, int ld_src, int rows,
+                                                          int cols, unsigned short* __restrict__ dst, int ld_dst,
+                                                          long long s_src, long long s_dst) {
+    __shared__ unsigned short tile[64][66];
+    const long long b = blockIdx.z;
+    src += b * s_src;
+    dst += b * s_dst;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;           // dst row = source column
+        if (c < cols && r < ld_dst) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+// x [B*S][nh*hd] (16-bit) -> [B][nh][S][hd]
+__global__ void split_heads16_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int B, int S,
+                                     int nh, int hd) {
+    const size_t total = (size_t)B * S * nh * hd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % hd);
+        const int h = (int)((i / hd) % nh);
+        const size_t row = i / ((size_t)hd * nh);           // b*S + s
+        const size_t b = row / S, s = row % S;
+        y[((b * nh + h) * S + s) * hd + d] = x[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// causal softmax over rows of raw scores: P[b][i][j] = softmax_j(scale * sc[b][i][j]) for j <= i, else 0;
+// bf16 output with pitch ldp (pad columns zero).  One wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void causal_softmax_rows_kernel(const float* __restrict__ sc, int S, float scale,
+                                                                  bf16_t* __restrict__ P, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t b = blockIdx.y;
+    if (i >= S) return;
+    const float* row = sc + (b * S + i) * (size_t)S;
+    bf16_t* prow = P + (b * S + i) * (size_t)ldp;
+    float mx = -INFINITY;
+    for (int j = lane; j <= i; j += 64) mx = fmaxf(mx, row[j] * scale);
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j <= i; j += 64) sum += expf(row[j] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < ldp; j += 64) prow[j] = (j <= i) ? (bf16_t)(expf(row[j] * scale - mx) * inv) : (bf16_t)0.0f;
+}
+
+// dS = P o (dP - rowsum(P o dP)) * scale   (softmax backward; P bf16 pitch ldp, dP fp32 [S][S], dS bf16 pitch ldp)
+__global__ __launch_bounds__(256) void attn_ds_kernel(const bf16_t* __restrict__ P, const float* __restrict__ dP, int S,
+                                                      float scale, bf16_t* __restrict__ dS, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t b = blockIdx.y;
+    if (i >= S) return;
+    const bf16_t* prow = P + (b * S + i) * (size_t)ldp;
+    const float* drow = dP + (b * S + i) * (size_t)S;
+    bf16_t* out = dS + (b * S + i) * (size_t)ldp;
+    float dot = 0.0f;
+    for (int j = lane; j <= i; j += 64) dot += (float)prow[j] * drow[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < ldp; j += 64) out[j] = (j <= i) ? (bf16_t)((float)prow[j] * (drow[j] - dot) * scale) : (bf16_t)0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE backward + merge heads: dq/dk/dv fp32 [B][nh][S][128] -> dqkv bf16 [B*S][3*nh*128].
+// forward: y1 = x1 c - x2 s ; y2 = x2 c + x1 s   =>   dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s
+// ------------------------------------------------------------------------------------------
+__global__ void rope_merge_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ dk, const float* __restrict__ dv,
+                                      const float* __restrict__ cos_t, const float* __restrict__ sin_t, int B, int S, int nh,
+                                      int pos0, bf16_t* __restrict__ dqkv) {
+    const int hd = 128, H = nh * hd;
+    const size_t total = (size_t)B * nh * S * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i & 63);
+        const size_t r = i >> 6;                       // (b*nh + h)*S + s
+        const int s = (int)(r % S);
+        const size_t bh = r / S;
+        const int h = (int)(bh % nh);
+        const size_t b = bh / nh;
+        const float c = cos_t[(size_t)(pos0 + s) * 64 + d], sn = sin_t[(size_t)(pos0 + s) * 64 + d];
+        const size_t in = r * hd;
+        bf16_t* out = dqkv + (b * S + s) * (size_t)(3 * H) + h * hd;
+        const float q1 = dq[in + d], q2 = dq[in + d + 64], k1 = dk[in + d], k2 = dk[in + d + 64];
+        out[d] = (bf16_t)(q1 * c + q2 * sn);
+        out[d + 64] = (bf16_t)(q2 * c - q1 * sn);
+        out[H + d] = (bf16_t)(k1 * c + k2 * sn);
+        out[H + d + 64] = (bf16_t)(k2 * c - k1 * sn);
+        out[2 * H + d] = (bf16_t)dv[in + d];
+        out[2 * H + d + 64] = (bf16_t)dv[in + d + 64];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm backward: y = w * (x * rstd).  dx += rstd * (g - xhat * mean(g o xhat)), g = dy o w ; dw += sum_rows dy o xhat
+// One wave per row; dw accumulated with fp32 atomics (per-block partial sums first).
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ dy, int rows, int width, float eps,
+                                                          float* __restrict__ dx, float* __restrict__ dw, int accumulate) {
+    extern __shared__ float sdw[];                      // [width] per-block partial dw
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < width; c += 256) sdw[c] = 0.0f;
+    __syncthreads();
+    const int row = blockIdx.x * 4 + wv;
+    if (row < rows) {
+        const float* xr = x + (size_t)row * width;
+        const float* dr = dy + (size_t)row * width;
+        float xv[NV * 4], gv[NV * 4];
+        float ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            xv[k] = c < width ? xr[c] : 0.0f;
+            ss += xv[k] * xv[k];
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)width + eps);
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            const float d = c < width ? dr[c] : 0.0f;
+            const float xh = xv[k] * rstd;
+            gv[k] = c < width ? d * w[c] : 0.0f;
+            dot += gv[k] * xh;
+            if (c < width) atomicAdd(&sdw[c], d * xh);
+        }
+        const float mdot = wave_sum(dot) / (float)width;
+        float* dxr = dx + (size_t)row * width;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < width) {
+                const float v = rstd * (gv[k] - xv[k] * rstd * mdot);
+                dxr[c] = accumulate ? dxr[c] + v : v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256)
+        if (sdw[c] != 0.0f) atomicAdd(&dw[c], sdw[c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// SwiGLU on the interleaved gate/up layout ([32 gate | 32 up] per 64 columns of gu):
+//   fwd: act[m][32q+j] = silu(g) * u ;  bwd: dg = dact * u * sig * (1 + g (1 - sig)), du = dact * g * sig
+// ------------------------------------------------------------------------------------------
+__global__ void swiglu_fwd_kernel(const float* __restrict__ gu, int rows, int inter, bf16_t* __restrict__ act) {
+    const size_t total = (size_t)rows * inter;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % inter);
+        const size_t m = i / inter;
+        const float* p = gu + m * (size_t)(2 * inter) + (c >> 5) * 64 + (c & 31);
+        const float g = p[0], u = p[32];
+        act[i] = (bf16_t)((g / (1.0f + expf(-g))) * u);
+    }
+}
+__global__ void swiglu_bwd_kernel(const float* __restrict__ gu, const float* __restrict__ dact, int rows, int inter,
+                                  bf16_t* __restrict__ dgu) {
+    const size_t total = (size_t)rows * inter;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % inter);
+        const size_t m = i / inter;
+        const size_t o = m * (size_t)(2 * inter) + (c >> 5) * 64 + (c & 31);
+        const float g = gu[o], u = gu[o + 32], d = dact[i];
+        const float sig = 1.0f / (1.0f + expf(-g));
+        dgu[o] = (bf16_t)(d * u * sig * (1.0f + g * (1.0f - sig)));
+        dgu[o + 32] = (bf16_t)(d * g * sig);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-entropy backward on shifted logits: dlogits[row][v] = (softmax(logits[row])_v - [v == tgt]) / count for the
+// counted rows (row_loss >= 0, written by the forward kernel), zero otherwise; bf16, pitch ldd (pads zero).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int ldl, int S, int vocab,
+                                                     const long long* __restrict__ labels, const float* __restrict__ row_loss,
+                                                     const float* __restrict__ loss_cnt, bf16_t* __restrict__ dlogits, int ldd,
+                                                     float loss_scale) {
+    __shared__ float red[8];
+    const int s = blockIdx.x, b = blockIdx.y;
+    const int row = b * S + s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bf16_t* out = dlogits + (size_t)row * ldd;
+    if (row_loss[row] < 0.0f) {
+        for (int c = threadIdx.x; c < ldd; c += 256) out[c] = (bf16_t)0.0f;
+        return;
+    }
+    const long long tgt = labels[(size_t)b * S + s + 1];
+    const float* lr = logits + (size_t)row * ldl;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < vocab; c += 256) mx = fmaxf(mx, lr[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.0f;
+    for (int c = threadIdx.x; c < vocab; c += 256) sum += expf(lr[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wv] = sum;
+    __syncthreads();
+    const float inv = loss_scale / (((red[4] + red[5]) + (red[6] + red[7])) * loss_cnt[1]);
+    const float one = loss_scale / loss_cnt[1];
+    for (int c = threadIdx.x; c < ldd; c += 256) {
+        float v = 0.0f;
+        if (c < vocab) v = expf(lr[c] - mx) * inv - (c == tgt ? one : 0.0f);
+        out[c] = (bf16_t)v;
+    }
+}
+
+// out[c] (+)= sum_r x[r][c]
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * ld + c];
+    out[c] += s;
+}
+
+// gathers rows: dst[i][:] (+)= src[idx[i]][:]  (fp32)    /   scatter-add: dst[idx[i]][:] += src[i][:]
+__global__ void gather_rows_kernel(const float* __restrict__ src, int ld_src, const long long* __restrict__ idx, int n,
+                                   int cols, float* __restrict__ dst, int ld_dst) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)i * ld_dst + c] = src[(size_t)idx[i] * ld_src + c];
+}
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int ld_src, const long long* __restrict__ idx, int n,
+                                        int cols, float* __restrict__ dst, int ld_dst) {
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) atomicAdd(&dst[(size_t)idx[i] * ld_dst + c], src[(size_t)i * ld_src + c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW (torch.optim.AdamW semantics, decoupled weight decay, bias correction) on bf16 parameters with fp32
+// gradients and fp32 moments:  p <- p (1 - lr wd) - lr * mhat / (sqrt(vhat) + eps)
+// ------------------------------------------------------------------------------------------
+__global__ void adamw_bf16_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                  float bc1, float bc2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float pi = (float)p[i];
+        pi = pi * (1.0f - lr * wd) - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        p[i] = (bf16_t)pi;
+    }
+}
+__global__ void adamw_f32_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                                 float bc1, float bc2, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] * (1.0f - lr * wd) - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    }
+}
+
+static inline int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+extern "C" int llark_transpose16(const void* src, int ld_src, int rows, int cols, void* dst, int ld_dst, int batch,
+                                 long long stride_src, long long stride_dst, llark_stream_t stream) {
+    LLARK_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows && batch >= 1, "transpose16: bad arguments");
+    dim3 grid(cdiv(cols, 64), cdiv(ld_dst, 64), batch);
+    transpose16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)src, ld_src, rows, cols,
+                                                               (unsigned short*)dst, ld_dst, stride_src, stride_dst);
+    return check_launch("transpose16");
+}
+
+extern "C" int llark_split_heads16(const void* x, int batch, int s, int nh, int hd, void* y, llark_stream_t stream) {
+    LLARK_REQUIRE(x && y && batch > 0 && s > 0 && nh > 0 && hd > 0, "split_heads16: bad arguments");
+    const size_t total = (size_t)batch * s * nh * hd;
+    split_heads16_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned short*)y, batch, s, nh, hd);
+    return check_launch("split_heads16");
+}
+
+extern "C" int llark_causal_softmax_rows(const float* scores, int batch, int s, float scale, void* p_out, int ldp,
+                                         llark_stream_t stream) {
+    LLARK_REQUIRE(scores && p_out && batch > 0 && s > 0 && ldp >= s, "causal_softmax_rows: bad arguments");
+    dim3 grid(cdiv(s, 4), batch);
+    causal_softmax_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(scores, s, scale, (bf16_t*)p_out, ldp);
+    return check_launch("causal_softmax_rows");
+}
+
+extern "C" int llark_attn_ds(const void* p, const float* dp, int batch, int s, float scale, void* ds_out, int ldp,
+                             llark_stream_t stream) {
+    LLARK_REQUIRE(p && dp && ds_out && batch > 0 && s > 0 && ldp >= s, "attn_ds: bad arguments");
+    dim3 grid(cdiv(s, 4), batch);
+    attn_ds_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)p, dp, s, scale, (bf16_t*)ds_out, ldp);
+    return check_launch("attn_ds");
+}
+
+extern "C" int llark_rope_merge_bwd(const float* dq, const float* dk, const float* dv, const float* cos_t, const float* sin_t,
+                                    int batch, int s, int nh, int hd, int pos0, void* dqkv, llark_stream_t stream) {
+    LLARK_REQUIRE(dq && dk && dv && cos_t && sin_t && dqkv && hd == 128, "rope_merge_bwd: bad arguments (head_dim must be 128)");
+    const size_t total = (size_t)batch * nh * s * 64;
+    rope_merge_bwd_kernel<<<grid_for(total), 256, 0, (hipStream_t)stream>>>(dq, dk, dv, cos_t, sin_t, batch, s, nh, pos0, (bf16_t*)dqkv);
+    return check_launch("rope_merge_bwd");
+}
+
+extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx,
+                                 int accumulate, float* dw, llark_stream_t stream) {
+    LLARK_REQUIRE(x && w && dy && dx && dw && rows > 0 && width > 0, "rmsnorm_bwd: bad arguments");
+    dim3 grid(cdiv(rows, 4));
+    const size_t lds = (size_t)width * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define RB(NV) rmsnorm_bwd_kernel<NV><<<grid, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate)
+    if (width <= 256) RB(1);
+    else if (width <= 1024) RB(4);
+    else if (width <= 4096) RB(16);
+    else if (width <= 8192) RB(32);
+    else {
+        set_error("rmsnorm_bwd: width %d too large", width);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+#undef RB
+    return check_launch("rmsnorm_bwd");
+}
+
+extern "C" int llark_swiglu_fwd(const float* gu, int rows, int inter, void* act, llark_stream_t stream) {
+    LLARK_REQUIRE(gu && act && rows > 0 && inter % 32 == 0, "swiglu_fwd: bad arguments");
+    swiglu_fwd_kernel<<<grid_for((size_t)rows * inter), 256, 0, (hipStream_t)stream>>>(gu, rows, inter, (bf16_t*)act);
+    return check_launch("swiglu_fwd");
+}
+
+extern "C" int llark_swiglu_bwd(const float* gu, const float* dact, int rows, int inter, void* dgu, llark_stream_t stream) {
+    LLARK_REQUIRE(gu && dact && dgu && rows > 0 && inter % 32 == 0, "swiglu_bwd: bad arguments");
+    swiglu_bwd_kernel<<<grid_for((size_t)rows * inter), 256, 0, (hipStream_t)stream>>>(gu, dact, rows, inter, (bf16_t*)dgu);
+    return check_launch("swiglu_bwd");
+}
+
+extern "C" int llark_cross_entropy_bwd(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
+                                       const float* row_loss, const float* loss_cnt, float loss_scale, void* dlogits, int ldd,
+                                       llark_stream_t stream) {
+    LLARK_REQUIRE(logits && labels && row_loss && loss_cnt && dlogits && ldd >= vocab, "cross_entropy_bwd: bad arguments");
+    dim3 grid(s, batch);
+    ce_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(logits, ldl, s, vocab, (const long long*)labels, row_loss, loss_cnt,
+                                                          (bf16_t*)dlogits, ldd, loss_scale);
+    return check_launch("cross_entropy_bwd");
+}
+
+extern "C" int llark_colsum_f32(const float* x, int ld, int rows, int cols, float* out, llark_stream_t stream) {
+    LLARK_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
+    colsum_kernel<<<cdiv(cols, 256), 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols, out);
+    return check_launch("colsum");
+}
+
+extern "C" int llark_gather_rows_f32(const float* src, int ld_src, const int64_t* idx, int n, int cols, float* dst, int ld_dst,
+                                     llark_stream_t stream) {
+    LLARK_REQUIRE(src && idx && dst && n > 0 && cols > 0, "gather_rows: bad arguments");
+    gather_rows_kernel<<<n, 256, 0, (hipStream_t)stream>>>(src, ld_src, (const long long*)idx, n, cols, dst, ld_dst);
+    return check_launch("gather_rows");
+}
+
+extern "C" int llark_scatter_add_rows_f32(const float* src, int ld_src, const int64_t* idx, int n, int cols, float* dst,
+                                          int ld_dst, llark_stream_t stream) {
+    LLARK_REQUIRE(src && idx && dst && n > 0 && cols > 0, "scatter_add_rows: bad arguments");
+    scatter_add_rows_kernel<<<n, 256, 0, (hipStream_t)stream>>>(src, ld_src, (const long long*)idx, n, cols, dst, ld_dst);
+    return check_launch("scatter_add_rows");
+}
+
+extern "C" int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float grad_scale, llark_stream_t stream) {
+    LLARK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipStream_t s = (hipStream_t)stream;
+    if (param_dtype == LLARK_BF16)
+        adamw_bf16_kernel<<<grid_for((size_t)n), 256, 0, s>>>((bf16_t*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else if (param_dtype == 2)
+        adamw_f32_kernel<<<grid_for((size_t)n), 256, 0, s>>>((float*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else {
+        set_error("adamw: parameter dtype must be bf16 (1) or fp32 (2), got %d", param_dtype);
+        return LLARK_ERR_INVALID;
+    }
+    return check_launch("adamw");
+}

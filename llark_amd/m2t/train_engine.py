@@ -1,0 +1,280 @@
+"""Training step of the LLM half on the HIP kernels: forward with saved activations, full backward, AdamW, and the
+data-parallel gradient all-reduce (RCCL over xGMI via ``torch.distributed``; gloo in the CPU tests).
+
+Replaces what the reference reaches through ``trainer.train()`` (m2t/train.py:255-260 -> HF ``Trainer.training_step``
+-> ``WrappedLlamav2ForCausalLM.forward(labels=...)`` m2t/models/llamav2.py:259-337, ``loss.backward()``, DDP gradient
+all-reduce, ``torch.optim.AdamW``; hyper-parameters scripts/training/train_llark.sh:20-49).
+
+Semantics kept from the reference's default recipe (``--freeze_backbone False --tune_mm_mlp_adapter True --bf16 True``):
+  * trainable: every Llama weight, ``mm_projector`` and -- through ``orig_embeds_params`` (m2t/models/llamav2.py:176-198)
+    -- only the ``<audio_start>`` / ``<audio_end>`` rows of ``embed_tokens``; ``lm_head`` is frozen
+    (m2t/models/llamav2.py:412-415);
+  * bf16 parameters and matrix operands, fp32 accumulation; loss = mean shifted CE over labels != -100;
+  * gradient accumulation over micro-batches (``--gradient_accumulation_steps``) then one AdamW step.
+Differences (documented in DESIGN.md): AdamW moments are fp32 (torch keeps them in the parameter dtype); no
+gradient checkpointing (288 GB of HBM hold the ~13 GB of saved activations of a 4 x 512 micro-batch).
+
+Gradients live in ONE flat fp32 buffer (views per tensor, kernel layouts: fused q|k|v rows, interleaved gate/up) so the
+data-parallel exchange is a handful of large all-reduces.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+from .engine import HipLlamaEngine
+
+_BF = torch.bfloat16
+
+
+class HipLlamaTrainer:
+    def __init__(self, engine: HipLlamaEngine, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, embed_grad_tokens: Sequence[int] = (), train_embed_all: bool = False):
+        if engine.split:
+            raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
+        self.eng = engine
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.embed_grad_tokens = set(int(t) for t in embed_grad_tokens)
+        self.train_embed_all = train_embed_all
+        self.step_count = 0
+        d, dev = engine.dims, engine.device
+        # ---- parameter table: (name, tensor) in kernel layout; lm_head is frozen like the reference ----
+        self.params: List[Tuple[str, torch.Tensor]] = []
+        for i, L in enumerate(engine.layers):
+            for nm in ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2"):
+                self.params.append((f"layers.{i}.{nm}", getattr(L, nm)))
+        self.params += [("norm", engine.norm), ("embed", engine.embed)]
+        if engine.proj_w is not None:
+            self.params += [("proj_w", engine.proj_w), ("proj_b", engine.proj_b)]
+        total = sum(p.numel() for _, p in self.params)
+        self.flat_grad = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros_like(self.flat_grad)
+        self.flat_v = torch.zeros_like(self.flat_grad)
+        self.grads: Dict[str, torch.Tensor] = {}
+        self._slices: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, p in self.params:
+            n = p.numel()
+            self.grads[name] = self.flat_grad[off: off + n].view(p.shape)
+            self._slices[name] = (off, n)
+            off += n
+        self.micro_batches = 0
+
+    # ------------------------------------------------------------------------------------------
+    def zero_grad(self) -> None:
+        self.flat_grad.zero_()
+        self.micro_batches = 0
+
+    def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor) -> None:
+        """grad[N][K] += dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16)."""
+        dyT = ops.transposed16(dy16)
+        xT = ops.transposed16(x16)
+        n, k = dy16.shape[1], x16.shape[1]
+        ops.gemm16(dyT, None, xT, None, k, ops.EPI_RESID, c=grad, resid=grad, m=n)
+
+    def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
+        """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout)."""
+        wT = ops.transposed16(w)                      # [K][Np]
+        if dy16.shape[1] < wT.shape[1]:               # pad dY columns up to the 64-multiple K of this product
+            pad = torch.zeros((dy16.shape[0], wT.shape[1]), dtype=_BF, device=dy16.device)
+            pad[:, : dy16.shape[1]] = dy16
+            dy16 = pad
+        ops.gemm16(dy16, None, wT, None, w.shape[1], ops.EPI_F32, c=out)
+
+    # ------------------------------------------------------------------------------------------
+    def forward_backward(self, input_ids: torch.Tensor, audio_segments, labels: torch.Tensor, loss_scale: float = 1.0) -> torch.Tensor:
+        """One micro-batch: returns the (unscaled) loss as a device scalar and ACCUMULATES gradients.
+        ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer."""
+        eng, d = self.eng, self.eng.dims
+        dev = eng.device
+        B, S = input_ids.shape
+        rows = B * S
+        H, I, nh, hd, V = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim, d.vocab_size
+        f32 = dict(dtype=torch.float32, device=dev)
+        bf = dict(dtype=_BF, device=dev)
+        eng.reset(B)
+        ids_flat = input_ids.reshape(-1).contiguous()
+        h = torch.empty((rows, H), **f32)
+        ops.embed_gather(ids_flat, eng.embed, h)
+        seg_rows, seg_a16 = [], []
+        for (b, start, frames) in audio_segments:
+            F = frames.shape[0]
+            a16, _ = ops.split16(frames.contiguous(), _BF, want_lo=False, kmult=64)
+            r0 = b * S + start + 1
+            ops.gemm16(a16, None, eng.proj_w, eng.proj_b, H, ops.EPI_F32, c=h[r0: r0 + F])
+            seg_rows.append(torch.arange(r0, r0 + F, device=dev))
+            seg_a16.append(a16[:, : d.mm_hidden_size])
+        # ---------------- forward, saving what the backward needs ----------------
+        saved = []
+        for i, L in enumerate(eng.layers):
+            st = {"h_in": h.clone()}
+            x1 = torch.empty((rows, H), **bf)
+            ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x1)
+            qkv = torch.empty((rows, 3 * H), **f32)
+            ops.gemm16(x1, None, L.wqkv, None, 3 * H, ops.EPI_F32, c=qkv)
+            q = torch.empty((B, nh, S, hd), **bf)
+            kc, vc = eng.k_cache[i, :B], eng.vt_cache[i, :B]
+            ops.rope_split_heads(qkv, B, S, nh, hd, 0, eng.cos, eng.sin, q, kc, vc)
+            att = torch.empty((rows, H), **bf)
+            ops.attn_prefill(q, kc, vc, B, S, nh, hd, 0, att)
+            ops.gemm16(att, None, L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+            st.update(x1=x1, q=q, att=att, h_mid=h.clone())
+            x2 = torch.empty((rows, H), **bf)
+            ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
+            gu = torch.empty((rows, 2 * I), **f32)
+            ops.gemm16(x2, None, L.wgu, None, 2 * I, ops.EPI_F32, c=gu)
+            act = torch.empty((rows, I), **bf)
+            ops.swiglu_fwd(gu, act)
+            ops.gemm16(act, None, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+            st.update(x2=x2, gu=gu, act=act)
+            saved.append(st)
+        xf = torch.empty((rows, H), **bf)
+        ops.rmsnorm_bf16(h, eng.norm, d.rms_norm_eps, xf)
+        logits = torch.empty((rows, V), **f32)
+        ops.gemm16(xf, None, eng.lm_head, None, V, ops.EPI_F32, c=logits)
+        Vp = ops.round_up(V, 64)
+        dlogits = torch.empty((rows, Vp), **bf)
+        loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale)
+        del logits
+        # ---------------- backward ----------------
+        g = self.grads
+        dtmp = torch.empty((rows, H), **f32)
+        self._dx(dlogits, eng.lm_head, dtmp)                           # d(norm output); lm_head itself is frozen
+        dh = torch.empty((rows, H), **f32)
+        ops.rmsnorm_bwd(h, eng.norm, dtmp, d.rms_norm_eps, dh, False, g["norm"])
+        del dlogits
+        Sp = ops.round_up(S, 64)
+        BH = B * nh
+        scale = 1.0 / math.sqrt(hd)
+        smax = eng.smax
+        for i in reversed(range(len(eng.layers))):
+            L, st = eng.layers[i], saved[i]
+            pre = f"layers.{i}."
+            # ---- MLP ----
+            dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
+            dh16 = dh16[:, :H]
+            dact = torch.empty((rows, I), **f32)
+            self._dx(dh16, L.wdown, dact)
+            self._dw(dh16, st["act"], g[pre + "wdown"])
+            dgu = torch.empty((rows, 2 * I), **bf)
+            ops.swiglu_bwd(st["gu"], dact, dgu)
+            del dact
+            self._dx(dgu, L.wgu, dtmp)
+            self._dw(dgu, st["x2"], g[pre + "wgu"])
+            del dgu
+            ops.rmsnorm_bwd(st["h_mid"], L.ln2, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln2"])
+            # ---- attention ----
+            dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
+            dh16 = dh16[:, :H]
+            self._dx(dh16, L.wo, dtmp)                                  # d(att)
+            self._dw(dh16, st["att"], g[pre + "wo"])
+            datt16, _ = ops.split16(dtmp, _BF, want_lo=False, kmult=64)
+            dO = torch.empty((BH, S, hd), **bf)
+            ops.split_heads16(datt16[:, :H].contiguous() if datt16.shape[1] != H else datt16, B, S, nh, hd, dO)
+            q = st["q"].view(BH, S, hd)
+            kc = eng.k_cache[i, :B]                                      # [B][nh][smax][hd]
+            vtc = eng.vt_cache[i, :B]                                    # [B][nh][hd][smax]
+            sc = torch.empty((BH, S, S), **f32)
+            ops.gemm16_batched(q, S * hd, hd, kc, smax * hd, hd, S, S, hd, BH, sc, S, S * S)
+            P = torch.empty((BH, S, Sp), **bf)
+            ops.causal_softmax_rows(sc, BH, S, scale, P)
+            v_rm = torch.empty((BH, S, hd), **bf)                        # V row-major from the transposed cache
+            ops.transpose16(vtc, smax, hd, S, v_rm, hd, BH, hd * smax, S * hd)
+            ops.gemm16_batched(dO, S * hd, hd, v_rm, S * hd, hd, S, S, hd, BH, sc, S, S * S)      # sc <- dP
+            dS = torch.empty((BH, S, Sp), **bf)
+            ops.attn_ds(P, sc, BH, S, scale, dS)
+            PT = torch.empty((BH, S, Sp), **bf)
+            ops.transpose16(P, Sp, S, S, PT, Sp, BH, S * Sp, S * Sp)
+            dOT = torch.empty((BH, hd, Sp), **bf)
+            ops.transpose16(dO, hd, S, hd, dOT, Sp, BH, S * hd, hd * Sp)
+            dv = torch.empty((BH, S, hd), **f32)
+            ops.gemm16_batched(PT, S * Sp, Sp, dOT, hd * Sp, Sp, S, hd, Sp, BH, dv, hd, S * hd)
+            kT = torch.empty((BH, hd, Sp), **bf)
+            ops.transpose16(kc, hd, S, hd, kT, Sp, BH, smax * hd, hd * Sp)
+            dq = torch.empty((BH, S, hd), **f32)
+            ops.gemm16_batched(dS, S * Sp, Sp, kT, hd * Sp, Sp, S, hd, Sp, BH, dq, hd, S * hd)
+            dST = PT                                                     # reuse the buffer
+            ops.transpose16(dS, Sp, S, S, dST, Sp, BH, S * Sp, S * Sp)
+            qT = kT
+            ops.transpose16(q, hd, S, hd, qT, Sp, BH, S * hd, hd * Sp)
+            dk = torch.empty((BH, S, hd), **f32)
+            ops.gemm16_batched(dST, S * Sp, Sp, qT, hd * Sp, Sp, S, hd, Sp, BH, dk, hd, S * hd)
+            dqkv = torch.empty((rows, 3 * H), **bf)
+            ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
+            self._dx(dqkv, L.wqkv, dtmp)
+            self._dw(dqkv, st["x1"], g[pre + "wqkv"])
+            ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"])
+            saved[i] = None
+        # ---- bottom: projector and the trainable embedding rows ----
+        if seg_rows:
+            ridx = torch.cat(seg_rows)
+            dya = torch.empty((ridx.numel(), H), **f32)
+            ops.gather_rows(dh, ridx, dya)
+            ops.colsum_add(dya, g["proj_b"])
+            dya16, _ = ops.split16(dya, _BF, want_lo=False, kmult=64)
+            self._dw(dya16[:, :H], torch.cat(seg_a16, dim=0).contiguous(), g["proj_w"])
+        ids_cpu = input_ids.reshape(-1).cpu()
+        if self.train_embed_all:
+            audio_rows = set(torch.cat(seg_rows).tolist()) if seg_rows else set()
+            sel = [r for r in range(rows) if r not in audio_rows]
+        else:
+            sel = [r for r in range(rows) if int(ids_cpu[r]) in self.embed_grad_tokens]
+        if sel:
+            ridx = torch.tensor(sel, dtype=torch.int64, device=dev)
+            tmp = torch.empty((len(sel), H), **f32)
+            ops.gather_rows(dh, ridx, tmp)
+            ops.scatter_add_rows(tmp, ids_flat[ridx].contiguous(), g["embed"])
+        self.micro_batches += 1
+        return loss
+
+    # ------------------------------------------------------------------------------------------
+    def allreduce_grads(self, world: int, bucket_elems: int = 64 * 1024 * 1024) -> None:
+        """Sum gradients over the data-parallel ranks (RCCL on GPUs): large flat buckets; the division by the world
+        size is folded into the optimizer's grad_scale."""
+        if world <= 1:
+            return
+        import torch.distributed as dist
+
+        n = self.flat_grad.numel()
+        works = [dist.all_reduce(self.flat_grad[o: min(o + bucket_elems, n)], op=dist.ReduceOp.SUM, async_op=True)
+                 for o in range(0, n, bucket_elems)]
+        for w in works:
+            w.wait()
+
+    def step(self, world: int = 1) -> None:
+        """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients."""
+        self.step_count += 1
+        b1, b2 = self.betas
+        for name, p in self.params:
+            off, n = self._slices[name]
+            ops.adamw(p.view(-1), self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n],
+                      self.lr, b1, b2, self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world)
+        self.zero_grad()
+
+    # ------------------------------------------------------------------------------------------
+    def export_grads_hf(self) -> Dict[str, torch.Tensor]:
+        """Gradients under the reference's state-dict names / layouts (for parity tests and checkpoint tooling)."""
+        d = self.eng.dims
+        H, I = d.hidden_size, d.intermediate_size
+        out = {}
+        for i in range(d.num_hidden_layers):
+            p = f"model.layers.{i}"
+            gq = self.grads[f"layers.{i}.wqkv"]
+            out[f"{p}.self_attn.q_proj.weight"], out[f"{p}.self_attn.k_proj.weight"], out[f"{p}.self_attn.v_proj.weight"] = (
+                gq[:H], gq[H: 2 * H], gq[2 * H:])
+            out[f"{p}.self_attn.o_proj.weight"] = self.grads[f"layers.{i}.wo"]
+            gg = self.grads[f"layers.{i}.wgu"].view(I // 32, 2, 32, H)
+            out[f"{p}.mlp.gate_proj.weight"] = gg[:, 0].reshape(I, H)
+            out[f"{p}.mlp.up_proj.weight"] = gg[:, 1].reshape(I, H)
+            out[f"{p}.mlp.down_proj.weight"] = self.grads[f"layers.{i}.wdown"]
+            out[f"{p}.input_layernorm.weight"] = self.grads[f"layers.{i}.ln1"]
+            out[f"{p}.post_attention_layernorm.weight"] = self.grads[f"layers.{i}.ln2"]
+        out["model.norm.weight"] = self.grads["norm"]
+        out["model.embed_tokens.weight"] = self.grads["embed"]
+        if "proj_w" in self.grads:
+            out["model.mm_projector.weight"] = self.grads["proj_w"]
+            out["model.mm_projector.bias"] = self.grads["proj_b"]
+        return out

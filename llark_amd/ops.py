@@ -311,6 +311,114 @@ def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, ignore_ind
     return out[0]
 
 
+# ------------------------------------------------------------------------------------------------
+# training step pieces
+# ------------------------------------------------------------------------------------------------
+def gemm16_batched(a: torch.Tensor, stride_a: int, lda: int, wt: torch.Tensor, stride_w: int, ldw: int, m: int, n: int,
+                   kp: int, batch: int, c: torch.Tensor, ldc: int, stride_c: int) -> None:
+    """fp32 C[b] = A[b] . Wt[b]^T for b < batch (bf16 operands given as flat tensors + element strides)."""
+    check(_lib.lib().llark_gemm16_batched(_DT[a.dtype], 0, EPI_F32, _dev(a, "a"), None, lda, stride_a, _dev(wt, "wt"), ldw,
+                                          stride_w, m, n, kp, _dev(c, "c", torch.float32), ldc, stride_c, None, None, 0, 0,
+                                          batch, _stream()), "gemm16_batched")
+
+
+def transpose16(src: torch.Tensor, ld_src: int, rows: int, cols: int, dst: torch.Tensor, ld_dst: int, batch: int = 1,
+                stride_src: int = 0, stride_dst: int = 0) -> None:
+    check(_lib.lib().llark_transpose16(_dev(src, "src"), ld_src, rows, cols, _dev(dst, "dst"), ld_dst, batch, stride_src,
+                                       stride_dst, _stream()), "transpose16")
+
+
+def transposed16(x: torch.Tensor, kmult: int = 64) -> torch.Tensor:
+    """[R][C] 16-bit -> new [C][round_up(R)] (zero padded): the K-contiguous operand of a dW / dX GEMM."""
+    R, C = x.shape
+    out = torch.empty((C, round_up(R, kmult)), dtype=x.dtype, device=x.device)
+    transpose16(x, x.stride(0), R, C, out, out.shape[1])
+    return out
+
+
+def split_heads16(x: torch.Tensor, batch: int, s: int, nh: int, hd: int, out: torch.Tensor) -> None:
+    check(_lib.lib().llark_split_heads16(_dev(x, "x"), batch, s, nh, hd, _dev(out, "out"), _stream()), "split_heads16")
+
+
+def causal_softmax_rows(scores: torch.Tensor, batch: int, s: int, scale: float, p_out: torch.Tensor) -> None:
+    check(_lib.lib().llark_causal_softmax_rows(_dev(scores, "scores", torch.float32), batch, s, float(scale),
+                                               _dev(p_out, "p", torch.bfloat16), p_out.shape[-1], _stream()), "causal_softmax_rows")
+
+
+def attn_ds(p: torch.Tensor, dp: torch.Tensor, batch: int, s: int, scale: float, ds_out: torch.Tensor) -> None:
+    check(_lib.lib().llark_attn_ds(_dev(p, "p", torch.bfloat16), _dev(dp, "dp", torch.float32), batch, s, float(scale),
+                                   _dev(ds_out, "ds", torch.bfloat16), p.shape[-1], _stream()), "attn_ds")
+
+
+def rope_merge_bwd(dq, dk, dv, cos_t, sin_t, batch: int, s: int, nh: int, hd: int, pos0: int, dqkv: torch.Tensor) -> None:
+    f = torch.float32
+    check(_lib.lib().llark_rope_merge_bwd(_dev(dq, "dq", f), _dev(dk, "dk", f), _dev(dv, "dv", f), _dev(cos_t, "cos", f),
+                                          _dev(sin_t, "sin", f), batch, s, nh, hd, pos0, _dev(dqkv, "dqkv", torch.bfloat16),
+                                          _stream()), "rope_merge_bwd")
+
+
+def rmsnorm_bwd(x, w, dy, eps: float, dx, accumulate: bool, dw) -> None:
+    rows, width = x.shape
+    f = torch.float32
+    check(_lib.lib().llark_rmsnorm_bwd(_dev(x, "x", f), _dev(w, "w", f), _dev(dy, "dy", f), rows, width, float(eps),
+                                       _dev(dx, "dx", f), int(accumulate), _dev(dw, "dw", f), _stream()), "rmsnorm_bwd")
+
+
+def swiglu_fwd(gu: torch.Tensor, act: torch.Tensor) -> None:
+    rows, two_i = gu.shape
+    check(_lib.lib().llark_swiglu_fwd(_dev(gu, "gu", torch.float32), rows, two_i // 2, _dev(act, "act", torch.bfloat16),
+                                      _stream()), "swiglu_fwd")
+
+
+def swiglu_bwd(gu: torch.Tensor, dact: torch.Tensor, dgu: torch.Tensor) -> None:
+    rows, two_i = gu.shape
+    check(_lib.lib().llark_swiglu_bwd(_dev(gu, "gu", torch.float32), _dev(dact, "dact", torch.float32), rows, two_i // 2,
+                                      _dev(dgu, "dgu", torch.bfloat16), _stream()), "swiglu_bwd")
+
+
+def cross_entropy_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor, dlogits: torch.Tensor, loss_scale: float = 1.0,
+                          ignore_index: int = -100) -> torch.Tensor:
+    """Mean shifted CE (device scalar) and its gradient w.r.t. the logits as bf16 [B*S][ldd]."""
+    B, S, V = logits.shape
+    row_loss = torch.empty((B * S,), dtype=torch.float32, device=logits.device)
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    lab = labels.contiguous()
+    check(_lib.lib().llark_cross_entropy_shifted(_dev(logits, "logits", torch.float32), logits.stride(1), B, S, V,
+                                                 _dev(lab, "labels", torch.int64), ignore_index, _dev(row_loss, "row_loss"),
+                                                 _dev(out, "loss"), _stream()), "cross_entropy_shifted")
+    check(_lib.lib().llark_cross_entropy_bwd(_dev(logits, "logits"), logits.stride(1), B, S, V, _dev(lab, "labels"),
+                                             _dev(row_loss, "row_loss"), _dev(out, "loss"), float(loss_scale),
+                                             _dev(dlogits, "dlogits", torch.bfloat16), dlogits.stride(0), _stream()),
+          "cross_entropy_bwd")
+    return out[0]
+
+
+def colsum_add(x: torch.Tensor, out: torch.Tensor) -> None:
+    rows, cols = x.shape
+    check(_lib.lib().llark_colsum_f32(_dev(x, "x", torch.float32), x.stride(0), rows, cols, _dev(out, "out", torch.float32),
+                                      _stream()), "colsum")
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> None:
+    check(_lib.lib().llark_gather_rows_f32(_dev(src, "src", torch.float32), src.stride(0), _dev(idx, "idx", torch.int64),
+                                           idx.numel(), src.shape[1], _dev(dst, "dst", torch.float32), dst.stride(0), _stream()),
+          "gather_rows")
+
+
+def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> None:
+    check(_lib.lib().llark_scatter_add_rows_f32(_dev(src, "src", torch.float32), src.stride(0), _dev(idx, "idx", torch.int64),
+                                                idx.numel(), src.shape[1], _dev(dst, "dst", torch.float32), dst.stride(0),
+                                                _stream()), "scatter_add_rows")
+
+
+def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+          weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    check(_lib.lib().llark_adamw(_DT[p.dtype], _dev(p, "p"), _dev(g, "g", torch.float32), _dev(m, "m", torch.float32),
+                                 _dev(v, "v", torch.float32), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                 float(weight_decay), int(step), float(grad_scale), _stream()), "adamw")
+
+
 def device_info(device: int = 0) -> Tuple[int, str]:
     import ctypes
     buf = ctypes.create_string_buffer(64)

@@ -66,3 +66,36 @@ def test_shard_range_properties():
             parts = [list(shard_range(n, r, w)) for r in range(w)]
             assert sum(parts, []) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from llark_amd import dist as D
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+
+    D.init(backend="gloo")
+    tr = object.__new__(HipLlamaTrainer)                   # only the gradient-exchange logic is exercised on CPU
+    tr.flat_grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    tr.allreduce_grads(world, bucket_elems=300)            # 4 buckets, async all-reduces
+    q.put((rank, tr.flat_grad.clone()))
+    D.shutdown(world)
+
+
+def test_gradient_allreduce_two_ranks():
+    """The one exchange step of the path (config 4): bucketed SUM all-reduce of the flat gradient buffer."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = torch.arange(1000, dtype=torch.float32) * 3          # (1 + 2) x
+    for _, gsum in res:
+        assert torch.equal(gsum, expect)
