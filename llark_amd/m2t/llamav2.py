@@ -90,6 +90,30 @@ def plan_audio_splice(input_ids: torch.Tensor, audio_features: Union[None, torch
     return segs
 
 
+class _HipTrainStep(torch.autograd.Function):
+    """``loss = model(input_ids, labels=..., audio_encodings=...)`` followed by ``loss.backward()`` on the HIP training
+    kernels: the forward AND the whole backward run eagerly inside ``forward`` (llark_amd.m2t.train_engine); ``backward``
+    only hands the per-parameter gradients (reference layouts / dtypes) to autograd, so ``param.grad`` accumulation,
+    DDP gradient hooks and any torch optimizer keep working unchanged."""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, segs, labels, names, *params):
+        tr = model._hip_trainer()
+        tr.zero_grad()
+        loss = tr.forward_backward(input_ids, segs, labels)
+        grads = tr.export_grads_hf()
+        ctx.grads = [grads.get(n) for n in names]
+        ctx.dtypes = [p.dtype for p in params]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        outs = []
+        for g, dt in zip(ctx.grads, ctx.dtypes):
+            outs.append(None if g is None else (g * grad_out).to(dt))
+        return (None, None, None, None, None, *outs)
+
+
 class WrappedLlamav2Model(LlamaModel):
     """m2t/models/llamav2.py:46-234."""
 
@@ -170,9 +194,8 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
                 output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
                 return_dict: Optional[bool] = None, audio_encodings=None, **kwargs):
         """m2t/models/llamav2.py:259-337.  Returns CausalLMOutputWithPast(loss, logits, past_key_values)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and labels is not None:
-            raise NotImplementedError("the training step (backward kernels + RCCL gradient all-reduce) is the next "
-                                      "SURVEY section-8 row; run inference under torch.no_grad()/inference_mode()")
+        if torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters()):
+            return self._forward_train(input_ids, labels, audio_encodings, attention_mask, return_dict)
         if output_attentions or output_hidden_states:
             raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused kernels")
         if position_ids is not None:
@@ -210,6 +233,46 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
             out = (logits, cache)
             return (loss,) + out if loss is not None else out
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=None, attentions=None)
+
+    # ---- training (m2t/train.py path) ---------------------------------------------------------
+    def _hip_trainer(self):
+        from .train_engine import HipLlamaTrainer
+
+        if getattr(self, "_trainer", None) is None or self._trainer.eng is not self._train_engine:
+            cfg = self.model.audio_encoder_config
+            toks = [t for t in (cfg.audio_start_token, cfg.audio_end_token) if isinstance(t, int)]
+            orig = getattr(self.model, "orig_embeds_params", None)
+            self._trainer = HipLlamaTrainer(self._train_engine, embed_grad_tokens=toks, train_embed_all=orig is None)
+        return self._trainer
+
+    def _forward_train(self, input_ids, labels, audio_encodings, attention_mask, return_dict):
+        """Training forward (bf16 flow, like the reference's bf16 recipe).  The kernel-layout weights are re-packed
+        from the nn.Parameters on every call because an external optimizer may have changed them."""
+        if attention_mask is not None:
+            am = attention_mask.to(torch.bool)
+            if am.shape[1] > 1 and not bool((am[:, :-1] | ~am[:, 1:]).all()):
+                raise NotImplementedError("only right-padded attention masks are supported")
+        prec = self._engine_precision
+        self._engine_precision = "bf16"
+        try:
+            self._train_engine = self.sync_engine()
+        finally:
+            self._engine_precision = prec
+        self._engine = None                                     # the inference engine is rebuilt lazily in its own mode
+        eng = self._train_engine
+        input_ids = input_ids.to(eng.device)
+        feats = audio_encodings
+        segs = []
+        if feats is not None and getattr(self.config, "use_mm_proj", False):
+            feats = [f.to(device=eng.device, dtype=torch.float32) for f in feats] if isinstance(feats, (list, tuple)) \
+                else feats.to(device=eng.device, dtype=torch.float32)
+            segs = plan_audio_splice(input_ids, feats, self.model.audio_encoder_config, False)
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        names = [n for n, _ in named]
+        loss = _HipTrainStep.apply(self, input_ids, segs, labels.to(eng.device), names, *[p for _, p in named])
+        if return_dict is False:
+            return (loss, None)
+        return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=None, hidden_states=None, attentions=None)
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
                                       **kwargs):

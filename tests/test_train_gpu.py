@@ -111,3 +111,58 @@ def test_training_reduces_loss():
     # the engine used for inference sees the updated weights (same tensors)
     lg = eng.forward_tokens(ids.cuda(), segs)
     assert torch.isfinite(lg).all()
+
+
+def test_wrapped_model_loss_backward_dropin():
+    """The reference's call pattern: loss = model(input_ids, labels, audio_encodings).loss; loss.backward();
+    torch optimizer step -- on the HIP training step through the autograd bridge."""
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    del eng
+    cfg = WrappedLlamav2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                               num_key_value_heads=2, vocab_size=spec.vocab_size, max_position_embeddings=512,
+                               rms_norm_eps=1e-5, tie_word_embeddings=False)
+    cfg.mm_hidden_size = 96
+    m = WrappedLlamav2ForCausalLM(cfg)
+    m.get_model().initialize_adapter_modules()
+    m.load_state_dict(w, strict=False)
+    ac = m.get_model().audio_encoder_config
+    ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = spec.audio_start_token, spec.audio_end_token, spec.audio_patch_token
+    m.get_model().orig_embeds_params = [m.get_input_embeddings().weight.data.clone()]   # tune_mm_mlp_adapter semantics
+    for p in m.get_output_embeddings().parameters():
+        p.requires_grad = False                                                           # lm_head frozen (llamav2.py:414)
+    m.cuda().train()
+    m.configure_engine(max_batch=2, max_seq=64)
+    out = m(input_ids=ids.cuda(), labels=labels.cuda(), audio_encodings=aud.cuda())
+    out.loss.backward()
+    ref_loss, ref = _oracle_grads(spec, w, ids, aud, labels)
+    assert abs(out.loss.item() - ref_loss) <= 5e-3 * max(1.0, abs(ref_loss))
+    for name in ("model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.mm_projector.weight",
+                 "model.mm_projector.bias", "model.norm.weight"):
+        gp = dict(m.named_parameters())[name].grad.float().cpu()
+        rel = ((gp - ref[name]).norm() / ref[name].norm()).item()
+        assert rel <= 3e-2, f"{name}: {rel:.3e}"
+    assert m.lm_head.weight.grad is None
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=2e-3)
+    l0 = out.loss.item()
+    for _ in range(5):
+        opt.step()
+        opt.zero_grad()
+        out = m(input_ids=ids.cuda(), labels=labels.cuda(), audio_encodings=aud.cuda())
+        out.loss.backward()
+    assert out.loss.item() < 0.8 * l0, (l0, out.loss.item())
+
+
+def test_train_loop_schedule():
+    from llark_amd.m2t import AudioEncoderConfig
+    from llark_amd.m2t.train import TrainConfig, lr_at, train
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    cfg = TrainConfig(learning_rate=2e-3, max_steps=20, gradient_accumulation_steps=2)
+    assert lr_at(0, cfg) == 0.0 and abs(lr_at(1, cfg) - 2e-3) < 1e-12 and lr_at(20, cfg) == 0.0     # warm-up = ceil(0.6) = 1 step
+    ac = AudioEncoderConfig()
+    ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = spec.audio_start_token, spec.audio_end_token, spec.audio_patch_token
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool), audio_encodings=aud)
+    logs = []
+    losses = train(eng, [batch] * 12, ac, cfg, world=1, log=logs.append)
+    assert len(losses) == 6 and logs[-1]["step"] == 6
+    assert losses[-1] < losses[1]
