@@ -60,6 +60,11 @@ def build_workload(args, device):
     from llark_amd.jukebox.synthetic import init_codebook_from_encodings, make_jukebox_weights, synthetic_clip
 
     hps = hparams_tiny() if args.tiny else hparams_5b()
+    if args.stages == "train":
+        from llark_amd.m2t import bench_support
+
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        return hps, None, None, None, bench_support.TrainWorkload(args, device, world, layers=args.llm_layers or None)
     if args.depth:
         hps.prior_depth = args.depth
     weights = make_jukebox_weights(hps, seed=0, device=device)
@@ -129,8 +134,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step (BASELINE configs[1]: 8)")
-    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama"])
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default 8 = BASELINE configs[1]; 4 for --stages train = configs[3]: 32 clips over 8 GPUs)")
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train"])
+    ap.add_argument("--micro-batch", type=int, default=2, help="train: clips per micro-step (train_llark.sh per_device_train_batch_size 2)")
+    ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
+    ap.add_argument("--llm-layers", type=int, default=0, help="debug: override the number of Llama layers (train stage)")
     ap.add_argument("--depth", type=int, default=0, help="debug: override prior depth (result is then NOT the headline)")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,6 +146,8 @@ def main():
     ap.add_argument("--llm-precision", default="split", choices=["split", "bf16"],
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
+    if not args.batch:
+        args.batch = 4 if args.stages == "train" else 8
 
     rank, world, local = _dist_setup(args.gpus)
     device = torch.device("cuda", local)
@@ -146,12 +156,16 @@ def main():
     hps, weights, enc, audio, llm = build_workload(args, device)
 
     def step():
+        if args.stages == "train":
+            return llm.step()
         emb = enc(audio) if args.stages != "llama" else None
         if llm is not None:
             return llm.forward(emb)
         return emb
 
     with torch.no_grad():
+        if args.stages == "train":
+            torch.cuda.reset_peak_memory_stats()
         for _ in range(args.warmup):
             step()
         _barrier(world)
@@ -193,26 +207,37 @@ def main():
             roof = llm.roofline(timers, args)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(hps, weights, args)
+            if args.stages == "train":
+                from llark_amd.m2t import bench_support
+
+                cpu = bench_support.cpu_baseline_train(args)
+            else:
+                cpu = cpu_baseline(hps, weights, args)
         workload = {"e2e": "configs[1]+llm: 8x25s clips -> Jukebox VQ-VAE+36-layer prior -> 240x4800 -> projector -> Llama-2-7B fwd (S=371) logits",
                     "jukebox": "configs[1]: Jukebox encoder+prior forward, batch=8x25s clips -> (240,4800) embeddings",
-                    "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings"}[args.stages]
+                    "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings",
+                    "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+AdamW"
+                             % (args.batch, args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq)}[args.stages]
         line = {
-            "metric": "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd",
+            "metric": "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd" if args.stages != "train" else "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "jukebox": "fp16x2-split(fp32-class)",
-                                           "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16"}[args.stages],
+                                           "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
+                                           "train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)"}[args.stages],
             "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": 371,
-                       "prior_depth": hps.prior_depth, "parallelism": f"dp{world} (clip-sharded, no collective)",
+                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": 371 if args.stages != "train" else args.train_seq,
+                       "prior_depth": hps.prior_depth,
+                       "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients once per optimizer step)",
                        "debug_overrides": bool(args.depth or args.tiny)},
-            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None else None),
+            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages != "train" else None),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
+        if args.stages == "train":
+            line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         print(json.dumps(line), flush=True)
     D.shutdown(world)
 

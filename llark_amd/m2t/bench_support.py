@@ -73,6 +73,71 @@ class LLMWorkload:
                 "avg_launch_ms": round(ms / launches, 4)}
 
 
+class TrainWorkload:
+    """BASELINE configs[3]: instruction-tuning step of random-init Llama-2-7B + projector on frozen (precomputed)
+    Jukebox features.  Per GPU: ``batch`` clips per optimizer step = ``micro`` clips x (batch/micro) accumulation
+    micro-steps (train_llark.sh: per_device_train_batch_size 2), sequence = 371 prompt+audio positions + answer tokens
+    padded to ``seq`` (labels -100 on everything but the answer, like the reference's collator)."""
+
+    def __init__(self, args, device, world, layers=None):
+        from .train_engine import HipLlamaTrainer
+
+        dims = LlamaDims(vocab_size=VOCAB)
+        if layers:
+            dims.num_hidden_layers = layers
+        self.dims, self.device, self.world = dims, device, world
+        self.micro, self.accum, self.seq = args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq
+        eng = HipLlamaEngine(dims, device, max_batch=self.micro, max_seq=ops.round_up(self.seq, 64), precision="bf16")
+        g = torch.Generator(device=device).manual_seed(0)
+        H, I = dims.hidden_size, dims.intermediate_size
+
+        def n(*shape):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+        ones = torch.ones(H, device=device)
+        for i in range(dims.num_hidden_layers):
+            eng.set_layer(i, n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I), ones, ones)
+        eng.set_globals(n(VOCAB, H), ones, n(VOCAB, H), n(H, dims.mm_hidden_size), torch.zeros(H, device=device))
+        self.engine = eng
+        self.trainer = HipLlamaTrainer(eng, lr=5e-5, embed_grad_tokens=[START, END])
+        gen = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
+        self.batches = []
+        for k in range(self.accum):
+            ids = make_prompt_ids(self.micro, seed=100 + k)
+            ans = torch.randint(3, 32000, (self.micro, self.seq - ids.shape[1]), generator=gen)
+            full = torch.cat([ids, ans], dim=1)
+            labels = full.clone()
+            labels[:, : ids.shape[1]] = -100
+            emb = torch.randn(self.micro, FRAMES, dims.mm_hidden_size, generator=gen)
+            self.batches.append((full.to(device), labels.to(device), emb.to(device)))
+
+    def step(self):
+        tr = self.trainer
+        loss = None
+        for ids, labels, emb in self.batches:
+            segs = [(b, 1, emb[b]) for b in range(self.micro)]
+            loss = tr.forward_backward(ids, segs, labels, 1.0 / self.accum)
+        tr.allreduce_grads(self.world)
+        tr.step(self.world)
+        return loss
+
+    def flops_per_step(self) -> float:
+        d = self.dims
+        rows = self.micro * self.accum * self.seq
+        per_layer = 2.0 * rows * (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size)
+        # fwd + dX + dW for every layer GEMM; lm_head: fwd + dX only (frozen)
+        return 3.0 * per_layer * d.num_hidden_layers + 2.0 * 2.0 * rows * d.hidden_size * d.vocab_size
+
+    def roofline(self, timers, args):
+        if "gemm_bf16" not in timers:
+            return None
+        launches, ms, _ = timers["gemm_bf16"]
+        achieved = self.flops_per_step() * args.steps / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "gemm_kernel<bf16> (fwd + dX + dW)", "mfma_passes": 1, "achieved": round(achieved, 2),
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None, "launches": launches,
+                "avg_launch_ms": round(ms / launches, 4)}
+
+
 def build(args, device):
     return LLMWorkload(args, device)
 
@@ -98,3 +163,40 @@ def cpu_baseline(args):
     total = t_head + t_layers / layers * 32
     return total, (f"Llama fwd B=1 S=371 fp32 oracle: embed+projector+lm_head {t_head:.2f}s + {layers} of 32 layers "
                    f"{t_layers:.2f}s extrapolated to 32")
+
+
+def cpu_baseline_train(args):
+    """Oracle training step on the host (torch fp32 autograd over oracle/llama_ref.py): 1 clip, S = train_seq,
+    `cpu_layers` of 32 layers + lm_head, extrapolated to 32 layers (optimizer step excluded)."""
+    import os
+
+    from oracle import llama_ref as LR
+
+    layers = max(1, args.cpu_layers)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = LR.LlamaSpec(num_hidden_layers=layers, vocab_size=VOCAB, audio_start_token=START, audio_end_token=END,
+                        audio_patch_token=PATCH)
+    w = LR.make_weights(spec, seed=0, std=0.02)
+    for k, v in w.items():
+        if v.is_floating_point() and "lm_head" not in k:
+            v.requires_grad_(True)
+    ids = make_prompt_ids(1)
+    ans = torch.randint(3, 32000, (1, args.train_seq - ids.shape[1]))
+    full = torch.cat([ids, ans], 1)
+    labels = full.clone()
+    labels[:, : ids.shape[1]] = -100
+    aud = torch.randn(1, FRAMES, 4800)
+
+    def run(nl):
+        t0 = time.time()
+        out = LR.forward(w, spec, full, aud, labels=labels, num_layers=nl)
+        out["loss"].backward()
+        return time.time() - t0
+
+    t_head = run(0)
+    t_all = run(None)
+    t_layers = max(t_all - t_head, 1e-6)
+    total = t_head + t_layers / layers * 32
+    return {"value": 1.0 / total, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"1 clip fwd+bwd S={args.train_seq} fp32 torch-autograd oracle: head {t_head:.2f}s + {layers} of 32 layers {t_layers:.2f}s extrapolated to 32"}

@@ -216,17 +216,20 @@ class HipLlamaTrainer:
             ops.colsum_add(dya, g["proj_b"])
             dya16, _ = ops.split16(dya, _BF, want_lo=False, kmult=64)
             self._dw(dya16[:, :H], torch.cat(seg_a16, dim=0).contiguous(), g["proj_w"])
-        ids_cpu = input_ids.reshape(-1).cpu()
         if self.train_embed_all:
-            audio_rows = set(torch.cat(seg_rows).tolist()) if seg_rows else set()
-            sel = [r for r in range(rows) if r not in audio_rows]
+            keep = torch.ones((rows,), dtype=torch.bool, device=dev)
+            if seg_rows:
+                keep[torch.cat(seg_rows)] = False
+        elif self.embed_grad_tokens:
+            keep = torch.isin(ids_flat, torch.tensor(sorted(self.embed_grad_tokens), dtype=ids_flat.dtype, device=dev))
         else:
-            sel = [r for r in range(rows) if int(ids_cpu[r]) in self.embed_grad_tokens]
-        if sel:
-            ridx = torch.tensor(sel, dtype=torch.int64, device=dev)
-            tmp = torch.empty((len(sel), H), **f32)
-            ops.gather_rows(dh, ridx, tmp)
-            ops.scatter_add_rows(tmp, ids_flat[ridx].contiguous(), g["embed"])
+            keep = None
+        if keep is not None:
+            ridx = keep.nonzero().reshape(-1)
+            if ridx.numel():
+                tmp = torch.empty((ridx.numel(), H), **f32)
+                ops.gather_rows(dh, ridx, tmp)
+                ops.scatter_add_rows(tmp, ids_flat[ridx].contiguous(), g["embed"])
         self.micro_batches += 1
         return loss
 
