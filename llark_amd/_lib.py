@@ -57,6 +57,9 @@ _SIGS = {
                      _P, _P, c_int, _P],
     "llark_gemm16_ex": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                         _P, _P, c_int, _P],
+    "llark_pack_weight16_frag": [_P, c_int, c_int, c_int, _P, _P],
+    "llark_gemm16_fragw": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                           _P, _P, c_int, _P],
     "llark_gemm16_batched": [c_int, c_int, c_int, _P, _P, c_int, c_int64, _P, c_int, c_int64, c_int, c_int, c_int, _P, c_int,
                              c_int64, _P, _P, c_int, c_int64, c_int, _P],
     "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],

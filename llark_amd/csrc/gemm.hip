@@ -120,6 +120,91 @@ __device__ __forceinline__ float fast_sigmoid_mul(float x, float a) {
 __device__ __forceinline__ float quick_gelu(float x) { return fast_sigmoid_mul(x, 1.702f); }
 __device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
 
+// C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Shared by every main-loop variant.
+template <typename T, bool SPLIT, int EPI, typename C>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
+                                              const int wm, const int wn, const int lane, const long long bz) {
+    // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
+    // `buffer_store v, voff, rsrc, soff` with ONE per-lane byte offset (same for all tiles/registers) and a
+    // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
+    const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
+    const int mrow0 = m0 + wm * C::TM * 32;                      // uniform
+    const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
+    const int ocol0 = IS_SWIGLU(EPI) ? (ncol0 >> 1) : ncol0;
+    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+    const int lr = 4 * (lane >> 5), lc = lane & 31;
+    constexpr unsigned RSRC_FLAGS = 0x00020000u;
+    __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
+    int vC = 0, vR = 0, vO = 0;
+    if (EPI == EPI_F32 || EPI == EPI_RESID) {
+        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + bz * p.sC + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vC = (lr * p.ldc + lc) * 4;
+    }
+    if (EPI == EPI_RESID) {
+        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + bz * p.sR + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vR = (lr * p.ldr + lc) * 4;
+    }
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
+        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vO = (lr * p.ldo + lc) * 2;
+    }
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
+        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+
+    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) {
+                if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
+                // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
+                // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
+                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : tn * 32;                 // compile-time
+                if (!FULL && ocol0 + ocl + lc >= nlim) continue;
+                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
+                    if (!FULL && mrow0 + ml + lr >= p.M) continue;
+                    float v = acc[tm][tn][r] + bv;
+                    if (EPI == EPI_F32) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
+                    } else if (EPI == EPI_RESID) {
+                        const float res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + ocl) * 4, 0));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
+                    } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
+                        if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
+                        const T hi = Mfma<T>::cvt(v);
+                        const T lo = Mfma<T>::cvt(v - Mfma<T>::back(hi));
+                        const int so = (ml * p.ldo + ocl) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
+                    } else if (EPI == EPI_OUT16) {
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
+                                                              (ml * p.ldo + ocl) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU16) {
+                        constexpr int tu = (C::TN > 1) ? 1 : 0;
+                        const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
+                                                              vO, (ml * p.ldo + ocl) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU_SPLIT) {
+                        constexpr int tu = (C::TN > 1) ? 1 : 0;
+                        const float a = silu(acc[tm][tn][r]) * acc[tm][(tn + tu) % C::TN][r];
+                        const T hi = Mfma<T>::cvt(a);
+                        const T lo = Mfma<T>::cvt(a - Mfma<T>::back(hi));
+                        const int so = (ml * p.ldo + ocl) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
+                    }
+                }
+            }
+        }
+    };
+    if (full) epilogue(std::true_type{});      // interior tile: no per-element bounds checks
+    else epilogue(std::false_type{});
+}
+
 template <typename T, bool SPLIT, int EPI, typename C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
@@ -242,86 +327,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
         }
     }
 
-    // ---- epilogue ----  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
-    // `buffer_store v, voff, rsrc, soff` with ONE per-lane byte offset (same for all tiles/registers) and a
-    // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
-    const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
-    const int mrow0 = m0 + wm * C::TM * 32;                      // uniform
-    const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
-    const int ocol0 = IS_SWIGLU(EPI) ? (ncol0 >> 1) : ncol0;
-    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
-    const int lr = 4 * (lane >> 5), lc = lane & 31;
-    constexpr unsigned RSRC_FLAGS = 0x00020000u;
-    __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
-    int vC = 0, vR = 0, vO = 0;
-    if (EPI == EPI_F32 || EPI == EPI_RESID) {
-        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + bz * p.sC + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vC = (lr * p.ldc + lc) * 4;
-    }
-    if (EPI == EPI_RESID) {
-        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + bz * p.sR + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vR = (lr * p.ldr + lc) * 4;
-    }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
-        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vO = (lr * p.ldo + lc) * 2;
-    }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
-        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-
-    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn) {
-                if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
-                // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
-                // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
-                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : tn * 32;                 // compile-time
-                if (!FULL && ocol0 + ocl + lc >= nlim) continue;
-                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
-                    if (!FULL && mrow0 + ml + lr >= p.M) continue;
-                    float v = acc[tm][tn][r] + bv;
-                    if (EPI == EPI_F32) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
-                    } else if (EPI == EPI_RESID) {
-                        const float res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + ocl) * 4, 0));
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
-                    } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
-                        if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
-                        const T hi = Mfma<T>::cvt(v);
-                        const T lo = Mfma<T>::cvt(v - Mfma<T>::back(hi));
-                        const int so = (ml * p.ldo + ocl) * 2;
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
-                    } else if (EPI == EPI_OUT16) {
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
-                                                              (ml * p.ldo + ocl) * 2, 0);
-                    } else if (EPI == EPI_SWIGLU16) {
-                        constexpr int tu = (C::TN > 1) ? 1 : 0;
-                        const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
-                                                              vO, (ml * p.ldo + ocl) * 2, 0);
-                    } else if (EPI == EPI_SWIGLU_SPLIT) {
-                        constexpr int tu = (C::TN > 1) ? 1 : 0;
-                        const float a = silu(acc[tm][tn][r]) * acc[tm][(tn + tu) % C::TN][r];
-                        const T hi = Mfma<T>::cvt(a);
-                        const T lo = Mfma<T>::cvt(a - Mfma<T>::back(hi));
-                        const int so = (ml * p.ldo + ocl) * 2;
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
-                    }
-                }
-            }
-        }
-    };
-    if (full) epilogue(std::true_type{});      // interior tile: no per-element bounds checks
-    else epilogue(std::false_type{});
+    gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
 }
 
 template <typename T, bool SPLIT, int EPI, typename C>
@@ -357,6 +363,198 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 #undef CASE
     set_error("gemm: unknown epilogue %d", epi);
     return LLARK_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------------------------------
+// "B-direct" main loop.  Measured on MI355X (profiles/r01_gemm_ablation.txt): the stage-load latency of the
+// LDS-staged kernel (~2 us per 64 KiB burst) cannot be hidden inside 160 KiB of LDS.  Here the WEIGHT operand
+// never touches LDS: it is pre-packed fragment-major (llark_pack_weight16_frag: one contiguous 1 KiB chunk per
+// (32 weight rows, 16 k) = exactly one wave-wide MFMA B fragment), and every wave streams the fragments of its
+// own TN column tiles L2 -> VGPR with perfectly coalesced global_load_dwordx4 through a 4-deep register ring
+// (3 k16 sub-steps ahead).  Waves are laid out 1 x NW over N, so no weight byte is fetched twice by a block.
+// Only A (hi + lo planes) goes through LDS, double-buffered: the tile for K-step kt+1 is loaded into registers
+// at the top of K-step kt, stays in flight during the whole compute of kt and is written to the other LDS stage
+// just before the single barrier of the K-step.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool SPLIT, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const GemmParams p) {
+    typedef typename Mfma<T>::frag frag;
+    static_assert(C::WM == 1 && C::BK == 64, "B-direct layout: waves side by side over N, K-step 64");
+    constexpr int ASTAGE = (SPLIT ? 2 : 1) * C::A_BYTES;
+    constexpr int OFF_L = C::A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 A stages
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = 0, wn = w;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    constexpr int GM = 8;
+    const int gsz = GM * p.tiles_n;
+    const int g = bid / gsz;
+    const int first_m = g * GM;
+    const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+    const int tile_m = first_m + (bid % gsz) % gm;
+    const int tile_n = (bid % gsz) / gm;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const long long bz = 0;
+
+    const T* Ahi = (const T*)p.Ahi;
+    const T* Alo = SPLIT ? (const T*)p.Alo : nullptr;
+
+    // A tile: global -> VGPR -> LDS (ds_write_b128 at the swizzled offset).  Plain loads, so the compiler's
+    // counted vmcnt tracking is exact (LDS-DMA would make it drain vmcnt(0) before every ds_read).
+    constexpr int APW = (C::BM / C::RPI) / C::NW;                    // 1-KiB row groups per wave and plane
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 areg[(SPLIT ? 2 : 1) * APW];
+    const int a_rl = lane / C::CH, a_ch = lane % C::CH;
+    auto loadA = [&](int kt) {
+        const int k0 = kt * C::BK;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            int r = m0 + (w + i * C::NW) * C::RPI + a_rl;
+            r = r < p.M ? r : p.M - 1;
+            areg[i] = *(const u32x4*)(Ahi + (size_t)r * p.lda + k0 + a_ch * 8);
+            if (SPLIT) areg[APW + i] = *(const u32x4*)(Alo + (size_t)r * p.lda + k0 + a_ch * 8);
+        }
+    };
+    auto storeA = [&](int buf) {
+        char* base = smem + buf * ASTAGE;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int row = (w + i * C::NW) * C::RPI + a_rl;
+            *(u32x4*)(base + C::off(row, a_ch)) = areg[i];
+            if (SPLIT) *(u32x4*)(base + OFF_L + C::off(row, a_ch)) = areg[APW + i];
+        }
+    };
+
+    // fragment-major weights: chunk (row tile R, k16 step q) at ((R * nk16 + q) * 64 + lane) * 16 B
+    const int nk = p.Kp / C::BK;
+    const int nk16 = nk * 4;
+    const int rtiles = (p.N + 31) >> 5;
+    const frag* wbase[C::TN];
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        int R = (n0 >> 5) + wn * C::TN + tn;
+        R = R < rtiles ? R : rtiles - 1;                                   // edge tiles: any valid chunk (stores are masked)
+        wbase[tn] = (const frag*)p.Wt + ((size_t)R * nk16) * 64 + lane;
+    }
+    frag ring[4][C::TN];
+    auto loadB = [&](int slot, int q) {
+        q = q < nk16 ? q : nk16 - 1;                                       // tail: harmless re-load of the last chunk
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) ring[slot][tn] = wbase[tn][(size_t)q * 64];
+    };
+
+    f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    loadA(0);
+    loadB(0, 0);
+    loadB(1, 1);
+    loadB(2, 2);
+    storeA(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+#if GEMM_ABLATE != 12 && GEMM_ABLATE != 14
+        loadA(kt + 1 < nk ? kt + 1 : kt);          // unconditional (tail: harmless re-load) so the counted vmcnt waits stay exact
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const char* sA = smem + (kt & 1) * ASTAGE;
+        const char* sL = sA + OFF_L;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#if GEMM_ABLATE != 11 && GEMM_ABLATE != 14
+            loadB((s + 3) & 3, kt * 4 + s + 3);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const int c = s * 2 + (lane >> 5);
+            frag ah[C::TM], al[C::TM];
+#if GEMM_ABLATE == 13 || GEMM_ABLATE == 14
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" : "=v"(ah[tm])); asm volatile("" : "=v"(al[tm])); }
+#else
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                ah[tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
+                if (SPLIT) al[tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
+            }
+#endif
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
+                    if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if GEMM_ABLATE != 12 && GEMM_ABLATE != 14
+        if (kt + 1 < nk) storeA((kt + 1) & 1);
+#endif
+        __syncthreads();
+    }
+    gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
+}
+
+template <typename T, bool SPLIT, int EPI, typename C>
+static int launch_gemm_bd(GemmParams p, hipStream_t s) {
+    constexpr int LDS = 2 * (SPLIT ? 2 : 1) * C::A_BYTES;
+    auto kern = gemm_bd_kernel<T, SPLIT, EPI, C>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    kern<<<dim3(p.tiles_m * p.tiles_n), C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm_bd");
+}
+
+template <typename T, typename C>
+static int dispatch_bd(const GemmParams& p, bool split, int epi, hipStream_t s) {
+#define CASE(E)                                                      \
+    case E:                                                          \
+        return split ? launch_gemm_bd<T, true, E, C>(p, s) : launch_gemm_bd<T, false, E, C>(p, s);
+    switch (epi) {
+        CASE(EPI_F32)
+        CASE(EPI_RESID)
+        CASE(EPI_QGELU_SPLIT)
+        CASE(EPI_OUT16)
+        CASE(EPI_SWIGLU16)
+        CASE(EPI_SPLIT16)
+        CASE(EPI_SWIGLU_SPLIT)
+    }
+#undef CASE
+    set_error("gemm: unknown epilogue %d", epi);
+    return LLARK_ERR_INVALID;
+}
+
+// [N][ld] row-major 16-bit weights -> fragment-major chunks (see gemm_bd_kernel); rows >= n are zero.
+__global__ void pack_frag_kernel(const unsigned short* __restrict__ src, int ld, int n, int kp, uint4* __restrict__ dst, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-B lane slot each
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const long long chunk = i >> 6;
+    const int nk16 = kp >> 4;
+    const int q = (int)(chunk % nk16);
+    const int R = (int)(chunk / nk16);
+    const int row = R * 32 + (lane & 31);
+    const int k = q * 16 + (lane >> 5) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n) v = *(const uint4*)(src + (size_t)row * ld + k);
+    dst[i] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -503,6 +701,8 @@ typedef Cfg<4, 2, 2, 4, 32, 2, 3> Cfg6;   // 256x256x32, 8 waves, 3-stage ring, 
 typedef Cfg<2, 4, 2, 2, 64, 2, 2> Cfg10;  // 128x256x64, 8 waves (64x64 per wave), double buffer 128 KiB : 1 block/CU
 typedef Cfg<2, 2, 2, 2, 64, 3, 1> Cfg11;  // 128x128x64, 4 waves, single stage 48 KiB                    : 3 blocks/CU
 typedef Cfg<2, 2, 2, 4, 64, 2, 1> Cfg12;  // 128x256x64, 4 waves (64x128 per wave), single stage 64 KiB  : 2 blocks/CU
+// B-direct kernels (weights fragment-major, L2 -> VGPR): waves 1 x 4 over N
+typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBD0;  // 128x256x64, wave 128x64, A double-buffered 64 KiB (split)    : 2 blocks/CU
 
 template <typename T>
 static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
@@ -584,6 +784,38 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
                                llark_stream_t stream) {
     return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
                        out_lo, ldo, 0, 0, 0, 0, 0, 0, stream);
+}
+
+extern "C" int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, llark_stream_t stream) {
+    LLARK_REQUIRE(wt && dst && n > 0 && kp > 0 && kp % 64 == 0 && ldw >= kp && ldw % 8 == 0, "pack_weight16_frag: bad arguments (kp must be a multiple of 64)");
+    LLARK_REQUIRE(((uintptr_t)wt & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pack_weight16_frag: pointers must be 16-byte aligned");
+    const long long total = (long long)cdiv(n, 32) * (kp / 16) * 64;
+    pack_frag_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>((const unsigned short*)wt, ldw, n, kp, (uint4*)dst, total);
+    return check_launch("pack_weight16_frag");
+}
+
+extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                                  const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
+                                  const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && wfrag && m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_fragw: null pointer / empty problem / kp not a multiple of 64");
+    LLARK_REQUIRE(lda % 8 == 0 && lda >= kp, "gemm16_fragw: lda must be >= kp and a multiple of 8");
+    LLARK_REQUIRE(!split || a_lo, "gemm16_fragw: split mode needs the lo plane");
+    LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wfrag & 15) == 0 && (!a_lo || ((uintptr_t)a_lo & 15) == 0),
+                  "gemm16_fragw: operands must be 16-byte aligned");
+    if (epilogue == EPI_F32 || epilogue == EPI_RESID) LLARK_REQUIRE(c && ldc >= n, "gemm16_fragw: fp32 output missing");
+    if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16_fragw: residual missing");
+    if (epilogue == EPI_QGELU_SPLIT || epilogue == EPI_SPLIT16) LLARK_REQUIRE(out_hi && out_lo && ldo >= n, "gemm16_fragw: split outputs missing");
+    if (epilogue == EPI_OUT16) LLARK_REQUIRE(out_hi && ldo >= n, "gemm16_fragw: 16-bit output missing");
+    if (IS_SWIGLU(epilogue)) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2 && (epilogue != EPI_SWIGLU_SPLIT || out_lo), "gemm16_fragw: SwiGLU needs n%%64==0 and 16-bit outputs");
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.ldw = 0; p.bias = bias; p.M = m; p.N = n; p.Kp = kp;
+    p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant > 0) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
+    if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD0>(p, split != 0, epilogue, s);
+    if (dtype == LLARK_BF16) return dispatch_bd<bf16_t, CfgBD0>(p, split != 0, epilogue, s);
+    set_error("gemm16_fragw: unknown dtype %d", dtype);
+    return LLARK_ERR_INVALID;
 }
 
 extern "C" int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,

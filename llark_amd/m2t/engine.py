@@ -58,7 +58,10 @@ class HipLlamaEngine:
     MFMA passes -- logits then match the reference's fp32 CPU path (bf16-valued weights) to ~1e-5;
     "bf16" = the reference's GPU dtype flow (single bf16 rounding at those points), ~2x fewer MFMAs."""
 
-    def __init__(self, dims: LlamaDims, device="cuda", max_batch: int = 8, max_seq: int = 512, precision: str = "split"):
+    def __init__(self, dims: LlamaDims, device="cuda", max_batch: int = 8, max_seq: int = 512, precision: str = "split", frag_weights: bool = True):
+        """frag_weights: keep a fragment-major twin of every Linear weight for the B-direct GEMM (inference; the
+        training step updates the row-major weights in place and therefore builds its engine with False)."""
+        self.frag_weights = frag_weights
         if precision not in ("split", "bf16"):
             raise ValueError(f"precision must be 'split' or 'bf16', got {precision!r}")
         self.precision = precision
@@ -99,12 +102,31 @@ class HipLlamaEngine:
         L.wgu = interleave_gate_up(self._bf16(gate), self._bf16(up))
         L.wdown = self._bf16(down)
         L.ln1, L.ln2 = self._f32(ln1), self._f32(ln2)
+        old = self.layers[i]
+        if old is not None:
+            for t in (old.wqkv, old.wo, old.wgu, old.wdown):
+                ops.detach_frag(t)
+        if self.frag_weights:
+            for t in (L.wqkv, L.wo, L.wgu, L.wdown):
+                ops.attach_frag(t, t.shape[0])
         self.layers[i] = L
 
     def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
         self.embed, self.norm, self.lm_head = self._bf16(embed), self._f32(norm), self._bf16(lm_head)
         if proj_w is not None:
             self.proj_w, self.proj_b = self._bf16(proj_w), self._f32(proj_b)
+        if self.frag_weights:
+            ops.attach_frag(self.lm_head, self.lm_head.shape[0])
+
+    def drop_frag_weights(self) -> None:
+        """Called by the training step: the row-major weights are about to be updated in place."""
+        self.frag_weights = False
+        for L in self.layers:
+            if L is not None:
+                for t in (L.wqkv, L.wo, L.wgu, L.wdown):
+                    ops.detach_frag(t)
+        if self.lm_head is not None:
+            ops.detach_frag(self.lm_head)
 
     def load_state_dict(self, sd) -> None:
         """HF / reference state-dict names (model.layers.N.self_attn.q_proj.weight, ..., model.mm_projector.*)."""

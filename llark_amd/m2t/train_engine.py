@@ -36,6 +36,7 @@ class HipLlamaTrainer:
         if engine.split:
             raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
         self.eng = engine
+        engine.drop_frag_weights()                    # weights change in place from now on
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.embed_grad_tokens = set(int(t) for t in embed_grad_tokens)
         self.train_embed_all = train_embed_all

@@ -7,6 +7,7 @@ stream to the library.  There is no fallback: a missing library or a non-GPU ten
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -216,6 +217,25 @@ def split16(x: torch.Tensor, dtype: torch.dtype, want_lo: bool = True, kmult: in
     return hi, lo
 
 
+# Fragment-major weight copies for the B-direct kernel live as an attribute ON the row-major tensor object they
+# mirror (same lifetime, no address-keyed registry that could go stale).  Attached explicitly by the inference
+# engines; a training engine whose weights change in place must not attach.
+FRAG_MIN_ROWS = 512
+
+
+def attach_frag(wt: torch.Tensor, n: int) -> None:
+    """Pack and remember the fragment-major copy of `wt` ([>=n][kp], kp % 64 == 0); gemm16 then streams it
+    L2 -> VGPR for large-M products.  No-op when the shape does not qualify."""
+    if wt.shape[1] % 64 or wt.stride(1) != 1 or os.environ.get("LLARK_FRAG", "1") == "0":
+        return
+    wt._llark_frag = (pack_weight16_frag(wt, n), n, wt.shape[1])
+
+
+def detach_frag(wt: torch.Tensor) -> None:
+    if hasattr(wt, "_llark_frag"):
+        del wt._llark_frag
+
+
 def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], n: int,
            epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
            out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
@@ -229,6 +249,10 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
     if epilogue == EPI_SWIGLU_SPLIT and out_lo is None:
         raise ValueError("gemm16: EPI_SWIGLU_SPLIT needs out_lo")
+    if variant < 0 and m >= FRAG_MIN_ROWS:
+        fr = getattr(wt, "_llark_frag", None)
+        if fr is not None and fr[1] == n and fr[2] == kp:
+            return gemm16_fragw(a_hi, a_lo, fr[0], bias, n, kp, epilogue, c=c, resid=resid, out_hi=out_hi, out_lo=out_lo, m=m)
     with _timed(name, 2.0 * m * n * kp):
       check(_lib.lib().llark_gemm16_ex(
         variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
@@ -238,6 +262,34 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         _dev(out_hi, "out_hi", dtype) if out_hi is not None else None,
         _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
         out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16")
+
+
+def pack_weight16_frag(wt: torch.Tensor, n: int) -> torch.Tensor:
+    """wt [>=n][kp] 16-bit (pack_weight16 output, kp % 64 == 0) -> fragment-major copy for gemm16_fragw."""
+    kp = wt.shape[1]
+    out = torch.empty((round_up(n, 32) * kp,), dtype=wt.dtype, device=wt.device)
+    check(_lib.lib().llark_pack_weight16_frag(_dev(wt, "wt"), wt.stride(0), n, kp, _dev(out, "out"), _stream()), "pack_weight16_frag")
+    return out
+
+
+def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.Tensor, bias: Optional[torch.Tensor], n: int, kp: int,
+                 epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+                 out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
+    """Same product / epilogues as gemm16, weights given fragment-major (pack_weight16_frag)."""
+    dtype = a_hi.dtype
+    assert dtype in (torch.float16, torch.bfloat16) and wfrag.dtype == dtype and a_hi.shape[1] >= kp
+    assert wfrag.numel() == round_up(n, 32) * kp
+    m = a_hi.shape[0] if m is None else m
+    name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
+    with _timed(name, 2.0 * m * n * kp):
+      check(_lib.lib().llark_gemm16_fragw(
+        -1, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
+        a_hi.stride(0), _dev(wfrag, "wfrag"), _dev(bias, "bias", torch.float32) if bias is not None else None,
+        m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
+        _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+        _dev(out_hi, "out_hi", dtype) if out_hi is not None else None,
+        _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
+        out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16_fragw")
 
 
 # ------------------------------------------------------------------------------------------------

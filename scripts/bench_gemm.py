@@ -11,6 +11,19 @@ VARIANTS = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0
 dev = "cuda"
 
 
+_FRAG = {}
+
+
+def G(a_hi, a_lo, wt, bias, n, epi, variant=-1, **kw):
+    """variant >= 100: the B-direct kernel on fragment-major weights (packed once per weight tensor)."""
+    if variant < 100:
+        return ops.gemm16(a_hi, a_lo, wt, bias, n, epi, variant=variant, **kw)
+    key = (wt.data_ptr(), n)
+    if key not in _FRAG:
+        _FRAG[key] = ops.pack_weight16_frag(wt, n)
+    return ops.gemm16_fragw(a_hi, a_lo, _FRAG[key], bias, n, wt.shape[1], epi, **kw)
+
+
 def check(variant):
     g = torch.Generator().manual_seed(1)
     m, n, k = 333, 450, 200
@@ -20,7 +33,7 @@ def check(variant):
     hi, lo = ops.split16(a.to(dev), torch.float16, kmult=64)
     wt = ops.pack_weight16(w.to(dev), True, torch.float16, kmult=64)
     c = torch.full((m, n), float("nan"), device=dev)
-    ops.gemm16(hi, lo, wt, b.to(dev), n, ops.EPI_F32, c=c, variant=variant)
+    G(hi, lo, wt, b.to(dev), n, ops.EPI_F32, c=c, variant=variant)
     ref = a.double() @ w.double() + b.double()
     err = ((c.cpu().double() - ref).abs() / (a.abs().double() @ w.abs().double() + 1e-30)).max().item()
     # swiglu bf16
@@ -31,7 +44,7 @@ def check(variant):
     wts = ops.pack_weight16(packed.to(dev), False, torch.bfloat16, kmult=64)
     ab, _ = ops.split16(a.to(dev), torch.bfloat16, want_lo=False, kmult=64)
     osw = torch.zeros((m, inter), dtype=torch.bfloat16, device=dev)
-    ops.gemm16(ab, None, wts, None, n - 2, ops.EPI_SWIGLU16, out_hi=osw, variant=variant)
+    G(ab, None, wts, None, n - 2, ops.EPI_SWIGLU16, out_hi=osw, variant=variant)
     abf = a.bfloat16().double()
     refs = torch.nn.functional.silu(abf @ gate.double().t()) * (abf @ up.double().t())
     err2 = ((osw.float().cpu().double() - refs).abs() / (refs.abs() + 1.0)).max().item()
@@ -73,11 +86,11 @@ def main():
         for v in VARIANTS:
             def fn():
                 if epi == ops.EPI_QGELU_SPLIT:
-                    ops.gemm16(a_hi, a_lo, wt, bias, n, epi, out_hi=ohi, out_lo=olo, variant=v)
+                    G(a_hi, a_lo, wt, bias, n, epi, out_hi=ohi, out_lo=olo, variant=v)
                 elif epi == ops.EPI_RESID:
-                    ops.gemm16(a_hi, a_lo, wt, bias, n, epi, c=c, resid=c, variant=v)
+                    G(a_hi, a_lo, wt, bias, n, epi, c=c, resid=c, variant=v)
                 else:
-                    ops.gemm16(a_hi, a_lo, wt, bias, n, epi, c=c[:, :n].contiguous() if n != 4800 else c, variant=v)
+                    G(a_hi, a_lo, wt, bias, n, epi, c=c[:, :n].contiguous() if n != 4800 else c, variant=v)
             ms = timeit(fn)
             tf = 2.0 * M * n * k / ms / 1e9
             res[f"{name}_v{v}"] = (ms, tf)
@@ -95,11 +108,11 @@ def main():
         for v in VARIANTS:
             def fn():
                 if epi == ops.EPI_SWIGLU16:
-                    ops.gemm16(a, None, wt, None, n, epi, out_hi=o16, variant=v)
+                    G(a, None, wt, None, n, epi, out_hi=o16, variant=v)
                 elif epi == ops.EPI_RESID:
-                    ops.gemm16(a, None, wt, None, n, epi, c=h2, resid=h2, variant=v)
+                    G(a, None, wt, None, n, epi, c=h2, resid=h2, variant=v)
                 else:
-                    ops.gemm16(a, None, wt, None, n, epi, c=c2[:, :n].contiguous() if n != 32004 else c2, variant=v)
+                    G(a, None, wt, None, n, epi, c=c2[:, :n].contiguous() if n != 32004 else c2, variant=v)
             ms = timeit(fn)
             tf = 2.0 * M2 * n * k / ms / 1e9
             res[f"llama_{name}_v{v}"] = (ms, tf)

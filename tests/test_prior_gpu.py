@@ -81,6 +81,61 @@ def test_gemm_tile_variants(variant):
     assert worst < 6e-7, worst
 
 
+@pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
+def test_gemm_fragment_major_weights_bit_identical(m, n, k):
+    """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
+    k order as the LDS-staged kernel (k16 steps ascending, hi pass then lo pass), so the two agree BIT FOR BIT:
+    ragged M / N (row clamping, masked stores, zero-filled weight rows of the last 32-row tile), every epilogue."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = torch.randn(m, n, generator=g).cuda()
+    hi, lo = ops.split16(a.cuda(), torch.float16, kmult=64)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16, kmult=64)
+    wf = ops.pack_weight16_frag(wt, n)
+    kp = wt.shape[1]
+    for split in (True, False):
+        l = lo if split else None
+        c0 = torch.full((m, n), float("nan"), device="cuda")
+        c1 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16(hi, l, wt, b, n, ops.EPI_F32, c=c0, variant=12)
+        ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_F32, c=c1)
+        assert torch.equal(c0, c1), f"F32 split={split}: max diff {(c0 - c1).abs().max().item():.3e}"
+        c0, c1 = r.clone(), r.clone()
+        ops.gemm16(hi, l, wt, b, n, ops.EPI_RESID, c=c0, resid=c0, variant=12)
+        ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_RESID, c=c1, resid=c1)
+        assert torch.equal(c0, c1)
+        o0 = [torch.zeros((m, n), dtype=torch.float16, device="cuda") for _ in range(2)]
+        o1 = [torch.zeros((m, n), dtype=torch.float16, device="cuda") for _ in range(2)]
+        ops.gemm16(hi, l, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o0[0], out_lo=o0[1], variant=12)
+        ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_QGELU_SPLIT, out_hi=o1[0], out_lo=o1[1])
+        assert torch.equal(o0[0], o1[0]) and torch.equal(o0[1], o1[1])
+    # the automatic route: a weight with an attached twin goes to the B-direct kernel for M >= FRAG_MIN_ROWS
+    if m >= ops.FRAG_MIN_ROWS:
+        ops.attach_frag(wt, n)
+        c2 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c2)
+        c3 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_F32, c=c3)
+        assert torch.equal(c2, c3)
+        ops.detach_frag(wt)
+    if n % 64 == 0:                                                     # SwiGLU pairs (bf16)
+        wb = (torch.randn(n, k, generator=g) * 0.1).bfloat16()
+        wts = ops.pack_weight16(wb.cuda(), False, torch.bfloat16, kmult=64)
+        wfs = ops.pack_weight16_frag(wts, n)
+        ab, abl = ops.split16(a.cuda(), torch.bfloat16, kmult=64)
+        s0 = [torch.zeros((m, n // 2), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        s1 = [torch.zeros((m, n // 2), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        ops.gemm16(ab, abl, wts, None, n, ops.EPI_SWIGLU_SPLIT, out_hi=s0[0], out_lo=s0[1], variant=12)
+        ops.gemm16_fragw(ab, abl, wfs, None, n, wts.shape[1], ops.EPI_SWIGLU_SPLIT, out_hi=s1[0], out_lo=s1[1])
+        assert torch.equal(s0[0], s1[0]) and torch.equal(s0[1], s1[1])
+        ops.gemm16(ab, None, wts, None, n, ops.EPI_SWIGLU16, out_hi=s0[0], variant=12)
+        ops.gemm16_fragw(ab, None, wfs, None, n, wts.shape[1], ops.EPI_SWIGLU16, out_hi=s1[0])
+        assert torch.equal(s0[0], s1[0])
+
+
 def test_gemm_epilogues():
     from llark_amd import ops
     g = torch.Generator().manual_seed(9)
