@@ -19,6 +19,7 @@
 // fragment reads are bank-conflict free; one barrier per K-step; 48 KiB LDS -> 3 blocks/CU.
 // blockIdx is remapped XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and
 // grouped over M so that co-resident blocks share A and W panels.
+#include <cstdlib>
 #include <type_traits>
 
 // Profiling-only compile-time ablations (results invalid): 1 = no DMA in the K loop, 2 = no LDS fragment
@@ -69,6 +70,9 @@ struct GemmParams {
     // batched mode (grid.y = batch): element strides added per batch index; 0 = operand shared by all batches
     int batch;
     long long sA, sW, sC, sR, sO;
+    // persistent mode: resident workgroups per XCD and this launch's per-XCD chunk counters
+    int slots;
+    int* sync;
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
@@ -205,12 +209,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     else epilogue(std::false_type{});
 }
 
+// One output tile (linear tile index `bid` in the M-grouped order) computed by the calling workgroup.
 template <typename T, bool SPLIT, int EPI, typename C>
-__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid, char* smem) {
     typedef typename Mfma<T>::frag frag;
     constexpr int STAGE = (SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES;     // [Ahi, (Alo), W]
     constexpr int OFF_L = C::A_BYTES, OFF_W = (SPLIT ? 2 : 1) * C::A_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // NSTAGE stages
     constexpr int NS = C::NSTAGE;
     constexpr int LOADS_PER_STAGE = ((SPLIT ? 2 : 1) * (C::BM / C::RPI) + (C::BN / C::RPI)) / C::NW;   // DMA instrs per wave
 
@@ -218,13 +222,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
 
-    // ---- XCD-aware + M-grouped tile mapping (speed only; any mapping is correct) ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
+    // M-grouped tile order: groups of GM tile rows, N-major inside a group, so that tiles with neighbouring
+    // indices share A / W panels (speed only; any mapping is correct)
     constexpr int GM = 8;
     const int gsz = GM * p.tiles_n;
     const int g = bid / gsz;
@@ -330,6 +329,93 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
     gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
 }
 
+// XCD-aware remap of the hardware block index: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets the
+// contiguous band [base, base + count) of the linear tile order and its private L2 sees neighbouring tiles.
+__device__ __forceinline__ void xcd_band(int nwg, int xcd, int& base, int& count) {
+    const int q = nwg >> 3, r = nwg & 7;
+    base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    count = q + (xcd < r ? 1 : 0);
+}
+
+template <typename T, bool SPLIT, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // NSTAGE stages
+    int base, count;
+    xcd_band(p.tiles_m * p.tiles_n, blockIdx.x & 7, base, count);
+    gemm_tile<T, SPLIT, EPI, C>(p, base + (blockIdx.x >> 3), smem);
+}
+
+// Persistent form for large grids.  PMC on MI355X (profiles/r01_pmc_gemm.json): with one workgroup per tile the
+// L2 hit rate of the prior's M = 65536 GEMMs is 68 % and the memory side moves 6x the algorithmic bytes, because
+// workgroups that share an A or W panel start whenever a slot frees up and drift apart along K by more than the
+// 4 MiB L2 of their XCD can bridge.  Here exactly `p.slots` workgroups per XCD stay resident and walk that XCD's
+// band of tiles in CHUNKS of `slots` neighbouring tiles (8 tile rows x 8 tile columns for the default order),
+// with a barrier among the XCD's workgroups between chunks: every chunk starts at K = 0 together and streams its
+// shared panels through L2 in lock-step.  The barrier is a monotonically increasing counter per XCD (zeroed by
+// the host before the launch); all workgroups of the grid are co-resident by construction (grid = occupancy x
+// CUs) and the spin is bounded anyway: the barrier is a locality aid, never a correctness dependency.
+template <typename T, bool SPLIT, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_persist_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int base, count;
+    const int nwg = p.tiles_m * p.tiles_n;
+    xcd_band(nwg, xcd, base, count);
+    const int nchunks = ((nwg >> 3) + ((nwg & 7) ? 1 : 0) + p.slots - 1) / p.slots;      // same for every XCD
+    int* cnt = p.sync + xcd * 32;                                                       // one 128-B line per XCD
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int local = ch * p.slots + slot;
+        if (local < count) gemm_tile<T, SPLIT, EPI, C>(p, base + local, smem);
+        if (ch + 1 < nchunks) {
+            __syncthreads();                                       // also: everyone is done reading LDS of this tile
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int target = (ch + 1) * p.slots;
+                // bounded spin (~30 ms): the barrier only aligns the chunk starts for L2 locality, results never
+                // depend on it, so a workgroup that is (unexpectedly) not co-resident cannot hang the kernel
+                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+static int* persist_sync_slot(hipStream_t s) {
+    // ring of counter blocks so that GEMMs in flight on different streams never share one
+    constexpr int RING = 64, BYTES = 8 * 32 * sizeof(int);
+    static int* buf = nullptr;
+    static unsigned next = 0;
+    if (!buf && hipMalloc((void**)&buf, (size_t)RING * BYTES) != hipSuccess) return nullptr;
+    int* slot = buf + (size_t)(next++ % RING) * (BYTES / sizeof(int));
+    if (hipMemsetAsync(slot, 0, BYTES, s) != hipSuccess) return nullptr;
+    return slot;
+}
+
+template <typename T, bool SPLIT, int EPI, typename C>
+static int launch_gemm_persist(GemmParams p, hipStream_t s) {
+    constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
+    auto kern = gemm_persist_kernel<T, SPLIT, EPI, C>;
+    static int grid = -1;                                          // resident workgroups of THIS instantiation (0 = unusable)
+    if (grid < 0) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, C::THREADS, LDS) != hipSuccess) per_cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        grid = per_cu * cus;
+        if (grid % 8) grid = 0;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    if (grid <= 0 || p.batch > 1 || p.tiles_m * p.tiles_n < 4 * grid) return -1000;      // caller falls back to one workgroup per tile
+    p.slots = grid / 8;
+    p.sync = persist_sync_slot(s);
+    if (!p.sync) return -1000;
+    kern<<<dim3(grid), C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm_persist");
+}
+
 template <typename T, bool SPLIT, int EPI, typename C>
 static int launch_gemm(GemmParams p, hipStream_t s) {
     constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
@@ -344,6 +430,24 @@ static int launch_gemm(GemmParams p, hipStream_t s) {
     p.tiles_n = cdiv(p.N, C::BN);
     kern<<<dim3(p.tiles_m * p.tiles_n, p.batch > 0 ? p.batch : 1), C::THREADS, LDS, s>>>(p);
     return check_launch("gemm");
+}
+
+template <typename T, typename C>
+static int dispatch_persist(const GemmParams& p, bool split, int epi, hipStream_t s) {
+#define CASE(E)                                                      \
+    case E:                                                          \
+        return split ? launch_gemm_persist<T, true, E, C>(p, s) : launch_gemm_persist<T, false, E, C>(p, s);
+    switch (epi) {
+        CASE(EPI_F32)
+        CASE(EPI_RESID)
+        CASE(EPI_QGELU_SPLIT)
+        CASE(EPI_OUT16)
+        CASE(EPI_SWIGLU16)
+        CASE(EPI_SPLIT16)
+        CASE(EPI_SWIGLU_SPLIT)
+    }
+#undef CASE
+    return -1000;
 }
 
 template <typename T, typename C>
@@ -716,6 +820,10 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 10: return dispatch<T, Cfg10>(p, split, epi, s);
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
+        case 20: {                                                  // persistent 128x256x64 (large grids), else plain variant 12
+            const int rc = dispatch_persist<T, Cfg12>(p, split, epi, s);
+            return rc == -1000 ? dispatch<T, Cfg12>(p, split, epi, s) : rc;
+        }
     }
     set_error("gemm: unknown tile variant %d", variant);
     return LLARK_ERR_INVALID;
@@ -737,6 +845,8 @@ static int pick_variant(int split, int m, int n, int kp) {
     if (m <= 128 || n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
     if (kp < 2048) return 1;                      // shallow K (attention c_proj, K = 1216): 8-wave 256x128 block
+    static const bool persist = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
+    if (m >= 16384 && persist) return 20;                    // very tall products (the prior, M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
     if (!split && n < 16384) return 11;           // plain 16-bit, mid-size N (Llama q/k/v/o, down): 128x128x64, 3 blocks/CU
     return 12;                                    // 128x256x64
 }
