@@ -136,6 +136,37 @@ def test_gemm_fragment_major_weights_bit_identical(m, n, k):
         assert torch.equal(s0[0], s1[0])
 
 
+def test_gemm_persistent_chunk_synchronous_bit_identical():
+    """M >= 16384 routes to the persistent kernel (resident workgroups walk chunks of neighbouring tiles with a
+    per-XCD counter barrier in between).  Same tiles, same k order => bit-identical to one-workgroup-per-tile;
+    ragged M and N, several chunks per XCD (2196 tiles over 512 resident workgroups), residual epilogue in place."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    m, n, k = 70100, 1000, 128                      # 548 x 4 tiles of 128x256
+    a = torch.randn(m, k, generator=g, device="cuda")
+    w = (torch.randn(k, n, generator=g, device="cuda") * 0.1).half()
+    b = torch.randn(n, generator=g, device="cuda")
+    hi, lo = ops.split16(a, torch.float16, kmult=64)
+    wt = ops.pack_weight16(w, True, torch.float16, kmult=64)
+    c12 = torch.full((m, n), float("nan"), device="cuda")
+    c20 = torch.full((m, n), float("nan"), device="cuda")
+    cdef = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c12, variant=12)
+    ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c20, variant=20)
+    ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=cdef)                      # library default for this shape
+    assert torch.isfinite(c20).all()
+    assert torch.equal(c12, c20) and torch.equal(c12, cdef)
+    ref = a.double() @ w.double() + b.double()
+    worst = ((c20.double() - ref).abs() / (a.abs().double() @ w.abs().double())).max().item()
+    assert worst < 6e-7, worst
+    r = torch.randn(m, n, generator=g, device="cuda")
+    r12, r20 = r.clone(), r.clone()
+    for _ in range(3):                                                     # back-to-back launches reuse the counter ring
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=r12, resid=r12, variant=12)
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=r20, resid=r20, variant=20)
+    assert torch.equal(r12, r20)
+
+
 def test_gemm_epilogues():
     from llark_amd import ops
     g = torch.Generator().manual_seed(9)
