@@ -86,7 +86,7 @@ def build_workload(args, device):
 
     audio = torch.from_numpy(np.stack([clip(i) for i in clip_indices(rank, args.batch)])).to(device)
     llm = None
-    if args.stages in ("e2e", "llama"):
+    if args.stages in ("e2e", "llama", "generate"):
         from llark_amd.m2t import bench_support
 
         llm = bench_support.build(args, device)
@@ -120,7 +120,7 @@ def cpu_baseline(hps, weights, args):
     total = t_enc + t_prior
     sample = (f"1 clip: VQ-VAE encode (C oracle, {t_enc:.2f}s) + {args.cpu_layers} of {hps.prior_depth} prior layers "
               f"(torch fp32, {t_layers:.2f}s) extrapolated to {hps.prior_depth}")
-    if args.stages in ("e2e", "llama"):
+    if args.stages in ("e2e", "llama", "generate"):
         from llark_amd.m2t import bench_support
 
         t_llm, s_llm = bench_support.cpu_baseline(args)
@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default 8 = BASELINE configs[1]; 4 for --stages train = configs[3]: 32 clips over 8 GPUs)")
-    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train"])
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate"])
+    ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=2, help="train: clips per micro-step (train_llark.sh per_device_train_batch_size 2)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
     ap.add_argument("--llm-layers", type=int, default=0, help="debug: override the number of Llama layers (train stage)")
@@ -147,7 +148,7 @@ def main():
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = 4 if args.stages == "train" else 8
+        args.batch = {"train": 4, "generate": 1}.get(args.stages, 8)
 
     rank, world, local = _dist_setup(args.gpus)
     device = torch.device("cuda", local)
@@ -159,6 +160,8 @@ def main():
         if args.stages == "train":
             return llm.step()
         emb = enc(audio) if args.stages != "llama" else None
+        if args.stages == "generate":
+            return llm.generate(emb, args.new_tokens)
         if llm is not None:
             return llm.forward(emb)
         return emb
@@ -216,15 +219,18 @@ def main():
         workload = {"e2e": "configs[1]+llm: 8x25s clips -> Jukebox VQ-VAE+36-layer prior -> 240x4800 -> projector -> Llama-2-7B fwd (S=371) logits",
                     "jukebox": "configs[1]: Jukebox encoder+prior forward, batch=8x25s clips -> (240,4800) embeddings",
                     "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings",
+                    "generate": "configs[2]: %d clip(s) -> Jukebox embed -> projector -> Llama-2-7B prefill (S=371) + %d greedy decode steps (KV cache, stopping criterion off)" % (args.batch, args.new_tokens),
                     "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+AdamW"
                              % (args.batch, args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq)}[args.stages]
         line = {
-            "metric": "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd" if args.stages != "train" else "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",
+            "metric": {"train": "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",
+                       "generate": "clips/sec embed + prefill + %d-token greedy decode" % args.new_tokens}.get(args.stages, "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd"),
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "jukebox": "fp16x2-split(fp32-class)",
                                            "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
+                                           "generate": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)"}[args.stages],
             "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
@@ -238,6 +244,16 @@ def main():
         }
         if args.stages == "train":
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+        if args.stages == "generate":
+            key = "gemm_split_bf16_skinny" if args.llm_precision == "split" else "gemm_bf16_skinny"
+            if key in timers:
+                launches, ms, _ = timers[key]
+                nsteps = (args.new_tokens - 1) * args.steps
+                gbs = llm.decode_weight_bytes() * nsteps / (ms * 1e-3) / 1e9
+                line["roofline_decode"] = {"bound": "hbm", "kernel": "gemm_skinny_kernel (M <= 16 weight streaming)", "achieved": round(gbs, 1),
+                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                                           "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                                           "decode_ms_per_token": round(sum(v[1] for k, v in timers.items() if k.endswith("_skinny")) / nsteps, 3)}
         print(json.dumps(line), flush=True)
     D.shutdown(world)
 

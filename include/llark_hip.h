@@ -150,6 +150,15 @@ int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_c
 int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
                            const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
                            void* out, void* out_lo, llark_stream_t stream);
+/* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the
+ * new token; s = 1): lets ONE captured hipGraph of the whole decode step serve every generated token of
+ * m2t/models/llamav2.py:339-365 / m2t/infer.py:137-148. */
+int llark_rope_split_heads_dpos(const float* qkv, int batch, int nh, int hd, const int* pos_dev, const float* cos_t,
+                                const float* sin_t, void* q, void* k_cache, void* vt_cache, void* q_lo, void* k_cache_lo,
+                                void* vt_cache_lo, int smax, llark_stream_t stream);
+int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd,
+                                const int* pos_dev, int smax, void* out, void* out_lo, llark_stream_t stream);
 /* CrossEntropyLoss on shifted logits (m2t/models/llamav2.py:316-325). logits fp32 [batch*s][ldl]; labels
  * int64 [batch][s]; row_loss scratch float[batch*s]; loss_out float[2] = {mean loss, counted rows}. */
 int llark_cross_entropy_shifted(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,

@@ -679,11 +679,11 @@ struct Mfma16<bf16_t> {
     static __device__ __forceinline__ f32x4_t run(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
-template <typename T, bool SPLIT, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
+template <typename T, bool SPLIT, int EPI, int KW>
+__global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
     constexpr int NT = IS_SWIGLU(EPI) ? 2 : 1;
-    __shared__ float red[4][NT][16][17];
+    __shared__ float red[KW][NT][16][17];
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // column tiles: plain: rows n0..n0+15 of W.  SwiGLU: gate rows 64q+16t.., up rows 64q+32+16t.. (t = 0,1)
@@ -699,8 +699,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
         ocol = wrow[0];
     }
     const int ksteps = p.Kp / 32;
-    const int per = (ksteps + 3) / 4;
-    const int ks0 = w * per, ks1 = (ks0 + per) < ksteps ? (ks0 + per) : ksteps;
+    const int per = (ksteps + KW - 1) / KW;
+    const int ks0 = w * per < ksteps ? w * per : ksteps, ks1 = (ks0 + per) < ksteps ? (ks0 + per) : ksteps;
     const T* Ahi = (const T*)p.Ahi;
     const T* Alo = (const T*)p.Alo;
     const T* Wt = (const T*)p.Wt;
@@ -755,7 +755,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
         const int m = 4 * g + r;
         float v[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) v[t] = (red[0][t][m][c] + red[1][t][m][c]) + (red[2][t][m][c] + red[3][t][m][c]);
+        for (int t = 0; t < NT; ++t) {
+            float part[KW];
+#pragma unroll
+            for (int q = 0; q < KW; ++q) part[q] = red[q][t][m][c];
+#pragma unroll
+            for (int st = 1; st < KW; st *= 2)                  // fixed pairwise tree: deterministic
+#pragma unroll
+                for (int q = 0; q < KW; q += 2 * st) part[q] += part[q + st];
+            v[t] = part[0];
+        }
         const int n = ocol + c;
         const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
         if (m >= p.M || n >= nlim) continue;
@@ -775,7 +784,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
 template <typename T, bool SPLIT, int EPI>
 static int launch_skinny(const GemmParams& p, hipStream_t s) {
     const int blocks = IS_SWIGLU(EPI) ? (p.N / 64) * 2 : cdiv(p.N, 16);
-    gemm_skinny_kernel<T, SPLIT, EPI><<<blocks, 256, 0, s>>>(p);
+    // K is split over the waves of a block; HBM streaming needs many bytes in flight per CU, so problems with few
+    // column tiles (o_proj / down_proj: 256 blocks) or a deep K get 16 waves, the wide ones 8
+    static const int force = [] { const char* e = getenv("LLARK_SKINNY_KW"); return e ? atoi(e) : 0; }();
+    const int kw = force ? force : ((blocks <= 512 || p.Kp >= 8192) ? 16 : 8);
+    if (kw == 16) gemm_skinny_kernel<T, SPLIT, EPI, 16><<<blocks, 1024, 0, s>>>(p);
+    else if (kw == 8) gemm_skinny_kernel<T, SPLIT, EPI, 8><<<blocks, 512, 0, s>>>(p);
+    else gemm_skinny_kernel<T, SPLIT, EPI, 4><<<blocks, 256, 0, s>>>(p);
     return check_launch("gemm_skinny");
 }
 

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
                                                          const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                          bf16_t* __restrict__ q, bf16_t* __restrict__ kc,
                                                          bf16_t* __restrict__ vtc, bf16_t* __restrict__ q_lo,
-                                                         bf16_t* __restrict__ kc_lo, bf16_t* __restrict__ vtc_lo, int smax) {
+                                                         bf16_t* __restrict__ kc_lo, bf16_t* __restrict__ vtc_lo, int smax,
+                                                         const int* __restrict__ pos_dev) {
     __shared__ float sv[64][129];
+    if (pos_dev) pos0 = *pos_dev;                 // graph-captured decode: the position lives in device memory
     const int hd = 128, H = nh * hd;
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int ns = (S - s0) < 64 ? (S - s0) : 64;
@@ -324,8 +326,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
                                                           const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
-                                                          int nh, int total, int smax, float scale) {
+                                                          int nh, int total, int smax, float scale,
+                                                          const int* __restrict__ pos_dev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (pos_dev) total = *pos_dev + 1;            // graph-captured decode: keys 0..pos are visible
     float* sp = (float*)smem;                    // [total] scores / probabilities
     __shared__ float sq[128];
     __shared__ float red[8];
@@ -500,8 +504,26 @@ extern "C" int llark_rope_split_heads(const float* qkv, int batch, int s, int nh
                   "rope_split_heads: give all three lo planes (fp32-class mode) or none");
     rope_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, s, nh, pos0, cos_t, sin_t, (bf16_t*)q, (bf16_t*)k_cache,
                                                               (bf16_t*)vt_cache, (bf16_t*)q_lo, (bf16_t*)k_cache_lo,
-                                                              (bf16_t*)vt_cache_lo, smax);
+                                                              (bf16_t*)vt_cache_lo, smax, nullptr);
     return check_launch("rope_split_heads");
+}
+
+// Decode-step forms whose sequence position is read from DEVICE memory (*pos_dev = tokens already in the cache =
+// position of the new token), so that one captured hipGraph of the whole decode step can be replayed for every
+// generated token (m2t/models/llamav2.py:339-365 calls the model once per token with a growing cache).
+extern "C" int llark_rope_split_heads_dpos(const float* qkv, int batch, int nh, int hd, const int* pos_dev, const float* cos_t,
+                                           const float* sin_t, void* q, void* k_cache, void* vt_cache, void* q_lo,
+                                           void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream) {
+    LLARK_REQUIRE(qkv && cos_t && sin_t && q && k_cache && vt_cache && pos_dev, "rope_split_heads_dpos: null pointer");
+    LLARK_REQUIRE(hd == 128, "rope_split_heads_dpos: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && nh > 0 && smax % 8 == 0, "rope_split_heads_dpos: bad shape");
+    LLARK_REQUIRE((q_lo == nullptr) == (k_cache_lo == nullptr) && (q_lo == nullptr) == (vt_cache_lo == nullptr),
+                  "rope_split_heads_dpos: give all three lo planes (fp32-class mode) or none");
+    dim3 grid(1, nh, batch);
+    rope_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, 1, nh, 0, cos_t, sin_t, (bf16_t*)q, (bf16_t*)k_cache,
+                                                              (bf16_t*)vt_cache, (bf16_t*)q_lo, (bf16_t*)k_cache_lo,
+                                                              (bf16_t*)vt_cache_lo, smax, pos_dev);
+    return check_launch("rope_split_heads_dpos");
 }
 
 extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
@@ -543,6 +565,28 @@ extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const 
     attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
                                                                 (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
                                                                 (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
-                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale);
+                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale, nullptr);
     return check_launch("attn_decode");
+}
+
+extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                           const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd,
+                                           const int* pos_dev, int smax, void* out, void* out_lo, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && vt_cache && out && pos_dev, "attn_decode_dpos: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_decode_dpos: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && nh > 0 && smax > 0, "attn_decode_dpos: bad shape");
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    const size_t lds = (size_t)smax * sizeof(float);              // sized for the longest context the cache can hold
+    LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode_dpos: cache length %d too long for the LDS score buffer", smax);
+    static int attr_lds = 0;                                      // not a stream op: raise the limit outside any capture
+    if ((int)lds > 48 * 1024 && (int)lds > attr_lds) {
+        (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = (int)lds;
+    }
+    dim3 grid(nh, batch);
+    attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
+                                                                (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
+                                                                (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
+                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, 1, smax, scale, pos_dev);
+    return check_launch("attn_decode_dpos");
 }

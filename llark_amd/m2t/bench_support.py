@@ -29,7 +29,7 @@ class LLMWorkload:
             dims.num_hidden_layers = layers
         self.dims = dims
         self.batch = args.batch
-        eng = HipLlamaEngine(dims, device, max_batch=args.batch, max_seq=448, precision=args.llm_precision)
+        eng = HipLlamaEngine(dims, device, max_batch=args.batch, max_seq=512, precision=args.llm_precision)
         g = torch.Generator(device=device).manual_seed(0)
         H, I = dims.hidden_size, dims.intermediate_size
 
@@ -54,6 +54,30 @@ class LLMWorkload:
             emb = self._rand_emb
         segs = [(b, 1, emb[b]) for b in range(self.batch)]
         return self.engine.forward_tokens(self.ids, segs)
+
+    def generate(self, emb, new_tokens: int):
+        """BASELINE configs[2]: prefill (prompt + audio) then `new_tokens` greedy decode steps against the KV cache
+        (argmax on device, stopping criterion disabled for timing -- SURVEY 8d)."""
+        logits = self.forward_last(emb)
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        out = [nxt]
+        for _ in range(new_tokens - 1):
+            logits = self.engine.forward_tokens(nxt, (), pos0=self.engine.cur_len, last_only=True)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+            out.append(nxt)
+        return torch.cat(out, dim=1)
+
+    def forward_last(self, emb):
+        if emb is None:
+            self.forward(None)                                   # creates the N(0,1) stand-in
+            emb = self._rand_emb
+        segs = [(b, 1, emb[b]) for b in range(self.batch)]
+        return self.engine.forward_tokens(self.ids, segs, last_only=True)
+
+    def decode_weight_bytes(self) -> float:
+        d = self.dims
+        per_layer = (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size) * 2
+        return per_layer * d.num_hidden_layers + d.vocab_size * d.hidden_size * 2
 
     def flops_per_step(self) -> float:
         d = self.dims

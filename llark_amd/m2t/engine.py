@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -87,6 +88,9 @@ class HipLlamaEngine:
         self.k_cache = self.vt_cache = self.k_cache_lo = self.vt_cache_lo = None
         self.cur_len = 0
         self.cur_batch = 0
+        # graph-captured decode step (one hipGraph per batch size; position read from device memory)
+        self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
+        self._dec: Dict[int, dict] = {}
 
     # ---- weights -------------------------------------------------------------------------------
     def _bf16(self, t: torch.Tensor) -> torch.Tensor:
@@ -102,6 +106,7 @@ class HipLlamaEngine:
         L.wgu = interleave_gate_up(self._bf16(gate), self._bf16(up))
         L.wdown = self._bf16(down)
         L.ln1, L.ln2 = self._f32(ln1), self._f32(ln2)
+        self._dec.clear()                                     # captured graphs hold the old weight pointers
         old = self.layers[i]
         if old is not None:
             for t in (old.wqkv, old.wo, old.wgu, old.wdown):
@@ -112,6 +117,7 @@ class HipLlamaEngine:
         self.layers[i] = L
 
     def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
+        self._dec.clear()
         self.embed, self.norm, self.lm_head = self._bf16(embed), self._f32(norm), self._bf16(lm_head)
         if proj_w is not None:
             self.proj_w, self.proj_b = self._bf16(proj_w), self._f32(proj_b)
@@ -167,6 +173,7 @@ class HipLlamaEngine:
     def _ensure_cache(self, batch: int):
         d = self.dims
         if self.k_cache is None or self.k_cache.shape[1] < batch:
+            self._dec.clear()                                 # captured graphs hold the old cache pointers
             shape_k = (d.num_hidden_layers, batch, d.num_attention_heads, self.smax, d.head_dim)
             shape_v = (d.num_hidden_layers, batch, d.num_attention_heads, d.head_dim, self.smax)
             self.k_cache = torch.zeros(shape_k, dtype=torch.bfloat16, device=self.device)
@@ -175,7 +182,7 @@ class HipLlamaEngine:
             self.vt_cache_lo = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device) if self.split else None
 
     # ---- forward -------------------------------------------------------------------------------
-    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None):
+    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None):
         d = self.dims
         H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
         h = ws["h"]
@@ -190,9 +197,16 @@ class HipLlamaEngine:
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
             ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
             ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
-            ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc,
-                                 ws["q_lo"], kcl, vcl)
-            if s == 1:
+            if pos_dev is not None:                 # decode step, position in device memory (graph-capturable)
+                ops.rope_split_heads_dpos(ws["qkv"], batch, nh, hd, pos_dev, self.cos, self.sin, ws["q"], kc, vc,
+                                          ws["q_lo"], kcl, vcl)
+                ops.attn_decode_dpos(ws["q"], kc, vc, batch, nh, hd, pos_dev, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+            else:
+                ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc,
+                                     ws["q_lo"], kcl, vcl)
+            if pos_dev is not None:
+                pass
+            elif s == 1:
                 ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
             else:
                 ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
@@ -201,6 +215,49 @@ class HipLlamaEngine:
             ops.gemm16(ws["x16"], ws["x16_lo"], L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16,
                        out_hi=ws["act"], out_lo=ws["act_lo"])
             ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+
+    def _decode_body(self, st) -> None:
+        """One decode step on static buffers: ids -> logits, new K/V written at *pos."""
+        d = self.dims
+        B = st["ids"].shape[0]
+        ws = st["ws"]
+        ops.embed_gather(st["ids"].view(-1), self.embed, ws["h"])
+        self._layers_forward(ws, B, 1, 0, None, pos_dev=st["pos"])
+        ops.rmsnorm_bf16(ws["h"], self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+        ops.gemm16(ws["x16"], ws["x16_lo"], self.lm_head, None, d.vocab_size, ops.EPI_F32, c=st["logits"])
+
+    def _decode_step_graph(self, input_ids: torch.Tensor, pos0: int) -> torch.Tensor:
+        """Greedy-decode step as ONE hipGraph replay (opt-in: `decode_graph` / LLARK_DECODE_GRAPH=1).  Bit-identical
+        to the eager launches; measured on MI355X / ROCm 7.2 it does NOT shorten the step (7.41 vs 7.52 ms, B=8): the
+        ~260 kernels of a step each keep their ~10 us dispatch + drain boundary inside the graph, so the lever for
+        decode is fewer kernels (fusion), not graph replay.  First call per batch size runs eagerly on the static
+        buffers (first-launch attribute calls happen outside capture), the second captures, later ones replay."""
+        d = self.dims
+        B = input_ids.shape[0]
+        st = self._dec.get(B)
+        if st is None:
+            ws = dict(self._workspace(B, 1))                  # private copies: the graph owns these buffers
+            ws = {k: (torch.empty_like(v) if v is not None else None) for k, v in ws.items()}
+            st = {"ids": torch.zeros((B, 1), dtype=torch.int64, device=self.device),
+                  "pos": torch.zeros((1,), dtype=torch.int32, device=self.device),
+                  "logits": torch.empty((B, d.vocab_size), dtype=torch.float32, device=self.device),
+                  "ws": ws, "graph": None, "calls": 0}
+            self._dec[B] = st
+        st["ids"].copy_(input_ids)
+        st["pos"].fill_(pos0)
+        if st["graph"] is not None:
+            st["graph"].replay()
+        elif st["calls"] == 0:
+            self._decode_body(st)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_body(st)
+            st["graph"] = g
+            g.replay()
+        st["calls"] += 1
+        self.cur_len = pos0 + 1
+        return st["logits"].clone().view(B, 1, d.vocab_size)
 
     def reset(self, batch: int) -> None:
         if self.k_cache is not None and self.k_cache.shape[1] != batch:
@@ -224,6 +281,9 @@ class HipLlamaEngine:
         assert B == self.cur_batch and pos0 == self.cur_len, "KV cache is out of sync with the requested positions"
         if pos0 + S > self.smax:
             raise ValueError(f"sequence of {pos0 + S} exceeds the engine's max_seq {self.smax}")
+        if (S == 1 and pos0 > 0 and self.decode_graph and not audio_segments and num_layers is None and not return_hidden
+                and not ops.kernel_timing_active()):
+            return self._decode_step_graph(input_ids, pos0)
         ws = self._workspace(B, S)
         h = ws["h"]
         ops.embed_gather(input_ids.reshape(-1).contiguous(), self.embed, h)

@@ -31,6 +31,10 @@ def start_kernel_timing() -> None:
     _TIMERS = {}
 
 
+def kernel_timing_active() -> bool:
+    return _TIMERS is not None
+
+
 def stop_kernel_timing():
     """Returns {name: (launches, total_ms, total_work)} and disables timing."""
     global _TIMERS
@@ -246,7 +250,7 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     m = a_hi.shape[0] if m is None else m
     kp = wt.shape[1]
     assert a_hi.shape[1] >= kp and wt.shape[0] >= n, f"gemm16: A has {a_hi.shape[1]} cols, wt {tuple(wt.shape)}, n={n}"
-    name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
+    name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16") + ("_skinny" if m <= 16 else "")
     if epilogue == EPI_SWIGLU_SPLIT and out_lo is None:
         raise ValueError("gemm16: EPI_SWIGLU_SPLIT needs out_lo")
     if variant < 0 and m >= FRAG_MIN_ROWS:
@@ -328,6 +332,29 @@ def rope_split_heads(qkv: torch.Tensor, batch: int, s: int, nh: int, hd: int, po
                                             _dev(vt_cache, "vt_cache", bf), _opt(q_lo, "q_lo", bf),
                                             _opt(k_cache_lo, "k_cache_lo", bf), _opt(vt_cache_lo, "vt_cache_lo", bf), smax,
                                             _stream()), "rope_split_heads")
+
+
+def rope_split_heads_dpos(qkv, batch: int, nh: int, hd: int, pos_dev: torch.Tensor, cos_t, sin_t, q, k_cache, vt_cache,
+                          q_lo=None, k_cache_lo=None, vt_cache_lo=None) -> None:
+    """Decode step (s = 1) with the position in device memory (int32 scalar tensor): graph-capturable."""
+    smax = k_cache.shape[-2]
+    bf = torch.bfloat16
+    check(_lib.lib().llark_rope_split_heads_dpos(_dev(qkv, "qkv", torch.float32), batch, nh, hd, _dev(pos_dev, "pos", torch.int32),
+                                                 _dev(cos_t, "cos", torch.float32), _dev(sin_t, "sin", torch.float32),
+                                                 _dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                                 _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                                 _opt(vt_cache_lo, "vt_cache_lo", bf), smax, _stream()), "rope_split_heads_dpos")
+
+
+def attn_decode_dpos(q, k_cache, vt_cache, batch: int, nh: int, hd: int, pos_dev: torch.Tensor, out,
+                     q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None) -> None:
+    smax = k_cache.shape[-2]
+    bf = torch.bfloat16
+    check(_lib.lib().llark_attn_decode_bf16_dpos(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                                 _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                                 _opt(vt_cache_lo, "vt_cache_lo", bf), batch, nh, hd,
+                                                 _dev(pos_dev, "pos", torch.int32), smax, _dev(out, "out", bf),
+                                                 _opt(out_lo, "out_lo", bf), _stream()), "attn_decode_dpos")
 
 
 def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, past: int, out: torch.Tensor,

@@ -58,16 +58,20 @@ if "decode" in which:
         eng = wl.engine
         wl.forward(None)                                    # prefill (fills the KV cache up to 371)
         tok = torch.randint(3, 32000, (8, 1), device=dev)
-        torch.cuda.synchronize()
         import time
-        n = 16
-        t0 = time.perf_counter()
-        for i in range(n):
-            eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
         wbytes = 32 * (4 * 4096 * 4096 + 3 * 4096 * 11008) * 2 + 32004 * 4096 * 2
-        print(f"decode step B=8 ({prec}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
+        for graph in (False, True):
+            eng.decode_graph = graph
+            for _ in range(3):                                  # graph mode: eager, capture, first replay
+                eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
+            torch.cuda.synchronize()
+            n = 16
+            t0 = time.perf_counter()
+            for i in range(n):
+                eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            print(f"decode step B=8 ({prec}, {'hipGraph replay' if graph else 'eager launches'}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
         del wl, eng
         torch.cuda.empty_cache()
 if "vqvae" in which:

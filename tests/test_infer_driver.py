@@ -1,0 +1,132 @@
+"""the `.npy` representation contract and the batched / fused inference drivers.
+The batched drivers must return, per example, exactly what the reference's one-example-at-a-time loop
+(scripts/inference/infer_from_encodings.py:73-108 -> m2t/infer.py:infer_with_prompt) returns."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from toy_tokenizer import ToyTokenizer  # noqa: E402
+
+PROMPT = "Describe the tempo of this clip ."
+MM_CFG = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+
+
+def _tok():
+    from llark_amd.m2t.prompting import DEFAULT_CONVERSATION_HEADER
+    tok = ToyTokenizer()
+    for text in (DEFAULT_CONVERSATION_HEADER, "### Human: Assistant: <empty> \n " + PROMPT):
+        tok.encode(text)
+    return tok
+
+
+def test_npy_contract_and_prompt_ids(tmp_path):
+    from llark_amd.m2t import prompting as P
+    from llark_amd.m2t.infer_driver import build_prompt_ids, load_encoding
+    rep = np.random.default_rng(0).standard_normal((240, 4800)).astype(np.float32)
+    np.save(tmp_path / "a.npy", rep)                                   # what jukebox/main.py:254 writes
+    got = load_encoding(str(tmp_path / "a.npy"))
+    assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"] and got.shape == (240, 4800) and np.array_equal(got, rep)
+    np.save(tmp_path / "g.npy", rep.mean(0))                           # --pool-frames-per-second 0: one global frame
+    assert load_encoding(str(tmp_path / "g.npy")).shape == (1, 4800)
+    np.save(tmp_path / "f.npy", np.asfortranarray(rep))                # Fortran order on disk is normalised to C order
+    assert load_encoding(str(tmp_path / "f.npy")).flags["C_CONTIGUOUS"]
+    np.save(tmp_path / "d.npy", rep.astype(np.float64))
+    with pytest.raises(ValueError, match="float32"):
+        load_encoding(str(tmp_path / "d.npy"))
+    np.save(tmp_path / "w.npy", rep[:, :100])
+    with pytest.raises(ValueError, match="shape"):
+        load_encoding(str(tmp_path / "w.npy"))
+    # the prompt ids are those infer_with_prompt builds: header, human turn with <audio_start> + patches + <audio_end>
+    tok = _tok()
+    tok.add_tokens(["<audio_patch>", "<audio_start>", "<audio_end>"], special_tokens=True)
+    end_seq = tok("\n### Assistant:").input_ids[1:]
+    ids = build_prompt_ids(PROMPT, 7, tok, MM_CFG, end_seq, audio_first=True)
+    enc = torch.zeros(7, 4)
+    elem = {"audio_encoding": enc, "audio_encoding_shape": [7, 4], "example_id": None, "id": None,
+            "conversations": [{"from": "human", "value": P.concat_audio_token_and_prompt(PROMPT, True)}, {"from": "gpt", "value": "<empty>"}]}
+    elem = P.preprocess_for_lm_mappable(P.preprocess_multimodal_mappable(elem, MM_CFG), tokenizer=tok)
+    assert torch.equal(ids, P.extract_prompt_tokens(elem["input_ids"], end_seq))
+    patch = tok.convert_tokens_to_ids(["<audio_patch>"])[0]
+    assert int((ids == patch).sum()) == 7 and ids.tolist()[-len(end_seq):] == list(end_seq)
+
+
+def _tiny_model(tok, mm_hidden, max_batch):
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    torch.manual_seed(0)
+    cfg = WrappedLlamav2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                               vocab_size=len(tok), max_position_embeddings=512, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    cfg.mm_hidden_size = mm_hidden
+    m = WrappedLlamav2ForCausalLM(cfg).eval()
+    m.get_model().initialize_adapter_modules()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_((p * 4).bfloat16().float())
+    m.initialize_audio_tokenizer(mm_use_audio_start_end=True, tokenizer=tok, device="cpu")
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(p.bfloat16().float())
+    m.cuda()
+    m.configure_engine(max_batch=max_batch, max_seq=160)
+    return m
+
+
+@pytest.mark.gpu
+def test_infer_from_encodings_batched_equals_per_example(tmp_path, monkeypatch):
+    import pandas as pd
+    from llark_amd.m2t import infer_driver as D
+    from llark_amd.m2t.infer import infer_with_prompt
+    from llark_amd.m2t.prompting import extract_response_tokens
+    monkeypatch.setattr(D, "EMBED_DIM", 96)
+    tok = _tok()
+    m = _tiny_model(tok, 96, 3)
+    end_seq = tok("\n### Assistant:").input_ids[1:]
+    rng = np.random.default_rng(1)
+    d = tmp_path / "reps"
+    d.mkdir()
+    shapes = {"c": 5, "a": 5, "e": 7, "b": 5, "d": 5}                  # 4 examples of 5 frames (batches of 3 + 1), 1 of 7
+    for name, frames in shapes.items():
+        np.save(d / f"{name}.npy", rng.standard_normal((frames, 96)).astype(np.float32))
+    orig = D.load_encoding
+    monkeypatch.setattr(D, "load_encoding", lambda p: orig(p, 96))
+    out_csv = tmp_path / "out" / "res.csv"
+    recs = D.infer_from_encodings(m, tok, str(d), PROMPT, MM_CFG, end_seq, outfile=str(out_csv), batch_size=3, max_new_tokens=10)
+    assert [os.path.basename(r["example_id"]) for r in recs] == ["a", "b", "c", "d", "e"]           # sorted file order
+    m.configure_engine(max_batch=1, max_seq=160)
+    for r in recs:
+        enc = torch.from_numpy(np.load(r["example_id"] + ".npy"))
+        one = infer_with_prompt(PROMPT, model=m, audio_encoding=enc, end_seq=end_seq, multimodal_cfg=MM_CFG, tokenizer=tok,
+                                audio_first=True, max_new_tokens=10).cpu()
+        assert r["model_completion_text"] == tok.decode(extract_response_tokens(one[0], end_seq)), r["example_id"]
+        assert r["prompt_text"] == PROMPT
+    df = pd.read_csv(out_csv)
+    assert list(df.columns) == ["example_id", "prompt_text", "model_completion_text"] and len(df) == 5
+
+
+@pytest.mark.gpu
+def test_infer_from_audio_fused_equals_two_stage():
+    """audio -> WrappedAudioEncoder -> generate in one process == (encoder per clip -> .npy-style array -> infer_with_prompt)."""
+    from llark_amd.jukebox import extract as E
+    from llark_amd.jukebox.hparams import hparams_tiny
+    from llark_amd.jukebox.synthetic import make_jukebox_weights, synthetic_clip
+    from llark_amd.m2t import infer_driver as D
+    from llark_amd.m2t.infer import infer_with_prompt
+    from llark_amd.m2t.prompting import extract_response_tokens
+    hps = hparams_tiny()
+    enc = E.WrappedAudioEncoder(hps=hps, weights=make_jukebox_weights(hps, seed=0, device="cuda"), device="cuda")
+    tok = _tok()
+    m = _tiny_model(tok, hps.prior_width, 2)
+    end_seq = tok("\n### Assistant:").input_ids[1:]
+    clips = [(f"clip{i}", synthetic_clip(i, seconds=1.2 + 0.3 * i)) for i in range(3)]        # ragged lengths: padded / truncated
+    recs = D.infer_from_audio(enc, m, tok, clips, PROMPT, MM_CFG, end_seq, batch_size=2, max_new_tokens=8)
+    assert [r["example_id"] for r in recs] == ["clip0", "clip1", "clip2"]
+    m.configure_engine(max_batch=1, max_seq=160)
+    for (name, audio), r in zip(clips, recs):
+        a = E.maybe_pad_audio_to_max_len(E._normalize(audio), hps.sample_length)[: hps.sample_length].astype(np.float32)
+        rep = enc(torch.from_numpy(a)[None].cuda())[0].cpu()
+        one = infer_with_prompt(PROMPT, model=m, audio_encoding=rep, end_seq=end_seq, multimodal_cfg=MM_CFG, tokenizer=tok,
+                                audio_first=True, max_new_tokens=8).cpu()
+        assert r["model_completion_text"] == tok.decode(extract_response_tokens(one[0], end_seq)), name
