@@ -636,9 +636,13 @@ static int dispatch_bd(const GemmParams& p, bool split, int epi, hipStream_t s) 
         CASE(EPI_RESID)
         CASE(EPI_QGELU_SPLIT)
         CASE(EPI_OUT16)
-        CASE(EPI_SWIGLU16)
         CASE(EPI_SPLIT16)
-        CASE(EPI_SWIGLU_SPLIT)
+    }
+    if constexpr (C::TN >= 2) {                                       // SwiGLU pairs (gate, up) live in one wave's tiles
+        switch (epi) {
+            CASE(EPI_SWIGLU16)
+            CASE(EPI_SWIGLU_SPLIT)
+        }
     }
 #undef CASE
     set_error("gemm: unknown epilogue %d", epi);
@@ -822,6 +826,7 @@ typedef Cfg<2, 2, 2, 2, 64, 3, 1> Cfg11;  // 128x128x64, 4 waves, single stage 4
 typedef Cfg<2, 2, 2, 4, 64, 2, 1> Cfg12;  // 128x256x64, 4 waves (64x128 per wave), single stage 64 KiB  : 2 blocks/CU
 // B-direct kernels (weights fragment-major, L2 -> VGPR): waves 1 x 4 over N
 typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBD0;  // 128x256x64, wave 128x64, A double-buffered 64 KiB (split)    : 2 blocks/CU
+typedef Cfg<1, 4, 4, 1, 64, 3, 2> CfgBD1;  // 128x128x64, wave 128x32, 32 KiB (plain) / 64 KiB (split)       : 3 / 2 blocks/CU
 
 template <typename T>
 static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
@@ -936,7 +941,17 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.ldw = 0; p.bias = bias; p.M = m; p.N = n; p.Kp = kp;
     p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
     hipStream_t s = (hipStream_t)stream;
-    if (variant > 0) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
+    if (variant > 1) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
+    // variant 1 (128x128 tiles, 3 workgroups per CU) removes the ragged last wave of the mid-size Llama products
+    // (qkv at M = 2968: 1152 big tiles = 2.25 waves vs 2304 small tiles = 3.0), but measured on MI355X it is still
+    // slower there (791 vs 839 TFLOP/s; only down_proj gains, 863 vs 819): bytes per flop, not wave quantisation,
+    // is what limits these kernels.  The library choice therefore stays the 128x256 tile.
+    if (variant < 0) variant = 0;
+    if (variant == 1) {
+        if (IS_SWIGLU(epilogue)) { set_error("gemm16_fragw: variant 1 (128x128 tiles) has no SwiGLU epilogue"); return LLARK_ERR_UNSUPPORTED; }
+        if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD1>(p, split != 0, epilogue, s);
+        if (dtype == LLARK_BF16) return dispatch_bd<bf16_t, CfgBD1>(p, split != 0, epilogue, s);
+    }
     if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD0>(p, split != 0, epilogue, s);
     if (dtype == LLARK_BF16) return dispatch_bd<bf16_t, CfgBD0>(p, split != 0, epilogue, s);
     set_error("gemm16_fragw: unknown dtype %d", dtype);

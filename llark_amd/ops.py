@@ -278,8 +278,10 @@ def pack_weight16_frag(wt: torch.Tensor, n: int) -> torch.Tensor:
 
 def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.Tensor, bias: Optional[torch.Tensor], n: int, kp: int,
                  epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
-                 out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
-    """Same product / epilogues as gemm16, weights given fragment-major (pack_weight16_frag)."""
+                 out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
+                 variant: int = -1) -> None:
+    """Same product / epilogues as gemm16, weights given fragment-major (pack_weight16_frag).
+    variant: -1 library choice, 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogue)."""
     dtype = a_hi.dtype
     assert dtype in (torch.float16, torch.bfloat16) and wfrag.dtype == dtype and a_hi.shape[1] >= kp
     assert wfrag.numel() == round_up(n, 32) * kp
@@ -287,7 +289,7 @@ def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
     with _timed(name, 2.0 * m * n * kp):
       check(_lib.lib().llark_gemm16_fragw(
-        -1, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
+        variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
         a_hi.stride(0), _dev(wfrag, "wfrag"), _dev(bias, "bias", torch.float32) if bias is not None else None,
         m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
         _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,

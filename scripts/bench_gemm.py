@@ -21,7 +21,9 @@ def G(a_hi, a_lo, wt, bias, n, epi, variant=-1, **kw):
     key = (wt.data_ptr(), n)
     if key not in _FRAG:
         _FRAG[key] = ops.pack_weight16_frag(wt, n)
-    return ops.gemm16_fragw(a_hi, a_lo, _FRAG[key], bias, n, wt.shape[1], epi, **kw)
+    if variant == 101 and epi in (ops.EPI_SWIGLU16, ops.EPI_SWIGLU_SPLIT):
+        variant = 100
+    return ops.gemm16_fragw(a_hi, a_lo, _FRAG[key], bias, n, wt.shape[1], epi, variant={100: 0, 101: 1, 102: -1}[variant], **kw)
 
 
 def check(variant):

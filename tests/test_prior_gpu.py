@@ -101,8 +101,10 @@ def test_gemm_fragment_major_weights_bit_identical(m, n, k):
         c0 = torch.full((m, n), float("nan"), device="cuda")
         c1 = torch.full((m, n), float("nan"), device="cuda")
         ops.gemm16(hi, l, wt, b, n, ops.EPI_F32, c=c0, variant=12)
-        ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_F32, c=c1)
-        assert torch.equal(c0, c1), f"F32 split={split}: max diff {(c0 - c1).abs().max().item():.3e}"
+        for bd_variant in (0, 1, -1):                                  # 128x256 tiles, 128x128 tiles, library choice
+            c1.fill_(float("nan"))
+            ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_F32, c=c1, variant=bd_variant)
+            assert torch.equal(c0, c1), f"F32 split={split} variant={bd_variant}: max diff {(c0 - c1).abs().max().item():.3e}"
         c0, c1 = r.clone(), r.clone()
         ops.gemm16(hi, l, wt, b, n, ops.EPI_RESID, c=c0, resid=c0, variant=12)
         ops.gemm16_fragw(hi, l, wf, b, n, kp, ops.EPI_RESID, c=c1, resid=c1)
