@@ -108,6 +108,13 @@ int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, 
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                        int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* Decode step (m <= 16 rows, bf16): h[m][n] += a . wt^T and then RMSNorm(h; norm_w, eps) -> bf16 planes x_hi (/x_lo),
+ * in one launch (the last workgroup to finish normalises the complete rows; bit-identical to llark_gemm16 +
+ * llark_rmsnorm_bf16).  Replaces o_proj / down_proj + the next LlamaRMSNorm of the cached decode path
+ * (m2t/models/llamav2.py:224-234 -> HF LlamaDecoderLayer). */
+int llark_gemm16_resid_rmsnorm(int dtype, int split, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw,
+                               int m, int n, int kp, float* h, int ldh, const float* norm_w, float eps, void* x_hi,
+                               void* x_lo, int ldx, llark_stream_t stream);
 /* Batched form (grid.y = batch): per-batch element strides for A, wt, c and the 16-bit outputs (no bias / residual).
  * Used by the attention backward of the training step (one product per (sequence, head)). */
 int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, long long stride_a,

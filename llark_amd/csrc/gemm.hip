@@ -73,6 +73,13 @@ struct GemmParams {
     // persistent mode: resident workgroups per XCD and this launch's per-XCD chunk counters
     int slots;
     int* sync;
+    // skinny kernel, EPI_RESID only: fused RMSNorm of the COMPLETE output rows by the last workgroup to finish
+    const float* nw;   // norm weight [N] (nullptr = off)
+    float neps;
+    void* nhi;         // bf16 [M][ldn] normalised rows (hi plane), optional lo plane
+    void* nlo;
+    int ldn;
+    int* ncnt;         // arrival counter (self-resetting)
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[w][t][4 * g + r][c] = acc[t][r];
     __syncthreads();
-    if (w != 0) return;
+    if (w == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = 4 * g + r;
@@ -781,6 +788,48 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             const T hi = Mfma<T>::cvt(a);
             ((T*)p.Ohi)[(size_t)m * p.ldo + n] = hi;
             if (EPI == EPI_SWIGLU_SPLIT) ((T*)p.Olo)[(size_t)m * p.ldo + n] = Mfma<T>::cvt(a - Mfma<T>::back(hi));
+        }
+    }
+    }
+    if (EPI == EPI_RESID && p.nw != nullptr) {
+        // Fused RMSNorm (decode): the workgroup that arrives last owns complete rows of C = h and normalises them
+        // with the arithmetic of rmsnorm_kernel (llama.hip) -- same per-lane float4 order, same wave reduction,
+        // y = g * (x * rstd), hi = bf16(y), lo = bf16(y - hi) -- so the result is bit-identical to a separate launch.
+        __shared__ int s_last;
+        __threadfence();                                         // release: this workgroup's C stores
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(p.ncnt, 1) == (int)gridDim.x - 1);
+        __syncthreads();
+        if (s_last) {
+            if (threadIdx.x == 0) *p.ncnt = 0;                   // ready for the next launch
+            __threadfence();                                     // acquire: drop stale L1 lines of C
+            const int w4 = p.N >> 2;
+            for (int row = w; row < p.M; row += KW) {
+                const float4* xr = (const float4*)(p.C + (size_t)row * p.ldc);
+                float sq = 0.0f;
+                for (int cidx = lane; cidx < w4; cidx += 64) {
+                    const float4 v = xr[cidx];
+                    sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+                const float var = wave_sum(sq) / (float)p.N;
+                const float rstd = 1.0f / sqrtf(var + p.neps);
+                const float4* g4 = (const float4*)p.nw;
+                bf16x4_t* hr = (bf16x4_t*)((bf16_t*)p.nhi + (size_t)row * p.ldn);
+                bf16x4_t* lr = p.nlo ? (bf16x4_t*)((bf16_t*)p.nlo + (size_t)row * p.ldn) : nullptr;
+                for (int cidx = lane; cidx < w4; cidx += 64) {
+                    const float4 v = xr[cidx];
+                    const float4 gg = g4[cidx];
+                    float y[4] = {gg.x * (v.x * rstd), gg.y * (v.y * rstd), gg.z * (v.z * rstd), gg.w * (v.w * rstd)};
+                    bf16x4_t hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hh[e] = (bf16_t)y[e];
+                        ll[e] = (bf16_t)(y[e] - (float)hh[e]);
+                    }
+                    hr[cidx] = hh;
+                    if (lr) lr[cidx] = ll;
+                }
+            }
         }
     }
 }
@@ -888,7 +937,7 @@ static int gemm16_impl(int variant, int dtype, int split, int epilogue, const vo
     if (epilogue == EPI_OUT16) LLARK_REQUIRE(out_hi && ldo >= n, "gemm16: 16-bit output missing");
     if (IS_SWIGLU(epilogue)) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2, "gemm16: swiglu needs n%%64==0 and an output");
     if (epilogue == EPI_SWIGLU_SPLIT) LLARK_REQUIRE(out_lo, "gemm16: swiglu-split needs the lo output");
-    GemmParams p;
+    GemmParams p = {};
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
     p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
@@ -956,6 +1005,34 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
     if (dtype == LLARK_BF16) return dispatch_bd<bf16_t, CfgBD0>(p, split != 0, epilogue, s);
     set_error("gemm16_fragw: unknown dtype %d", dtype);
     return LLARK_ERR_INVALID;
+}
+
+// Decode-step form of `h += x . W^T` followed by RMSNorm(h) -> bf16 planes, in ONE launch (m <= 16 rows): the skinny
+// weight-streaming kernel plus a last-workgroup-done tail.  Replaces o_proj / down_proj + the following
+// LlamaRMSNorm of m2t/models/llamav2.py:224-234 (HF LlamaDecoderLayer) in the cached decode path.
+extern "C" int llark_gemm16_resid_rmsnorm(int dtype, int split, const void* a_hi, const void* a_lo, int lda, const void* wt,
+                                          int ldw, int m, int n, int kp, float* h, int ldh, const float* norm_w, float eps,
+                                          void* x_hi, void* x_lo, int ldx, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && wt && h && norm_w && x_hi && m > 0 && n > 0 && kp > 0 && kp % 32 == 0, "gemm16_resid_rmsnorm: bad arguments");
+    LLARK_REQUIRE(m <= 16, "gemm16_resid_rmsnorm: decode form only (m <= 16), got m=%d", m);
+    LLARK_REQUIRE(n % 4 == 0 && ldh % 4 == 0 && ldx % 4 == 0 && ldh >= n && ldx >= n && lda >= kp && ldw >= kp, "gemm16_resid_rmsnorm: bad leading dimensions");
+    LLARK_REQUIRE(!split || (a_lo && x_lo), "gemm16_resid_rmsnorm: split mode needs the lo planes");
+    LLARK_REQUIRE(dtype == LLARK_BF16, "gemm16_resid_rmsnorm: bf16 only");
+    static int* counters = nullptr;
+    static unsigned next = 0;
+    if (!counters) {
+        if (hipMalloc((void**)&counters, 64 * sizeof(int)) != hipSuccess || hipMemset(counters, 0, 64 * sizeof(int)) != hipSuccess) {
+            set_error("gemm16_resid_rmsnorm: cannot allocate the arrival counters");
+            return LLARK_ERR_LAUNCH;
+        }
+    }
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.M = m; p.N = n; p.Kp = kp;
+    p.C = h; p.ldc = ldh; p.R = h; p.ldr = ldh;
+    p.nw = norm_w; p.neps = eps; p.nhi = x_hi; p.nlo = x_lo; p.ldn = ldx; p.ncnt = counters + (next++ % 64);
+    const int rc = dispatch_skinny<bf16_t>(p, split != 0, EPI_RESID, (hipStream_t)stream);
+    if (rc == 1) { set_error("gemm16_resid_rmsnorm: no skinny kernel for this epilogue"); return LLARK_ERR_UNSUPPORTED; }
+    return rc;
 }
 
 extern "C" int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,

@@ -338,50 +338,94 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 128) sq[tid] = (float)q[bh * 128 + tid] + (q_lo ? (float)q_lo[bh * 128 + tid] : 0.0f);
     __syncthreads();
+    // ---- scores: 16 lanes per key (16 B each = one 256-B cache row per 16-lane group, 1 KiB per wave instruction),
+    //      4 keys per wave and iteration; the 16 partial dot products meet in a shuffle tree
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
+    const bf16_t* kbl = kc_lo ? kc_lo + bh * (size_t)smax * 128 : nullptr;
+    const int chunk = lane & 15, sub = lane >> 4;
+    float qv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = sq[chunk * 8 + e];
     float lmax = -INFINITY;
-    for (int j = tid; j < total; j += 256) {
-        const bf16x8_t* kr = (const bf16x8_t*)(kb + (size_t)j * 128);
-        const bf16x8_t* krl = kc_lo ? (const bf16x8_t*)(kc_lo + bh * (size_t)smax * 128 + (size_t)j * 128) : nullptr;
-        float s = 0.0f;
+    constexpr int UB = 8;                                          // loads in flight per lane: the loop is a latency chain otherwise
+    for (int jb = wv * 4 + sub; jb < total + 15; jb += 16 * UB) {  // uniform trip count per 16-lane group (shuffles stay inside it)
+        bf16x8_t kv[UB], kl[UB];
 #pragma unroll
-        for (int ch = 0; ch < 16; ++ch) {
-            const bf16x8_t kv = kr[ch];
-            if (krl) {
-                const bf16x8_t kl = krl[ch];
+        for (int u = 0; u < UB; ++u) {
+            int j = jb + 16 * u;
+            j = j < total ? j : total - 1;
+            kv[u] = *(const bf16x8_t*)(kb + (size_t)j * 128 + chunk * 8);
+            if (kbl) kl[u] = *(const bf16x8_t*)(kbl + (size_t)j * 128 + chunk * 8);
+        }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e] + (float)kl[e], s);
+        for (int u = 0; u < UB; ++u) {
+            const int j = jb + 16 * u;
+            float s = 0.0f;
+            if (kbl) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(qv[e], (float)kv[u][e] + (float)kl[u][e], s);
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s = fmaf(sq[ch * 8 + e], (float)kv[e], s);
+                for (int e = 0; e < 8; ++e) s = fmaf(qv[e], (float)kv[u][e], s);
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            s *= scale;
+            if (j < total) {
+                if (chunk == 0) sp[j] = s;
+                lmax = fmaxf(lmax, s);
             }
         }
-        s *= scale;
-        sp[j] = s;
-        lmax = fmaxf(lmax, s);
     }
     lmax = wave_max(lmax);
     if (lane == 0) red[wv] = lmax;
     __syncthreads();
     const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float lsum = 0.0f;
-    for (int j = tid; j < total; j += 256) {
-        const float p = expf(sp[j] - mx);                     // fp32 probabilities (PV below is an fp32 fma chain)
+    const int tpad = (total + 7) & ~7;
+    for (int j = tid; j < tpad; j += 256) {
+        float p = 0.0f;                                       // keys total..tpad-1 only pad the 8-key PV chunks
+        if (j < total) {
+            p = expf(sp[j] - mx);                             // fp32 probabilities (PV below is an fp32 fma chain)
+            lsum += p;
+        }
         sp[j] = p;
-        lsum += p;
     }
     lsum = wave_sum(lsum);
     __syncthreads();
     if (lane == 0) red[4 + wv] = lsum;
     __syncthreads();
     const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    // O[d] = sum_j p_j V[j][d]; V^T rows are contiguous in j. 2 threads per d.
+    // ---- O[d] = sum_j p_j V[j][d]: V^T rows are contiguous in j; 2 threads per d, each walking 16-B chunks of 8 keys
     const int d = tid >> 1, half = tid & 1;
     const bf16_t* vr = vtc + (bh * 128 + d) * (size_t)smax;
     const bf16_t* vrl = vtc_lo ? vtc_lo + (bh * 128 + d) * (size_t)smax : nullptr;
     float acc = 0.0f;
-    if (vrl) for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j] + (float)vrl[j], acc);
-    else for (int j = half; j < total; j += 2) acc = fmaf(sp[j], (float)vr[j], acc);
+    for (int cb = half * 8; cb < tpad; cb += 16 * UB) {
+        bf16x8_t vv[UB], vl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int c8 = cb + 16 * u;
+            c8 = c8 < tpad ? c8 : tpad - 8;                        // clamped re-load; its probabilities are skipped below
+            vv[u] = *(const bf16x8_t*)(vr + c8);
+            if (vrl) vl[u] = *(const bf16x8_t*)(vrl + c8);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int c8 = cb + 16 * u;
+            if (c8 < tpad) {
+                if (vrl) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = fmaf(sp[c8 + e], (float)vv[u][e] + (float)vl[u][e], acc);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc = fmaf(sp[c8 + e], (float)vv[u][e], acc);
+                }
+            }
+        }
+    }
     acc += __shfl_xor(acc, 1, 64);
     if (half == 0) store_split(out, out_lo, (size_t)b * (nh * 128) + h * 128 + d, acc * inv);
 }
@@ -557,7 +601,7 @@ extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const 
     LLARK_REQUIRE(hd == 128, "attn_decode: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && nh > 0 && total > 0 && total <= smax, "attn_decode: bad shape total=%d smax=%d", total, smax);
     const float scale = (float)(1.0 / sqrt((double)hd));
-    const size_t lds = (size_t)total * sizeof(float);
+    const size_t lds = (size_t)((total + 7) & ~7) * sizeof(float);
     LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode: context %d too long for the LDS score buffer", total);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

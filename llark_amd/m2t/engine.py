@@ -89,6 +89,10 @@ class HipLlamaEngine:
         self.cur_len = 0
         self.cur_batch = 0
         # graph-captured decode step (one hipGraph per batch size; position read from device memory)
+        # o_proj / down_proj + following RMSNorm in one launch ("last workgroup done" tail).  Bit-identical, but OFF by
+        # default: on the 8-XCD MI355X the device-scope release/acquire fences it needs write back / invalidate L2
+        # (the XCD L2s are not coherent with each other) and cost ~65 us per launch -- 10.1 vs 5.9 ms per decode step.
+        self.fuse_decode_norm = os.environ.get("LLARK_DECODE_FUSE_NORM", "0") == "1"
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         self._dec: Dict[int, dict] = {}
 
@@ -184,12 +188,18 @@ class HipLlamaEngine:
             self.vt_cache_lo = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device) if self.split else None
 
     # ---- forward -------------------------------------------------------------------------------
-    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None):
+    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None) -> bool:
+        """Runs the decoder layers on ws["h"].  Returns True when ws["x16"] already holds RMSNorm_final(h) (the fused
+        decode path normalises inside the producing GEMM), False when the caller still has to apply the final norm."""
         d = self.dims
         H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
         h = ws["h"]
         n_layers = d.num_hidden_layers if num_layers is None else num_layers
         sp = self.split
+        # decode (one token per sequence): o_proj / down_proj carry the FOLLOWING RMSNorm in their launch
+        fused = s == 1 and batch <= 16 and n_layers > 0 and self.fuse_decode_norm and H <= 8192
+        if fused:
+            ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         for i in range(n_layers):
             L = self.layers[i]
             kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
@@ -197,7 +207,8 @@ class HipLlamaEngine:
             vcl = self.vt_cache_lo[i, :batch] if sp else None
             if not kc.is_contiguous():            # batch smaller than the allocated cache
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
-            ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            if not fused:
+                ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
             ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
             if pos_dev is not None:                 # decode step, position in device memory (graph-capturable)
                 ops.rope_split_heads_dpos(ws["qkv"], batch, nh, hd, pos_dev, self.cos, self.sin, ws["q"], kc, vc,
@@ -206,17 +217,23 @@ class HipLlamaEngine:
             else:
                 ops.rope_split_heads(ws["qkv"], batch, s, nh, hd, pos0, self.cos, self.sin, ws["q"], kc, vc,
                                      ws["q_lo"], kcl, vcl)
-            if pos_dev is not None:
-                pass
-            elif s == 1:
-                ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+                if s == 1:
+                    ops.attn_decode(ws["q"], kc, vc, batch, nh, hd, pos0 + 1, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+                else:
+                    ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+            if fused:
+                ops.gemm16_resid_rmsnorm(ws["att"], ws["att_lo"], L.wo, h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
             else:
-                ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
-            ops.gemm16(ws["att"], ws["att_lo"], L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
-            ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+                ops.gemm16(ws["att"], ws["att_lo"], L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+                ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
             ops.gemm16(ws["x16"], ws["x16_lo"], L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16,
                        out_hi=ws["act"], out_lo=ws["act_lo"])
-            ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+            if fused:
+                nxt = self.layers[i + 1].ln1 if i + 1 < n_layers else self.norm
+                ops.gemm16_resid_rmsnorm(ws["act"], ws["act_lo"], L.wdown, h, nxt, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            else:
+                ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+        return fused
 
     def _decode_body(self, st) -> None:
         """One decode step on static buffers: ids -> logits, new K/V written at *pos."""
@@ -224,8 +241,8 @@ class HipLlamaEngine:
         B = st["ids"].shape[0]
         ws = st["ws"]
         ops.embed_gather(st["ids"].view(-1), self.embed, ws["h"])
-        self._layers_forward(ws, B, 1, 0, None, pos_dev=st["pos"])
-        ops.rmsnorm_bf16(ws["h"], self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+        if not self._layers_forward(ws, B, 1, 0, None, pos_dev=st["pos"]):
+            ops.rmsnorm_bf16(ws["h"], self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         ops.gemm16(ws["x16"], ws["x16_lo"], self.lm_head, None, d.vocab_size, ops.EPI_F32, c=st["logits"])
 
     def _decode_step_graph(self, input_ids: torch.Tensor, pos0: int) -> torch.Tensor:
@@ -295,7 +312,7 @@ class HipLlamaEngine:
             a16, a16_lo = ops.split16(frames.contiguous(), torch.bfloat16, want_lo=self.split)
             r0 = b * S + start + 1
             ops.gemm16(a16, a16_lo, self.proj_w, self.proj_b, d.hidden_size, ops.EPI_F32, c=h[r0: r0 + F])
-        self._layers_forward(ws, B, S, pos0, num_layers)
+        normed = self._layers_forward(ws, B, S, pos0, num_layers)
         self.cur_len = pos0 + S
         if return_hidden:
             return h.view(B, S, d.hidden_size)
@@ -307,7 +324,8 @@ class HipLlamaEngine:
             logits = torch.empty((B, d.vocab_size), dtype=torch.float32, device=self.device)
             ops.gemm16(x16, x16_lo, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
             return logits.view(B, 1, d.vocab_size)
-        ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+        if not normed:
+            ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
         ops.gemm16(ws["x16"], ws["x16_lo"], self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
         return logits.view(B, S, d.vocab_size)

@@ -268,6 +268,19 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16")
 
 
+def gemm16_resid_rmsnorm(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, h: torch.Tensor, norm_w: torch.Tensor,
+                         eps: float, x_hi: torch.Tensor, x_lo: Optional[torch.Tensor] = None) -> None:
+    """Decode step: h += a . wt^T, then x = RMSNorm(h) as bf16 planes -- one launch (m <= 16)."""
+    m, n, kp = a_hi.shape[0], h.shape[1], wt.shape[1]
+    bf = torch.bfloat16
+    name = ("gemm_split_" if a_lo is not None else "gemm_") + "bf16_skinny"
+    with _timed(name, 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_resid_rmsnorm(
+            _DT[bf], int(a_lo is not None), _dev(a_hi, "a_hi", bf), _opt(a_lo, "a_lo", bf), a_hi.stride(0), _dev(wt, "wt", bf),
+            wt.stride(0), m, n, kp, _dev(h, "h", torch.float32), h.stride(0), _dev(norm_w, "norm_w", torch.float32), float(eps),
+            _dev(x_hi, "x_hi", bf), _opt(x_lo, "x_lo", bf), x_hi.stride(0), _stream()), "gemm16_resid_rmsnorm")
+
+
 def pack_weight16_frag(wt: torch.Tensor, n: int) -> torch.Tensor:
     """wt [>=n][kp] 16-bit (pack_weight16 output, kp % 64 == 0) -> fragment-major copy for gemm16_fragw."""
     kp = wt.shape[1]

@@ -417,3 +417,31 @@ def test_decode_graph_replay_matches_eager(precision):
             assert torch.equal(a, b)
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+@pytest.mark.parametrize("batch", [1, 5])
+def test_decode_fused_resid_rmsnorm_bit_identical(precision, batch):
+    """o_proj / down_proj + the following RMSNorm in one launch (last workgroup normalises the complete rows) gives
+    exactly the logits and hidden state of the separate launches, over several decode steps and layers."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from oracle import llama_ref as LR
+    spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2, vocab_size=320,
+                        mm_hidden_size=96, audio_start_token=317, audio_end_token=318, audio_patch_token=319)
+    w = LR.make_weights(spec, seed=11)
+    dims = LlamaDims(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2, vocab_size=320,
+                     mm_hidden_size=96, rms_norm_eps=spec.rms_norm_eps)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(3, 300, (batch, 13), generator=g).cuda()
+    toks = torch.randint(3, 300, (5, batch, 1), generator=g).cuda()
+    res = []
+    for fuse in (False, True):
+        eng = HipLlamaEngine(dims, "cuda", batch, 64, precision=precision)
+        eng.load_state_dict(w)
+        eng.fuse_decode_norm = fuse
+        eng.forward_tokens(ids)
+        outs = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(5)]
+        hid = eng.forward_tokens(toks[0], (), pos0=eng.cur_len, return_hidden=True).clone()
+        res.append((torch.stack(outs), hid))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
