@@ -166,6 +166,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) {
+            // Residual epilogue: R may alias C (in-place h += ...), so a load placed after a store can never be
+            // hoisted above it -- interleaved load/add/store degenerates into one full memory round trip per
+            // element (measured: +0.8 ms on the 65536 x 4800 products).  Fetch the residuals of this whole tile
+            // row (TN x 16 values per lane) first, all loads in flight together, then add and store.
+            float res[C::TN][16];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    const bool col_ok = FULL || (ocol0 + tn * 32 + lc < nlim);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);
+                        res[tn][r] = (col_ok && (FULL || mrow0 + ml + lr < p.M))
+                                         ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + tn * 32) * 4, 0))
+                                         : 0.0f;
+                    }
+                }
+            }
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn) {
                 if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
@@ -182,8 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                     if (EPI == EPI_F32) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
                     } else if (EPI == EPI_RESID) {
-                        const float res = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + ocl) * 4, 0));
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[tn][r] + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
                     } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
                         if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
                         const T hi = Mfma<T>::cvt(v);
