@@ -63,18 +63,29 @@ class HipLlamaTrainer:
             self._slices[name] = (off, n)
             off += n
         self.micro_batches = 0
+        self._matrix_grads = {n for n, p in self.params if p.dim() == 2 and n != "embed"}
+        self._fresh = set()                            # flat_grad starts zeroed: accumulate until the first zero_grad()
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
-        self.flat_grad.zero_()
+        """Weight-matrix gradients are WRITTEN by the first micro-batch's dW product (no 27 GB memset, no residual read
+        in that epilogue); only the small accumulate-only slices (norm gains, embedding rows, projector bias) are zeroed."""
+        for name, _ in self.params:
+            if name not in self._matrix_grads:
+                self.grads[name].zero_()
+        self._fresh = set(self._matrix_grads)
         self.micro_batches = 0
 
-    def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor) -> None:
-        """grad[N][K] += dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16)."""
+    def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor, name: str) -> None:
+        """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch."""
         dyT = ops.transposed16(dy16)
         xT = ops.transposed16(x16)
         n, k = dy16.shape[1], x16.shape[1]
-        ops.gemm16(dyT, None, xT, None, k, ops.EPI_RESID, c=grad, resid=grad, m=n)
+        if name in self._fresh:
+            self._fresh.discard(name)
+            ops.gemm16(dyT, None, xT, None, k, ops.EPI_F32, c=grad, m=n)
+        else:
+            ops.gemm16(dyT, None, xT, None, k, ops.EPI_RESID, c=grad, resid=grad, m=n)
 
     def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
         """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout)."""
@@ -159,19 +170,19 @@ class HipLlamaTrainer:
             dh16 = dh16[:, :H]
             dact = torch.empty((rows, I), **f32)
             self._dx(dh16, L.wdown, dact)
-            self._dw(dh16, st["act"], g[pre + "wdown"])
+            self._dw(dh16, st["act"], g[pre + "wdown"], pre + "wdown")
             dgu = torch.empty((rows, 2 * I), **bf)
             ops.swiglu_bwd(st["gu"], dact, dgu)
             del dact
             self._dx(dgu, L.wgu, dtmp)
-            self._dw(dgu, st["x2"], g[pre + "wgu"])
+            self._dw(dgu, st["x2"], g[pre + "wgu"], pre + "wgu")
             del dgu
             ops.rmsnorm_bwd(st["h_mid"], L.ln2, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln2"])
             # ---- attention ----
             dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
             dh16 = dh16[:, :H]
             self._dx(dh16, L.wo, dtmp)                                  # d(att)
-            self._dw(dh16, st["att"], g[pre + "wo"])
+            self._dw(dh16, st["att"], g[pre + "wo"], pre + "wo")
             datt16, _ = ops.split16(dtmp, _BF, want_lo=False, kmult=64)
             dO = torch.empty((BH, S, hd), **bf)
             ops.split_heads16(datt16[:, :H].contiguous() if datt16.shape[1] != H else datt16, B, S, nh, hd, dO)
@@ -206,7 +217,7 @@ class HipLlamaTrainer:
             dqkv = torch.empty((rows, 3 * H), **bf)
             ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
             self._dx(dqkv, L.wqkv, dtmp)
-            self._dw(dqkv, st["x1"], g[pre + "wqkv"])
+            self._dw(dqkv, st["x1"], g[pre + "wqkv"], pre + "wqkv")
             ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"])
             saved[i] = None
         # ---- bottom: projector and the trainable embedding rows ----
@@ -216,7 +227,7 @@ class HipLlamaTrainer:
             ops.gather_rows(dh, ridx, dya)
             ops.colsum_add(dya, g["proj_b"])
             dya16, _ = ops.split16(dya, _BF, want_lo=False, kmult=64)
-            self._dw(dya16[:, :H], torch.cat(seg_a16, dim=0).contiguous(), g["proj_w"])
+            self._dw(dya16[:, :H], torch.cat(seg_a16, dim=0).contiguous(), g["proj_w"], "proj_w")
         if self.train_embed_all:
             keep = torch.ones((rows,), dtype=torch.bool, device=dev)
             if seg_rows:
@@ -235,9 +246,17 @@ class HipLlamaTrainer:
         return loss
 
     # ------------------------------------------------------------------------------------------
+    def _finalize_grads(self) -> None:
+        """A matrix whose dW product never ran since zero_grad() (e.g. mm_projector on a text-only batch) still holds the
+        previous step's values: zero it before anyone reads the gradients."""
+        for name in getattr(self, "_fresh", ()):
+            self.grads[name].zero_()
+        self._fresh = set()
+
     def allreduce_grads(self, world: int, bucket_elems: int = 64 * 1024 * 1024) -> None:
         """Sum gradients over the data-parallel ranks (RCCL on GPUs): large flat buckets; the division by the world
         size is folded into the optimizer's grad_scale."""
+        self._finalize_grads()
         if world <= 1:
             return
         import torch.distributed as dist
@@ -250,6 +269,7 @@ class HipLlamaTrainer:
 
     def step(self, world: int = 1) -> None:
         """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients."""
+        self._finalize_grads()
         self.step_count += 1
         b1, b2 = self.betas
         for name, p in self.params:
@@ -261,6 +281,7 @@ class HipLlamaTrainer:
     # ------------------------------------------------------------------------------------------
     def export_grads_hf(self) -> Dict[str, torch.Tensor]:
         """Gradients under the reference's state-dict names / layouts (for parity tests and checkpoint tooling)."""
+        self._finalize_grads()
         d = self.eng.dims
         H, I = d.hidden_size, d.intermediate_size
         out = {}
