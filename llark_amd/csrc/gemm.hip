@@ -930,7 +930,8 @@ using namespace llark;
 static int pick_variant(int split, int m, int n, int kp) {
     if (m <= 128 || n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
-    if (kp < 2048) return 1;                      // shallow K (attention c_proj, K = 1216): 8-wave 256x128 block
+    if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
+                                                  // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
     static const bool persist = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
     if (m >= 16384 && persist) return 20;                    // very tall products (the prior, M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
     if (!split && n < 16384) return 11;           // plain 16-bit, mid-size N (Llama q/k/v/o, down): 128x128x64, 3 blocks/CU
