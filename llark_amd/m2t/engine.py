@@ -130,6 +130,28 @@ class HipLlamaEngine:
         if self.frag_weights:
             ops.attach_frag(self.lm_head, self.lm_head.shape[0])
 
+    def state_dict_hf(self) -> Dict[str, torch.Tensor]:
+        """Weights under the reference's state-dict names and layouts (inverse of :meth:`load_state_dict`): the fused
+        q|k|v rows are split, gate/up rows de-interleaved.  Tensors are views / copies on the engine's device."""
+        d = self.dims
+        H, I = d.hidden_size, d.intermediate_size
+        sd: Dict[str, torch.Tensor] = {}
+        for i, L in enumerate(self.layers):
+            p = f"model.layers.{i}"
+            sd[f"{p}.self_attn.q_proj.weight"], sd[f"{p}.self_attn.k_proj.weight"], sd[f"{p}.self_attn.v_proj.weight"] = (
+                L.wqkv[:H], L.wqkv[H: 2 * H], L.wqkv[2 * H:])
+            sd[f"{p}.self_attn.o_proj.weight"] = L.wo
+            gu = L.wgu.view(I // 32, 2, 32, H)
+            sd[f"{p}.mlp.gate_proj.weight"] = gu[:, 0].reshape(I, H)
+            sd[f"{p}.mlp.up_proj.weight"] = gu[:, 1].reshape(I, H)
+            sd[f"{p}.mlp.down_proj.weight"] = L.wdown
+            sd[f"{p}.input_layernorm.weight"] = L.ln1
+            sd[f"{p}.post_attention_layernorm.weight"] = L.ln2
+        sd["model.embed_tokens.weight"], sd["model.norm.weight"], sd["lm_head.weight"] = self.embed, self.norm, self.lm_head
+        if self.proj_w is not None:
+            sd["model.mm_projector.weight"], sd["model.mm_projector.bias"] = self.proj_w, self.proj_b
+        return sd
+
     def drop_frag_weights(self) -> None:
         """Called by the training step: the row-major weights are about to be updated in place."""
         self.frag_weights = False

@@ -43,12 +43,19 @@ def lr_at(step: int, cfg: TrainConfig) -> float:
 
 
 def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainConfig(), world: int = 1,
-          max_optimizer_steps: Optional[int] = None, log=None):
+          max_optimizer_steps: Optional[int] = None, log=None, output_dir: Optional[str] = None, save_steps: int = 5000,
+          save_total_limit: Optional[int] = 1, rank: int = 0):
     """engine: a bf16 ``HipLlamaEngine`` holding the weights; batches: collated micro-batches of THIS rank
-    (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``).  Returns the list of logged losses."""
+    (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``).  Returns the list of logged losses.
+    With ``output_dir``: resumes from the newest ``checkpoint-*`` there (m2t/train.py:257-260), saves every
+    ``save_steps`` optimizer steps (train_llark.sh:31,41-42) and once more at the end."""
     toks = [t for t in (audio_cfg.audio_start_token, audio_cfg.audio_end_token) if isinstance(t, int)]
     tr = HipLlamaTrainer(engine, lr=cfg.learning_rate, betas=(cfg.adam_beta1, cfg.adam_beta2), eps=cfg.adam_epsilon,
                          weight_decay=cfg.weight_decay, embed_grad_tokens=toks)
+    from . import checkpoint as CK
+
+    if output_dir:
+        CK.maybe_resume(tr, output_dir)
     losses, acc, micro = [], 0.0, 0
     for batch in batches:
         ids = batch["input_ids"].to(engine.device)
@@ -69,6 +76,10 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
             if log:
                 log(dict(step=tr.step_count, loss=mean_loss, lr=tr.lr))
             acc = 0.0
+            if output_dir and tr.step_count % save_steps == 0:
+                CK.save_checkpoint(tr, output_dir, save_total_limit, rank)
             if max_optimizer_steps and tr.step_count >= max_optimizer_steps:
                 break
+    if output_dir:
+        CK.save_checkpoint(tr, output_dir, save_total_limit, rank)
     return losses

@@ -4,6 +4,8 @@ oracle evaluated in the same bf16 flow (reference recipe: bf16, lm_head frozen, 
 
 Tolerance: gradients are compared per tensor by relative Frobenius error <= 3e-2 and cosine >= 0.999 (bf16 operands
 in both the forward and the backward products; the oracle back-propagates in fp32 through bf16-rounded activations)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -181,3 +183,36 @@ def test_train_loop_schedule():
     losses = train(eng, [batch] * 12, ac, cfg, world=1, log=logs.append)
     assert len(losses) == 6 and logs[-1]["step"] == 6
     assert losses[-1] < losses[1]
+
+
+def test_checkpoint_resume_and_adapter_sidefile(tmp_path):
+    """Save after 2 optimizer steps, resume in a NEW engine + trainer, take a 3rd step == 3 uninterrupted steps; the
+    on-disk names are the reference's (full model + mm_projector side-file), old checkpoints are pruned."""
+    from llark_amd.m2t import checkpoint as CK
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    toks = (spec.audio_start_token, spec.audio_end_token)
+    tr = HipLlamaTrainer(eng, lr=2e-3, embed_grad_tokens=toks)
+    out = str(tmp_path / "run")
+    for step in range(3):
+        tr.forward_backward(ids.cuda(), segs, labels.cuda())
+        tr.step()
+        if step < 2:
+            CK.save_checkpoint(tr, out, save_total_limit=1)
+    final = {k: v.float().cpu().clone() for k, v in eng.state_dict_hf().items()}
+    assert [os.path.basename(p) for p in CK.list_checkpoints(out)] == ["checkpoint-2"]          # checkpoint-1 pruned
+    side = torch.load(os.path.join(out, "mm_projector", "checkpoint-2.bin"))
+    assert sorted(side) == ["model.embed_tokens.weight", "model.mm_projector.bias", "model.mm_projector.weight"]
+    full = torch.load(os.path.join(out, "checkpoint-2", "pytorch_model.bin"))
+    assert set(full) == set(w) and all(full[k].shape == w[k].shape for k in w)                  # the reference's names / shapes
+    # resume: fresh engine with the ORIGINAL weights, then load
+    spec2, w2, ids2, aud2, labels2, eng2, segs2 = _setup(B=2)
+    tr2 = HipLlamaTrainer(eng2, lr=2e-3, embed_grad_tokens=toks)
+    assert CK.maybe_resume(tr2, out) == 2 and tr2.step_count == 2
+    tr2.forward_backward(ids.cuda(), segs2, labels.cuda())
+    tr2.step()
+    got = {k: v.float().cpu() for k, v in eng2.state_dict_hf().items()}
+    for k in final:
+        assert torch.allclose(got[k], final[k], rtol=0, atol=2 ** -8 * max(1e-3, final[k].abs().max().item())), k
+    # the wrapped model of the inference path loads the saved file under the same names
+    assert CK.maybe_resume(HipLlamaTrainer(_setup(B=2)[5], lr=2e-3, embed_grad_tokens=toks), str(tmp_path / "empty")) == 0
