@@ -138,9 +138,10 @@ class TrainWorkload:
     def step(self):
         tr = self.trainer
         loss = None
-        for ids, labels, emb in self.batches:
+        for k, (ids, labels, emb) in enumerate(self.batches):
             segs = [(b, 1, emb[b]) for b in range(self.micro)]
-            loss = tr.forward_backward(ids, segs, labels, 1.0 / self.accum)
+            loss = tr.forward_backward(ids, segs, labels, 1.0 / self.accum,
+                                       overlap_allreduce_world=self.world if k == len(self.batches) - 1 else 1)
         tr.allreduce_grads(self.world)
         tr.step(self.world)
         return loss

@@ -64,7 +64,9 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
             feats = [f.to(engine.device, torch.float32) for f in feats] if isinstance(feats, (list, tuple)) \
                 else feats.to(engine.device, torch.float32)
         segs = plan_audio_splice(ids, feats, audio_cfg, False)
-        loss = tr.forward_backward(ids, segs, batch["labels"].to(engine.device), 1.0 / cfg.gradient_accumulation_steps)
+        last = (micro + 1) % cfg.gradient_accumulation_steps == 0          # DDP no_sync boundary: exchange only on the last micro-step
+        loss = tr.forward_backward(ids, segs, batch["labels"].to(engine.device), 1.0 / cfg.gradient_accumulation_steps,
+                                   overlap_allreduce_world=world if last else 1)
         acc += float(loss.item()) / cfg.gradient_accumulation_steps
         micro += 1
         if micro % cfg.gradient_accumulation_steps == 0:

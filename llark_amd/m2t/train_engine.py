@@ -97,9 +97,14 @@ class HipLlamaTrainer:
         ops.gemm16(dy16, None, wT, None, w.shape[1], ops.EPI_F32, c=out)
 
     # ------------------------------------------------------------------------------------------
-    def forward_backward(self, input_ids: torch.Tensor, audio_segments, labels: torch.Tensor, loss_scale: float = 1.0) -> torch.Tensor:
+    def forward_backward(self, input_ids: torch.Tensor, audio_segments, labels: torch.Tensor, loss_scale: float = 1.0,
+                         overlap_allreduce_world: int = 1) -> torch.Tensor:
         """One micro-batch: returns the (unscaled) loss as a device scalar and ACCUMULATES gradients.
-        ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer."""
+        ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer.
+        ``overlap_allreduce_world`` > 1 (pass it on the LAST micro-batch of an optimizer step, the reference's DDP
+        ``no_sync`` boundary): as soon as the backward of decoder layer i is complete its ~0.8 GB gradient slice is
+        all-reduced asynchronously (RCCL stream) while layers i-1 ... 0 are still being differentiated; call
+        :meth:`allreduce_grads` afterwards -- it only exchanges what is left and waits."""
         eng, d = self.eng, self.eng.dims
         dev = eng.device
         B, S = input_ids.shape
@@ -220,6 +225,8 @@ class HipLlamaTrainer:
             self._dw(dqkv, st["x1"], g[pre + "wqkv"], pre + "wqkv")
             ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"])
             saved[i] = None
+            if overlap_allreduce_world > 1:
+                self._start_layer_allreduce(i)
         # ---- bottom: projector and the trainable embedding rows ----
         if seg_rows:
             ridx = torch.cat(seg_rows)
@@ -246,6 +253,21 @@ class HipLlamaTrainer:
         return loss
 
     # ------------------------------------------------------------------------------------------
+    def _layer_span(self, i: int) -> Tuple[int, int]:
+        """[start, end) of decoder layer i inside the flat gradient (its six tensors are contiguous)."""
+        o0, _ = self._slices[f"layers.{i}.wqkv"]
+        o1, n1 = self._slices[f"layers.{i}.ln2"]
+        return o0, o1 + n1
+
+    def _start_layer_allreduce(self, i: int) -> None:
+        import torch.distributed as dist
+
+        o0, o1 = self._layer_span(i)
+        if not hasattr(self, "_inflight"):
+            self._inflight, self._reduced = [], []
+        self._inflight.append(dist.all_reduce(self.flat_grad[o0:o1], op=dist.ReduceOp.SUM, async_op=True))
+        self._reduced.append((o0, o1))
+
     def _finalize_grads(self) -> None:
         """A matrix whose dW product never ran since zero_grad() (e.g. mm_projector on a text-only batch) still holds the
         previous step's values: zero it before anyone reads the gradients."""
@@ -255,15 +277,21 @@ class HipLlamaTrainer:
 
     def allreduce_grads(self, world: int, bucket_elems: int = 64 * 1024 * 1024) -> None:
         """Sum gradients over the data-parallel ranks (RCCL on GPUs): large flat buckets; the division by the world
-        size is folded into the optimizer's grad_scale."""
+        size is folded into the optimizer's grad_scale.  Slices already exchanged during the backward
+        (``overlap_allreduce_world``) are skipped; everything in flight is waited for."""
         self._finalize_grads()
-        if world <= 1:
-            return
-        import torch.distributed as dist
+        done = sorted(getattr(self, "_reduced", []))
+        works = list(getattr(self, "_inflight", []))
+        self._inflight, self._reduced = [], []
+        if world > 1:
+            import torch.distributed as dist
 
-        n = self.flat_grad.numel()
-        works = [dist.all_reduce(self.flat_grad[o: min(o + bucket_elems, n)], op=dist.ReduceOp.SUM, async_op=True)
-                 for o in range(0, n, bucket_elems)]
+            n = self.flat_grad.numel()
+            pos = 0
+            for a, b in done + [(n, n)]:                  # the gaps between the spans reduced so far
+                for o in range(pos, a, bucket_elems):
+                    works.append(dist.all_reduce(self.flat_grad[o: min(o + bucket_elems, a)], op=dist.ReduceOp.SUM, async_op=True))
+                pos = max(pos, b)
         for w in works:
             w.wait()
 

@@ -79,6 +79,14 @@ def _grad_worker(rank, world, port, q):
     tr = object.__new__(HipLlamaTrainer)                   # only the gradient-exchange logic is exercised on CPU
     tr.flat_grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     tr.allreduce_grads(world, bucket_elems=300)            # 4 buckets, async all-reduces
+    first = tr.flat_grad.clone()
+    # overlapped form: two "layers" are exchanged during the backward (newest layer first), the rest afterwards
+    tr.flat_grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    tr._slices = {"layers.0.wqkv": (100, 50), "layers.0.ln2": (340, 10), "layers.1.wqkv": (350, 200), "layers.1.ln2": (690, 10)}
+    tr._start_layer_allreduce(1)
+    tr._start_layer_allreduce(0)
+    tr.allreduce_grads(world, bucket_elems=128)
+    assert torch.equal(tr.flat_grad, first), "overlapped exchange must reduce every element exactly once"
     q.put((rank, tr.flat_grad.clone()))
     D.shutdown(world)
 
