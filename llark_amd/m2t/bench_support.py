@@ -165,63 +165,3 @@ class TrainWorkload:
 
 def build(args, device):
     return LLMWorkload(args, device)
-
-
-def cpu_baseline(args):
-    """Oracle Llama forward on the host: B=1, S=371, `cpu_layers` of 32 layers at full width + lm_head,
-    extrapolated to 32 layers."""
-    from oracle import llama_ref as LR
-
-    layers = max(1, args.cpu_layers)
-    spec = LR.LlamaSpec(num_hidden_layers=layers, vocab_size=VOCAB, audio_start_token=START, audio_end_token=END,
-                        audio_patch_token=PATCH)
-    w = LR.make_weights(spec, seed=0, std=0.02)
-    ids = make_prompt_ids(1)
-    aud = torch.randn(1, FRAMES, 4800)
-    t0 = time.time()
-    LR.forward(w, spec, ids, aud, num_layers=0)
-    t_head = time.time() - t0
-    t0 = time.time()
-    LR.forward(w, spec, ids, aud)
-    t_all = time.time() - t0
-    t_layers = max(t_all - t_head, 1e-6)
-    total = t_head + t_layers / layers * 32
-    return total, (f"Llama fwd B=1 S=371 fp32 oracle: embed+projector+lm_head {t_head:.2f}s + {layers} of 32 layers "
-                   f"{t_layers:.2f}s extrapolated to 32")
-
-
-def cpu_baseline_train(args):
-    """Oracle training step on the host (torch fp32 autograd over oracle/llama_ref.py): 1 clip, S = train_seq,
-    `cpu_layers` of 32 layers + lm_head, extrapolated to 32 layers (optimizer step excluded)."""
-    import os
-
-    from oracle import llama_ref as LR
-
-    layers = max(1, args.cpu_layers)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    spec = LR.LlamaSpec(num_hidden_layers=layers, vocab_size=VOCAB, audio_start_token=START, audio_end_token=END,
-                        audio_patch_token=PATCH)
-    w = LR.make_weights(spec, seed=0, std=0.02)
-    for k, v in w.items():
-        if v.is_floating_point() and "lm_head" not in k:
-            v.requires_grad_(True)
-    ids = make_prompt_ids(1)
-    ans = torch.randint(3, 32000, (1, args.train_seq - ids.shape[1]))
-    full = torch.cat([ids, ans], 1)
-    labels = full.clone()
-    labels[:, : ids.shape[1]] = -100
-    aud = torch.randn(1, FRAMES, 4800)
-
-    def run(nl):
-        t0 = time.time()
-        out = LR.forward(w, spec, full, aud, labels=labels, num_layers=nl)
-        out["loss"].backward()
-        return time.time() - t0
-
-    t_head = run(0)
-    t_all = run(None)
-    t_layers = max(t_all - t_head, 1e-6)
-    total = t_head + t_layers / layers * 32
-    return {"value": 1.0 / total, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"1 clip fwd+bwd S={args.train_seq} fp32 torch-autograd oracle: head {t_head:.2f}s + {layers} of 32 layers {t_layers:.2f}s extrapolated to 32"}

@@ -40,3 +40,18 @@ def test_invalid_arguments_are_reported_not_crashed():
     assert b"gemm16" in L.llark_last_error()
     rc = L.llark_prior_attn(None, 0, 1, 64, 48, 2, 8, 1, None, None, 0, None)
     assert rc == -1
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under llark_amd/ may import, call or link it (only tests/,
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg do)."""
+    import pathlib
+    import re
+    root = pathlib.Path(__file__).resolve().parents[1] / "llark_amd"
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)|oracle/_build|libjukebox_ref", re.M)
+    offenders = [str(p) for p in root.rglob("*.py") if pat.search(p.read_text())]
+    inc = re.compile(r"#\s*include\s*[<\"][^>\"]*(oracle|jukebox_ref)[^>\"]*[>\"]")
+    offenders += [str(p) for ext in ("*.hip", "*.h") for p in root.rglob(ext) if inc.search(p.read_text())]
+    mk = root / "csrc" / "Makefile"
+    assert "oracle" not in mk.read_text()
+    assert not offenders, offenders
