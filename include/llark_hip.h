@@ -102,7 +102,7 @@ int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void*
 /* Fragment-major weights for the "B-direct" GEMM: wt [n][ldw] (16-bit, K-contiguous, kp % 64 == 0) -> dst of
  * ceil(n/32)*32 * kp elements laid out as 1-KiB chunks [row tile][k16 step][lane 0..63][8 elements] = one MFMA
  * B fragment per chunk (rows >= n are zero).  llark_gemm16_fragw computes the same product as llark_gemm16 but
- * streams these chunks L2 -> VGPR (the weight never goes through LDS); variant: -1 library choice (= 0),
+ * streams these chunks L2 -> VGPR (the weight never goes through LDS); variant: -1 library choice,
  * 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogues). */
 int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, llark_stream_t stream);
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,

@@ -1009,11 +1009,11 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
     p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
     hipStream_t s = (hipStream_t)stream;
     if (variant > 1) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
-    // variant 1 (128x128 tiles, 3 workgroups per CU) removes the ragged last wave of the mid-size Llama products
-    // (qkv at M = 2968: 1152 big tiles = 2.25 waves vs 2304 small tiles = 3.0), but measured on MI355X it is still
-    // slower there (791 vs 839 TFLOP/s; only down_proj gains, 863 vs 819): bytes per flop, not wave quantisation,
-    // is what limits these kernels.  The library choice therefore stays the 128x256 tile.
-    if (variant < 0) variant = 0;
+    // variant 1 (128x128 tiles, 3 workgroups per CU) fills the chip where the big tile leaves a ragged wave.  Measured
+    // at M = 2968, bf16 (profiles/r01_gemm_variants.txt): it wins only on the narrow outputs -- o_proj 844 vs 798,
+    // down_proj 939 vs 903 TFLOP/s (N = 4096: 768 small tiles = exactly one wave) -- and loses on qkv / lm_head
+    // (822 vs 865, 852 vs 974), where bytes per flop matter more than wave quantisation.
+    if (variant < 0) variant = (!split && !IS_SWIGLU(epilogue) && n <= 4096) ? 1 : 0;
     if (variant == 1) {
         if (IS_SWIGLU(epilogue)) { set_error("gemm16_fragw: variant 1 (128x128 tiles) has no SwiGLU epilogue"); return LLARK_ERR_UNSUPPORTED; }
         if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD1>(p, split != 0, epilogue, s);

@@ -116,9 +116,7 @@ class HipLlamaEngine:
             for t in (old.wqkv, old.wo, old.wgu, old.wdown):
                 ops.detach_frag(t)
         if self.frag_weights:
-            # down_proj (N = 4096, K = 11008) in single-pass mode is the one shape where the LDS-staged 128x128x64
-            # kernel (3 workgroups/CU, exactly one wave of 768 tiles at M = 2968) beats B-direct: 894 vs 819 TFLOP/s
-            for t in ((L.wqkv, L.wo, L.wgu, L.wdown) if self.split else (L.wqkv, L.wo, L.wgu)):
+            for t in (L.wqkv, L.wo, L.wgu, L.wdown):
                 ops.attach_frag(t, t.shape[0])
         self.layers[i] = L
 

@@ -103,7 +103,7 @@ def main():
     c2 = torch.zeros(M2, 32004, device=dev)
     h2 = torch.zeros(M2, 4096, device=dev)
     o16 = torch.zeros(M2, 11008, dtype=torch.bfloat16, device=dev)
-    for name, n, k, epi in [("qkv", 12288, 4096, ops.EPI_F32), ("gate_up", 22016, 4096, ops.EPI_SWIGLU16), ("down", 4096, 11008, ops.EPI_RESID),
+    for name, n, k, epi in [("qkv", 12288, 4096, ops.EPI_F32), ("o", 4096, 4096, ops.EPI_RESID), ("gate_up", 22016, 4096, ops.EPI_SWIGLU16), ("down", 4096, 11008, ops.EPI_RESID),
                             ("lm_head", 32004, 4096, ops.EPI_F32)]:
         wt = (torch.randn(n, k, generator=g, device=dev) * 0.02).bfloat16()
         a = x[:, :k].contiguous()

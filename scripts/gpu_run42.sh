@@ -1,2 +1,2 @@
 export TMPDIR=/tmp
-timeout 300 python scripts/bench_gemm.py 12,13,20,21 2>&1 | grep -E "^split|^variant"
+timeout 300 python scripts/bench_gemm.py 11,12,100,101 2>&1 | grep -E "^bf16"
