@@ -16,6 +16,9 @@
 // steps, so LDS reads are conflict-free and HBM traffic is exactly one read + one write per layer.
 #include <stdlib.h>
 
+#ifndef RES_ABLATE
+#define RES_ABLATE 0      // profiling-only: 1 = no global loads in the staging phase, 2 = no MFMA phase (results invalid)
+#endif
 #include "common.h"
 
 namespace llark {
@@ -265,7 +268,11 @@ __global__ __launch_bounds__(256, 3) void resblock_mfma_kernel(const float* __re
             for (int it = 0; it < NIT; ++it) {
                 int gi = t0 - dil + lane + 64 * it;
                 gi = gi < 0 ? 0 : (gi >= t ? t - 1 : gi);
+#if RES_ABLATE == 1
+                v[it] = (float)gi;
+#else
                 v[it] = src[gi];
+#endif
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -291,6 +298,7 @@ __global__ __launch_bounds__(256, 3) void resblock_mfma_kernel(const float* __re
         f32x16_t acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = b1[(r & 3) + 8 * (r >> 2) + 4 * h];
+#if RES_ABLATE != 2
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
             const float* col = lds + tl + tap * dil + h * span;
@@ -300,11 +308,16 @@ __global__ __launch_bounds__(256, 3) void resblock_mfma_kernel(const float* __re
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[tap * 16 + j], b, acc, 0, 0, 0);
             }
         }
+#endif
         f32x16_t out;
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * h];
+#if RES_ABLATE != 2
 #pragma unroll
         for (int j = 0; j < 16; ++j) out = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], fmaxf(acc[j], 0.0f), out, 0, 0, 0);
+#else
+        out = acc;
+#endif
         const int tg = t0 + tl;
         if (tg < t) {
 #pragma unroll
