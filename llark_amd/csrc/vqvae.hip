@@ -293,37 +293,51 @@ __global__ __launch_bounds__(256, 3) void resblock_mfma_kernel(const float* __re
     for (int j = 0; j < 16; ++j) wb[j] = w2p[(size_t)((j & 3) + 8 * (j >> 2) + 4 * h) * C + co];
     __syncthreads();
     float* yn = y + (size_t)n * C * t;
-    for (int tile = 0; tile < NTILE; ++tile) {
-        const int tl = (wv * NTILE + tile) * 32 + (lane & 31);       // this lane's time step within the block tile
-        f32x16_t acc;
+    // the NTILE accumulator chains are interleaved (independent MFMAs between dependent ones)
+    f32x16_t acc[NTILE], out[NTILE];
+    int tls[NTILE];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = b1[(r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int sub = 0; sub < NTILE; ++sub) {
+        tls[sub] = (wv * NTILE + sub) * 32 + (lane & 31);       // this lane's time step within the block tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sub][r] = b1[(r & 3) + 8 * (r >> 2) + 4 * h];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+#pragma unroll
+            for (int sub = 0; sub < NTILE; ++sub) {
 #if RES_ABLATE != 2
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap) {
-            const float* col = lds + tl + tap * dil + h * span;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float b = fmaxf(col[2 * j * span], 0.0f);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[tap * 16 + j], b, acc, 0, 0, 0);
+                const float b = fmaxf(lds[tls[sub] + tap * dil + h * span + 2 * j * span], 0.0f);
+                acc[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[tap * 16 + j], b, acc[sub], 0, 0, 0);
+#endif
             }
         }
-#endif
-        f32x16_t out;
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = b2[(r & 3) + 8 * (r >> 2) + 4 * h];
+    for (int sub = 0; sub < NTILE; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[sub][r] = b2[(r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int sub = 0; sub < NTILE; ++sub) {
 #if RES_ABLATE != 2
-#pragma unroll
-        for (int j = 0; j < 16; ++j) out = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], fmaxf(acc[j], 0.0f), out, 0, 0, 0);
+            out[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], fmaxf(acc[sub][j], 0.0f), out[sub], 0, 0, 0);
 #else
-        out = acc;
+            out[sub] = acc[sub];
 #endif
+        }
+#pragma unroll
+    for (int sub = 0; sub < NTILE; ++sub) {
+        const int tl = tls[sub];
         const int tg = t0 + tl;
         if (tg < t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cr = (r & 3) + 8 * (r >> 2) + 4 * h;
-                yn[(size_t)cr * t + tg] = lds[cr * span + tl + dil] + out[r];
+                yn[(size_t)cr * t + tg] = lds[cr * span + tl + dil] + out[sub][r];
             }
         }
     }
