@@ -158,6 +158,28 @@ int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_c
 int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
                            const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
                            void* out, void* out_lo, llark_stream_t stream);
+/* Same two kernels with ALiBi (MPT, m2t/llava/model/mpt/attention.py:build_alibi_bias + :58): alibi_slopes fp32 [nh]
+ * (nullptr = none); slope_h * (key - (keys_visible - 1)) is added to the scaled scores before the softmax. */
+int llark_attn_prefill_bf16_alibi(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                  const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd, int past,
+                                  int smax, void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream);
+int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                 const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
+                                 void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MPT backbone (m2t/models/mpt.py over m2t/llava/model/mpt/{blocks,attention,norm}.py): the row-wise / element-wise
+ * pieces that differ from Llama.  LayerNorm (norm.py; beta may be NULL for no_bias models) to bf16 hi (+ lo) planes
+ * for the next GEMM, or fp32 -> fp32 (qk_ln over the q / k column blocks of the fused qkv, attention.py:330-333);
+ * clip_qkv (attention.py:325-326); exact erf GELU between up_proj and down_proj (blocks.py:15,19) to bf16 planes.
+ * ------------------------------------------------------------------------------------------- */
+int llark_layernorm_bf16(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                         void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+int llark_layernorm_f32(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                        float* y, int ldy, llark_stream_t stream);
+int llark_clamp_f32(float* x, long long n, float limit, llark_stream_t stream);
+int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
+                          llark_stream_t stream);
 /* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the
  * new token; s = 1): lets ONE captured hipGraph of the whole decode step serve every generated token of
  * m2t/models/llamav2.py:339-365 / m2t/infer.py:137-148. */

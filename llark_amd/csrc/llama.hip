@@ -153,7 +153,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
                                                            const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                            bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
-                                                           int S, int nh, int past, int smax, float scale) {
+                                                           int S, int nh, int past, int smax, float scale,
+                                                           const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 16 KiB
     char* sV = smem + 16384;         // 16 KiB
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * 64;
     const int total = past + S;                                     // keys available
+    // ALiBi (MPT, m2t/llava/model/mpt/attention.py build_alibi_bias): additive bias slope_h * (key - (total - 1))
+    const float slope = alibi ? alibi[h] : 0.0f;
     const size_t bh = (size_t)b * nh + h;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             for (int sub = 0; sub < 4; ++sub) {
                 const int key = key0 + sub * 16 + c;
                 float sv = sacc[sub][r] * scale;
+                if (alibi) sv += slope * (float)(key - (total - 1));
                 if (key > past + qi || key >= total) sv = -INFINITY;
                 sacc[sub][r] = sv;
                 mloc = fmaxf(mloc, sv);
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                           int nh, int total, int smax, float scale,
-                                                          const int* __restrict__ pos_dev) {
+                                                          const int* __restrict__ pos_dev, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (pos_dev) total = *pos_dev + 1;            // graph-captured decode: keys 0..pos are visible
     float* sp = (float*)smem;                    // [total] scores / probabilities
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             s += __shfl_xor(s, 4, 64);
             s += __shfl_xor(s, 8, 64);
             s *= scale;
+            if (alibi) s += alibi[blockIdx.x] * (float)(j - (total - 1));
             if (j < total) {
                 if (chunk == 0) sp[j] = s;
                 lmax = fmaxf(lmax, s);
@@ -570,9 +575,11 @@ extern "C" int llark_rope_split_heads_dpos(const float* qkv, int batch, int nh, 
     return check_launch("rope_split_heads_dpos");
 }
 
-extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
-                                       const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd,
-                                       int past, int smax, void* out, void* out_lo, llark_stream_t stream) {
+// alibi_slopes: nullptr (Llama) or fp32 [nh] (MPT): bias slope_h * (key - (past + s - 1)) added to the scaled scores.
+extern "C" int llark_attn_prefill_bf16_alibi(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                             const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd,
+                                             int past, int smax, void* out, void* out_lo, const float* alibi_slopes,
+                                             llark_stream_t stream) {
     LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_prefill: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_prefill: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && past >= 0 && past + s <= smax && smax % 8 == 0, "attn_prefill: bad shape");
@@ -585,18 +592,25 @@ extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const
         (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_prefill_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(
             (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo,
-            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale);
+            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale, alibi_slopes);
     } else {
         attn_prefill_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(
             (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr,
-            s, nh, past, smax, scale);
+            s, nh, past, smax, scale, alibi_slopes);
     }
     return check_launch("attn_prefill");
 }
 
-extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
-                                      const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total,
-                                      int smax, void* out, void* out_lo, llark_stream_t stream) {
+extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                       const void* k_cache_lo, const void* vt_cache_lo, int batch, int s, int nh, int hd,
+                                       int past, int smax, void* out, void* out_lo, llark_stream_t stream) {
+    return llark_attn_prefill_bf16_alibi(q, k_cache, vt_cache, q_lo, k_cache_lo, vt_cache_lo, batch, s, nh, hd, past, smax, out,
+                                         out_lo, nullptr, stream);
+}
+
+extern "C" int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                            const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total,
+                                            int smax, void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream) {
     LLARK_REQUIRE(q && k_cache && vt_cache && out, "attn_decode: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_decode: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && nh > 0 && total > 0 && total <= smax, "attn_decode: bad shape total=%d smax=%d", total, smax);
@@ -609,8 +623,16 @@ extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const 
     attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
                                                                 (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
                                                                 (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
-                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale, nullptr);
+                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale, nullptr,
+                                                                alibi_slopes);
     return check_launch("attn_decode");
+}
+
+extern "C" int llark_attn_decode_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
+                                      const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total,
+                                      int smax, void* out, void* out_lo, llark_stream_t stream) {
+    return llark_attn_decode_bf16_alibi(q, k_cache, vt_cache, q_lo, k_cache_lo, vt_cache_lo, batch, nh, hd, total, smax, out, out_lo,
+                                        nullptr, stream);
 }
 
 extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,
@@ -631,6 +653,6 @@ extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, c
     attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
                                                                 (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
                                                                 (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
-                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, 1, smax, scale, pos_dev);
+                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, 1, smax, scale, pos_dev, nullptr);
     return check_launch("attn_decode_dpos");
 }

@@ -1,0 +1,152 @@
+// MPT-specific element-wise / row-wise kernels (the MPT-1B backbone of
+// m2t/models/mpt.py over m2t/llava/model/mpt/{blocks,attention,norm}.py).  Everything GEMM- or attention-shaped is
+// shared with the Llama path (gemm.hip; llama.hip's attention kernels take the ALiBi slopes); what MPT adds is
+// LayerNorm instead of RMSNorm, an optional LayerNorm over q and k (qk_ln), an optional clamp of the fused qkv
+// (clip_qkv) and an exact (erf) GELU between up_proj and down_proj.
+#include "common.h"
+
+namespace llark {
+
+// LayerNorm (m2t/llava/model/mpt/norm.py LPLayerNorm / nn.LayerNorm, eps 1e-5): fp32 statistics over the row held in
+// registers (one wave per row), y = (x - mean) * rstd * gamma (+ beta); written either as bf16 hi (+ lo) planes for
+// the next GEMM (OUT16) or back as fp32 (qk_ln on the q / k column blocks of the fused qkv buffer).
+template <int NV, bool OUT16>
+__global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restrict__ x, int ldx, int rows, int width,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                            float* __restrict__ y32, int ldo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int w4 = width >> 2;
+    const float4* xr = (const float4*)(x + (size_t)row * ldx);
+    float4 v[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w4) {
+            v[k] = xr[c];
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        } else {
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w4) {
+            const float a = v[k].x - mean, b = v[k].y - mean, cc = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + eps);
+    const float4* g4 = (const float4*)gamma;
+    const float4* b4 = (const float4*)beta;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w4) {
+            const float4 g = g4[c];
+            const float4 b = beta ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float y[4];
+            y[0] = (v[k].x - mean) * rstd * g.x + b.x;
+            y[1] = (v[k].y - mean) * rstd * g.y + b.y;
+            y[2] = (v[k].z - mean) * rstd * g.z + b.z;
+            y[3] = (v[k].w - mean) * rstd * g.w + b.w;
+            if (OUT16) {
+                bf16x4_t h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (bf16_t)y[e];
+                    l[e] = (bf16_t)(y[e] - (float)h[e]);
+                }
+                ((bf16x4_t*)(hi + (size_t)row * ldo))[c] = h;
+                if (lo) ((bf16x4_t*)(lo + (size_t)row * ldo))[c] = l;
+            } else {
+                ((float4*)(y32 + (size_t)row * ldo))[c] = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+    }
+}
+
+__global__ void clamp_f32_kernel(float* __restrict__ x, long long n, float lim) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = fminf(fmaxf(x[i], -lim), lim);
+}
+
+// exact GELU (nn.GELU(approximate="none"), m2t/llava/model/mpt/blocks.py:15): 0.5 x (1 + erf(x / sqrt 2)) -> bf16 planes
+__global__ void gelu_split_kernel(const float* __restrict__ x, int ldx, int rows, int width, bf16_t* __restrict__ hi,
+                                  bf16_t* __restrict__ lo, int ldo) {
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x;        // float4 column index
+    const int row = blockIdx.y;
+    if (c4 * 4 >= width) return;
+    const float4 v = ((const float4*)(x + (size_t)row * ldx))[c4];
+    const float in[4] = {v.x, v.y, v.z, v.w};
+    bf16x4_t h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float y = 0.5f * in[e] * (1.0f + erff(in[e] * 0.70710678118654752440f));
+        h[e] = (bf16_t)y;
+        l[e] = (bf16_t)(y - (float)h[e]);
+    }
+    ((bf16x4_t*)(hi + (size_t)row * ldo))[c4] = h;
+    if (lo) ((bf16x4_t*)(lo + (size_t)row * ldo))[c4] = l;
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+template <bool OUT16>
+static int launch_mpt_ln(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps, void* hi,
+                         void* lo, float* y32, int ldo, hipStream_t s) {
+    const int w4 = width / 4;
+    dim3 grid(cdiv(rows, 4));
+#define LN_CASE(NV) mpt_layernorm_kernel<NV, OUT16><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (bf16_t*)hi, (bf16_t*)lo, y32, ldo)
+    if (w4 <= 64) LN_CASE(1);
+    else if (w4 <= 256) LN_CASE(4);
+    else if (w4 <= 512) LN_CASE(8);
+    else if (w4 <= 1024) LN_CASE(16);
+    else if (w4 <= 2048) LN_CASE(32);
+    else {
+        set_error("mpt_layernorm: width %d too large (max 8192)", width);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+#undef LN_CASE
+    return check_launch("mpt_layernorm");
+}
+
+extern "C" int llark_layernorm_bf16(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                                    void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && gamma && out_hi, "layernorm_bf16: null pointer");
+    LLARK_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width && ldx >= width,
+                  "layernorm_bf16: bad shape rows=%d width=%d ldx=%d ldo=%d", rows, width, ldx, ldo);
+    return launch_mpt_ln<true>(x, ldx, rows, width, gamma, beta, eps, out_hi, out_lo, nullptr, ldo, (hipStream_t)stream);
+}
+
+extern "C" int llark_layernorm_f32(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                                   float* y, int ldy, llark_stream_t stream) {
+    LLARK_REQUIRE(x && gamma && y, "layernorm_f32: null pointer");
+    LLARK_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= width && ldx >= width &&
+                      ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0,
+                  "layernorm_f32: bad shape / alignment rows=%d width=%d ldx=%d ldy=%d", rows, width, ldx, ldy);
+    return launch_mpt_ln<false>(x, ldx, rows, width, gamma, beta, eps, nullptr, nullptr, y, ldy, (hipStream_t)stream);
+}
+
+extern "C" int llark_clamp_f32(float* x, long long n, float limit, llark_stream_t stream) {
+    LLARK_REQUIRE(x && n > 0 && limit > 0.0f, "clamp_f32: bad arguments");
+    clamp_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, n, limit);
+    return check_launch("clamp_f32");
+}
+
+extern "C" int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
+                                     llark_stream_t stream) {
+    LLARK_REQUIRE(x && out_hi && rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width && ldx >= width,
+                  "gelu_split_bf16: bad arguments");
+    dim3 grid(cdiv(width / 4, 256), rows);
+    gelu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, rows, width, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo);
+    return check_launch("gelu_split_bf16");
+}

@@ -373,23 +373,60 @@ def attn_decode_dpos(q, k_cache, vt_cache, batch: int, nh: int, hd: int, pos_dev
 
 
 def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, past: int, out: torch.Tensor,
-                 q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None) -> None:
+                 q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None, alibi_slopes=None) -> None:
     smax = k_cache.shape[-2]
     bf = torch.bfloat16
-    check(_lib.lib().llark_attn_prefill_bf16(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
-                                             _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
-                                             _opt(vt_cache_lo, "vt_cache_lo", bf), batch, s, nh, hd, past, smax,
-                                             _dev(out, "out", bf), _opt(out_lo, "out_lo", bf), _stream()), "attn_prefill")
+    check(_lib.lib().llark_attn_prefill_bf16_alibi(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                                   _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                                   _opt(vt_cache_lo, "vt_cache_lo", bf), batch, s, nh, hd, past, smax,
+                                                   _dev(out, "out", bf), _opt(out_lo, "out_lo", bf),
+                                                   _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_prefill")
 
 
 def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, out: torch.Tensor,
-                q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None) -> None:
+                q_lo=None, k_cache_lo=None, vt_cache_lo=None, out_lo=None, alibi_slopes=None) -> None:
     smax = k_cache.shape[-2]
     bf = torch.bfloat16
-    check(_lib.lib().llark_attn_decode_bf16(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
-                                            _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
-                                            _opt(vt_cache_lo, "vt_cache_lo", bf), batch, nh, hd, total, smax,
-                                            _dev(out, "out", bf), _opt(out_lo, "out_lo", bf), _stream()), "attn_decode")
+    check(_lib.lib().llark_attn_decode_bf16_alibi(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+                                                  _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                                  _opt(vt_cache_lo, "vt_cache_lo", bf), batch, nh, hd, total, smax,
+                                                  _dev(out, "out", bf), _opt(out_lo, "out_lo", bf),
+                                                  _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_decode")
+
+
+# ------------------------------------------------------------------------------------------------
+# MPT
+# ------------------------------------------------------------------------------------------------
+def layernorm_bf16(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float, out_hi: torch.Tensor,
+                   out_lo: Optional[torch.Tensor] = None) -> None:
+    rows, width = x.shape
+    bf = torch.bfloat16
+    check(_lib.lib().llark_layernorm_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(gamma, "gamma", torch.float32),
+                                          _opt(beta, "beta", torch.float32), float(eps), _dev(out_hi, "out_hi", bf),
+                                          _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "layernorm_bf16")
+
+
+def layernorm_f32_(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float) -> None:
+    """In-place LayerNorm of a (possibly column-sliced) fp32 matrix: rows of x.shape[1] values with stride x.stride(0)."""
+    if x.stride(1) != 1:
+        raise ValueError("layernorm_f32_: rows must be contiguous")
+    if not x.is_cuda:
+        raise _lib.LlarkHipError("x: tensor must live on the GPU (there is no CPU fallback)")
+    rows, width = x.shape
+    check(_lib.lib().llark_layernorm_f32(x.data_ptr(), x.stride(0), rows, width, _dev(gamma, "gamma", torch.float32),
+                                         _opt(beta, "beta", torch.float32), float(eps), x.data_ptr(), x.stride(0), _stream()),
+          "layernorm_f32")
+
+
+def clamp_f32_(x: torch.Tensor, limit: float) -> None:
+    check(_lib.lib().llark_clamp_f32(_dev(x, "x", torch.float32), x.numel(), float(limit), _stream()), "clamp_f32")
+
+
+def gelu_split_bf16(x: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> None:
+    rows, width = x.shape
+    bf = torch.bfloat16
+    check(_lib.lib().llark_gelu_split_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(out_hi, "out_hi", bf),
+                                           _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "gelu_split_bf16")
 
 
 def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
