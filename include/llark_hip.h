@@ -178,6 +178,7 @@ int llark_layernorm_bf16(const float* x, int ldx, int rows, int width, const flo
 int llark_layernorm_f32(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
                         float* y, int ldy, llark_stream_t stream);
 int llark_clamp_f32(float* x, long long n, float limit, llark_stream_t stream);
+int llark_scale_f32(float* x, long long n, float a, llark_stream_t stream);   /* logits *= logit_scale */
 int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
                           llark_stream_t stream);
 /* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the

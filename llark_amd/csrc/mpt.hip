@@ -72,6 +72,11 @@ __global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restr
     }
 }
 
+__global__ void scale_f32_kernel(float* __restrict__ x, long long n, float a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= a;
+}
+
 __global__ void clamp_f32_kernel(float* __restrict__ x, long long n, float lim) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = fminf(fmaxf(x[i], -lim), lim);
@@ -140,6 +145,12 @@ extern "C" int llark_clamp_f32(float* x, long long n, float limit, llark_stream_
     LLARK_REQUIRE(x && n > 0 && limit > 0.0f, "clamp_f32: bad arguments");
     clamp_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, n, limit);
     return check_launch("clamp_f32");
+}
+
+extern "C" int llark_scale_f32(float* x, long long n, float a, llark_stream_t stream) {     // logits *= logit_scale (modeling_mpt.py:410-416)
+    LLARK_REQUIRE(x && n > 0, "scale_f32: bad arguments");
+    scale_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, n, a);
+    return check_launch("scale_f32");
 }
 
 extern "C" int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,

@@ -422,6 +422,10 @@ def clamp_f32_(x: torch.Tensor, limit: float) -> None:
     check(_lib.lib().llark_clamp_f32(_dev(x, "x", torch.float32), x.numel(), float(limit), _stream()), "clamp_f32")
 
 
+def scale_f32_(x: torch.Tensor, a: float) -> None:
+    check(_lib.lib().llark_scale_f32(_dev(x, "x", torch.float32), x.numel(), float(a), _stream()), "scale_f32")
+
+
 def gelu_split_bf16(x: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> None:
     rows, width = x.shape
     bf = torch.bfloat16
