@@ -57,17 +57,21 @@ class EngineCache:
         return self.engine.cur_len > 0
 
     def __len__(self) -> int:
-        return self.engine.dims.num_hidden_layers if self.engine.cur_len > 0 else 0
+        d = self.engine.dims
+        return getattr(d, "num_hidden_layers", getattr(d, "n_layers", 1)) if self.engine.cur_len > 0 else 0
 
 
 def plan_audio_splice(input_ids: torch.Tensor, audio_features: Union[None, torch.Tensor, Sequence[torch.Tensor]],
-                      cfg: AudioEncoderConfig, has_past: bool) -> List[Tuple[int, int, torch.Tensor]]:
+                      cfg: AudioEncoderConfig, has_past: bool, patch_branch: bool = False) -> List[Tuple[int, int, torch.Tensor]]:
     """Validation + placement rules of m2t/models/llamav2.py:141-222 (use_audio_start_end=True):
-    returns [(batch index, position of <audio_start>, frames (F, mm))].  Same ValueErrors."""
+    returns [(batch index, position of <audio_start>, frames (F, mm))].  Same ValueErrors.
+    ``patch_branch``: the MPT wrapper also implements use_audio_start_end=False (m2t/models/mpt.py:190-232)."""
     if audio_features is None:
         return []
     if not cfg.use_audio_start_end:
-        raise NotImplementedError("audio_encoder_config.use_audio_start_end=False is not implemented.")
+        if not patch_branch:
+            raise NotImplementedError("audio_encoder_config.use_audio_start_end=False is not implemented.")
+        return _plan_patch_splice(input_ids, audio_features, cfg)
     ids = input_ids.detach().cpu()
     segs = []
     cur_audio_idx = 0
@@ -87,6 +91,24 @@ def plan_audio_splice(input_ids: torch.Tensor, audio_features: Union[None, torch
                 raise ValueError("The image end token should follow the image start token.")
             segs.append((b, pos, feats))
             cur_audio_idx += 1
+    return segs
+
+
+def _plan_patch_splice(input_ids, audio_features, cfg: AudioEncoderConfig) -> List[Tuple[int, int, torch.Tensor]]:
+    """m2t/models/mpt.py:190-232: exactly num_frames consecutive <audio_patch> tokens per example are replaced by the
+    projected frames.  Returned in the (batch, start, frames) convention of the engines (rows start+1 .. start+F)."""
+    ids = input_ids.detach().cpu()
+    segs = []
+    for b in range(ids.shape[0]):
+        feats = audio_features[b]
+        num_frames = feats.shape[0]
+        where = torch.where(ids[b] == cfg.audio_patch_token)[0]
+        if len(where) != num_frames:
+            raise ValueError("The number of audio patch tokens should be the same as the number of audio frames.")
+        first = int(where[0])
+        if (where != torch.arange(first, first + num_frames)).any():
+            raise ValueError("The image patch tokens should be consecutive.")
+        segs.append((b, first - 1, feats))
     return segs
 
 

@@ -89,3 +89,79 @@ def test_mpt_1b_width_two_blocks():
     eng = _engine(spec, w, "split", max_batch=B, max_seq=192)
     lg = eng.forward_tokens(ids.cuda(), [(b, 1, aud[b].cuda()) for b in range(B)])
     report_close("mpt-1b width logits vs oracle", lg.cpu(), ref, 1e-4 * ref.abs().max().item())
+
+
+def test_wrapped_mpt_surface_forward_generate_errors():
+    """The reference surface (m2t/models/mpt.py): state-dict names, forward with audio splice (start/end AND the
+    patch-token branch :190-232), loss, greedy generate through prepare_inputs_for_generation, tokenizer set-up, errors."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from toy_tokenizer import ToyTokenizer
+    from llark_amd.m2t.mpt import WrappedMPTConfig, WrappedMPTForCausalLM
+    from oracle import mpt_ref as MR
+    spec = MR.MptSpec(**BASE, audio_start_token=93, audio_end_token=94, audio_patch_token=95)
+    w = MR.make_weights(spec, seed=21)
+    cfg = WrappedMPTConfig(d_model=256, n_heads=2, n_layers=2, expansion_ratio=4, max_seq_len=128, vocab_size=96, mm_hidden_size=64)
+    m = WrappedMPTForCausalLM(cfg)
+    missing = m.load_state_dict(w, strict=True)                               # the reference's names, nothing missing / unexpected
+    ac = m.get_model().audio_encoder_config
+    ac.use_audio_start_end, ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = True, 93, 94, 95
+    with pytest.raises(Exception, match="GPU"):
+        m(input_ids=torch.zeros((1, 4), dtype=torch.long))                     # CPU model: loud, no fallback
+    m.cuda().eval()
+    m.configure_engine(max_batch=2, max_seq=96)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 90, (2, 23), generator=g)
+    ids[:, 1], ids[:, 2:6], ids[:, 6] = 93, 95, 94
+    aud = torch.randn(2, 4, 64, generator=g)
+    lab = ids.clone()
+    lab[:, :8] = -100
+    ref = MR.forward(w, spec, ids, aud, labels=lab)
+    with torch.no_grad():
+        out = m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), labels=lab.cuda())
+    report_close("wrapped mpt logits", out.logits.cpu(), ref["logits"], 1e-4 * ref["logits"].abs().max().item())
+    assert abs(out.loss.item() - ref["loss"].item()) < 1e-4 * max(1.0, ref["loss"].item())
+    # list-of-tensors encodings take the same path
+    with torch.no_grad():
+        out_l = m(input_ids=ids.cuda(), audio_encodings=[aud[0].cuda(), aud[1].cuda()])
+    assert torch.equal(out_l.logits, out.logits)
+    # patch-token branch (use_audio_start_end = False): the frames replace exactly the <audio_patch> run
+    ac.use_audio_start_end = False
+    ids_p = ids.clone()
+    ids_p[:, 1], ids_p[:, 6] = 5, 6                                            # no start / end tokens any more
+    x = torch.nn.functional.embedding(ids_p, w["transformer.wte.weight"])
+    x[:, 2:6] = torch.nn.functional.linear(aud, w["transformer.mm_projector.weight"], w["transformer.mm_projector.bias"])
+    h = x
+    for i in range(spec.n_layers):
+        h, _ = MR.block(w, spec, i, h, None)
+    ref_p = torch.nn.functional.linear(torch.nn.functional.layer_norm(h, (256,), w["transformer.norm_f.weight"], None, 1e-5), w["transformer.wte.weight"])
+    with torch.no_grad():
+        out_p = m(input_ids=ids_p.cuda(), audio_encodings=aud.cuda())
+    report_close("patch-branch logits", out_p.logits.cpu(), ref_p, 1e-4 * ref_p.abs().max().item())
+    bad = ids_p.clone()
+    bad[0, 4] = 7                                                              # only 3 patch tokens for 4 frames
+    with pytest.raises(ValueError, match="number of audio patch tokens"):
+        m(input_ids=bad.cuda(), audio_encodings=aud.cuda())
+    gap = ids_p.clone()
+    gap[0, 5], gap[0, 9] = 7, 95                                               # 4 patch tokens, not consecutive
+    with pytest.raises(ValueError, match="consecutive"):
+        m(input_ids=gap.cuda(), audio_encodings=aud.cuda())
+    ac.use_audio_start_end = True
+    # greedy generate == oracle greedy (prompt with audio once, then cached single-token steps)
+    gen = m.generate(input_ids=ids.cuda(), audio_encodings=aud.cuda(), max_new_tokens=6).cpu()
+    ref_gen = MR.greedy_generate(w, spec, ids, aud, 6)
+    assert torch.equal(gen, ref_gen), (gen[:, -6:].tolist(), ref_gen[:, -6:].tolist())
+    with pytest.raises(NotImplementedError, match="right padding"):
+        m.prepare_inputs_for_generation(ids, attention_mask=torch.tensor([[1] * 22 + [0]] * 2))
+    # tokenizer set-up: 3 new rows, start/end rows = mean of the earlier rows (tied table)
+    tok = ToyTokenizer()
+    for t in ("a b c d e f g",):
+        tok.encode(t)
+    m2 = WrappedMPTForCausalLM(WrappedMPTConfig(d_model=256, n_heads=2, n_layers=1, expansion_ratio=4, max_seq_len=64, vocab_size=len(tok), mm_hidden_size=64))
+    base = len(tok)
+    m2.initialize_audio_tokenizer(True, tok, "cpu")
+    emb = m2.get_input_embeddings().weight.data
+    assert emb.shape[0] == base + 3 and torch.allclose(emb[-2:], emb[:-2].mean(0, keepdim=True).expand(2, -1), atol=1e-6)
+    a2 = m2.get_model().audio_encoder_config
+    assert (a2.audio_patch_token, a2.audio_start_token, a2.audio_end_token) == tuple(tok.convert_tokens_to_ids(["<audio_patch>", "<audio_start>", "<audio_end>"]))
