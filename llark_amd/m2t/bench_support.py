@@ -165,3 +165,50 @@ class TrainWorkload:
 
 def build(args, device):
     return LLMWorkload(args, device)
+
+
+class MptWorkload:
+    """BASELINE configs[4] LLM half: MPT-1B (d_model 2048, 24 blocks, 16 heads, ALiBi, vocab 50432 + 3) prefill over the
+    prompt with ONE 512-d CLAP frame per clip (the reference's scripts/clap embeddings are (1, 512); the HTSAT encoder
+    itself is not built -- embeddings are synthetic) followed by `new_tokens` greedy decode steps."""
+
+    def __init__(self, args, device):
+        from .mpt_engine import HipMptEngine, MptDims
+
+        self.batch = args.batch
+        V = 50432 + 3
+        self.dims = MptDims(vocab_size=V, mm_hidden_size=512)
+        self.start, self.end, self.patch = V - 2, V - 1, V - 3
+        eng = HipMptEngine(self.dims, device, max_batch=args.batch, max_seq=256, precision=args.llm_precision)
+        g = torch.Generator(device=device).manual_seed(0)
+        D, E = self.dims.d_model, 4 * self.dims.d_model
+
+        def n(*shape):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+
+        sd = {"transformer.wte.weight": n(V, D), "transformer.norm_f.weight": torch.ones(D, device=device),
+              "transformer.mm_projector.weight": n(D, 512), "transformer.mm_projector.bias": torch.zeros(D, device=device)}
+        for i in range(self.dims.n_layers):
+            p = f"transformer.blocks.{i}"
+            sd.update({f"{p}.norm_1.weight": torch.ones(D, device=device), f"{p}.norm_2.weight": torch.ones(D, device=device),
+                       f"{p}.attn.Wqkv.weight": n(3 * D, D), f"{p}.attn.out_proj.weight": n(D, D),
+                       f"{p}.ffn.up_proj.weight": n(E, D), f"{p}.ffn.down_proj.weight": n(D, E)})
+        eng.load_state_dict(sd)
+        self.engine = eng
+        gi = torch.Generator().manual_seed(7)
+        rows = [[0, self.start, self.patch, self.end] + torch.randint(3, 50000, (PROMPT,), generator=gi).tolist() for _ in range(args.batch)]
+        self.ids = torch.tensor(rows, dtype=torch.int64, device=device)                   # S = 4 + 128 = 132
+        self.emb = torch.randn(args.batch, 1, 512, generator=g, device=device)
+
+    def generate(self, new_tokens: int):
+        eng = self.engine
+        logits = eng.forward_tokens(self.ids, [(b, 1, self.emb[b]) for b in range(self.batch)], last_only=True)
+        nxt = logits[:, -1].argmax(-1, keepdim=True)
+        for _ in range(new_tokens - 1):
+            nxt = eng.forward_tokens(nxt, (), pos0=eng.cur_len)[:, -1].argmax(-1, keepdim=True)
+        return nxt
+
+    def prefill_flops(self) -> float:
+        d = self.dims
+        rows = self.batch * self.ids.shape[1]
+        return 2.0 * rows * (12 * d.d_model * d.d_model * d.n_layers + d.d_model * d.vocab_size)
