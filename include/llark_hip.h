@@ -115,6 +115,12 @@ int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const vo
 int llark_gemm16_resid_rmsnorm(int dtype, int split, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw,
                                int m, int n, int kp, float* h, int ldh, const float* norm_w, float eps, void* x_hi,
                                void* x_lo, int ldx, llark_stream_t stream);
+/* Decode step (m <= 16 rows, bf16): RMSNorm(x; norm_w, eps) . wt^T with the norm fused INTO the consuming weight-streaming
+ * GEMM (every workgroup re-derives the row scales; bit-identical to llark_rmsnorm_bf16 + llark_gemm16).  epilogue: F32 or
+ * SwiGLU(16/split).  Replaces LlamaRMSNorm + q/k/v, gate/up and lm_head projections of the cached decode path. */
+int llark_gemm16_rmsnorm_a(int dtype, int split, int epilogue, const float* x, int ldx, const float* norm_w, float eps,
+                           const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, void* out_hi,
+                           void* out_lo, int ldo, llark_stream_t stream);
 /* Batched form (grid.y = batch): per-batch element strides for A, wt, c and the 16-bit outputs (no bias / residual).
  * Used by the attention backward of the training step (one product per (sequence, head)). */
 int llark_gemm16_batched(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, long long stride_a,

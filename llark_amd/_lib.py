@@ -62,6 +62,8 @@ _SIGS = {
                            _P, _P, c_int, _P],
     "llark_gemm16_resid_rmsnorm": [c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_float, _P, _P,
                                    c_int, _P],
+    "llark_gemm16_rmsnorm_a": [c_int, c_int, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P,
+                               c_int, _P],
     "llark_gemm16_batched": [c_int, c_int, c_int, _P, _P, c_int, c_int64, _P, c_int, c_int64, c_int, c_int, c_int, _P, c_int,
                              c_int64, _P, _P, c_int, c_int64, c_int, _P],
     "llark_pack_weight16": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P],

@@ -80,6 +80,11 @@ struct GemmParams {
     void* nlo;
     int ldn;
     int* ncnt;         // arrival counter (self-resetting)
+    // skinny kernel: A operand = RMSNorm(xn) computed on the fly (decode: norm fused INTO the consuming GEMM)
+    const float* xn;   // fp32 [M][ldxn] un-normalised rows (nullptr = A comes from Ahi / Alo)
+    const float* xg;   // norm weight [Kp]
+    int ldxn;
+    float xeps;
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
@@ -733,8 +738,8 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     const T* Alo = (const T*)p.Alo;
     const T* Wt = (const T*)p.Wt;
     const int arow = c < p.M ? c : p.M - 1;
-    const T* ah_p = Ahi + (size_t)arow * p.lda + g * 8;
-    const T* al_p = SPLIT ? Alo + (size_t)arow * p.lda + g * 8 : nullptr;
+    const T* ah_p = Ahi ? Ahi + (size_t)arow * p.lda + g * 8 : nullptr;
+    const T* al_p = (SPLIT && Alo) ? Alo + (size_t)arow * p.lda + g * 8 : nullptr;
     const T* w_p[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -742,6 +747,48 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         r = r < p.N ? r : p.N - 1;
         w_p[t] = Wt + (size_t)r * p.ldw + g * 8;
     }
+    // Fused RMSNorm of the A rows (decode): every workgroup re-derives the <= 16 row scales itself -- one wave per row,
+    // the per-lane float4 order and wave reduction of rmsnorm_kernel (llama.hip), so rstd and therefore the hi / lo
+    // operand planes are bit-identical to a separate rmsnorm launch -- and normalises its A fragments on the fly:
+    // y = g * (x * rstd), hi = bf16(y), lo = bf16(y - hi).  Costs ~128 KiB of L2 reads per workgroup, saves a launch.
+    __shared__ float s_rstd[16];
+    const bool norm_a = p.xn != nullptr;
+    float my_rstd = 0.0f;
+    const float* xn_p = nullptr;
+    if (norm_a) {
+        const int w4 = p.Kp >> 2;
+        for (int row = w; row < p.M; row += KW) {
+            const float4* xr = (const float4*)(p.xn + (size_t)row * p.ldxn);
+            float sq = 0.0f;
+            for (int cidx = lane; cidx < w4; cidx += 64) {
+                const float4 v = xr[cidx];
+                sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+            const float var = wave_sum(sq) / (float)p.Kp;
+            if (lane == 0) s_rstd[row] = 1.0f / sqrtf(var + p.xeps);
+        }
+        __syncthreads();
+        my_rstd = s_rstd[arow];
+        xn_p = p.xn + (size_t)arow * p.ldxn + g * 8;
+    }
+    auto load_a = [&](int kstep, frag& hi, frag& lo) __attribute__((always_inline)) {
+        if (!norm_a) {
+            hi = *(const frag*)(ah_p + kstep * 32);
+            if (SPLIT) lo = *(const frag*)(al_p + kstep * 32);
+        } else {
+            const float4 x0 = *(const float4*)(xn_p + kstep * 32), x1 = *(const float4*)(xn_p + kstep * 32 + 4);
+            const float4 g0 = *(const float4*)(p.xg + kstep * 32 + g * 8), g1 = *(const float4*)(p.xg + kstep * 32 + g * 8 + 4);
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y = gv[e] * (xv[e] * my_rstd);
+                const T h = Mfma<T>::cvt(y);
+                hi[e] = h;
+                if (SPLIT) lo[e] = Mfma<T>::cvt(y - Mfma<T>::back(h));
+            }
+        }
+    };
     f32x4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -752,8 +799,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) bw[t][u] = *(const frag*)(w_p[t] + (ks + u) * 32);
-            ah[u] = *(const frag*)(ah_p + (ks + u) * 32);
-            if (SPLIT) al[u] = *(const frag*)(al_p + (ks + u) * 32);
+            load_a(ks + u, ah[u], al[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -764,11 +810,13 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             }
     }
     for (; ks < ks1; ++ks) {
+        frag a1, a1l;
+        load_a(ks, a1, a1l);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const frag bw = *(const frag*)(w_p[t] + ks * 32);
-            acc[t] = Mfma16<T>::run(*(const frag*)(ah_p + ks * 32), bw, acc[t]);
-            if (SPLIT) acc[t] = Mfma16<T>::run(*(const frag*)(al_p + ks * 32), bw, acc[t]);
+            acc[t] = Mfma16<T>::run(a1, bw, acc[t]);
+            if (SPLIT) acc[t] = Mfma16<T>::run(a1l, bw, acc[t]);
         }
     }
     // C layout of 16x16 MFMA: col = c (weight row within the tile), rows m = 4g + r
@@ -1050,6 +1098,28 @@ extern "C" int llark_gemm16_resid_rmsnorm(int dtype, int split, const void* a_hi
     p.nw = norm_w; p.neps = eps; p.nhi = x_hi; p.nlo = x_lo; p.ldn = ldx; p.ncnt = counters + (next++ % 64);
     const int rc = dispatch_skinny<bf16_t>(p, split != 0, EPI_RESID, (hipStream_t)stream);
     if (rc == 1) { set_error("gemm16_resid_rmsnorm: no skinny kernel for this epilogue"); return LLARK_ERR_UNSUPPORTED; }
+    return rc;
+}
+
+// Decode-step form of  RMSNorm(x) . W^T  in ONE launch (m <= 16 rows): the skinny weight-streaming kernel normalises its A
+// rows on the fly (bit-identical to llark_rmsnorm_bf16 + llark_gemm16).  Replaces LlamaRMSNorm + {q,k,v}_proj / gate,up /
+// lm_head of the cached decode path (m2t/models/llamav2.py:224-234,312 -> HF LlamaDecoderLayer).  epilogue: F32 or SwiGLU.
+extern "C" int llark_gemm16_rmsnorm_a(int dtype, int split, int epilogue, const float* x, int ldx, const float* norm_w, float eps,
+                                      const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                                      void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && norm_w && wt && m > 0 && n > 0 && kp > 0 && kp % 32 == 0, "gemm16_rmsnorm_a: bad arguments");
+    LLARK_REQUIRE(m <= 16, "gemm16_rmsnorm_a: decode form only (m <= 16), got m=%d", m);
+    LLARK_REQUIRE(dtype == LLARK_BF16, "gemm16_rmsnorm_a: bf16 only");
+    LLARK_REQUIRE(ldx % 4 == 0 && ldx >= kp && ldw >= kp && ((uintptr_t)x & 15) == 0 && ((uintptr_t)norm_w & 15) == 0,
+                  "gemm16_rmsnorm_a: x / norm_w must be 16-byte aligned with ldx >= kp");
+    LLARK_REQUIRE(epilogue == EPI_F32 || IS_SWIGLU(epilogue), "gemm16_rmsnorm_a: epilogue must be F32 or SwiGLU");
+    if (epilogue == EPI_F32) LLARK_REQUIRE(c && ldc >= n, "gemm16_rmsnorm_a: fp32 output missing");
+    if (IS_SWIGLU(epilogue)) LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2 && (epilogue != EPI_SWIGLU_SPLIT || out_lo), "gemm16_rmsnorm_a: SwiGLU outputs missing");
+    GemmParams p = {};
+    p.Wt = wt; p.ldw = ldw; p.bias = bias; p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    p.xn = x; p.xg = norm_w; p.ldxn = ldx; p.xeps = eps;
+    const int rc = dispatch_skinny<bf16_t>(p, split != 0, epilogue, (hipStream_t)stream);
+    if (rc == 1) { set_error("gemm16_rmsnorm_a: no skinny kernel for this epilogue"); return LLARK_ERR_UNSUPPORTED; }
     return rc;
 }
 

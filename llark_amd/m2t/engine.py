@@ -93,6 +93,12 @@ class HipLlamaEngine:
         # default: on the 8-XCD MI355X the device-scope release/acquire fences it needs write back / invalidate L2
         # (the XCD L2s are not coherent with each other) and cost ~65 us per launch -- 10.1 vs 5.9 ms per decode step.
         self.fuse_decode_norm = os.environ.get("LLARK_DECODE_FUSE_NORM", "0") == "1"
+        # RMSNorm fused INTO the consuming decode GEMM (each workgroup re-derives the row scales): bit-identical, saves
+        # two launches per layer (+ the final norm before lm_head).  Measured at B = 8: 5.89 vs 6.04 ms per step in split
+        # mode, but 5.26 vs 4.85 ms in single-pass mode (the on-the-fly normalisation of fp32 rows costs more than the
+        # launches it saves there) -> on by default only for the fp32-class mode.
+        env = os.environ.get("LLARK_DECODE_FUSE_NORM_A")
+        self.fuse_decode_norm_a = (precision == "split") if env is None else env == "1"
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         self._dec: Dict[int, dict] = {}
 
@@ -218,6 +224,7 @@ class HipLlamaEngine:
         sp = self.split
         # decode (one token per sequence): o_proj / down_proj carry the FOLLOWING RMSNorm in their launch
         fused = s == 1 and batch <= 16 and n_layers > 0 and self.fuse_decode_norm and H <= 8192
+        norm_a = s == 1 and batch <= 16 and self.fuse_decode_norm_a and not fused and H % 32 == 0
         if fused:
             ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         for i in range(n_layers):
@@ -227,9 +234,12 @@ class HipLlamaEngine:
             vcl = self.vt_cache_lo[i, :batch] if sp else None
             if not kc.is_contiguous():            # batch smaller than the allocated cache
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
-            if not fused:
-                ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
-            ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
+            if norm_a:                               # decode: RMSNorm fused into the consuming weight-streaming GEMM
+                ops.gemm16_rmsnorm_a(h, L.ln1, d.rms_norm_eps, L.wqkv, 3 * H, ops.EPI_F32, sp, c=ws["qkv"])
+            else:
+                if not fused:
+                    ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+                ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
             if pos_dev is not None:                 # decode step, position in device memory (graph-capturable)
                 ops.rope_split_heads_dpos(ws["qkv"], batch, nh, hd, pos_dev, self.cos, self.sin, ws["q"], kc, vc,
                                           ws["q_lo"], kcl, vcl)
@@ -245,9 +255,14 @@ class HipLlamaEngine:
                 ops.gemm16_resid_rmsnorm(ws["att"], ws["att_lo"], L.wo, h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
             else:
                 ops.gemm16(ws["att"], ws["att_lo"], L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
-                ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
-            ops.gemm16(ws["x16"], ws["x16_lo"], L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16,
-                       out_hi=ws["act"], out_lo=ws["act_lo"])
+                if not norm_a:
+                    ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            if norm_a:
+                ops.gemm16_rmsnorm_a(h, L.ln2, d.rms_norm_eps, L.wgu, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16, sp,
+                                     out_hi=ws["act"], out_lo=ws["act_lo"])
+            else:
+                ops.gemm16(ws["x16"], ws["x16_lo"], L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16,
+                           out_hi=ws["act"], out_lo=ws["act_lo"])
             if fused:
                 nxt = self.layers[i + 1].ln1 if i + 1 < n_layers else self.norm
                 ops.gemm16_resid_rmsnorm(ws["act"], ws["act_lo"], L.wdown, h, nxt, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
@@ -344,8 +359,11 @@ class HipLlamaEngine:
             logits = torch.empty((B, d.vocab_size), dtype=torch.float32, device=self.device)
             ops.gemm16(x16, x16_lo, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
             return logits.view(B, 1, d.vocab_size)
+        logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
+        if S == 1 and B <= 16 and self.fuse_decode_norm_a and not normed:
+            ops.gemm16_rmsnorm_a(h, self.norm, d.rms_norm_eps, self.lm_head, d.vocab_size, ops.EPI_F32, self.split, c=logits)
+            return logits.view(B, S, d.vocab_size)
         if not normed:
             ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
-        logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
         ops.gemm16(ws["x16"], ws["x16_lo"], self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
         return logits.view(B, S, d.vocab_size)

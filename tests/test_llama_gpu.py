@@ -436,12 +436,13 @@ def test_decode_fused_resid_rmsnorm_bit_identical(precision, batch):
     ids = torch.randint(3, 300, (batch, 13), generator=g).cuda()
     toks = torch.randint(3, 300, (5, batch, 1), generator=g).cuda()
     res = []
-    for fuse in (False, True):
+    for fuse in ("none", "tail", "norm_a"):                 # separate launches | producer-side tail | consumer-side (default)
         eng = HipLlamaEngine(dims, "cuda", batch, 64, precision=precision)
         eng.load_state_dict(w)
-        eng.fuse_decode_norm = fuse
+        eng.fuse_decode_norm, eng.fuse_decode_norm_a = fuse == "tail", fuse == "norm_a"
         eng.forward_tokens(ids)
         outs = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(5)]
         hid = eng.forward_tokens(toks[0], (), pos0=eng.cur_len, return_hidden=True).clone()
         res.append((torch.stack(outs), hid))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
