@@ -66,6 +66,15 @@ int llark_codebook_norms_f32(const float* k, int bins, int emb, float* kk, llark
 /* BottleneckBlock.quantise: codes[n][t] = argmin_j |x[n][:,t] - k[j]|^2 (first minimum); min_dist optional. */
 int llark_codebook_argmin(const float* x, int n, int emb, int t, const float* k, const float* kk, int bins,
                           int64_t* codes, float* min_dist, llark_stream_t stream);
+/* The whole level-2 encode of jukebox/main.py:61 (`vqvae.encode(x)` -> zs[-1]) as ONE call: a plan lists the layers
+ * (device pointers to llark_pack_conv_weight outputs and biases stay owned by the caller), llark_vqvae_encode runs
+ * conv / residual blocks through two ping-pong buffers and finishes with the codebook search. */
+void* llark_vqvae_plan_create(void);
+void llark_vqvae_plan_destroy(void* plan);
+int llark_vqvae_plan_add_conv(void* plan, const float* wp, const float* bias, int cin, int cout, int k, int stride, int pad);
+int llark_vqvae_plan_add_resblock(void* plan, const float* w1p, const float* b1, const float* w2p, const float* b2, int width, int dil);
+int llark_vqvae_encode(void* plan, const float* audio, int n, int t, float* buf0, float* buf1, long long buf_elems,
+                       const float* codebook, const float* kk, int bins, int64_t* codes, int* t_out, llark_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Jukebox top prior, only_encode: replaces `top_prior.prior.forward(...)` at jukebox/main.py:108

@@ -53,6 +53,9 @@ _SIGS = {
     "llark_pool_window": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_pool_mean": [_P, c_int, c_int, c_int, _P, _P, _P],
     "llark_zero_pad16": [_P, c_int, c_int, c_int, _P],
+    "llark_vqvae_plan_add_conv": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int],
+    "llark_vqvae_plan_add_resblock": [_P, _P, _P, _P, _P, c_int, c_int],
+    "llark_vqvae_encode": [_P, _P, c_int, c_int, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P],
     "llark_gemm16": [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                      _P, _P, c_int, _P],
     "llark_gemm16_ex": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
@@ -101,7 +104,7 @@ _SIGS = {
 
 def declared_symbols():
     """Every symbol ``include/llark_hip.h`` declares (kept in sync by tests/test_abi.py)."""
-    return sorted(list(_SIGS.keys()) + ["llark_last_error"])
+    return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy"])
 
 
 def lib():
@@ -120,6 +123,10 @@ def lib():
             fn.restype = c_int
         L.llark_last_error.argtypes = []
         L.llark_last_error.restype = c_char_p
+        L.llark_vqvae_plan_create.argtypes = []
+        L.llark_vqvae_plan_create.restype = c_void_p
+        L.llark_vqvae_plan_destroy.argtypes = [c_void_p]
+        L.llark_vqvae_plan_destroy.restype = None
         _lib = L
     return _lib
 

@@ -19,6 +19,9 @@
 #ifndef RES_ABLATE
 #define RES_ABLATE 0      // profiling-only: 1 = no global loads in the staging phase, 2 = no MFMA phase (results invalid)
 #endif
+#include <new>
+#include <vector>
+
 #include "common.h"
 
 namespace llark {
@@ -521,4 +524,70 @@ extern "C" int llark_codebook_argmin(const float* x, int n, int emb, int t, cons
     dim3 grid(cdiv(t, 64), n);
     codebook_argmin_kernel<64, 8><<<grid, 256, 0, (hipStream_t)stream>>>(x, k, kk, (long long*)codes, min_dist, t, bins);
     return check_launch("codebook_argmin");
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Whole-encoder entry point: replaces `vqvae.encode(x)` at jukebox/main.py:61 with ONE C call (the entry SURVEY 8b
+// sketches as llark_jb_encode).  The ~40 launches of the level-2 encoder are 12-490 us each; issued one by one through
+// the Python binding the host is slower than the GPU drains them (measured 5.1 ms per 8 clips against 3.8 ms of kernel
+// time).  A plan holds the layer list (device pointers to the packed weights, owned by the caller).
+// ------------------------------------------------------------------------------------------
+namespace {
+struct VqLayer {
+    int kind;                       // 0 = conv, 1 = residual block
+    const float *w1, *b1, *w2, *b2;
+    int cin, cout, k, stride, pad, dil;
+};
+struct VqPlan {
+    std::vector<VqLayer> layers;
+};
+}  // namespace
+
+extern "C" void* llark_vqvae_plan_create(void) { return new (std::nothrow) VqPlan(); }
+
+extern "C" void llark_vqvae_plan_destroy(void* plan) { delete (VqPlan*)plan; }
+
+extern "C" int llark_vqvae_plan_add_conv(void* plan, const float* wp, const float* bias, int cin, int cout, int k, int stride, int pad) {
+    LLARK_REQUIRE(plan && wp && bias && cin > 0 && cout > 0 && k > 0 && stride > 0 && pad >= 0, "vqvae_plan_add_conv: bad arguments");
+    ((VqPlan*)plan)->layers.push_back(VqLayer{0, wp, bias, nullptr, nullptr, cin, cout, k, stride, pad, 1});
+    return LLARK_OK;
+}
+
+extern "C" int llark_vqvae_plan_add_resblock(void* plan, const float* w1p, const float* b1, const float* w2p, const float* b2, int width,
+                                             int dil) {
+    LLARK_REQUIRE(plan && w1p && b1 && w2p && b2 && width > 0 && dil >= 1, "vqvae_plan_add_resblock: bad arguments");
+    ((VqPlan*)plan)->layers.push_back(VqLayer{1, w1p, b1, w2p, b2, width, width, 3, 1, dil, dil});
+    return LLARK_OK;
+}
+
+// audio [n][t] fp32 -> codes [n][t_out] int64.  buf0 / buf1: ping-pong activation buffers of `buf_elems` floats each (>= the
+// widest activation n * C * T of the plan).  emb_out (optional): receives a pointer to the final [n][emb][t_out] activation.
+extern "C" int llark_vqvae_encode(void* plan, const float* audio, int n, int t, float* buf0, float* buf1, long long buf_elems,
+                                  const float* codebook, const float* kk, int bins, int64_t* codes, int* t_out, llark_stream_t stream) {
+    LLARK_REQUIRE(plan && audio && buf0 && buf1 && codebook && kk && codes && n > 0 && t > 0, "vqvae_encode: bad arguments");
+    const VqPlan* P = (const VqPlan*)plan;
+    LLARK_REQUIRE(!P->layers.empty() && P->layers[0].kind == 0 && P->layers[0].cin == 1, "vqvae_encode: the plan must start with a 1-channel conv");
+    const float* x = audio;
+    int c = 1, tt = t, slot = 0;
+    for (const VqLayer& L : P->layers) {
+        float* y = slot ? buf1 : buf0;
+        int rc;
+        if (L.kind == 0) {
+            LLARK_REQUIRE(L.cin == c, "vqvae_encode: layer expects %d channels, activation has %d", L.cin, c);
+            const int tout = (tt + 2 * L.pad - (L.k - 1) - 1) / L.stride + 1;
+            LLARK_REQUIRE((long long)n * L.cout * tout <= buf_elems, "vqvae_encode: activation buffers too small");
+            rc = llark_conv1d_f32(x, n, c, tt, L.w1, L.b1, L.cout, L.k, L.stride, L.pad, 1, y, tout, stream);
+            c = L.cout;
+            tt = tout;
+        } else {
+            LLARK_REQUIRE(L.cin == c && (long long)n * c * tt <= buf_elems, "vqvae_encode: residual block does not match the activation");
+            rc = llark_resblock_f32(x, n, c, tt, L.w1, L.b1, L.w2, L.b2, L.dil, y, stream);
+        }
+        if (rc != LLARK_OK) return rc;
+        x = y;
+        slot ^= 1;
+    }
+    if (t_out) *t_out = tt;
+    return llark_codebook_argmin(x, n, c, tt, codebook, kk, bins, codes, nullptr, stream);
 }

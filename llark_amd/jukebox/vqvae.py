@@ -43,6 +43,7 @@ class VQVAE:
                                         hps.dilation_growth_rate ** r))
             b = f"{p}.level_blocks.{lb}.model.{down_t}"
             self.layers.append(("conv", ops.pack_conv_weight(f32(f"{b}.weight")), f32(f"{b}.bias"), 1, 1))
+        self._plan_handle = None
         self.set_codebook(weights["bottleneck.level_blocks.2.k"])
         self._bufs: Dict[tuple, torch.Tensor] = {}
 
@@ -84,12 +85,56 @@ class VQVAE:
             slot ^= 1
         return x
 
+    def _plan(self):
+        """C-side layer list for llark_vqvae_encode (built lazily; the packed weights stay owned by self.layers)."""
+        if self._plan_handle is None:
+            L = ops._lib.lib()
+            h = L.llark_vqvae_plan_create()
+            if not h:
+                raise ops._lib.LlarkHipError("vqvae_plan_create failed")
+            for layer in self.layers:
+                if layer[0] == "conv":
+                    _, wp, b, stride, pad = layer
+                    k, cin, cout = wp.shape
+                    ops.check(L.llark_vqvae_plan_add_conv(h, wp.data_ptr(), b.data_ptr(), cin, cout, k, stride, pad), "vqvae_plan_add_conv")
+                else:
+                    _, w1p, b1, w2p, b2, dil = layer
+                    ops.check(L.llark_vqvae_plan_add_resblock(h, w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                                                             w1p.shape[2], dil), "vqvae_plan_add_resblock")
+            self._plan_handle = h
+        return self._plan_handle
+
+    def __del__(self):
+        h = getattr(self, "_plan_handle", None)
+        if h:
+            try:
+                ops._lib.lib().llark_vqvae_plan_destroy(h)
+            except Exception:
+                pass
+
     def encode_top(self, audio: torch.Tensor, want_dist: bool = False):
-        """audio: (N, sample_length) fp32 device tensor -> codes (N, n_ctx) int64."""
+        """audio: (N, sample_length) fp32 device tensor -> codes (N, n_ctx) int64.  One C call runs the whole layer list
+        (`llark_vqvae_encode`): the ~40 short launches are issued without returning to Python in between."""
         assert audio.dim() == 2 and audio.shape[1] == self.sample_length, (
             f"expected (N,{self.sample_length}) audio, got {tuple(audio.shape)}")
-        xe = self.encoder_forward(audio.contiguous().view(audio.shape[0], 1, -1))
-        return ops.codebook_argmin(xe, self.k, self.kk, want_dist=want_dist)
+        if want_dist or ops.kernel_timing_active():            # per-layer path: distances / per-kernel event timers
+            xe = self.encoder_forward(audio.contiguous().view(audio.shape[0], 1, -1))
+            return ops.codebook_argmin(xe, self.k, self.kk, want_dist=want_dist)
+        n = audio.shape[0]
+        audio = audio.contiguous()
+        widest = n * max(layer[1].shape[2] for layer in self.layers) * (self.sample_length // 2 + 1)
+        b0, b1 = self._buf(0, (widest,)), self._buf(1, (widest,))
+        codes = torch.empty((n, self.hps.n_ctx), dtype=torch.int64, device=self.device)
+        import ctypes
+
+        t_out = ctypes.c_int(0)
+        ops.check(ops._lib.lib().llark_vqvae_encode(self._plan(), ops._dev(audio, "audio", torch.float32), n, self.sample_length,
+                                                    b0.data_ptr(), b1.data_ptr(), widest, ops._dev(self.k, "k", torch.float32),
+                                                    ops._dev(self.kk, "kk", torch.float32), self.k.shape[0], codes.data_ptr(),
+                                                    ctypes.byref(t_out), ops._stream()), "vqvae_encode")
+        if t_out.value != self.hps.n_ctx:
+            raise ops._lib.LlarkHipError(f"vqvae_encode produced {t_out.value} tokens per clip, hparams say {self.hps.n_ctx}")
+        return codes
 
     def encode(self, x: torch.Tensor):
         """Upstream-shaped entry: x (N, T, 1) like ``vqvae.encode(torch.cuda.FloatTensor(audio[None,:,None]))``."""
