@@ -94,11 +94,10 @@ class HipLlamaEngine:
         # (the XCD L2s are not coherent with each other) and cost ~65 us per launch -- 10.1 vs 5.9 ms per decode step.
         self.fuse_decode_norm = os.environ.get("LLARK_DECODE_FUSE_NORM", "0") == "1"
         # RMSNorm fused INTO the consuming decode GEMM (each workgroup re-derives the row scales): bit-identical, saves
-        # two launches per layer (+ the final norm before lm_head).  Measured at B = 8: 5.89 vs 6.04 ms per step in split
-        # mode, but 5.26 vs 4.85 ms in single-pass mode (the on-the-fly normalisation of fp32 rows costs more than the
-        # launches it saves there) -> on by default only for the fp32-class mode.
-        env = os.environ.get("LLARK_DECODE_FUSE_NORM_A")
-        self.fuse_decode_norm_a = (precision == "split") if env is None else env == "1"
+        # two launches per layer (+ the final norm before lm_head).  Measured: B = 8 split 5.89 vs 6.04 ms per step, but
+        # B = 8 single-pass 5.26 vs 4.85 ms and B = 1 split 492 vs 480 ms per 64-token generate -- the on-the-fly
+        # normalisation of fp32 rows costs about what the launches save.  Opt-in (LLARK_DECODE_FUSE_NORM_A=1).
+        self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "0") == "1"
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         self._dec: Dict[int, dict] = {}
 

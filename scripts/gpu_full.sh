@@ -7,3 +7,5 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > gpurun_out/bench_e2e.log 2>&1; echo "e2e exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": {[^}]*}' gpurun_out/bench_e2e.log | tr '\n' ' ')"
 timeout 600 python bench.py --stages train --no-cpu-baseline > gpurun_out/bench_train.log 2>&1; echo "train exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_train.log | tr '\n' ' ')"
 timeout 600 python bench.py --stages generate --no-cpu-baseline > gpurun_out/bench_generate_b1.log 2>&1; echo "gen exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"decode_ms_per_token": [0-9.]*' gpurun_out/bench_generate_b1.log | tr '\n' ' ')"
+timeout 600 python bench.py --stages jukebox --no-cpu-baseline > gpurun_out/bench_jukebox.log 2>&1; echo "jukebox exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_jukebox.log | tr '\n' ' ')"
+timeout 600 python bench.py --stages mpt > gpurun_out/bench_mpt.log 2>&1; echo "mpt exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_mpt.log | tr '\n' ' ')"
