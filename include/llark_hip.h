@@ -103,8 +103,8 @@ int llark_zero_pad16(void* plane, int rows, int ld, int from, llark_stream_t str
 int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt,
                  int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid, int ldr,
                  void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
-/* Same with an explicit tile variant (tuning knob: 0-4, 6, 10-12; -1 = library default). All variants compute
- * the same product; kp must be a multiple of 64 for the BK=64 variants (4, 10, 11, 12). */
+/* Same with an explicit tile variant (tuning knob: 0, 1, 2, 11, 12, 20 = persistent 12; -1 = library default). All
+ * variants compute the same product; kp must be a multiple of 64 for the BK=64 variants (11, 12, 20). */
 int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);

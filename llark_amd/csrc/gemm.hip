@@ -36,7 +36,8 @@ namespace llark {
 template <int WM_, int WN_, int TM_, int TN_, int BK_, int MINW_, int NSTAGE_ = 2>
 struct Cfg {
     static constexpr int MINW = MINW_;             // __launch_bounds__ waves/SIMD the register allocator must allow
-    static constexpr int NSTAGE = NSTAGE_;         // LDS ring depth (2 = double buffer; 3 keeps one tile in flight across the barrier)
+    static constexpr int NSTAGE = NSTAGE_;         // 1 = single LDS stage (overlap comes from the co-resident workgroup), 2 = double buffer
+    static_assert(NSTAGE_ == 1 || NSTAGE_ == 2, "a 3-deep LDS-DMA ring was measured (round 1): no gain over 2 stages, removed");
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
     static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static constexpr int NW = WM * WN, THREADS = NW * 64;
@@ -245,7 +246,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid, char* sm
     constexpr int STAGE = (SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES;     // [Ahi, (Alo), W]
     constexpr int OFF_L = C::A_BYTES, OFF_W = (SPLIT ? 2 : 1) * C::A_BYTES;
     constexpr int NS = C::NSTAGE;
-    constexpr int LOADS_PER_STAGE = ((SPLIT ? 2 : 1) * (C::BM / C::RPI) + (C::BN / C::RPI)) / C::NW;   // DMA instrs per wave
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,7 +293,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid, char* sm
 
     const int nk = p.Kp / C::BK;
     if (NS >= 2) stage(0, 0);
-    if (NS == 3 && nk > 1) stage(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
         if (NS == 1) {
             // single LDS stage, two barriers per K-step: overlap comes from the other blocks resident on the CU
@@ -305,16 +304,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid, char* sm
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt + 1 < nk && GEMM_ABLATE != 1) stage((kt + 1) & 1, kt + 1);
-        } else {
-            // 3-deep ring: tile kt must have landed, tile kt+1 may stay in flight across the barrier
-            // (counted vmcnt + raw s_barrier: __syncthreads() would drain the LDS-DMA queue).
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS_PER_STAGE) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
         }
-        const char* base = smem + (NS == 1 ? 0 : (NS == 2 ? (kt & 1) : (kt % 3))) * STAGE;
+        const char* base = smem + (NS == 1 ? 0 : (kt & 1)) * STAGE;
         const char* sA = base;
         const char* sL = base + OFF_L;
         const char* sW = base + OFF_W;
@@ -931,11 +922,7 @@ static int dispatch_skinny(const GemmParams& p, bool split, int epi, hipStream_t
 typedef Cfg<2, 2, 2, 2, 32, 3> Cfg0;   // 128x128x32, 4 waves, 48 KiB (split)      : 3 blocks/CU
 typedef Cfg<4, 2, 2, 2, 32, 4> Cfg1;   // 256x128x32, 8 waves, 80 KiB               : 2 blocks/CU
 typedef Cfg<2, 2, 2, 4, 32, 2> Cfg2;   // 128x256x32, 4 waves (64x128 per wave), 64 KiB : 2 blocks/CU
-typedef Cfg<4, 2, 2, 4, 32, 2> Cfg3;   // 256x256x32, 8 waves (64x128 per wave), 96 KiB : 1 block/CU
-typedef Cfg<2, 2, 2, 2, 64, 1> Cfg4;   // 128x128x64, 4 waves, 96 KiB               : 1 block/CU
-typedef Cfg<4, 2, 2, 4, 32, 2, 3> Cfg6;   // 256x256x32, 8 waves, 3-stage ring, 144 KiB      : 1 block/CU
 // BK = 64: every DMA instruction moves 8 rows x 128 B (full cache lines) instead of 16 rows x 64 B
-typedef Cfg<2, 4, 2, 2, 64, 2, 2> Cfg10;  // 128x256x64, 8 waves (64x64 per wave), double buffer 128 KiB : 1 block/CU
 typedef Cfg<2, 2, 2, 2, 64, 3, 1> Cfg11;  // 128x128x64, 4 waves, single stage 48 KiB                    : 3 blocks/CU
 typedef Cfg<2, 2, 2, 4, 64, 2, 1> Cfg12;  // 128x256x64, 4 waves (64x128 per wave), single stage 64 KiB  : 2 blocks/CU
 // B-direct kernels (weights fragment-major, L2 -> VGPR): waves 1 x 4 over N
@@ -948,10 +935,6 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 0: return dispatch<T, Cfg0>(p, split, epi, s);
         case 1: return dispatch<T, Cfg1>(p, split, epi, s);
         case 2: return dispatch<T, Cfg2>(p, split, epi, s);
-        case 3: return dispatch<T, Cfg3>(p, split, epi, s);
-        case 4: return dispatch<T, Cfg4>(p, split, epi, s);
-        case 6: return dispatch<T, Cfg6>(p, split, epi, s);
-        case 10: return dispatch<T, Cfg10>(p, split, epi, s);
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
         case 20: {                                                  // persistent 128x256x64 (large grids), else plain variant 12
@@ -991,7 +974,7 @@ static int gemm16_impl(int variant, int dtype, int split, int epilogue, const vo
                        const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, int batch, long long sa,
                        long long sw, long long sc, long long sr, long long so, llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
-    LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant != 4 && variant < 10),
+    LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant < 10),
                   "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
     LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16: lda/ldw must be >= kp and multiples of 8");
     LLARK_REQUIRE(!split || a_lo, "gemm16: split mode needs the lo plane");

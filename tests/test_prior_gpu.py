@@ -63,7 +63,7 @@ def test_gemm_split_f16(m, n, k):
         assert err1.max() > 8 * err.max()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 6, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 11, 12, 20])
 def test_gemm_tile_variants(variant):
     """Every tile variant computes the same product (ragged M/N, K padded to 64)."""
     from llark_amd import ops
