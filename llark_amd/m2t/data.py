@@ -1,0 +1,130 @@
+"""Training data path of the native loop: reads the reference's shard format without the ``webdataset`` dependency.
+
+The reference streams tar shards (``m2t/data_modules.py:466-520`` ``read_webdataset``): every sample is a group of tar
+members sharing a key -- ``<key>.json`` (``{"response": [{"question": ..., "answer": ...}, ...]}``) and
+``<key>.audio_encoding.pyd`` (a pickled array) -- which ``webdataset_element_to_conversation`` (:295-340) unpacks into one
+conversation per question/answer pair with the ``<audio>`` placeholder randomly first or last; the conversations then go
+through ``preprocess_multimodal_mappable`` / ``preprocess_for_lm_mappable`` and the collator (llark_amd.m2t.prompting).
+
+Here: a pure-``tarfile`` reader for local shards (``.npy`` members are read natively; ``.pyd`` pickles only with
+``allow_pickle=True`` -- unpickling is code execution, the caller must trust the shards), brace expansion of
+``name-{000..127}.tar`` lists (:436-438), the per-rank shard split of ``wds.split_by_node``, and a micro-batch generator
+for ``llark_amd.m2t.train.train``.  GCS URLs, resampling with task probabilities and the HF ``IterableDataset`` wrapper
+are not built (I/O glue outside the hot path).
+"""
+from __future__ import annotations
+
+import io
+import json
+import pickle
+import random
+import re
+import tarfile
+from typing import Any, Dict, Iterable, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .prompting import (DataCollatorForSupervisedDataset, concat_audio_token_and_prompt, preprocess_for_lm_mappable,
+                        preprocess_multimodal_mappable)
+
+_RANGE = re.compile(r"\{(\d+)\.\.(\d+)\}")
+
+
+def expand_urls(url: str) -> List[str]:
+    """``"a-{000..002}.tar,b.tar"`` -> ``[a-000.tar, a-001.tar, a-002.tar, b.tar]`` (numeric ranges, zero padding kept)."""
+    out: List[str] = []
+    for part in url.split(","):
+        part = part.strip()
+        if not part:
+            continue
+        todo = [part]
+        while todo:
+            cur = todo.pop(0)
+            m = _RANGE.search(cur)
+            if not m:
+                out.append(cur)
+                continue
+            lo, hi, width = int(m.group(1)), int(m.group(2)), len(m.group(1))
+            todo = [cur[: m.start()] + str(i).zfill(width) + cur[m.end():] for i in range(lo, hi + 1)] + todo
+    return out
+
+
+def split_by_rank(urls: Sequence[str], rank: int, world: int) -> List[str]:
+    """``wds.split_by_node``: rank r reads shards r, r + world, ...  (every rank needs at least one shard)."""
+    mine = list(urls[rank::world])
+    if not mine:
+        raise ValueError(f"{len(urls)} shard(s) cannot be split over {world} ranks")
+    return mine
+
+
+def _decode_member(name: str, data: bytes, allow_pickle: bool):
+    if name.endswith(".json"):
+        return json.loads(data.decode("utf-8"))
+    if name.endswith(".npy"):
+        return np.load(io.BytesIO(data), allow_pickle=False)
+    if name.endswith(".pyd"):
+        if not allow_pickle:
+            raise ValueError(f"{name}: pickled member; pass allow_pickle=True only for shards you trust (or store .npy)")
+        obj = pickle.loads(data)
+        return obj.numpy() if isinstance(obj, torch.Tensor) else np.asarray(obj)
+    return data
+
+
+def iter_tar_samples(shards: Iterable[str], allow_pickle: bool = False) -> Iterator[Dict[str, Any]]:
+    """Yields ``{"__key__", "__url__", "json", "audio_encoding.<ext>", ...}`` per key, in tar order (members of one sample
+    are adjacent, as webdataset requires)."""
+    for url in shards:
+        with tarfile.open(url, "r:*") as tf:
+            cur: Dict[str, Any] = {}
+            for member in tf:
+                if not member.isfile():
+                    continue
+                base = member.name.rsplit("/", 1)[-1]
+                key, _, ext = base.partition(".")
+                if cur and cur["__key__"] != key:
+                    yield cur
+                    cur = {}
+                if not cur:
+                    cur = {"__key__": key, "__url__": url}
+                cur[ext] = _decode_member(base, tf.extractfile(member).read(), allow_pickle)
+            if cur:
+                yield cur
+
+
+def element_to_conversations(elem: Dict[str, Any], rng: random.Random) -> Iterator[Dict[str, Any]]:
+    """m2t/data_modules.py:295-340: one training example per (question, answer) of a sample; malformed samples are skipped."""
+    js = elem.get("json")
+    if not isinstance(js, dict) or not isinstance(js.get("response"), list) or not js["response"]:
+        return
+    enc = elem.get("audio_encoding.pyd", elem.get("audio_encoding.npy"))
+    if enc is None or not hasattr(enc, "shape"):
+        return
+    for resp in js["response"]:
+        audio_first = rng.uniform(0.0, 1.0) > 0.5
+        yield {"audio_encoding": enc, "audio_encoding_shape": list(enc.shape), "id": elem["__key__"],
+               "conversations": [{"from": "human", "value": concat_audio_token_and_prompt(resp["question"], audio_first)},
+                                 {"from": "gpt", "value": resp["answer"]}]}
+
+
+def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any], batch_size: int, model_max_length: int,
+                  rank: int = 0, world: int = 1, seed: int = 0, epochs: Optional[int] = None, allow_pickle: bool = False):
+    """Collated micro-batches (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``) of THIS rank, forever
+    (``epochs=None``, like the reference's ``repeat()``) or for a number of passes over its shards."""
+    shards = split_by_rank(expand_urls(train_data_path), rank, world)
+    collate = DataCollatorForSupervisedDataset(tokenizer)
+    rng = random.Random(seed * 1000003 + rank)
+    epoch = 0
+    while epochs is None or epoch < epochs:
+        order = list(shards)
+        rng.shuffle(order)                                            # shardshuffle
+        pending: List[Dict[str, Any]] = []
+        for elem in iter_tar_samples(order, allow_pickle):
+            for conv in element_to_conversations(elem, rng):
+                ex = preprocess_for_lm_mappable(preprocess_multimodal_mappable(conv, multimodal_cfg), tokenizer=tokenizer)
+                ex["input_ids"], ex["labels"] = ex["input_ids"][:model_max_length], ex["labels"][:model_max_length]
+                pending.append(ex)
+                if len(pending) == batch_size:
+                    yield collate(pending)
+                    pending = []
+        epoch += 1

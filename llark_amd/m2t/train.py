@@ -85,3 +85,79 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
     if output_dir:
         CK.save_checkpoint(tr, output_dir, save_total_limit, rank)
     return losses
+
+
+def main(argv=None):
+    """CLI with the flag names of ``m2t/train.py`` / ``scripts/training/train_llark.sh`` that the native loop implements:
+    python -m llark_amd.m2t.train --model_name_or_path <hf dir> --train_data_path 'shards-{000..127}.tar' --output_dir out \
+        --mm_hidden_size 4800 --mm_use_audio_start_end True --per_device_train_batch_size 2 --gradient_accumulation_steps 4 \
+        --learning_rate 5e-5 --warmup_ratio 0.03 --max_steps 100000 --model_max_length 2048 --save_steps 5000 --save_total_limit 1
+    (one process per GPU under ``python -m torch.distributed.run``)."""
+    import argparse
+
+    import torch as _torch
+    from transformers import AutoTokenizer
+
+    from .. import dist as D
+    from .data import micro_batches
+    from .engine import HipLlamaEngine, LlamaDims
+    from .llamav2 import WrappedLlamav2ForCausalLM
+
+    boolean = lambda v: str(v).lower() in ("1", "true", "yes")
+    ap = argparse.ArgumentParser(description="LLark instruction tuning on the HIP training step")
+    ap.add_argument("--model_name_or_path", required=True)
+    ap.add_argument("--train_data_path", required=True)
+    ap.add_argument("--output_dir", required=True)
+    ap.add_argument("--mm_hidden_size", type=int, default=4800)
+    ap.add_argument("--mm_use_audio_start_end", type=boolean, default=True)
+    ap.add_argument("--tune_mm_mlp_adapter", type=boolean, default=True)
+    ap.add_argument("--per_device_train_batch_size", type=int, default=2)
+    ap.add_argument("--gradient_accumulation_steps", type=int, default=4)
+    ap.add_argument("--learning_rate", type=float, default=5e-5)
+    ap.add_argument("--weight_decay", type=float, default=0.0)
+    ap.add_argument("--warmup_ratio", type=float, default=0.03)
+    ap.add_argument("--max_steps", type=int, default=100000)
+    ap.add_argument("--model_max_length", type=int, default=2048)
+    ap.add_argument("--save_steps", type=int, default=5000)
+    ap.add_argument("--save_total_limit", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
+    for ignored in ("--bf16", "--tf32", "--report_to", "--logging_steps", "--lr_scheduler_type", "--evaluation_strategy", "--save_strategy",
+                    "--freeze_backbone", "--ddp_find_unused_parameters", "--dataloader_num_workers", "--num_train_epochs"):
+        ap.add_argument(ignored, default=None, help="accepted for script compatibility (fixed by the native loop)")
+    args = ap.parse_args(argv)
+
+    rank, world, local = D.env_rank_world()
+    _torch.cuda.set_device(local)
+    dev = _torch.device("cuda", local)
+    if world > 1:
+        D.init(backend="nccl", device=dev)
+    tok = AutoTokenizer.from_pretrained(args.model_name_or_path, model_max_length=args.model_max_length, padding_side="right", use_fast=False)
+    if tok.pad_token is None:
+        tok.add_special_tokens(dict(pad_token="[PAD]"))                    # m2t/train.py:110-124
+    model = WrappedLlamav2ForCausalLM.from_pretrained(args.model_name_or_path, torch_dtype=_torch.bfloat16)
+    model.config.mm_hidden_size = args.mm_hidden_size
+    model.get_model().initialize_adapter_modules(tune_mm_mlp_adapter=args.tune_mm_mlp_adapter)
+    model.resize_token_embeddings(len(tok))
+    model.initialize_audio_tokenizer(args.mm_use_audio_start_end, tok, device=dev, tune_mm_mlp_adapter=args.tune_mm_mlp_adapter)
+    c = model.config
+    dims = LlamaDims(hidden_size=c.hidden_size, intermediate_size=c.intermediate_size, num_hidden_layers=c.num_hidden_layers,
+                     num_attention_heads=c.num_attention_heads, vocab_size=len(tok), rms_norm_eps=c.rms_norm_eps,
+                     rope_theta=getattr(c, "rope_theta", 10000.0), mm_hidden_size=args.mm_hidden_size)
+    eng = HipLlamaEngine(dims, dev, max_batch=args.per_device_train_batch_size, max_seq=args.model_max_length, precision="bf16", frag_weights=False)
+    eng.load_state_dict(model.state_dict())
+    audio_cfg = model.get_model().audio_encoder_config
+    del model
+    mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
+    cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
+                      max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps)
+    batches = micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
+                            seed=args.seed, allow_pickle=args.allow_pickle)
+    log = (lambda rec: print(rec, flush=True)) if rank == 0 else None
+    train(eng, batches, audio_cfg, cfg, world=world, max_optimizer_steps=args.max_steps, log=log, output_dir=args.output_dir,
+          save_steps=args.save_steps, save_total_limit=args.save_total_limit, rank=rank)
+    D.shutdown(world)
+
+
+if __name__ == "__main__":
+    main()

@@ -216,3 +216,66 @@ def test_checkpoint_resume_and_adapter_sidefile(tmp_path):
         assert torch.allclose(got[k], final[k], rtol=0, atol=2 ** -8 * max(1e-3, final[k].abs().max().item())), k
     # the wrapped model of the inference path loads the saved file under the same names
     assert CK.maybe_resume(HipLlamaTrainer(_setup(B=2)[5], lr=2e-3, embed_grad_tokens=toks), str(tmp_path / "empty")) == 0
+
+
+def test_native_loop_from_tar_shards(tmp_path):
+    """m2t/train.py path end to end on synthetic shards in the reference's format: tar members (<key>.json +
+    <key>.audio_encoding.npy) -> conversations -> prompt glue -> collated micro-batches -> HIP training steps with gradient
+    accumulation -> checkpoint; the loss falls and a re-run resumes from the saved step."""
+    import io
+    import json
+    import sys
+    import tarfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from toy_tokenizer import ToyTokenizer
+    from llark_amd.m2t import AudioEncoderConfig
+    from llark_amd.m2t import checkpoint as CK
+    from llark_amd.m2t.data import micro_batches
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from llark_amd.m2t.prompting import DEFAULT_CONVERSATION_HEADER
+    from llark_amd.m2t.train import TrainConfig, train
+    from oracle import llama_ref as LR
+    rng = np.random.default_rng(0)
+    words = ["slow", "fast", "jazz", "rock", "piano", "drums"]
+    for s in range(2):
+        with tarfile.open(tmp_path / f"train-{s:03d}.tar", "w") as tf:
+            for k in range(3):
+                resp = {"response": [{"question": "what is the genre ?", "answer": f"it is {words[(s + k) % 6]} ."}]}
+                for name, payload in ((f"c{s}{k}.json", json.dumps(resp).encode()),):
+                    info = tarfile.TarInfo(name)
+                    info.size = len(payload)
+                    tf.addfile(info, io.BytesIO(payload))
+                b = io.BytesIO()
+                np.save(b, rng.standard_normal((4, 96)).astype(np.float32))
+                info = tarfile.TarInfo(f"c{s}{k}.audio_encoding.npy")
+                info.size = len(b.getvalue())
+                tf.addfile(info, io.BytesIO(b.getvalue()))
+    tok = ToyTokenizer()
+    for text in (DEFAULT_CONVERSATION_HEADER, "### Human: Assistant: what is the genre ? it is . \n " + " ".join(words)):
+        tok.encode(text)
+    tok.add_tokens(["<audio_patch>", "<audio_start>", "<audio_end>"], special_tokens=True)
+    V = len(tok)
+    spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=V, mm_hidden_size=96)
+    w = {k: _bf(v) for k, v in LR.make_weights(spec, seed=2, std=0.08).items()}
+    dims = LlamaDims(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=V, mm_hidden_size=96)
+    ac = AudioEncoderConfig()
+    ac.use_audio_start_end = True
+    ac.audio_patch_token, ac.audio_start_token, ac.audio_end_token = tok.convert_tokens_to_ids(["<audio_patch>", "<audio_start>", "<audio_end>"])
+    mm = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    out = str(tmp_path / "run")
+
+    def run(max_steps):
+        eng = HipLlamaEngine(dims, "cuda", 2, 128, precision="bf16", frag_weights=False)
+        eng.load_state_dict(w)
+        batches = micro_batches(str(tmp_path / "train-{000..001}.tar"), tok, mm, batch_size=2, model_max_length=128, seed=1)
+        cfg = TrainConfig(learning_rate=3e-3, max_steps=40, gradient_accumulation_steps=2)
+        logs = []
+        train(eng, batches, ac, cfg, world=1, max_optimizer_steps=max_steps, log=logs.append, output_dir=out, save_steps=4, save_total_limit=2)
+        return logs
+
+    logs = run(8)
+    assert [r["step"] for r in logs] == list(range(1, 9))
+    assert logs[-1]["loss"] < 0.8 * logs[0]["loss"], [round(r["loss"], 3) for r in logs]
+    assert [os.path.basename(p) for p in CK.list_checkpoints(out)] == ["checkpoint-4", "checkpoint-8"]
+    logs2 = run(10)                                                       # a fresh process state resumes at step 8
+    assert [r["step"] for r in logs2] == [9, 10]
