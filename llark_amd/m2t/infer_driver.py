@@ -101,16 +101,19 @@ def _write_csv(records: List[Dict[str, str]], outfile: Optional[str]) -> None:
 
 def infer_from_encodings(model, tokenizer, audio_encodings_dir: str, prompt: str, multimodal_cfg: Dict[str, Any],
                          end_seq: Sequence[int], outfile: Optional[str] = None, batch_size: int = 8,
-                         max_samples: Optional[int] = None, max_new_tokens: int = 512, audio_first: bool = True) -> List[Dict[str, str]]:
+                         max_samples: Optional[int] = None, max_new_tokens: int = 512, audio_first: bool = True,
+                         embed_dim: Optional[int] = None) -> List[Dict[str, str]]:
     """Directory of ``*.npy`` -> CSV, like ``scripts/inference/infer_from_encodings.py:main`` (same record fields; files
     in sorted order; ``example_id`` = path without ``.npy``).  Examples are grouped by frame count so that every batch
     shares one prompt length."""
+    if embed_dim is None:                                  # 4800 for Jukebox, 512 for CLAP (ModelArguments.mm_hidden_size)
+        embed_dim = int(getattr(getattr(model, "config", None), "mm_hidden_size", EMBED_DIM))
     paths = sorted(glob.glob(os.path.join(audio_encodings_dir, "*.npy")))
     if max_samples:
         paths = paths[:max_samples]
     by_frames: Dict[int, List[Tuple[str, np.ndarray]]] = {}
     for p in paths:
-        a = load_encoding(p)
+        a = load_encoding(p, embed_dim)
         by_frames.setdefault(a.shape[0], []).append((p, a))
     records: Dict[str, Dict[str, str]] = {}
     for frames, items in by_frames.items():

@@ -80,7 +80,6 @@ def test_infer_from_encodings_batched_equals_per_example(tmp_path, monkeypatch):
     from llark_amd.m2t import infer_driver as D
     from llark_amd.m2t.infer import infer_with_prompt
     from llark_amd.m2t.prompting import extract_response_tokens
-    monkeypatch.setattr(D, "EMBED_DIM", 96)
     tok = _tok()
     m = _tiny_model(tok, 96, 3)
     end_seq = tok("\n### Assistant:").input_ids[1:]
@@ -90,8 +89,6 @@ def test_infer_from_encodings_batched_equals_per_example(tmp_path, monkeypatch):
     shapes = {"c": 5, "a": 5, "e": 7, "b": 5, "d": 5}                  # 4 examples of 5 frames (batches of 3 + 1), 1 of 7
     for name, frames in shapes.items():
         np.save(d / f"{name}.npy", rng.standard_normal((frames, 96)).astype(np.float32))
-    orig = D.load_encoding
-    monkeypatch.setattr(D, "load_encoding", lambda p: orig(p, 96))
     out_csv = tmp_path / "out" / "res.csv"
     recs = D.infer_from_encodings(m, tok, str(d), PROMPT, MM_CFG, end_seq, outfile=str(out_csv), batch_size=3, max_new_tokens=10)
     assert [os.path.basename(r["example_id"]) for r in recs] == ["a", "b", "c", "d", "e"]           # sorted file order
@@ -130,3 +127,36 @@ def test_infer_from_audio_fused_equals_two_stage():
         one = infer_with_prompt(PROMPT, model=m, audio_encoding=rep, end_seq=end_seq, multimodal_cfg=MM_CFG, tokenizer=tok,
                                 audio_first=True, max_new_tokens=8).cpu()
         assert r["model_completion_text"] == tok.decode(extract_response_tokens(one[0], end_seq)), name
+
+
+@pytest.mark.gpu
+def test_infer_from_clap_style_encodings_with_mpt(tmp_path):
+    """configs[4] inference surface: (1, 512)-style CLAP embeddings (.npy, here 64-d) + the MPT backbone through the same
+    batched driver; equals the per-example generate of the wrapper."""
+    from llark_amd.m2t import infer_driver as D
+    from llark_amd.m2t.mpt import WrappedMPTConfig, WrappedMPTForCausalLM
+    from llark_amd.m2t.prompting import extract_response_tokens
+    tok = _tok()
+    torch.manual_seed(0)
+    m = WrappedMPTForCausalLM(WrappedMPTConfig(d_model=256, n_heads=2, n_layers=2, expansion_ratio=4, max_seq_len=256, vocab_size=len(tok),
+                                              mm_hidden_size=64)).eval()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_((torch.randn_like(p) * 0.08).bfloat16().float() if p.dim() > 1 else torch.ones_like(p))
+    m.initialize_audio_tokenizer(True, tok, "cpu")
+    m.cuda()
+    m.configure_engine(max_batch=3, max_seq=200)
+    end_seq = tok("\n### Assistant:").input_ids[1:]
+    rng = np.random.default_rng(2)
+    d = tmp_path / "clap"
+    d.mkdir()
+    for name in "abcd":
+        np.save(d / f"{name}.npy", rng.standard_normal((1, 64)).astype(np.float32))        # ONE frame per clip
+    recs = D.infer_from_encodings(m, tok, str(d), PROMPT, MM_CFG, end_seq, batch_size=3, max_new_tokens=6)
+    assert len(recs) == 4
+    m.configure_engine(max_batch=1, max_seq=200)
+    ids = D.build_prompt_ids(PROMPT, 1, tok, MM_CFG, end_seq)[None].cuda()
+    for r in recs:
+        enc = torch.from_numpy(np.load(r["example_id"] + ".npy"))[None].cuda()
+        one = D.generate_batch(m, ids, enc, tok, 6)[0]
+        assert r["model_completion_text"] == tok.decode(extract_response_tokens(one, end_seq)), r["example_id"]
