@@ -196,6 +196,14 @@ int llark_clamp_f32(float* x, long long n, float limit, llark_stream_t stream);
 int llark_scale_f32(float* x, long long n, float a, llark_stream_t stream);   /* logits *= logit_scale */
 int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
                           llark_stream_t stream);
+/* Backward pieces of the MPT training step: LayerNorm (dx [+= if accumulate], dgamma / dbeta accumulated with atomics),
+ * exact GELU (fp32 copy optional, bf16 copy for the GEMMs), causal softmax rows with the ALiBi bias (probabilities of the
+ * materialised attention backward; slopes fp32 [nh], row b of the batch belongs to head b % nh). */
+int llark_layernorm_bwd(const float* x, int ldx, const float* gamma, const float* dy, int ldy, int rows, int width, float eps,
+                        float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, llark_stream_t stream);
+int llark_gelu_bwd(const float* up, const float* dact, long long n, float* dup32, void* dup16, llark_stream_t stream);
+int llark_causal_softmax_rows_alibi(const float* scores, int batch, int s, float scale, const float* slopes, int nh, void* p_out,
+                                    int ldp, llark_stream_t stream);
 /* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the
  * new token; s = 1): lets ONE captured hipGraph of the whole decode step serve every generated token of
  * m2t/models/llamav2.py:339-365 / m2t/infer.py:137-148. */

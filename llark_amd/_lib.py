@@ -80,6 +80,9 @@ _SIGS = {
     "llark_clamp_f32": [_P, c_int64, c_float, _P],
     "llark_scale_f32": [_P, c_int64, c_float, _P],
     "llark_gelu_split_bf16": [_P, c_int, c_int, c_int, _P, _P, c_int, _P],
+    "llark_layernorm_bwd": [_P, c_int, _P, _P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P, c_int, _P],
+    "llark_gelu_bwd": [_P, _P, c_int64, _P, _P, _P],
+    "llark_causal_softmax_rows_alibi": [_P, c_int, c_int, c_float, _P, c_int, _P, c_int, _P],
     "llark_rope_split_heads_dpos": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P],
     "llark_attn_decode_bf16_dpos": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P],
     "llark_rope_split_heads": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P],

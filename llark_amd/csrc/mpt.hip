@@ -101,6 +101,107 @@ __global__ void gelu_split_kernel(const float* __restrict__ x, int ldx, int rows
     if (lo) ((bf16x4_t*)(lo + (size_t)row * ldo))[c4] = l;
 }
 
+// LayerNorm backward (training of the MPT backbone).  One wave per row:
+//   xh = (x - mean) rstd ;  g = dy * gamma ;  dx = rstd * (g - mean(g) - xh * mean(g * xh))
+//   dgamma += sum_rows dy * xh ;  dbeta += sum_rows dy     (per-block LDS partials, then fp32 atomics)
+template <int NV>
+__global__ __launch_bounds__(256) void mpt_layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ dy, int ldy, int rows, int width, float eps,
+                                                                float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int accumulate) {
+    extern __shared__ float sacc[];                          // [2][width]
+    float* sg = sacc;
+    float* sb = sacc + width;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < 2 * width; c += 256) sacc[c] = 0.0f;
+    __syncthreads();
+    const int row = blockIdx.x * 4 + wv;
+    if (row < rows) {
+        const float* xr = x + (size_t)row * ldx;
+        const float* dr = dy + (size_t)row * ldy;
+        float xv[NV * 4], gv[NV * 4];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            xv[k] = c < width ? xr[c] : 0.0f;
+            s += xv[k];
+        }
+        const float mean = wave_sum(s) / (float)width;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            const float d = c < width ? xv[k] - mean : 0.0f;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + eps);
+        float sum_g = 0.0f, sum_gx = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            const float d = c < width ? dr[c] : 0.0f;
+            const float xh = c < width ? (xv[k] - mean) * rstd : 0.0f;
+            xv[k] = xh;
+            gv[k] = c < width ? d * gamma[c] : 0.0f;
+            sum_g += gv[k];
+            sum_gx += gv[k] * xh;
+            if (c < width) {
+                atomicAdd(&sg[c], d * xh);
+                if (dbeta) atomicAdd(&sb[c], d);
+            }
+        }
+        const float mg = wave_sum(sum_g) / (float)width, mgx = wave_sum(sum_gx) / (float)width;
+        float* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+        for (int k = 0; k < NV * 4; ++k) {
+            const int c = lane + 64 * k;
+            if (c < width) {
+                const float v = rstd * (gv[k] - mg - xv[k] * mgx);
+                dxr[c] = accumulate ? dxr[c] + v : v;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256) {
+        if (sg[c] != 0.0f) atomicAdd(&dgamma[c], sg[c]);
+        if (dbeta && sb[c] != 0.0f) atomicAdd(&dbeta[c], sb[c]);
+    }
+}
+
+// exact-GELU backward: dup = dact * (0.5 (1 + erf(u / sqrt 2)) + u exp(-u^2 / 2) / sqrt(2 pi)); fp32 (bias gradient) + bf16 (GEMMs)
+__global__ void gelu_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dact, long long n, float* __restrict__ dup32,
+                                bf16_t* __restrict__ dup16) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = up[i];
+    const float d = dact[i] * (0.5f * (1.0f + erff(u * 0.70710678118654752440f)) + u * expf(-0.5f * u * u) * 0.39894228040143267794f);
+    if (dup32) dup32[i] = d;
+    dup16[i] = (bf16_t)d;
+}
+
+// causal softmax rows with the ALiBi bias (materialised-probabilities path of the attention backward):
+// P[b][i][j] = softmax_j(scale * sc[b][i][j] + slope_{b % nh} * (j - (S - 1))), j <= i
+__global__ __launch_bounds__(256) void causal_softmax_alibi_kernel(const float* __restrict__ sc, int S, float scale,
+                                                                   const float* __restrict__ slopes, int nh, bf16_t* __restrict__ P, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t b = blockIdx.y;
+    if (i >= S) return;
+    const float slope = slopes[b % nh];
+    const float* row = sc + (b * S + i) * (size_t)S;
+    bf16_t* prow = P + (b * S + i) * (size_t)ldp;
+    float mx = -INFINITY;
+    for (int j = lane; j <= i; j += 64) mx = fmaxf(mx, row[j] * scale + slope * (float)(j - (S - 1)));
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j <= i; j += 64) sum += expf(row[j] * scale + slope * (float)(j - (S - 1)) - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < ldp; j += 64)
+        prow[j] = (j <= i) ? (bf16_t)(expf(row[j] * scale + slope * (float)(j - (S - 1)) - mx) * inv) : (bf16_t)0.0f;
+}
+
 }  // namespace llark
 
 using namespace llark;
@@ -160,4 +261,39 @@ extern "C" int llark_gelu_split_bf16(const float* x, int ldx, int rows, int widt
     dim3 grid(cdiv(width / 4, 256), rows);
     gelu_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, ldx, rows, width, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo);
     return check_launch("gelu_split_bf16");
+}
+
+
+extern "C" int llark_layernorm_bwd(const float* x, int ldx, const float* gamma, const float* dy, int ldy, int rows, int width, float eps,
+                                   float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, llark_stream_t stream) {
+    LLARK_REQUIRE(x && gamma && dy && dx && dgamma && rows > 0 && width > 0 && ldx >= width && ldy >= width && lddx >= width,
+                  "layernorm_bwd: bad arguments");
+    dim3 grid(cdiv(rows, 4));
+    const size_t lds = (size_t)2 * width * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define LB(NV) mpt_layernorm_bwd_kernel<NV><<<grid, 256, lds, s>>>(x, ldx, gamma, dy, ldy, rows, width, eps, dx, lddx, dgamma, dbeta, accumulate)
+    if (width <= 256) LB(1);
+    else if (width <= 1024) LB(4);
+    else if (width <= 2048) LB(8);
+    else if (width <= 4096) LB(16);
+    else {
+        set_error("layernorm_bwd: width %d too large (max 4096)", width);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+#undef LB
+    return check_launch("layernorm_bwd");
+}
+
+extern "C" int llark_gelu_bwd(const float* up, const float* dact, long long n, float* dup32, void* dup16, llark_stream_t stream) {
+    LLARK_REQUIRE(up && dact && dup16 && n > 0, "gelu_bwd: bad arguments");
+    gelu_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(up, dact, n, dup32, (bf16_t*)dup16);
+    return check_launch("gelu_bwd");
+}
+
+extern "C" int llark_causal_softmax_rows_alibi(const float* scores, int batch, int s, float scale, const float* slopes, int nh,
+                                               void* p_out, int ldp, llark_stream_t stream) {
+    LLARK_REQUIRE(scores && slopes && p_out && batch > 0 && s > 0 && nh > 0 && ldp >= s, "causal_softmax_rows_alibi: bad arguments");
+    dim3 grid(cdiv(s, 4), batch);
+    causal_softmax_alibi_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(scores, s, scale, slopes, nh, (bf16_t*)p_out, ldp);
+    return check_launch("causal_softmax_rows_alibi");
 }

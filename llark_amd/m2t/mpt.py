@@ -7,7 +7,8 @@ module therefore keeps the *interface* -- parameter names of the state dict (``t
 ``transformer.mm_projector.*``), ``get_model()`` / ``.model``, ``initialize_adapter_modules``,
 ``initialize_audio_tokenizer``, ``forward(input_ids, ..., labels, audio_encodings)`` -> ``CausalLMOutputWithPast``,
 ``prepare_inputs_for_generation`` and a greedy ``generate`` -- on plain ``torch.nn.Module`` containers; the arithmetic runs
-in ``HipMptEngine``.  Inference only (the training step is built for the Llama backbone).
+in ``HipMptEngine``; the training step lives in ``llark_amd.m2t.mpt_train_engine.HipMptTrainer`` (native loop, not wired
+into this wrapper's autograd).
 """
 from __future__ import annotations
 
@@ -202,7 +203,7 @@ class WrappedMPTForCausalLM(nn.Module):
         if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
             raise NotImplementedError("padded batches are not built for the MPT engine (the reference cannot generate with them either)")
         if torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the HIP training step is built for the Llama backbone; run MPT under torch.no_grad()")
+            raise NotImplementedError("use llark_amd.m2t.mpt_train_engine.HipMptTrainer for MPT training; this wrapper's forward is inference (torch.no_grad())")
         eng = self.engine
         ids = input_ids.to(eng.device)
         cached = isinstance(past_key_values, EngineCache) and len(past_key_values) > 0

@@ -436,6 +436,29 @@ def clamp_f32_(x: torch.Tensor, limit: float) -> None:
     check(_lib.lib().llark_clamp_f32(_dev(x, "x", torch.float32), x.numel(), float(limit), _stream()), "clamp_f32")
 
 
+def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float, dx: torch.Tensor, dgamma: torch.Tensor,
+                  dbeta: Optional[torch.Tensor], accumulate: bool) -> None:
+    """x, dy, dx: fp32 [rows][width] views with unit column stride (column slices of wider buffers are fine)."""
+    rows, width = x.shape
+    for t, nm in ((x, "x"), (dy, "dy"), (dx, "dx")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise _lib.LlarkHipError(f"layernorm_bwd: {nm} must be an fp32 GPU tensor with contiguous rows")
+    check(_lib.lib().llark_layernorm_bwd(x.data_ptr(), x.stride(0), _dev(gamma, "gamma", torch.float32), dy.data_ptr(), dy.stride(0), rows, width,
+                                         float(eps), dx.data_ptr(), dx.stride(0), _dev(dgamma, "dgamma", torch.float32),
+                                         _opt(dbeta, "dbeta", torch.float32), int(accumulate), _stream()), "layernorm_bwd")
+
+
+def gelu_bwd(up: torch.Tensor, dact: torch.Tensor, dup16: torch.Tensor, dup32: Optional[torch.Tensor] = None) -> None:
+    check(_lib.lib().llark_gelu_bwd(_dev(up, "up", torch.float32), _dev(dact, "dact", torch.float32), up.numel(),
+                                    _opt(dup32, "dup32", torch.float32), _dev(dup16, "dup16", torch.bfloat16), _stream()), "gelu_bwd")
+
+
+def causal_softmax_rows_alibi(scores: torch.Tensor, batch: int, s: int, scale: float, slopes: torch.Tensor, nh: int, p_out: torch.Tensor) -> None:
+    check(_lib.lib().llark_causal_softmax_rows_alibi(_dev(scores, "scores", torch.float32), batch, s, float(scale),
+                                                     _dev(slopes, "slopes", torch.float32), nh, _dev(p_out, "p", torch.bfloat16),
+                                                     p_out.stride(-2), _stream()), "causal_softmax_rows_alibi")
+
+
 def scale_f32_(x: torch.Tensor, a: float) -> None:
     check(_lib.lib().llark_scale_f32(_dev(x, "x", torch.float32), x.numel(), float(a), _stream()), "scale_f32")
 
