@@ -64,6 +64,10 @@ def build_workload(args, device):
         from llark_amd.m2t import bench_support
 
         return hps, None, None, None, bench_support.MptWorkload(args, device)
+    if args.stages == "mpt-train":
+        from llark_amd.m2t import bench_support
+
+        return hps, None, None, None, bench_support.MptTrainWorkload(args, device, int(os.environ.get("WORLD_SIZE", "1")))
     if args.stages == "train":
         from llark_amd.m2t import bench_support
 
@@ -199,7 +203,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default 8 = BASELINE configs[1]; 4 for --stages train = configs[3]: 32 clips over 8 GPUs)")
-    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt"])
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt", "mpt-train"])
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
@@ -212,7 +216,7 @@ def main():
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = {"train": 4, "generate": 1}.get(args.stages, 8)
+        args.batch = {"train": 4, "mpt-train": 4, "generate": 1}.get(args.stages, 8)
 
     rank, world, local = _dist_setup(args.gpus)
     device = torch.device("cuda", local)
@@ -221,7 +225,7 @@ def main():
     hps, weights, enc, audio, llm = build_workload(args, device)
 
     def step():
-        if args.stages == "train":
+        if args.stages in ("train", "mpt-train"):
             return llm.step()
         if args.stages == "mpt":
             return llm.generate(args.new_tokens)
@@ -233,7 +237,7 @@ def main():
         return emb
 
     with torch.no_grad():
-        if args.stages == "train":
+        if args.stages in ("train", "mpt-train"):
             torch.cuda.reset_peak_memory_stats()
         for _ in range(args.warmup):
             step()
@@ -272,10 +276,10 @@ def main():
                     "traffic": traffic, "traffic_note": traffic_note, "launches": launches,
                     "avg_launch_ms": round(ms / launches, 4),
                     "mfma_passes": 2, "frac_of_issued_mfma": round(2 * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
-        elif llm is not None and args.stages != "mpt":
+        elif llm is not None and args.stages not in ("mpt", "mpt-train"):
             roof = llm.roofline(timers, args)
         cpu = None
-        if not args.no_cpu_baseline and world == 1 and args.stages != "mpt":
+        if not args.no_cpu_baseline and world == 1 and args.stages not in ("mpt", "mpt-train"):
             if args.stages == "train":
                 cpu = cpu_baseline_train(args)
             else:
@@ -285,12 +289,14 @@ def main():
                     "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings",
                     "generate": "configs[2]: %d clip(s) -> Jukebox embed -> projector -> Llama-2-7B prefill (S=371) + %d greedy decode steps (KV cache, stopping criterion off)" % (args.batch, args.new_tokens),
                     "mpt": "configs[4] LLM half: precomputed CLAP (1,512) embedding -> projector -> MPT-1B prefill (S=132) + %d greedy decode steps; HTSAT audio encoder not built" % args.new_tokens,
+                    "mpt-train": "MPT-1B instruction-tuning step on CLAP-style (1,512) embeddings: per GPU %d clips x %d tokens, fwd+bwd+all-reduce+AdamW (train_mpt_model.sh analogue of configs[3])" % (args.batch, args.train_seq),
                     "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+AdamW"
                              % (args.batch, args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq)}[args.stages]
         line = {
             "metric": {"train": "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",
                        "generate": "clips/sec embed + prefill + %d-token greedy decode" % args.new_tokens,
-                       "mpt": "clips/sec MPT-1B prefill + %d-token greedy decode on CLAP embeddings" % args.new_tokens}.get(args.stages, "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd"),
+                       "mpt": "clips/sec MPT-1B prefill + %d-token greedy decode on CLAP embeddings" % args.new_tokens,
+                       "mpt-train": "clips/sec MPT-1B instruction-tuning step (fwd+bwd+all-reduce+AdamW)"}.get(args.stages, "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd"),
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
@@ -298,18 +304,19 @@ def main():
                                            "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
                                            "generate": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "mpt": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
+                                           "mpt-train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)",
                                            "train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)"}[args.stages],
             "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": {"train": args.train_seq, "mpt": 132}.get(args.stages, 371),
+                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": {"train": args.train_seq, "mpt-train": args.train_seq, "mpt": 132}.get(args.stages, 371),
                        "prior_depth": hps.prior_depth,
                        "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients once per optimizer step)",
                        "debug_overrides": bool(args.depth or args.tiny)},
-            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt") else None),
+            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train") else None),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
-        if args.stages == "train":
+        if args.stages in ("train", "mpt-train"):
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if args.stages == "generate":
             key = "gemm_split_bf16_skinny" if args.llm_precision == "split" else "gemm_bf16_skinny"

@@ -212,3 +212,32 @@ class MptWorkload:
         d = self.dims
         rows = self.batch * self.ids.shape[1]
         return 2.0 * rows * (12 * d.d_model * d.d_model * d.n_layers + d.d_model * d.vocab_size)
+
+
+class MptTrainWorkload(MptWorkload):
+    """Instruction-tuning step of random-init MPT-1B on CLAP-style (1, 512) embeddings (train_mpt_model.sh analogue of
+    BASELINE configs[3]): per GPU `batch` clips x `train_seq` tokens in one micro-batch, fwd + bwd + all-reduce + AdamW."""
+
+    def __init__(self, args, device, world):
+        from .mpt_train_engine import HipMptTrainer
+
+        args_bf16 = type("A", (), dict(batch=args.batch, llm_precision="bf16"))()
+        super().__init__(args_bf16, device)
+        self.world = world
+        self.trainer = HipMptTrainer(self.engine, lr=5e-5)
+        g = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
+        ans = torch.randint(3, 50000, (args.batch, args.train_seq - self.ids.shape[1]), generator=g).to(device)
+        self.full = torch.cat([self.ids, ans], dim=1)
+        self.labels = self.full.clone()
+        self.labels[:, : self.ids.shape[1]] = -100
+        self.engine.smax = max(self.engine.smax, ops.round_up(args.train_seq, 64))
+        self.engine.cos = torch.ones((self.engine.smax, 64), dtype=torch.float32, device=device)
+        self.engine.sin = torch.zeros((self.engine.smax, 64), dtype=torch.float32, device=device)
+        self.engine.k_cache = None
+
+    def step(self):
+        segs = [(b, 1, self.emb[b]) for b in range(self.batch)]
+        loss = self.trainer.forward_backward(self.full, segs, self.labels)
+        self.trainer.allreduce_grads(self.world)
+        self.trainer.step(self.world)
+        return loss
