@@ -279,3 +279,59 @@ def test_native_loop_from_tar_shards(tmp_path):
     assert [os.path.basename(p) for p in CK.list_checkpoints(out)] == ["checkpoint-4", "checkpoint-8"]
     logs2 = run(10)                                                       # a fresh process state resumes at step 8
     assert [r["step"] for r in logs2] == [9, 10]
+
+
+def test_train_cli_end_to_end(tmp_path):
+    """`python -m llark_amd.m2t.train` (the m2t/train.py entry point, reference flag names) on a tiny HF-format checkpoint +
+    tokenizer saved locally and synthetic shards: parses the flags, loads model + tokenizer, sets up the audio tokens, runs
+    optimizer steps on the HIP training step, writes checkpoint-N/ + mm_projector/checkpoint-N.bin, and a second invocation
+    resumes."""
+    import io
+    import json
+    import tarfile
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from llark_amd.m2t import checkpoint as CK
+    from llark_amd.m2t import train as T
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    from llark_amd.m2t.prompting import DEFAULT_CONVERSATION_HEADER
+    # ---- tiny tokenizer + checkpoint in HF format
+    words = sorted(set((DEFAULT_CONVERSATION_HEADER + " ### Human: Assistant: what is the genre ? it is jazz rock piano . <audio>").split()))
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for wd in words:
+        vocab.setdefault(wd, len(vocab))
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    ckpt = tmp_path / "ckpt"
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", bos_token="<s>", eos_token="</s>")
+    fast.save_pretrained(str(ckpt))
+    cfg = WrappedLlamav2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                               vocab_size=len(vocab), max_position_embeddings=256, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    torch.manual_seed(0)
+    WrappedLlamav2ForCausalLM(cfg).save_pretrained(str(ckpt))
+    # ---- shards
+    rng = np.random.default_rng(0)
+    with tarfile.open(tmp_path / "s-000.tar", "w") as tf:
+        for k in range(4):
+            payload = json.dumps({"response": [{"question": "what is the genre ?", "answer": "it is jazz ."}]}).encode()
+            info = tarfile.TarInfo(f"k{k}.json")
+            info.size = len(payload)
+            tf.addfile(info, io.BytesIO(payload))
+            b = io.BytesIO()
+            np.save(b, rng.standard_normal((3, 96)).astype(np.float32))
+            info = tarfile.TarInfo(f"k{k}.audio_encoding.npy")
+            info.size = len(b.getvalue())
+            tf.addfile(info, io.BytesIO(b.getvalue()))
+    out = tmp_path / "out"
+    argv = ["--model_name_or_path", str(ckpt), "--train_data_path", str(tmp_path / "s-{000..000}.tar"), "--output_dir", str(out),
+            "--mm_hidden_size", "96", "--mm_use_audio_start_end", "True", "--per_device_train_batch_size", "2",
+            "--gradient_accumulation_steps", "2", "--learning_rate", "1e-3", "--max_steps", "3", "--model_max_length", "128",
+            "--save_steps", "2", "--save_total_limit", "2", "--bf16", "True", "--report_to", "none"]
+    T.main(argv)
+    assert [os.path.basename(p) for p in CK.list_checkpoints(str(out))] == ["checkpoint-2", "checkpoint-3"]
+    side = torch.load(out / "mm_projector" / "checkpoint-3.bin")
+    assert "model.mm_projector.weight" in side and side["model.mm_projector.weight"].shape == (256, 96)
+    full = torch.load(out / "checkpoint-3" / "pytorch_model.bin")
+    assert full["model.embed_tokens.weight"].shape[0] == len(vocab) + 1 + 3          # + [PAD] + the three audio tokens
+    T.main([("4" if a == "3" else a) for a in argv])                     # --max_steps 4: resumes from checkpoint-3, one more step
+    assert os.path.basename(CK.latest_checkpoint(str(out))) == "checkpoint-4"
