@@ -164,3 +164,69 @@ def infer_from_audio(encoder, model, tokenizer, clips: Iterable[Tuple[str, np.nd
     flush()
     _write_csv(records, outfile)
     return records
+
+
+def get_prompt_end_token_sequence(tokenizer, model_name: str, prompt_end_string: str = "\n### Assistant:") -> List[int]:
+    """m2t/tokenizer.py:33-52: the token ids that mark the end of the prompt; the Llama-2 SentencePiece tokenizer prepends a
+    piece to a string that starts with a newline, which is dropped."""
+    end_seq = tokenizer([prompt_end_string], add_special_tokens=False).input_ids[0]
+    if "meta-llama/Llama-2" in model_name:
+        end_seq = end_seq[1:]
+    return list(end_seq)
+
+
+def main(argv=None):
+    """CLI with the flags of the reference's ``scripts/inference/infer_from_encodings.py:120-156`` (+ ``--batch-size``):
+    python -m llark_amd.m2t.infer_driver --model_name_or_path <dir> --audio-encodings-dir reps/ --prompt "What genre is this song?" \
+        --outfile results/infer.csv [--max-samples N] [--max_new_tokens 512] [--batch-size 8] [--mm_hidden_size 4800]"""
+    import argparse
+
+    from transformers import AutoTokenizer
+
+    from .llamav2 import WrappedLlamav2ForCausalLM
+    from .special_tokens import DEFAULT_AUDIO_END_TOKEN, DEFAULT_AUDIO_PATCH_TOKEN, DEFAULT_AUDIO_START_TOKEN
+
+    ap = argparse.ArgumentParser(description="LLark inference over a directory of audio encodings on the HIP engine")
+    ap.add_argument("--model_name_or_path", required=True)
+    ap.add_argument("--audio-encodings-dir", required=True)
+    ap.add_argument("--prompt", required=True)
+    ap.add_argument("--outfile", default="infer_results.csv")
+    ap.add_argument("--max-samples", type=int, default=None)
+    ap.add_argument("--max_new_tokens", type=int, default=512)
+    ap.add_argument("--batch-size", type=int, default=8)
+    ap.add_argument("--mm_hidden_size", type=int, default=None)
+    ap.add_argument("--model_max_length", type=int, default=2048)
+    ap.add_argument("--llm-precision", default="split", choices=["split", "bf16"])
+    for ignored in ("--ckpt-num", "--report_to", "--bf16", "--tf32", "--output_dir"):
+        ap.add_argument(ignored, default=None, help="accepted for script compatibility")
+    args = ap.parse_args(argv)
+
+    tok = AutoTokenizer.from_pretrained(args.model_name_or_path, model_max_length=args.model_max_length, padding_side="right", use_fast=False)
+    model = WrappedLlamav2ForCausalLM.from_pretrained(args.model_name_or_path, torch_dtype=torch.bfloat16)
+    if args.mm_hidden_size:
+        model.config.mm_hidden_size = args.mm_hidden_size
+    if tok.pad_token is None:                                           # m2t/train.py:110-124 adds it at training time
+        tok.add_special_tokens(dict(pad_token="[PAD]"))
+        model.resize_token_embeddings(len(tok))
+    if not hasattr(model.get_model(), "mm_projector"):
+        model.get_model().initialize_adapter_modules()
+    known = set(tok.get_vocab())
+    if {DEFAULT_AUDIO_PATCH_TOKEN, DEFAULT_AUDIO_START_TOKEN, DEFAULT_AUDIO_END_TOKEN} <= known and model.get_input_embeddings().weight.shape[0] >= len(tok):
+        ac = model.get_model().audio_encoder_config                      # a trained checkpoint: the tokens are already in place
+        ac.use_audio_start_end = True
+        ac.audio_patch_token, ac.audio_start_token, ac.audio_end_token = tok.convert_tokens_to_ids(
+            [DEFAULT_AUDIO_PATCH_TOKEN, DEFAULT_AUDIO_START_TOKEN, DEFAULT_AUDIO_END_TOKEN])
+    else:
+        model.initialize_audio_tokenizer(mm_use_audio_start_end=True, tokenizer=tok, device="cpu")
+    model.cuda().eval()
+    model.configure_engine(max_batch=args.batch_size, max_seq=args.model_max_length, precision=args.llm_precision)
+    end_seq = get_prompt_end_token_sequence(tok, args.model_name_or_path)
+    mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    recs = infer_from_encodings(model, tok, args.audio_encodings_dir, args.prompt, mm_cfg, end_seq, outfile=args.outfile,
+                                batch_size=args.batch_size, max_samples=args.max_samples, max_new_tokens=args.max_new_tokens)
+    print(f"writing {len(recs)} results to {args.outfile}")
+    return recs
+
+
+if __name__ == "__main__":
+    main()

@@ -160,3 +160,39 @@ def test_infer_from_clap_style_encodings_with_mpt(tmp_path):
         enc = torch.from_numpy(np.load(r["example_id"] + ".npy"))[None].cuda()
         one = D.generate_batch(m, ids, enc, tok, 6)[0]
         assert r["model_completion_text"] == tok.decode(extract_response_tokens(one, end_seq)), r["example_id"]
+
+
+@pytest.mark.gpu
+def test_infer_cli_end_to_end(tmp_path):
+    """`python -m llark_amd.m2t.infer_driver` (flags of scripts/inference/infer_from_encodings.py) on a tiny HF-format
+    checkpoint + tokenizer saved locally: loads, sets up the audio tokens, generates for every .npy, writes the CSV."""
+    import pandas as pd
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    from llark_amd.m2t import infer_driver as D
+    from llark_amd.m2t.llamav2 import WrappedLlamav2Config, WrappedLlamav2ForCausalLM
+    from llark_amd.m2t.prompting import DEFAULT_CONVERSATION_HEADER
+    words = sorted(set((DEFAULT_CONVERSATION_HEADER + " ### Human: Assistant: <empty> " + PROMPT).split()))
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2, "\n": 3}
+    for wd in words:
+        vocab.setdefault(wd, len(vocab))
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    ckpt = tmp_path / "ckpt"
+    PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", bos_token="<s>", eos_token="</s>").save_pretrained(str(ckpt))
+    cfg = WrappedLlamav2Config(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                               vocab_size=len(vocab), max_position_embeddings=256, rms_norm_eps=1e-5, tie_word_embeddings=False)
+    cfg.mm_hidden_size = 96
+    torch.manual_seed(0)
+    WrappedLlamav2ForCausalLM(cfg).save_pretrained(str(ckpt))
+    reps = tmp_path / "reps"
+    reps.mkdir()
+    rng = np.random.default_rng(3)
+    for name in ("x", "y", "z"):
+        np.save(reps / f"{name}.npy", rng.standard_normal((4, 96)).astype(np.float32))
+    out = tmp_path / "res" / "infer.csv"
+    recs = D.main(["--model_name_or_path", str(ckpt), "--audio-encodings-dir", str(reps), "--prompt", PROMPT, "--outfile", str(out),
+                   "--max_new_tokens", "5", "--batch-size", "2", "--mm_hidden_size", "96", "--model_max_length", "128", "--ckpt-num", "7"])
+    df = pd.read_csv(out)
+    assert len(recs) == 3 and list(df.columns) == ["example_id", "prompt_text", "model_completion_text"]
+    assert [os.path.basename(e) for e in df["example_id"]] == ["x", "y", "z"] and (df["prompt_text"] == PROMPT).all()
