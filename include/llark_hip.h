@@ -204,6 +204,28 @@ int llark_layernorm_bwd(const float* x, int ldx, const float* gamma, const float
 int llark_gelu_bwd(const float* up, const float* dact, long long n, float* dup32, void* dup16, llark_stream_t stream);
 int llark_causal_softmax_rows_alibi(const float* scores, int batch, int s, float scale, const float* slopes, int nh, void* p_out,
                                     int ldp, llark_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * CLAP HTSAT-base audio encoder (scripts/clap/clap_embeddings.py:63-107 -> laion_clap
+ * CLAP_Module(enable_fusion=False, amodel="HTSAT-base").model.get_audio_embedding): the pieces that are not GEMM /
+ * LayerNorm / GELU.  patchify: log-mel x [batch][frames][mel] -> BatchNorm over mel bins ((x - mean) * scale + bias),
+ * 4-tap bicubic stretch of the time axis (tap_idx / tap_w [spec * spec / mel][4], host built), time-chunk fold to a
+ * spec x spec image, patch x patch im2col -> bf16 planes [batch * (spec/patch)^2][ldo] (k = kh * patch + kw).
+ * window_attn: Swin attention over 8x8 windows of a [batch][H][W] token map, qkv fp32 rows [q | k | v] of 3C in token
+ * order; cyclic shift, relative-position bias (table [(2*8-1)^2][heads]) and the shifted-window mask (-100) are applied
+ * in-kernel; context written to bf16 planes at the same token rows.  patch_merge: 2x2 neighbourhood gather to 4C-wide
+ * rows (quadrant order (0,0),(1,0),(0,1),(1,1)).  mean_rows: per-clip mean over L token rows.  l2_normalize_rows in place
+ * (x / max(||x||, eps)).
+ * ------------------------------------------------------------------------------------------- */
+int llark_clap_patchify(const float* x, int batch, int frames, int mel, const float* bn_mean, const float* bn_scale,
+                        const float* bn_bias, const int* tap_idx, const float* tap_w, int spec, int patch, void* out_hi,
+                        void* out_lo, int ldo, llark_stream_t stream);
+int llark_clap_window_attn(const float* qkv, int ldq, int batch, int H, int W, int C, int heads, int window, int shift,
+                           const float* bias_table, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+int llark_clap_patch_merge(const float* x, int ldx, int batch, int H, int W, int C, float* out, int ldo, llark_stream_t stream);
+int llark_mean_rows_f32(const float* x, int ldx, int batch, int L, int C, float* out, int ldo, llark_stream_t stream);
+int llark_relu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+int llark_l2_normalize_rows(float* x, int ldx, int rows, int width, float eps, llark_stream_t stream);
+
 /* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the
  * new token; s = 1): lets ONE captured hipGraph of the whole decode step serve every generated token of
  * m2t/models/llamav2.py:339-365 / m2t/infer.py:137-148. */

@@ -598,3 +598,56 @@ def device_info(device: int = 0) -> Tuple[int, str]:
     if cus < 0:
         check(cus, "device_info")
     return cus, buf.value.decode()
+
+
+# ---- CLAP HTSAT audio encoder (csrc/clap.hip) ----------------------------------------------------------------------------
+
+def clap_patchify(x: torch.Tensor, bn_mean: torch.Tensor, bn_scale: torch.Tensor, bn_bias: torch.Tensor, tap_idx: torch.Tensor,
+                  tap_w: torch.Tensor, spec: int, patch: int, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
+    """log-mel x (B, frames, mel) -> BatchNorm -> bicubic time stretch -> fold -> patch rows (bf16 planes)."""
+    B, frames, mel = x.shape
+    assert tap_idx.shape == (spec * spec // mel, 4) and tap_w.shape == tap_idx.shape and out_hi.shape[0] == B * (spec // patch) ** 2
+    bf = torch.bfloat16
+    check(_lib.lib().llark_clap_patchify(_dev(x, "x", torch.float32), B, frames, mel, _dev(bn_mean, "bn_mean", torch.float32),
+                                         _dev(bn_scale, "bn_scale", torch.float32), _dev(bn_bias, "bn_bias", torch.float32),
+                                         _dev(tap_idx, "tap_idx", torch.int32), _dev(tap_w, "tap_w", torch.float32), spec, patch,
+                                         _dev(out_hi, "out_hi", bf), _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()),
+          "clap_patchify")
+
+
+def clap_window_attn(qkv: torch.Tensor, batch: int, H: int, W: int, C: int, heads: int, window: int, shift: int,
+                     bias_table: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
+    """Swin window attention on a (batch, H, W) token map; qkv fp32 [batch*H*W][3C] in token order."""
+    assert qkv.shape == (batch * H * W, 3 * C) and bias_table.shape == ((2 * window - 1) ** 2, heads) and out_hi.shape[0] == batch * H * W
+    bf = torch.bfloat16
+    with _timed("clap_window_attn", 4.0 * batch * H * W * window * window * C):
+        check(_lib.lib().llark_clap_window_attn(_dev(qkv, "qkv", torch.float32), qkv.stride(0), batch, H, W, C, heads, window, shift,
+                                                _dev(bias_table, "bias_table", torch.float32), _dev(out_hi, "out_hi", bf),
+                                                _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "clap_window_attn")
+
+
+def clap_patch_merge(x: torch.Tensor, batch: int, H: int, W: int, out: torch.Tensor) -> None:
+    C = x.shape[1]
+    assert x.shape[0] == batch * H * W and out.shape == (batch * H * W // 4, 4 * C)
+    check(_lib.lib().llark_clap_patch_merge(_dev(x, "x", torch.float32), x.stride(0), batch, H, W, C, _dev(out, "out", torch.float32),
+                                            out.stride(0), _stream()), "clap_patch_merge")
+
+
+def mean_rows_f32(x: torch.Tensor, batch: int, out: torch.Tensor) -> None:
+    rows, C = x.shape
+    assert rows % batch == 0 and out.shape == (batch, C)
+    check(_lib.lib().llark_mean_rows_f32(_dev(x, "x", torch.float32), x.stride(0), batch, rows // batch, C,
+                                         _dev(out, "out", torch.float32), out.stride(0), _stream()), "mean_rows_f32")
+
+
+def relu_split_bf16(x: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> None:
+    rows, width = x.shape
+    bf = torch.bfloat16
+    check(_lib.lib().llark_relu_split_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(out_hi, "out_hi", bf),
+                                           _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "relu_split_bf16")
+
+
+def l2_normalize_rows_(x: torch.Tensor, eps: float = 1e-12) -> None:
+    rows, width = x.shape
+    check(_lib.lib().llark_l2_normalize_rows(_dev(x, "x", torch.float32), x.stride(0), rows, width, float(eps), _stream()),
+          "l2_normalize_rows")
