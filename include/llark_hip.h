@@ -216,6 +216,12 @@ int llark_causal_softmax_rows_alibi(const float* scores, int batch, int s, float
  * rows (quadrant order (0,0),(1,0),(0,1),(1,1)).  mean_rows: per-clip mean over L token rows.  l2_normalize_rows in place
  * (x / max(||x||, eps)).
  * ------------------------------------------------------------------------------------------- */
+/* waveform [batch][n] (48 kHz) -> log-mel dB [batch][n/480 + 1][64]: STFT n_fft 1024 / hop 480 / center-reflect with `window`
+ * [1024], radix-2 FFT with `twiddle` [512] (cos, -sin) pairs of exp(-2 pi i k / 1024), power, mel filters melw [64][513]
+ * (non-zero over bins [mel_lo, mel_hi)), 10 log10(max(x, 1e-10)).  quantize_int16 != 0 applies laion_clap's
+ * int16_to_float32(float32_to_int16(x)) round trip (clap_embeddings.py:139) to each sample as it is read. */
+int llark_clap_logmel(const float* wav, int batch, int n, int quantize_int16, const float* window, const float* twiddle,
+                      const float* melw, const int* mel_lo, const int* mel_hi, float* out, llark_stream_t stream);
 int llark_clap_patchify(const float* x, int batch, int frames, int mel, const float* bn_mean, const float* bn_scale,
                         const float* bn_bias, const int* tap_idx, const float* tap_w, int spec, int patch, void* out_hi,
                         void* out_lo, int ldo, llark_stream_t stream);

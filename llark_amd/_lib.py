@@ -83,6 +83,7 @@ _SIGS = {
     "llark_layernorm_bwd": [_P, c_int, _P, _P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P, c_int, _P],
     "llark_gelu_bwd": [_P, _P, c_int64, _P, _P, _P],
     "llark_causal_softmax_rows_alibi": [_P, c_int, c_int, c_float, _P, c_int, _P, c_int, _P],
+    "llark_clap_logmel": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P],
     "llark_clap_patchify": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P],
     "llark_clap_window_attn": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P],
     "llark_clap_patch_merge": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],

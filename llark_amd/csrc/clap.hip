@@ -141,6 +141,58 @@ __global__ __launch_bounds__(256) void clap_window_attn_kernel(const float* __re
     }
 }
 
+// Waveform -> log-mel (the torchlibrosa Spectrogram + LogmelFilterBank inside laion_clap's HTSAT, n_fft 1024 / hop 480 /
+// periodic hann / center + reflect padding / power 2 / slaney mel filters / 10 log10(max(x, 1e-10))), fused: one block
+// per STFT frame reads its 1024 samples (reflect-indexed, optionally through laion's int16 round trip), runs a radix-2
+// FFT in LDS (fp32, twiddles from a host table built in float64), forms the 513 powers, applies the 64 triangular mel
+// filters (each lane walks only its non-zero bins) and writes 64 dB values.  Nothing but the waveform is read from HBM
+// (1.9 MB per 10 s clip, each sample by ~2 overlapping frames, L2-resident) and nothing but the 64 x frames output is
+// written; the reference path materialises the (frames x 513 x 2) STFT and the power spectrogram in memory.
+__global__ __launch_bounds__(256) void clap_logmel_kernel(const float* __restrict__ wav, int n, int frames, int quantize,
+                                                          const float* __restrict__ window, const float2* __restrict__ twiddle,
+                                                          const float* __restrict__ melw, const int* __restrict__ mel_lo,
+                                                          const int* __restrict__ mel_hi, float* __restrict__ out) {
+    __shared__ float2 buf[1024];
+    __shared__ float pw[520];
+    const int f = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* x = wav + (size_t)b * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = tid + r * 256;
+        int pos = f * 480 + i - 512;
+        if (pos < 0) pos = -pos;
+        if (pos >= n) pos = 2 * (n - 1) - pos;
+        float v = x[pos];
+        if (quantize) v = (float)(int)(fminf(fmaxf(v, -1.0f), 1.0f) * 32767.0f) / 32767.0f;
+        buf[__brev((unsigned)i) >> 22] = make_float2(v * window[i], 0.0f);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int half = 1; half < 1024; half <<= 1) {
+        const int tstep = 512 / half;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int bf = tid + r * 256;
+            const int j = bf & (half - 1);
+            const int i0 = ((bf - j) << 1) + j, i1 = i0 + half;
+            const float2 w = twiddle[j * tstep];
+            const float2 u = buf[i0], v = buf[i1];
+            const float tr = v.x * w.x - v.y * w.y, ti = v.x * w.y + v.y * w.x;
+            buf[i0] = make_float2(u.x + tr, u.y + ti);
+            buf[i1] = make_float2(u.x - tr, u.y - ti);
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < 513; k += 256) pw[k] = buf[k].x * buf[k].x + buf[k].y * buf[k].y;
+    __syncthreads();
+    if (tid < 64) {
+        const float* wrow = melw + (size_t)tid * 513;
+        float s = 0.0f;
+        for (int k = mel_lo[tid]; k < mel_hi[tid]; ++k) s += pw[k] * wrow[k];
+        out[((size_t)b * frames + f) * 64 + tid] = 10.0f * log10f(fmaxf(s, 1e-10f));
+    }
+}
+
 // Swin patch merging gather: out[(b, h/2, w/2)][q*C + c] = x[(b, 2 h2 + (q & 1), 2 w2 + (q >> 1))][c]
 __global__ void clap_patch_merge_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, float* __restrict__ out, int ldo,
                                         long long total4) {
@@ -253,4 +305,15 @@ extern "C" int llark_l2_normalize_rows(float* x, int ldx, int rows, int width, f
     LLARK_REQUIRE(x && rows > 0 && width > 0 && ldx >= width && eps > 0.0f, "l2_normalize_rows: bad arguments");
     l2_normalize_rows_kernel<<<dim3(cdiv(rows, 4)), 256, 0, (hipStream_t)stream>>>(x, ldx, rows, width, eps);
     return check_launch("l2_normalize_rows");
+}
+
+extern "C" int llark_clap_logmel(const float* wav, int batch, int n, int quantize_int16, const float* window, const float* twiddle,
+                                 const float* melw, const int* mel_lo, const int* mel_hi, float* out, llark_stream_t stream) {
+    LLARK_REQUIRE(wav && window && twiddle && melw && mel_lo && mel_hi && out, "clap_logmel: null pointer");
+    LLARK_REQUIRE(batch > 0 && batch < 65536 && n > 512, "clap_logmel: bad shape batch=%d n=%d (reflect padding needs n > 512)", batch, n);
+    LLARK_REQUIRE(((uintptr_t)twiddle & 7) == 0, "clap_logmel: twiddle table must be 8-byte aligned");
+    const int frames = n / 480 + 1;
+    clap_logmel_kernel<<<dim3(frames, batch), 256, 0, (hipStream_t)stream>>>(wav, n, frames, quantize_int16, window, (const float2*)twiddle,
+                                                                             melw, mel_lo, mel_hi, out);
+    return check_launch("clap_logmel");
 }

@@ -651,3 +651,17 @@ def l2_normalize_rows_(x: torch.Tensor, eps: float = 1e-12) -> None:
     rows, width = x.shape
     check(_lib.lib().llark_l2_normalize_rows(_dev(x, "x", torch.float32), x.stride(0), rows, width, float(eps), _stream()),
           "l2_normalize_rows")
+
+
+def clap_logmel(wav: torch.Tensor, window: torch.Tensor, twiddle: torch.Tensor, melw: torch.Tensor, mel_lo: torch.Tensor,
+                mel_hi: torch.Tensor, quantize_int16: bool = False) -> torch.Tensor:
+    """wav (B, n) fp32 48 kHz -> (B, n // 480 + 1, 64) log-mel dB (fused STFT + mel + log kernel)."""
+    B, n = wav.shape
+    assert window.shape == (1024,) and twiddle.shape == (512, 2) and melw.shape == (64, 513) and mel_lo.shape == (64,) and mel_hi.shape == (64,)
+    out = torch.empty((B, n // 480 + 1, 64), dtype=torch.float32, device=wav.device)
+    with _timed("clap_logmel", 0.0):
+        check(_lib.lib().llark_clap_logmel(_dev(wav, "wav", torch.float32), B, n, int(quantize_int16), _dev(window, "window", torch.float32),
+                                           _dev(twiddle, "twiddle", torch.float32), _dev(melw, "melw", torch.float32),
+                                           _dev(mel_lo, "mel_lo", torch.int32), _dev(mel_hi, "mel_hi", torch.int32),
+                                           _dev(out, "out", torch.float32), _stream()), "clap_logmel")
+    return out

@@ -185,3 +185,65 @@ def make_weights(spec: ClapSpec, seed: int = 0, std: float = 0.05) -> Dict[str, 
     w["audio_projection.linear1.weight"], w["audio_projection.linear1.bias"] = r(spec.proj_dim, C), r(spec.proj_dim)
     w["audio_projection.linear2.weight"], w["audio_projection.linear2.bias"] = r(spec.proj_dim, spec.proj_dim), r(spec.proj_dim)
     return w
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Waveform -> log-mel front end.  In the reference the host side is scripts/clap/clap_embeddings.py:127-153 (48 kHz read,
+# int16 round trip, laion_clap get_audio_features with data_truncating="rand_trunc", data_filling="repeatpad" -> a 480000-sample
+# waveform) and the spectrogram is computed INSIDE the model by torchlibrosa (Spectrogram n_fft 1024 / hop 480 / hann / center
+# reflect / power 2 -> LogmelFilterBank sr 48000, 64 mels, 50..14000 Hz, slaney scale + slaney norm, 10 log10(max(x, 1e-10))).
+# Restated in float64 numpy (rfft instead of the DFT-matrix conv1d).  PINNING: against transformers.ClapFeatureExtractor's
+# non-fusion path (same published algorithm; tests/golden/clap_mel.npz).
+# ---------------------------------------------------------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+CLAP_SR, CLAP_NFFT, CLAP_HOP, CLAP_CLIP = 48000, 1024, 480, 480000
+
+
+def quantize_roundtrip(x: np.ndarray) -> np.ndarray:
+    """int16_to_float32(float32_to_int16(x)) of laion_clap (clap_embeddings.py:139)."""
+    x = np.clip(np.asarray(x, np.float32), -1.0, 1.0)
+    return ((x * 32767.0).astype(np.int16) / 32767.0).astype(np.float32)
+
+
+def fit_length(x: np.ndarray, max_len: int = CLAP_CLIP, offset: int = 0) -> np.ndarray:
+    """rand_trunc (crop at `offset`, the reference draws it at random) / repeatpad (whole repeats, then zeros)."""
+    if len(x) > max_len:
+        return x[offset:offset + max_len]
+    if len(x) < max_len:
+        x = np.tile(x, int(max_len / len(x)))
+        x = np.pad(x, (0, max_len - len(x)))
+    return x
+
+
+def mel_filterbank_slaney(sr=CLAP_SR, n_fft=CLAP_NFFT, n_mels=64, fmin=50.0, fmax=14000.0) -> np.ndarray:
+    """librosa.filters.mel (htk=False, norm='slaney'): (n_mels, n_fft/2+1) float64."""
+    f_sp, min_log_hz = 200.0 / 3, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.maximum(0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    return w * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]
+
+
+def logmel(wave: np.ndarray) -> np.ndarray:
+    """(n,) waveform -> (frames, 64) log-mel in dB, frames = n // hop + 1."""
+    x = np.asarray(wave, np.float64)
+    pad = np.pad(x, CLAP_NFFT // 2, mode="reflect")
+    n_frames = 1 + (len(pad) - CLAP_NFFT) // CLAP_HOP
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(CLAP_NFFT) / CLAP_NFFT)                   # periodic hann
+    idx = np.arange(CLAP_NFFT)[None, :] + CLAP_HOP * np.arange(n_frames)[:, None]
+    power = np.abs(np.fft.rfft(pad[idx] * win, axis=1)) ** 2
+    mel = power @ mel_filterbank_slaney().astype(np.float32).astype(np.float64).T         # librosa hands out fp32 filters
+    return 10.0 * np.log10(np.maximum(mel, 1e-10))

@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from llark_amd.clap.htsat import ClapDims, bicubic_time_taps, from_laion_state_dict
+from clap_util import to_laion_names
 from oracle import clap_ref as CR
 
 
@@ -27,31 +28,38 @@ def test_too_long_input_rejected_like_the_reference_model():
 def test_laion_checkpoint_rename_round_trip():
     spec = CR.ClapSpec(embed_dim=32, depths=[1, 1], heads=[1, 2], proj_dim=16)
     w = CR.make_weights(spec, seed=1)
-    e = "audio_model.audio_encoder."
-    laion = {"module.text_branch.embeddings.word_embeddings.weight": torch.zeros(2, 2),
-             "module.audio_branch.spectrogram_extractor.stft.conv_real.weight": torch.zeros(2, 1, 4),
-             "module.audio_branch.layers.0.blocks.0.attn.relative_position_index": torch.zeros(64, 64)}
-    inv = ((".layernorm_before.", ".norm1."), (".layernorm_after.", ".norm2."), (".attention.output.dense.", ".attn.proj."),
-           (".intermediate.dense.", ".mlp.fc1."), (".output.dense.", ".mlp.fc2."),
-           (".attention.self.relative_position_bias_table", ".attn.relative_position_bias_table"))
-    for k, v in w.items():
-        if k.startswith("audio_projection."):
-            laion["module." + k.replace("linear1", "0").replace("linear2", "2")] = v
-            continue
-        r = k[len(e):]
-        if r.startswith("batch_norm."):
-            laion["module.audio_branch.bn0." + r[len("batch_norm."):]] = v
-            continue
-        if ".attention.self.query." in r:
-            kk, vv = r.replace(".query.", ".key."), r.replace(".query.", ".value.")
-            laion["module.audio_branch." + r.replace(".attention.self.query.", ".attn.qkv.")] = torch.cat([v, w[e + kk], w[e + vv]], 0)
-            continue
-        if ".attention.self.key." in r or ".attention.self.value." in r:
-            continue
-        for a, b in inv:
-            r = r.replace(a, b)
-        laion["module.audio_branch." + r] = v
+    laion = to_laion_names(w)
     back = from_laion_state_dict(laion)
     assert sorted(back) == sorted(w)
     assert all(torch.equal(back[k], w[k]) for k in w)
     assert ClapDims().out_width == 1024
+
+
+def test_front_end_host_logic_matches_oracle_and_published_filters():
+    """Slaney filter bank == the one transformers.ClapFeatureExtractor publishes (golden) == the oracle's; rand_trunc /
+    repeatpad and the int16 round trip of load_audio_input == the oracle's restatement."""
+    import os
+    from llark_amd.clap import fit_clip, load_audio_input, slaney_mel_filters
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clap_mel.npz"))
+    bank = slaney_mel_filters()
+    assert bank.shape == (64, 513) and np.abs(bank.T - z["filters"]).max() < 1e-8
+    assert np.abs(bank - CR.mel_filterbank_slaney()).max() < 1e-8
+    rng = np.random.default_rng(0)
+    for n in (7, 16, 17, 40):
+        w = rng.standard_normal(n).astype(np.float32)
+        off = int(np.random.default_rng(5).integers(0, max(n - 17, 0) + 1)) if n > 17 else 0
+        assert np.array_equal(fit_clip(w, np.random.default_rng(5), max_len=17), CR.fit_length(w, 17, off))
+    w = (rng.standard_normal(1000) * 0.7).astype(np.float32)
+    el = load_audio_input({"waveform": w})
+    feats = el["audio_features"][0]["waveform"].numpy()
+    assert feats.shape == (480000,) and np.array_equal(feats, CR.fit_length(CR.quantize_roundtrip(w)))
+    with pytest.raises(ValueError):
+        fit_clip(np.zeros(0, np.float32))
+
+
+def test_oracle_logmel_pinned_against_feature_extractor():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clap_mel.npz"))
+    lm = CR.logmel(CR.fit_length(z["wave"]))
+    assert lm.shape == (1001, 64) and np.abs(lm - z["logmel"]).max() < 2e-5
+    assert lm.min() == -100.0                                   # the zero tail of repeatpad clamps at amin
