@@ -60,9 +60,14 @@ def build_workload(args, device):
     from llark_amd.jukebox.synthetic import init_codebook_from_encodings, make_jukebox_weights, synthetic_clip
 
     hps = hparams_tiny() if args.tiny else hparams_5b()
+    if args.stages == "clap":
+        from llark_amd.m2t import bench_support
+
+        return hps, None, None, None, bench_support.ClapWorkload(args, device, "fp32" if args.llm_precision == "split" else "bf16")
     if args.stages == "mpt":
         from llark_amd.m2t import bench_support
 
+        args.with_clap = True
         return hps, None, None, None, bench_support.MptWorkload(args, device)
     if args.stages == "mpt-train":
         from llark_amd.m2t import bench_support
@@ -197,16 +202,58 @@ def cpu_baseline_train(args):
             "sample": f"1 clip fwd+bwd S={args.train_seq} fp32 torch-autograd oracle: head {t_head:.2f}s + {layers} of 32 layers {t_layers:.2f}s extrapolated to 32"}
 
 
+def roofline_clap(timers, args, wl):
+    """HTSAT's matrix products on the 16-bit MFMA GEMM: algorithmic 2*M*N*K of one step / HIP-event time of the GEMM launches
+    (fp32 mode issues 3 bf16 MFMA passes per product: A_hi.W_hi + A_lo.W_hi + A_hi.W_lo)."""
+    from llark_amd.clap import algorithmic_flops_per_clip
+
+    fl = algorithmic_flops_per_clip(wl.dims)
+    keys = [k for k in timers if k.startswith("gemm_")]
+    if not keys:
+        return None
+    ms = sum(timers[k][1] for k in keys)
+    launches = sum(timers[k][0] for k in keys)
+    achieved = fl["gemm"] * args.batch * args.steps / (ms * 1e-3) / 1e12
+    passes = 3 if args.llm_precision == "split" else 1
+    return {"bound": "mfma", "kernel": "gemm_kernel<bf16> (HTSAT linears)", "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": None, "launches": launches,
+            "avg_launch_ms": round(ms / launches, 4), "mfma_passes": passes,
+            "frac_of_issued_mfma": round(passes * achieved / PEAK_F16_MFMA_TFLOPS, 4),
+            "note": "stage-0/1 products (K = 128 / 256 over 262144 / 65536 rows) are HBM-bound on their fp32 outputs, not MFMA-bound"}
+
+
+def cpu_baseline_clap(wl):
+    """The CPU oracle (numpy float64 log-mel + torch fp32 HTSAT) on 2 of the step's clips, same synthetic weights.
+    Thread count capped at 16: the oracle's products are small and slow down beyond that on a many-core host."""
+    from oracle import clap_ref as CR
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    from llark_amd.clap import random_state_dict
+
+    w = {k: v.cpu() for k, v in random_state_dict(wl.dims, device=wl.wav.device, seed=0).items()}
+    wav = wl.wav[:2].cpu().numpy()
+    t0 = time.time()
+    feats = np.stack([CR.logmel(CR.quantize_roundtrip(x)) for x in wav]).astype(np.float32)
+    with torch.no_grad():
+        CR.forward(w, CR.ClapSpec(), torch.from_numpy(feats)[:, None])
+    dt = time.time() - t0
+    return {"value": 2.0 / dt, "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"2 clips: float64 numpy log-mel + torch fp32 HTSAT-base oracle ({dt:.2f}s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default 8 = BASELINE configs[1]; 4 for --stages train = configs[3]: 32 clips over 8 GPUs)")
-    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt", "mpt-train"])
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt", "mpt-train", "clap"])
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
+    ap.add_argument("--grad-comm", dest="grad_comm", default="fp32", choices=["fp32", "bf16"],
+                    help="train: transport dtype of the gradient all-reduce (bf16 = what the reference's bf16 DDP buckets send)")
     ap.add_argument("--llm-layers", type=int, default=0, help="debug: override the number of Llama layers (train stage)")
     ap.add_argument("--depth", type=int, default=0, help="debug: override prior depth (result is then NOT the headline)")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
@@ -216,7 +263,7 @@ def main():
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
     if not args.batch:
-        args.batch = {"train": 4, "mpt-train": 4, "generate": 1}.get(args.stages, 8)
+        args.batch = {"train": 4, "mpt-train": 4, "generate": 1, "clap": 64}.get(args.stages, 8)
 
     rank, world, local = _dist_setup(args.gpus)
     device = torch.device("cuda", local)
@@ -229,6 +276,8 @@ def main():
             return llm.step()
         if args.stages == "mpt":
             return llm.generate(args.new_tokens)
+        if args.stages == "clap":
+            return llm.embed()
         emb = enc(audio) if args.stages != "llama" else None
         if args.stages == "generate":
             return llm.generate(emb, args.new_tokens)
@@ -276,11 +325,15 @@ def main():
                     "traffic": traffic, "traffic_note": traffic_note, "launches": launches,
                     "avg_launch_ms": round(ms / launches, 4),
                     "mfma_passes": 2, "frac_of_issued_mfma": round(2 * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+        elif args.stages == "clap":
+            roof = roofline_clap(timers, args, llm)
         elif llm is not None and args.stages not in ("mpt", "mpt-train"):
             roof = llm.roofline(timers, args)
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.stages not in ("mpt", "mpt-train"):
-            if args.stages == "train":
+            if args.stages == "clap":
+                cpu = cpu_baseline_clap(llm)
+            elif args.stages == "train":
                 cpu = cpu_baseline_train(args)
             else:
                 cpu = cpu_baseline(hps, weights, args)
@@ -288,14 +341,16 @@ def main():
                     "jukebox": "configs[1]: Jukebox encoder+prior forward, batch=8x25s clips -> (240,4800) embeddings",
                     "llama": "projector + Llama-2-7B forward (S=371) on precomputed embeddings",
                     "generate": "configs[2]: %d clip(s) -> Jukebox embed -> projector -> Llama-2-7B prefill (S=371) + %d greedy decode steps (KV cache, stopping criterion off)" % (args.batch, args.new_tokens),
-                    "mpt": "configs[4] LLM half: precomputed CLAP (1,512) embedding -> projector -> MPT-1B prefill (S=132) + %d greedy decode steps; HTSAT audio encoder not built" % args.new_tokens,
+                    "mpt": "configs[4]: 10 s 48 kHz clips -> log-mel -> CLAP HTSAT-base -> (1,512) embedding -> projector -> MPT-1B prefill (S=132) + %d greedy decode steps" % args.new_tokens,
+                    "clap": "configs[4] audio half: %d x 10 s 48 kHz clips -> int16 round trip + log-mel (1001x64) -> CLAP HTSAT-base -> (B,512) unit embeddings" % args.batch,
                     "mpt-train": "MPT-1B instruction-tuning step on CLAP-style (1,512) embeddings: per GPU %d clips x %d tokens, fwd+bwd+all-reduce+AdamW (train_mpt_model.sh analogue of configs[3])" % (args.batch, args.train_seq),
                     "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+AdamW"
                              % (args.batch, args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq)}[args.stages]
         line = {
             "metric": {"train": "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",
                        "generate": "clips/sec embed + prefill + %d-token greedy decode" % args.new_tokens,
-                       "mpt": "clips/sec MPT-1B prefill + %d-token greedy decode on CLAP embeddings" % args.new_tokens,
+                       "mpt": "clips/sec CLAP embed + MPT-1B prefill + %d-token greedy decode" % args.new_tokens,
+                       "clap": "clips/sec CLAP HTSAT-base audio embedding (waveform -> 512-d)",
                        "mpt-train": "clips/sec MPT-1B instruction-tuning step (fwd+bwd+all-reduce+AdamW)"}.get(args.stages, "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd"),
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -304,15 +359,16 @@ def main():
                                            "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
                                            "generate": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "mpt": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
+                                           "clap": "bf16x2-split activations x bf16x2-split weights (fp32-class)" if args.llm_precision == "split" else "bf16",
                                            "mpt-train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)",
                                            "train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)"}[args.stages],
             "data": "synthetic",
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "audio_samples": hps.sample_length, "prompt_tokens": 128, "seq_len": {"train": args.train_seq, "mpt-train": args.train_seq, "mpt": 132}.get(args.stages, 371),
-                       "prior_depth": hps.prior_depth,
-                       "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients once per optimizer step)",
+                       "audio_samples": 480000 if args.stages in ("clap", "mpt") else hps.sample_length, "prompt_tokens": 0 if args.stages == "clap" else 128, "seq_len": {"train": args.train_seq, "mpt-train": args.train_seq, "mpt": 132}.get(args.stages, 371),
+                       "prior_depth": None if args.stages in ("clap", "mpt", "mpt-train") else hps.prior_depth,
+                       "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients ({args.grad_comm} on the links) once per optimizer step)",
                        "debug_overrides": bool(args.depth or args.tiny)},
-            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train") else None),
+            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train", "clap") else None),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }

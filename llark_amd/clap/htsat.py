@@ -104,6 +104,54 @@ def from_laion_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     return out
 
 
+def random_state_dict(dims: Optional["ClapDims"] = None, device="cpu", seed: int = 0, std: float = 0.05) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights of the right shapes (benchmarks and smoke runs; there is no checkpoint on disk)."""
+    d = dims or ClapDims()
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *shape: torch.randn(*shape, generator=g, device=device) * std
+    e = "audio_model.audio_encoder"
+    sd = {f"{e}.batch_norm.weight": 1 + r(d.mel_bins), f"{e}.batch_norm.bias": r(d.mel_bins),
+          f"{e}.batch_norm.running_mean": r(d.mel_bins) * 40 - 30, f"{e}.batch_norm.running_var": 100 + r(d.mel_bins).abs() * 400,
+          f"{e}.patch_embed.proj.weight": r(d.embed_dim, 1, d.patch, d.patch) * 4, f"{e}.patch_embed.proj.bias": r(d.embed_dim),
+          f"{e}.patch_embed.norm.weight": 1 + r(d.embed_dim), f"{e}.patch_embed.norm.bias": r(d.embed_dim)}
+    C = d.embed_dim
+    for s, depth in enumerate(d.depths):
+        M = int(C * d.mlp_ratio)
+        for b in range(depth):
+            p = f"{e}.layers.{s}.blocks.{b}"
+            for ln in ("layernorm_before", "layernorm_after"):
+                sd[f"{p}.{ln}.weight"], sd[f"{p}.{ln}.bias"] = 1 + r(C), r(C)
+            sd[f"{p}.attention.self.relative_position_bias_table"] = r((2 * d.window - 1) ** 2, d.heads[s]) * 4
+            for nm, (n, k) in (("attention.self.query", (C, C)), ("attention.self.key", (C, C)), ("attention.self.value", (C, C)),
+                               ("attention.output.dense", (C, C)), ("intermediate.dense", (M, C)), ("output.dense", (C, M))):
+                sd[f"{p}.{nm}.weight"], sd[f"{p}.{nm}.bias"] = r(n, k), r(n)
+        if s < len(d.depths) - 1:
+            p = f"{e}.layers.{s}.downsample"
+            sd[f"{p}.reduction.weight"], sd[f"{p}.norm.weight"], sd[f"{p}.norm.bias"] = r(2 * C, 4 * C), 1 + r(4 * C), r(4 * C)
+            C *= 2
+    sd[f"{e}.norm.weight"], sd[f"{e}.norm.bias"] = 1 + r(C), r(C)
+    sd["audio_projection.linear1.weight"], sd["audio_projection.linear1.bias"] = r(d.proj_dim, C), r(d.proj_dim)
+    sd["audio_projection.linear2.weight"], sd["audio_projection.linear2.bias"] = r(d.proj_dim, d.proj_dim), r(d.proj_dim)
+    return sd
+
+
+def algorithmic_flops_per_clip(dims: Optional["ClapDims"] = None) -> Dict[str, float]:
+    """2*M*N*K of every matrix product of one clip (fp32-equivalent; extra MFMA passes of the split modes not counted)."""
+    d = dims or ClapDims()
+    L, C = (d.spec_size // d.patch) ** 2, d.embed_dim
+    gemm = 2.0 * L * d.patch * d.patch * C
+    attn = 0.0
+    for s, depth in enumerate(d.depths):
+        M = int(C * d.mlp_ratio)
+        gemm += depth * 2.0 * L * (4 * C * C + 2 * C * M)
+        attn += depth * 4.0 * L * d.window * d.window * C
+        if s < len(d.depths) - 1:
+            gemm += 2.0 * (L // 4) * 4 * C * 2 * C
+            L, C = L // 4, 2 * C
+    gemm += 2.0 * (C * d.proj_dim + d.proj_dim * d.proj_dim)
+    return {"gemm": gemm, "attention": attn}
+
+
 class _Linear:
     """nn.Linear weight [n][k] as bf16 hi (+ lo) K-contiguous planes, bias fp32."""
 

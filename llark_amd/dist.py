@@ -6,7 +6,7 @@ max-over-ranks of the elapsed time; the backend is RCCL ("nccl") on GPUs and glo
 from __future__ import annotations
 
 import os
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -81,3 +81,28 @@ def shutdown(world: int) -> None:
 
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+class _Exchange:
+    """Handle of one in-flight gradient all-reduce; ``wait()`` also unstages a reduced-precision transport buffer."""
+
+    def __init__(self, work, dst: torch.Tensor, staged: Optional[torch.Tensor]):
+        self.work, self.dst, self.staged = work, dst, staged
+
+    def wait(self) -> None:
+        self.work.wait()
+        if self.staged is not None:
+            self.dst.copy_(self.staged)                 # bf16 -> fp32 back into the gradient buffer
+            self.staged = None
+
+
+def all_reduce_sum_async(buf: torch.Tensor, comm_dtype: torch.dtype = torch.float32) -> _Exchange:
+    """Asynchronous SUM all-reduce of a slice of the flat fp32 gradient buffer.  ``comm_dtype=torch.bfloat16`` sends
+    bf16 over the links, which is what the reference's DDP does (m2t/train.py:94-103 casts the model to bf16, so its
+    gradient buckets are bf16): half the xGMI bytes of the fp32 exchange."""
+    import torch.distributed as dist
+
+    if comm_dtype == torch.float32:
+        return _Exchange(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf, None)
+    staged = buf.to(comm_dtype)
+    return _Exchange(dist.all_reduce(staged, op=dist.ReduceOp.SUM, async_op=True), buf, staged)

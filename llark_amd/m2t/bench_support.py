@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import time
 
+import math
+
 import torch
 
 from .. import ops
@@ -123,7 +125,8 @@ class TrainWorkload:
             eng.set_layer(i, n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I), ones, ones)
         eng.set_globals(n(VOCAB, H), ones, n(VOCAB, H), n(H, dims.mm_hidden_size), torch.zeros(H, device=device))
         self.engine = eng
-        self.trainer = HipLlamaTrainer(eng, lr=5e-5, embed_grad_tokens=[START, END])
+        self.trainer = HipLlamaTrainer(eng, lr=5e-5, embed_grad_tokens=[START, END],
+                                       grad_comm=torch.bfloat16 if getattr(args, "grad_comm", "fp32") == "bf16" else torch.float32)
         gen = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
         self.batches = []
         for k in range(self.accum):
@@ -167,10 +170,32 @@ def build(args, device):
     return LLMWorkload(args, device)
 
 
+class ClapWorkload:
+    """BASELINE configs[4] audio half: `batch` 10 s 48 kHz clips resident in HBM -> fused log-mel -> HTSAT-base (seeded
+    synthetic weights) -> (batch, 512) L2-normalised embeddings (scripts/clap/clap_embeddings.py:63-153)."""
+
+    def __init__(self, args, device, precision="fp32"):
+        from ..clap import ClapDims, ClapFrontend, HipClapAudioEncoder, random_state_dict
+        from ..clap.frontend import CLIP_SAMPLES
+
+        self.batch = args.batch
+        self.dims = ClapDims()
+        self.frontend = ClapFrontend(device)
+        self.encoder = HipClapAudioEncoder(random_state_dict(self.dims, device=device, seed=0), self.dims, device, precision)
+        g = torch.Generator(device=device).manual_seed(3 + int(__import__("os").environ.get("RANK", "0")))
+        t = torch.arange(CLIP_SAMPLES, device=device, dtype=torch.float32) / 48000.0
+        f0 = 110.0 * (1 + torch.rand(args.batch, 1, generator=g, device=device))
+        wav = sum(0.3 / h * torch.sin(2 * math.pi * f0 * h * t[None]) for h in range(1, 9))
+        self.wav = (wav * torch.exp(-2.0 * (t % 0.5))[None] + 0.01 * torch.randn(args.batch, CLIP_SAMPLES, generator=g, device=device)).contiguous()
+
+    def embed(self):
+        return self.encoder.embed(self.frontend.logmel(self.wav, quantize_int16=True))
+
+
 class MptWorkload:
-    """BASELINE configs[4] LLM half: MPT-1B (d_model 2048, 24 blocks, 16 heads, ALiBi, vocab 50432 + 3) prefill over the
-    prompt with ONE 512-d CLAP frame per clip (the reference's scripts/clap embeddings are (1, 512); the HTSAT encoder
-    itself is not built -- embeddings are synthetic) followed by `new_tokens` greedy decode steps."""
+    """BASELINE configs[4]: the CLAP HTSAT-base encoder turns `batch` 10 s clips into ONE 512-d frame per clip (the
+    reference's scripts/clap embeddings are (1, 512)), which MPT-1B (d_model 2048, 24 blocks, 16 heads, ALiBi, vocab
+    50432 + 3) takes through mm_projector into the prompt; prefill + `new_tokens` greedy decode steps."""
 
     def __init__(self, args, device):
         from .mpt_engine import HipMptEngine, MptDims
@@ -199,9 +224,12 @@ class MptWorkload:
         rows = [[0, self.start, self.patch, self.end] + torch.randint(3, 50000, (PROMPT,), generator=gi).tolist() for _ in range(args.batch)]
         self.ids = torch.tensor(rows, dtype=torch.int64, device=device)                   # S = 4 + 128 = 132
         self.emb = torch.randn(args.batch, 1, 512, generator=g, device=device)
+        self.clap = ClapWorkload(args, device) if getattr(args, "with_clap", False) else None
 
     def generate(self, new_tokens: int):
         eng = self.engine
+        if self.clap is not None:
+            self.emb = self.clap.embed().unsqueeze(1)                                # (B, 1, 512), never leaves HBM
         logits = eng.forward_tokens(self.ids, [(b, 1, self.emb[b]) for b in range(self.batch)], last_only=True)
         nxt = logits[:, -1].argmax(-1, keepdim=True)
         for _ in range(new_tokens - 1):
@@ -224,7 +252,7 @@ class MptTrainWorkload(MptWorkload):
         args_bf16 = type("A", (), dict(batch=args.batch, llm_precision="bf16"))()
         super().__init__(args_bf16, device)
         self.world = world
-        self.trainer = HipMptTrainer(self.engine, lr=5e-5)
+        self.trainer = HipMptTrainer(self.engine, lr=5e-5, grad_comm=torch.bfloat16 if getattr(args, "grad_comm", "fp32") == "bf16" else torch.float32)
         g = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
         ans = torch.randint(3, 50000, (args.batch, args.train_seq - self.ids.shape[1]), generator=g).to(device)
         self.full = torch.cat([self.ids, ans], dim=1)

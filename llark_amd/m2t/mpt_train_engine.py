@@ -26,8 +26,9 @@ _BF = torch.bfloat16
 
 class HipMptTrainer:
     def __init__(self, engine: HipMptEngine, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 train_wte: bool = False):
+                 train_wte: bool = False, grad_comm: torch.dtype = torch.float32):
         d = engine.dims
+        self.grad_comm = grad_comm
         if engine.split:
             raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
         if d.clip_qkv or d.logit_scale is not None:
@@ -242,11 +243,11 @@ class HipMptTrainer:
     def allreduce_grads(self, world: int, bucket_elems: int = 64 * 1024 * 1024) -> None:
         if world <= 1:
             return
-        import torch.distributed as dist
+        from .. import dist as D
 
         n = self.flat_grad.numel()
-        for wk in [dist.all_reduce(self.flat_grad[o: min(o + bucket_elems, n)], op=dist.ReduceOp.SUM, async_op=True)
-                   for o in range(0, n, bucket_elems)]:
+        comm = getattr(self, "grad_comm", torch.float32)
+        for wk in [D.all_reduce_sum_async(self.flat_grad[o: min(o + bucket_elems, n)], comm) for o in range(0, n, bucket_elems)]:
             wk.wait()
 
     def step(self, world: int = 1) -> None:

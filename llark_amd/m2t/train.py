@@ -31,6 +31,7 @@ class TrainConfig:
     adam_beta2: float = 0.999
     adam_epsilon: float = 1e-8
     lr_scheduler_type: str = "cosine"           # :35
+    grad_comm: str = "fp32"                     # "bf16" = the reference's bf16 DDP buckets (m2t/train.py:94-103): half the xGMI bytes
 
 
 def lr_at(step: int, cfg: TrainConfig) -> float:
@@ -51,7 +52,8 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
     ``save_steps`` optimizer steps (train_llark.sh:31,41-42) and once more at the end."""
     toks = [t for t in (audio_cfg.audio_start_token, audio_cfg.audio_end_token) if isinstance(t, int)]
     tr = HipLlamaTrainer(engine, lr=cfg.learning_rate, betas=(cfg.adam_beta1, cfg.adam_beta2), eps=cfg.adam_epsilon,
-                         weight_decay=cfg.weight_decay, embed_grad_tokens=toks)
+                         weight_decay=cfg.weight_decay, embed_grad_tokens=toks,
+                         grad_comm=torch.bfloat16 if cfg.grad_comm == "bf16" else torch.float32)
     from . import checkpoint as CK
 
     if output_dir:
@@ -121,6 +123,7 @@ def main(argv=None):
     ap.add_argument("--save_steps", type=int, default=5000)
     ap.add_argument("--save_total_limit", type=int, default=1)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--grad_comm", default="fp32", choices=["fp32", "bf16"], help="transport dtype of the gradient all-reduce")
     ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
     for ignored in ("--bf16", "--tf32", "--report_to", "--logging_steps", "--lr_scheduler_type", "--evaluation_strategy", "--save_strategy",
                     "--freeze_backbone", "--ddp_find_unused_parameters", "--dataloader_num_workers", "--num_train_epochs"):
@@ -150,7 +153,7 @@ def main(argv=None):
     del model
     mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
-                      max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps)
+                      max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm)
     batches = micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
                             seed=args.seed, allow_pickle=args.allow_pickle)
     log = (lambda rec: print(rec, flush=True)) if rank == 0 else None

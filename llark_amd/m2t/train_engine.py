@@ -32,7 +32,11 @@ _BF = torch.bfloat16
 
 class HipLlamaTrainer:
     def __init__(self, engine: HipLlamaEngine, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, embed_grad_tokens: Sequence[int] = (), train_embed_all: bool = False):
+                 weight_decay: float = 0.0, embed_grad_tokens: Sequence[int] = (), train_embed_all: bool = False,
+                 grad_comm: torch.dtype = torch.float32):
+        if grad_comm not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_comm must be torch.float32 or torch.bfloat16")
+        self.grad_comm = grad_comm                   # transport dtype of the gradient all-reduce (the reference's DDP sends bf16)
         if engine.split:
             raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
         self.eng = engine
@@ -260,12 +264,12 @@ class HipLlamaTrainer:
         return o0, o1 + n1
 
     def _start_layer_allreduce(self, i: int) -> None:
-        import torch.distributed as dist
+        from .. import dist as D
 
         o0, o1 = self._layer_span(i)
         if not hasattr(self, "_inflight"):
             self._inflight, self._reduced = [], []
-        self._inflight.append(dist.all_reduce(self.flat_grad[o0:o1], op=dist.ReduceOp.SUM, async_op=True))
+        self._inflight.append(D.all_reduce_sum_async(self.flat_grad[o0:o1], getattr(self, "grad_comm", torch.float32)))
         self._reduced.append((o0, o1))
 
     def _finalize_grads(self) -> None:
@@ -284,13 +288,14 @@ class HipLlamaTrainer:
         works = list(getattr(self, "_inflight", []))
         self._inflight, self._reduced = [], []
         if world > 1:
-            import torch.distributed as dist
+            from .. import dist as D
 
+            comm = getattr(self, "grad_comm", torch.float32)
             n = self.flat_grad.numel()
             pos = 0
             for a, b in done + [(n, n)]:                  # the gaps between the spans reduced so far
                 for o in range(pos, a, bucket_elems):
-                    works.append(dist.all_reduce(self.flat_grad[o: min(o + bucket_elems, a)], op=dist.ReduceOp.SUM, async_op=True))
+                    works.append(D.all_reduce_sum_async(self.flat_grad[o: min(o + bucket_elems, a)], comm))
                 pos = max(pos, b)
         for w in works:
             w.wait()

@@ -63,3 +63,25 @@ def test_oracle_logmel_pinned_against_feature_extractor():
     lm = CR.logmel(CR.fit_length(z["wave"]))
     assert lm.shape == (1001, 64) and np.abs(lm - z["logmel"]).max() < 2e-5
     assert lm.min() == -100.0                                   # the zero tail of repeatpad clamps at amin
+
+
+def test_embed_cli_host_side(tmp_path):
+    """File listing, rank sharding, wav decoding (int16 / float / stereo / other rates) and batching; no GPU involved."""
+    from scipy.io import wavfile
+    from llark_amd.clap.embed_cli import iter_batches, list_wavs, read_wav_48k, shard
+    rng = np.random.default_rng(0)
+    (tmp_path / "sub").mkdir()
+    a = (rng.standard_normal(4800) * 3000).astype(np.int16)
+    wavfile.write(tmp_path / "a.wav", 48000, a)
+    wavfile.write(tmp_path / "sub" / "b.WAV", 48000, rng.standard_normal((2400, 2)).astype(np.float32) * 0.1)
+    wavfile.write(tmp_path / "c.wav", 44100, (rng.standard_normal(4410) * 0.1).astype(np.float32))
+    (tmp_path / "broken.wav").write_bytes(b"not a wav")
+    (tmp_path / "notes.txt").write_text("x")
+    paths = list_wavs(str(tmp_path))
+    assert [p.split("/")[-1] for p in paths] == ["a.wav", "broken.wav", "c.wav", "b.WAV"]
+    assert shard(paths, 0, 2) + shard(paths, 1, 2) != [] and sorted(shard(paths, 0, 2) + shard(paths, 1, 2)) == sorted(paths)
+    xa = read_wav_48k(paths[0])
+    assert xa.dtype == np.float32 and np.array_equal(xa, a.astype(np.float32) / 32768.0)
+    assert read_wav_48k(paths[3]).shape == (2400,) and read_wav_48k(paths[2]).shape == (4800,)
+    got = list(iter_batches(paths, 2))
+    assert [len(n) for n, _ in got] == [2, 1] and got[0][0] == [paths[0], paths[2]]          # broken.wav skipped

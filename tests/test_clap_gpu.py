@@ -175,3 +175,58 @@ def test_module_waveform_to_embedding_like_the_reference_handler(tmp_path):
         m.model.get_audio_embedding([{"waveform": torch.zeros(1000)}])
     with pytest.raises(NotImplementedError):
         HipClapModule(enable_fusion=True)
+
+
+def test_config5_clap_into_mpt_matches_oracle_pipeline():
+    """BASELINE configs[4] in small: waveform -> HIP log-mel -> HIP HTSAT -> (B, 1, P) embedding -> HIP MPT (projector splice,
+    F = 1) logits, against oracle log-mel -> oracle HTSAT -> oracle MPT.  Tolerance 1e-3 relative on the logits (north_star)."""
+    from llark_amd.clap import ClapDims, ClapFrontend, HipClapAudioEncoder
+    from llark_amd.m2t.mpt_engine import HipMptEngine, MptDims
+    from oracle import mpt_ref as MR
+    cspec = CR.ClapSpec(**TINY)
+    cw = CR.make_weights(cspec, seed=5)
+    mspec = MR.MptSpec(d_model=256, n_heads=2, n_layers=2, expansion_ratio=4, vocab_size=96, max_seq_len=128, mm_hidden_size=64,
+                       audio_start_token=93, audio_end_token=94, audio_patch_token=95)
+    mw = MR.make_weights(mspec, seed=7)
+    rng = np.random.default_rng(3)
+    waves = np.stack([CR.fit_length((rng.standard_normal(n) * 0.2).astype(np.float32)) for n in (90000, 480000)])
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 90, (2, 21), generator=g)
+    ids[:, 1], ids[:, 2], ids[:, 3] = 93, 95, 94
+    # oracle pipeline
+    feats = np.stack([CR.logmel(CR.quantize_roundtrip(w)) for w in waves]).astype(np.float32)
+    aud_ref = CR.forward(cw, cspec, torch.from_numpy(feats)[:, None]).unsqueeze(1)
+    ref = MR.forward(mw, mspec, ids, aud_ref)["logits"]
+    # HIP pipeline (embeddings stay on the GPU)
+    fe = ClapFrontend("cuda:0")
+    enc = HipClapAudioEncoder(cw, ClapDims(**TINY), "cuda:0")
+    aud = enc.embed(fe.logmel(torch.from_numpy(waves).cuda(), quantize_int16=True)).unsqueeze(1)
+    dims = MptDims(d_model=256, n_heads=2, n_layers=2, expansion_ratio=4, vocab_size=96, max_seq_len=128, mm_hidden_size=64)
+    eng = HipMptEngine(dims, "cuda", 2, 64, precision="split")
+    eng.load_state_dict(mw)
+    logits = eng.forward_tokens(ids.cuda(), [(b, 2, aud[b]) for b in range(2)]).cpu()
+    assert _rel(aud.cpu(), aud_ref) <= 1e-4
+    assert _rel(logits, ref) <= 1e-3, _rel(logits, ref)
+
+
+def test_embed_cli_writes_one_npy_per_wav(tmp_path):
+    """python -m llark_amd.clap.embed_cli (clap_embeddings.py's job): HTSAT-base-shaped checkpoint under laion names ->
+    <name>.npy of shape (1, 512), equal to the module called directly on the same clips."""
+    from scipy.io import wavfile
+    from clap_util import to_laion_names
+    from llark_amd.clap import HipClapModule, random_state_dict
+    from llark_amd.clap.embed_cli import main, read_wav_48k
+    sd = random_state_dict(seed=4)
+    torch.save({"state_dict": to_laion_names(sd)}, tmp_path / "ck.pt")
+    rng = np.random.default_rng(0)
+    (tmp_path / "in").mkdir()
+    wavfile.write(tmp_path / "in" / "x.wav", 48000, (rng.standard_normal(60000) * 4000).astype(np.int16))
+    wavfile.write(tmp_path / "in" / "y.wav", 48000, (rng.standard_normal(20000) * 0.1).astype(np.float32))
+    assert main(["--input-dir", str(tmp_path / "in"), "--output-dir", str(tmp_path / "out"), "--ckpt-file", str(tmp_path / "ck.pt"), "--batch-size", "2"]) == 0
+    m = HipClapModule(device="cuda:0")
+    m.load_state_dict(sd)
+    want = m.get_audio_embedding_from_data([read_wav_48k(str(tmp_path / "in" / n)) for n in ("x.wav", "y.wav")])
+    for i, n in enumerate(("x", "y")):
+        e = np.load(tmp_path / "out" / f"{n}.npy")
+        assert e.shape == (1, 512) and e.dtype == np.float32 and abs(np.linalg.norm(e) - 1) < 1e-5
+        assert np.abs(e[0] - want[i]).max() <= 1e-6

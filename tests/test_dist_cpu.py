@@ -87,6 +87,16 @@ def _grad_worker(rank, world, port, q):
     tr._start_layer_allreduce(0)
     tr.allreduce_grads(world, bucket_elems=128)
     assert torch.equal(tr.flat_grad, first), "overlapped exchange must reduce every element exactly once"
+    # bf16 on the links (the reference's bf16 DDP buckets): same coverage, values rounded to bf16 before the sum
+    tr.grad_comm = torch.bfloat16
+    base = torch.arange(1000, dtype=torch.float32) * 1.001
+    tr.flat_grad = base * (rank + 1)
+    tr._start_layer_allreduce(1)
+    tr.allreduce_grads(world, bucket_elems=128)
+    want = sum((base * (r + 1)).to(torch.bfloat16) for r in range(world)).float()
+    assert tr.flat_grad.dtype == torch.float32 and torch.equal(tr.flat_grad, want), "bf16 exchange: every element once, fp32 buffer"
+    tr.grad_comm = torch.float32
+    tr.flat_grad = first.clone()
     q.put((rank, tr.flat_grad.clone()))
     D.shutdown(world)
 
