@@ -117,7 +117,45 @@ def declared_symbols():
     return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy"])
 
 
+# ---- host-side launch lists -------------------------------------------------------------------------------------------
+# A fixed-shape forward is the same sequence of C-ABI calls with the same pointers every time.  While a recorder is
+# installed, lib() hands out a proxy that executes each call AND appends (function, name, args, timing label) to the
+# recorder; ops.LaunchList.replay() then re-issues the list without re-deriving shapes, views or pointers in Python
+# (the per-launch host cost drops from tens of microseconds to the ctypes call itself).  hipGraph replay of the same
+# sequences measured slower than eager launches on ROCm 7.2 (profiles/r01_gemm_ablation.txt), hence a host list.
+_recorder = None
+current_label = None          # (name, work) of the ops._timed region the next call belongs to
+
+
+class _RecordingProxy:
+    def __init__(self, real, rec):
+        self._real, self._rec = real, rec
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not name.startswith("llark_") or name == "llark_last_error":
+            return fn
+        rec = self._rec
+
+        def call(*args):
+            rc = fn(*args)
+            rec.append((fn, name, args, current_label))
+            return rc
+
+        return call
+
+
+def set_recorder(rec) -> None:
+    global _recorder
+    _recorder = rec
+
+
 def lib():
+    L = _real_lib()
+    return _RecordingProxy(L, _recorder) if _recorder is not None else L
+
+
+def _real_lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

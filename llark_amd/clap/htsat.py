@@ -13,6 +13,7 @@ Weights use the parameter names of ``transformers.ClapAudioModelWithProjection``
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -207,21 +208,38 @@ class HipClapAudioEncoder:
         self.norm = (f32(f"{e}.norm.weight"), f32(f"{e}.norm.bias"))
         self.proj1, self.proj2 = lin("audio_projection.linear1"), lin("audio_projection.linear2")
         self._taps = {}
+        self._arena: Dict[str, torch.Tensor] = {}
+        self._arena_version = 0
+        self._plans = {}
+        self.replay = os.environ.get("LLARK_CLAP_REPLAY", "1") != "0"
 
-    # ---- helpers ----
-    def _planes(self, rows: int, width: int, zero: bool = False):
-        mk = torch.zeros if zero else torch.empty
-        hi = mk((rows, width), dtype=torch.bfloat16, device=self.device)
-        return hi, (mk((rows, width), dtype=torch.bfloat16, device=self.device) if self.fp32 else None)
+    # ---- persistent workspaces + recorded launch lists ----
+    def _ws(self, name: str, shape, dtype) -> torch.Tensor:
+        """View of the persistent flat buffer `name` (grown on demand; growth invalidates recorded launch lists)."""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        buf = self._arena.get(name)
+        if buf is None or buf.numel() < n or buf.dtype != dtype:
+            buf = torch.empty(n, dtype=dtype, device=self.device)
+            self._arena[name] = buf
+            self._arena_version += 1
+        return buf[:n].view(*shape)
+
+    def _planes(self, name: str, rows: int, width: int, zero: bool = False):
+        hi = self._ws(name + "_hi", (rows, width), torch.bfloat16)
+        lo = self._ws(name + "_lo", (rows, width), torch.bfloat16) if self.fp32 else None
+        if zero:                                      # pad columns of a K < 32 operand: written once, never touched by the kernels
+            hi.zero_()
+            if lo is not None:
+                lo.zero_()
+        return hi, lo
 
     def _linear(self, a_hi, a_lo, lin: _Linear, c: torch.Tensor, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
         O.gemm16(a_hi, a_lo, lin.hi, lin.bias, lin.n, O.EPI_RESID if resid is not None else O.EPI_F32, c=c, resid=resid)
         if lin.lo is not None:
             O.gemm16(a_hi, None, lin.lo, None, lin.n, O.EPI_RESID, c=c, resid=c)
         return c
-
-    def _f32(self, rows: int, width: int) -> torch.Tensor:
-        return torch.empty((rows, width), dtype=torch.float32, device=self.device)
 
     def _time_taps(self, frames: int):
         if frames not in self._taps:
@@ -232,56 +250,78 @@ class HipClapAudioEncoder:
 
     # ---- forward ----
     def embed(self, input_features: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-        """input_features (B, 1, frames, mel) or (B, frames, mel) fp32 log-mel on the GPU -> (B, proj_dim) fp32."""
+        """input_features (B, 1, frames, mel) or (B, frames, mel) fp32 log-mel on the GPU -> (B, proj_dim) fp32.
+        The first call for a (B, frames) shape runs the layer loop and records its launches; later calls copy the input
+        into the persistent buffer and replay the list (``LLARK_CLAP_REPLAY=0`` always runs the loop)."""
         d = self.dims
         x = input_features
         if x.dim() == 4:
             x = x[:, 0]
         if x.dim() != 3 or x.shape[2] != d.mel_bins:
             raise ValueError(f"expected (B, [1,] frames, {d.mel_bins}) log-mel features, got {tuple(input_features.shape)}")
-        x = x.to(torch.float32).contiguous()
+        if not x.is_cuda:
+            raise O._lib.LlarkHipError("input_features: tensor must live on the GPU (there is no CPU fallback)")
         B, frames, _ = x.shape
-        tap_idx, tap_w = self._time_taps(frames)
+        tap_idx, tap_w = self._time_taps(frames)          # raises for frames > spec * freq_ratio, before anything is launched
+        key = (B, frames, bool(normalize))
+        plan = self._plans.get(key)
+        if plan is not None and plan[0] == self._arena_version and self.replay:
+            plan[1].copy_(x)
+            plan[2].replay()
+            return plan[3].clone()
+        x_in = self._ws("x_in", (B, frames, d.mel_bins), torch.float32)
+        x_in.copy_(x)
+        self._planes("patch", B * (d.spec_size // d.patch) ** 2, O.round_up(d.patch * d.patch, 32), zero=True)
+        self._planes("relu", B, O.round_up(self.proj1.n, 32), zero=True)
+        self._planes("pool", B, O.round_up(d.out_width, 32), zero=True)
+        with O.LaunchList.record() as ll:
+            out = self._forward(x_in, tap_idx, tap_w, normalize)
+        # a buffer's first use in a forward is its largest (token count x width halves per stage), so nothing recorded
+        # above points at a buffer that was regrown later in the same pass; any later growth bumps the version
+        self._plans[key] = (self._arena_version, x_in, ll, out)
+        return out.clone()
+
+    def _forward(self, x: torch.Tensor, tap_idx, tap_w, normalize: bool) -> torch.Tensor:
+        d = self.dims
+        B = x.shape[0]
         G = d.spec_size // d.patch
         rows, C = B * G * G, d.embed_dim
-        p_hi, p_lo = self._planes(rows, O.round_up(d.patch * d.patch, 32), zero=True)
+        p_hi, p_lo = self._planes("patch", rows, O.round_up(d.patch * d.patch, 32))
         O.clap_patchify(x, self.bn_mean, self.bn_scale, self.bn_bias, tap_idx, tap_w, d.spec_size, d.patch, p_hi, p_lo)
-        h = self._linear(p_hi, p_lo, self.patch_proj, self._f32(rows, C))
+        h = self._linear(p_hi, p_lo, self.patch_proj, self._ws("h0", (rows, C), torch.float32))
         O.layernorm_f32_(h, self.patch_norm[0], self.patch_norm[1], d.ln_eps)
         H = W = G
         for s, (blocks, down) in enumerate(self.stages):
             heads = d.heads[s]
             for b, blk in enumerate(blocks):
                 shift = d.window // 2 if (b % 2 == 1 and min(H, W) > d.window) else 0
-                a_hi, a_lo = self._planes(rows, C)
+                a_hi, a_lo = self._planes("act", rows, C)
                 O.layernorm_bf16(h, blk["ln1"][0], blk["ln1"][1], d.ln_eps, a_hi, a_lo)
-                qkv = self._linear(a_hi, a_lo, blk["qkv"], self._f32(rows, 3 * C))
+                qkv = self._linear(a_hi, a_lo, blk["qkv"], self._ws("qkv", (rows, 3 * C), torch.float32))
                 O.clap_window_attn(qkv, B, H, W, C, heads, d.window, shift, blk["bias_table"], a_hi, a_lo)     # planes reused for the context
-                del qkv
                 self._linear(a_hi, a_lo, blk["proj"], h, resid=h)
                 O.layernorm_bf16(h, blk["ln2"][0], blk["ln2"][1], d.ln_eps, a_hi, a_lo)
-                mid = self._linear(a_hi, a_lo, blk["fc1"], self._f32(rows, blk["fc1"].n))
-                m_hi, m_lo = self._planes(rows, blk["fc1"].n)
+                mid = self._linear(a_hi, a_lo, blk["fc1"], self._ws("mid", (rows, blk["fc1"].n), torch.float32))
+                m_hi, m_lo = self._planes("mlp", rows, blk["fc1"].n)
                 O.gelu_split_bf16(mid, m_hi, m_lo)
-                del mid
                 self._linear(m_hi, m_lo, blk["fc2"], h, resid=h)
-                del m_hi, m_lo, a_hi, a_lo
             if down is not None:
-                merged = self._f32(rows // 4, 4 * C)
+                merged = self._ws("qkv", (rows // 4, 4 * C), torch.float32)               # the qkv buffer is free between blocks
                 O.clap_patch_merge(h, B, H, W, merged)
                 rows, H, W = rows // 4, H // 2, W // 2
-                g_hi, g_lo = self._planes(rows, 4 * C)
+                g_hi, g_lo = self._planes("act", rows, 4 * C)
                 O.layernorm_bf16(merged, down["norm"][0], down["norm"][1], d.ln_eps, g_hi, g_lo)
                 C *= 2
-                h = self._linear(g_hi, g_lo, down["red"], self._f32(rows, C))
+                h = self._linear(g_hi, g_lo, down["red"], self._ws(f"h{(s + 1) % 2}", (rows, C), torch.float32))
         O.layernorm_f32_(h, self.norm[0], self.norm[1], d.ln_eps)
-        pooled = self._f32(B, C)
+        pooled = self._ws("pooled", (B, C), torch.float32)
         O.mean_rows_f32(h, B, pooled)
-        q_hi, q_lo = O.split16(pooled, torch.bfloat16, want_lo=self.fp32)
-        y = self._linear(q_hi, q_lo, self.proj1, self._f32(B, self.proj1.n))
-        r_hi, r_lo = self._planes(B, O.round_up(self.proj1.n, 32), zero=True)
+        q_hi, q_lo = self._planes("pool", B, O.round_up(C, 32))
+        O.split16_into(pooled, q_hi, q_lo)
+        y = self._linear(q_hi, q_lo, self.proj1, self._ws("proj1", (B, self.proj1.n), torch.float32))
+        r_hi, r_lo = self._planes("relu", B, O.round_up(self.proj1.n, 32))
         O.relu_split_bf16(y, r_hi, r_lo)
-        out = self._linear(r_hi, r_lo, self.proj2, self._f32(B, self.proj2.n))
+        out = self._linear(r_hi, r_lo, self.proj2, self._ws("out", (B, self.proj2.n), torch.float32))
         if normalize:
             O.l2_normalize_rows_(out)
         return out

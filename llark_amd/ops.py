@@ -51,15 +51,59 @@ class _timed:
         self.name, self.work = name, work
 
     def __enter__(self):
+        _lib.current_label = (self.name, self.work)
         if _TIMERS is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record(torch.cuda.current_stream())
 
     def __exit__(self, *exc):
+        _lib.current_label = None
         if _TIMERS is not None:
             self.b.record(torch.cuda.current_stream())
             _TIMERS.setdefault(self.name, []).append((self.a, self.b, self.work))
+
+
+class LaunchList:
+    """A recorded sequence of C-ABI launches (see _lib._RecordingProxy).  ``with LaunchList.record() as ll: forward()``
+    runs ``forward`` once and keeps its launches; ``ll.replay()`` re-issues them on the current stream.  Valid only while
+    every buffer the recorded calls point at is alive and unmoved: the owner keeps them (persistent workspaces)."""
+
+    def __init__(self):
+        self.calls = []
+        self.stream = None
+
+    class _Rec:
+        def __init__(self, ll):
+            self.ll = ll
+
+        def __enter__(self):
+            if _lib._recorder is not None:
+                raise RuntimeError("LaunchList.record() does not nest")
+            self.ll.stream = _stream()
+            _lib.set_recorder(self.ll.calls)
+            return self.ll
+
+        def __exit__(self, *exc):
+            _lib.set_recorder(None)
+
+    @classmethod
+    def record(cls):
+        return cls._Rec(cls())
+
+    def replay(self) -> None:
+        s_now, s_rec = _stream(), self.stream
+        timing = _TIMERS is not None
+        for fn, name, args, label in self.calls:
+            if args and args[-1] == s_rec and s_now != s_rec:
+                args = args[:-1] + (s_now,)
+            if timing and label is not None:
+                with _timed(label[0], label[1]):
+                    rc = fn(*args)
+            else:
+                rc = fn(*args)
+            if rc:
+                check(rc, name)
 
 
 def _stream() -> int:
@@ -665,3 +709,10 @@ def clap_logmel(wav: torch.Tensor, window: torch.Tensor, twiddle: torch.Tensor, 
                                            _dev(mel_lo, "mel_lo", torch.int32), _dev(mel_hi, "mel_hi", torch.int32),
                                            _dev(out, "out", torch.float32), _stream()), "clap_logmel")
     return out
+
+
+def split16_into(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor]) -> None:
+    """split16 into caller-owned planes (row stride hi.stride(0) >= width; pad columns are the caller's to zero)."""
+    rows, width = x.shape
+    check(_lib.lib().llark_split16(_DT[hi.dtype], _dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(hi, "hi"),
+                                   _opt(lo, "lo", hi.dtype), hi.stride(0), _stream()), "split16")

@@ -9,3 +9,4 @@ timeout 600 python bench.py --stages train --no-cpu-baseline > gpurun_out/bench_
 timeout 600 python bench.py --stages generate --no-cpu-baseline > gpurun_out/bench_generate_b1.log 2>&1; echo "gen exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"decode_ms_per_token": [0-9.]*' gpurun_out/bench_generate_b1.log | tr '\n' ' ')"
 timeout 600 python bench.py --stages jukebox --no-cpu-baseline > gpurun_out/bench_jukebox.log 2>&1; echo "jukebox exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_jukebox.log | tr '\n' ' ')"
 timeout 600 python bench.py --stages mpt > gpurun_out/bench_mpt.log 2>&1; echo "mpt exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_mpt.log | tr '\n' ' ')"
+timeout 600 python bench.py --stages clap --no-cpu-baseline > gpurun_out/bench_clap.log 2>&1; echo "clap exit $?: $(grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_clap.log | tr '\n' ' ')"

@@ -204,7 +204,7 @@ def test_config5_clap_into_mpt_matches_oracle_pipeline():
     dims = MptDims(d_model=256, n_heads=2, n_layers=2, expansion_ratio=4, vocab_size=96, max_seq_len=128, mm_hidden_size=64)
     eng = HipMptEngine(dims, "cuda", 2, 64, precision="split")
     eng.load_state_dict(mw)
-    logits = eng.forward_tokens(ids.cuda(), [(b, 2, aud[b]) for b in range(2)]).cpu()
+    logits = eng.forward_tokens(ids.cuda(), [(b, 1, aud[b]) for b in range(2)]).cpu()      # (clip, index of the start token, frames)
     assert _rel(aud.cpu(), aud_ref) <= 1e-4
     assert _rel(logits, ref) <= 1e-3, _rel(logits, ref)
 
@@ -230,3 +230,25 @@ def test_embed_cli_writes_one_npy_per_wav(tmp_path):
         e = np.load(tmp_path / "out" / f"{n}.npy")
         assert e.shape == (1, 512) and e.dtype == np.float32 and abs(np.linalg.norm(e) - 1) < 1e-5
         assert np.abs(e[0] - want[i]).max() <= 1e-6
+
+
+def test_recorded_launch_list_replay_is_bit_identical_and_survives_shape_changes():
+    """embed() records its launches on the first call per (batch, frames) and replays them afterwards: replays equal the
+    recorded pass bit for bit, follow the input (no stale buffers), and a later, larger batch (workspaces regrow) neither
+    breaks older shapes nor reuses their stale lists."""
+    spec, w, eng = _engine(TINY, 5)
+    g = torch.Generator().manual_seed(8)
+    xa = (torch.randn(2, 1, 1001, 64, generator=g) * 20 - 30).cuda()
+    xb = (torch.randn(2, 1, 1001, 64, generator=g) * 20 - 30).cuda()
+    first = eng.embed(xa).cpu()                                   # records
+    assert len(eng._plans) == 1
+    assert torch.equal(eng.embed(xa).cpu(), first)                # replays
+    rb = eng.embed(xb).cpu()
+    assert not torch.equal(rb, first) and _rel(rb, CR.forward(w, spec, xb.cpu())) <= 1e-4
+    x5 = (torch.randn(5, 1, 700, 64, generator=g) * 20 - 30).cuda()
+    r5 = eng.embed(x5).cpu()                                      # bigger batch: workspaces regrow, version bumps
+    assert _rel(r5, CR.forward(w, spec, x5.cpu())) <= 1e-4
+    assert torch.equal(eng.embed(xa).cpu(), first)                # old shape re-records against the new buffers
+    assert torch.equal(eng.embed(xa).cpu(), first) and torch.equal(eng.embed(x5).cpu(), r5)
+    eng.replay = False
+    assert torch.equal(eng.embed(xa).cpu(), first)                # the plain layer loop gives the same bits
