@@ -226,7 +226,17 @@ int llark_clap_patchify(const float* x, int batch, int frames, int mel, const fl
                         const float* bn_bias, const int* tap_idx, const float* tap_w, int spec, int patch, void* out_hi,
                         void* out_lo, int ldo, llark_stream_t stream);
 int llark_clap_window_attn(const float* qkv, int ldq, int batch, int H, int W, int C, int heads, int window, int shift,
-                           const float* bias_table, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+                           const float* bias_table, void* out_hi, void* out_lo, void* out_hi_dup, int ldo, llark_stream_t stream);
+/* fp32-class linears over fp32 checkpoint weights W = W_hi + W_lo as ONE launch: the producer writes the activation as a
+ * K-concatenated [hi | lo | hi] operand (out_hi_dup = second copy of the hi plane, same row stride) and the product runs
+ * non-split against [W_hi | W_hi | W_lo].  layernorm_bf16_dup / window_attn (above) / gemm16_act are the producers;
+ * gemm16_act is a GEMM whose epilogue is acc + bias -> optional exact (erf) GELU (act = 2) -> 16-bit planes
+ * (epilogue LLARK_EPI_SPLIT16 or LLARK_EPI_OUT16), i.e. fc1 + GELU of a transformer MLP without the fp32 round trip. */
+int llark_layernorm_bf16_dup(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                             void* out_hi, void* out_lo, void* out_hi_dup, int ldo, llark_stream_t stream);
+int llark_gemm16_act(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt,
+                     int ldw, const float* bias, int m, int n, int kp, void* out_hi, void* out_lo, void* out_hi_dup, int ldo,
+                     int act, llark_stream_t stream);
 int llark_clap_patch_merge(const float* x, int ldx, int batch, int H, int W, int C, float* out, int ldo, llark_stream_t stream);
 int llark_mean_rows_f32(const float* x, int ldx, int batch, int L, int C, float* out, int ldo, llark_stream_t stream);
 int llark_relu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);

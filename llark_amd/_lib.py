@@ -85,7 +85,9 @@ _SIGS = {
     "llark_causal_softmax_rows_alibi": [_P, c_int, c_int, c_float, _P, c_int, _P, c_int, _P],
     "llark_clap_logmel": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P],
     "llark_clap_patchify": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P],
-    "llark_clap_window_attn": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P],
+    "llark_clap_window_attn": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P],
+    "llark_layernorm_bf16_dup": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, c_int, _P],
+    "llark_gemm16_act": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P],
     "llark_clap_patch_merge": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_mean_rows_f32": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_relu_split_bf16": [_P, c_int, c_int, c_int, _P, _P, c_int, _P],

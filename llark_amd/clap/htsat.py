@@ -162,6 +162,8 @@ class _Linear:
         self.hi = O.pack_weight16(w, False, torch.bfloat16)
         self.lo = O.pack_weight16((w - self.hi[:, :self.k].float()).contiguous(), False, torch.bfloat16) if fp32 else None
         self.bias = b.to(device=device, dtype=torch.float32).contiguous() if b is not None else None
+        # fp32-class product in ONE launch: [A_hi | A_lo | A_hi] . [W_hi | W_hi | W_lo]^T (K-concatenated, non-split kernel)
+        self.w3 = torch.cat([self.hi, self.hi, self.lo], dim=1).contiguous() if fp32 else None
 
 
 class HipClapAudioEncoder:
@@ -212,6 +214,8 @@ class HipClapAudioEncoder:
         self._arena_version = 0
         self._plans = {}
         self.replay = os.environ.get("LLARK_CLAP_REPLAY", "1") != "0"
+        self.kcat = self.fp32 and os.environ.get("LLARK_CLAP_KCAT", "1") != "0"        # one-launch linears (see _Linear.w3)
+        self.fuse_gelu = os.environ.get("LLARK_CLAP_FUSE_GELU", "1") != "0"           # exact GELU in the fc1 epilogue
 
     # ---- persistent workspaces + recorded launch lists ----
     def _ws(self, name: str, shape, dtype) -> torch.Tensor:
@@ -295,24 +299,53 @@ class HipClapAudioEncoder:
             heads = d.heads[s]
             for b, blk in enumerate(blocks):
                 shift = d.window // 2 if (b % 2 == 1 and min(H, W) > d.window) else 0
+                M = blk["fc1"].n
+                if self.kcat:
+                    a3 = self._ws("act3", (rows, 3 * C), torch.bfloat16)
+                    a_hi, a_lo, a_dup = a3[:, :C], a3[:, C:2 * C], a3[:, 2 * C:]
+                    m3 = self._ws("mlp3", (rows, 3 * M), torch.bfloat16)
+                    O.layernorm_bf16_dup(h, blk["ln1"][0], blk["ln1"][1], d.ln_eps, a_hi, a_lo, a_dup)
+                    qkv = self._ws("qkv", (rows, 3 * C), torch.float32)
+                    O.gemm16(a3, None, blk["qkv"].w3, blk["qkv"].bias, 3 * C, O.EPI_F32, c=qkv)
+                    O.clap_window_attn(qkv, B, H, W, C, heads, d.window, shift, blk["bias_table"], a_hi, a_lo, a_dup)
+                    O.gemm16(a3, None, blk["proj"].w3, blk["proj"].bias, C, O.EPI_RESID, c=h, resid=h)
+                    O.layernorm_bf16_dup(h, blk["ln2"][0], blk["ln2"][1], d.ln_eps, a_hi, a_lo, a_dup)
+                    if self.fuse_gelu:
+                        O.gemm16_act(a3, None, blk["fc1"].w3, blk["fc1"].bias, M, m3[:, :M], m3[:, M:2 * M], m3[:, 2 * M:], act=2)
+                    else:
+                        mid = self._ws("mid", (rows, M), torch.float32)
+                        O.gemm16(a3, None, blk["fc1"].w3, blk["fc1"].bias, M, O.EPI_F32, c=mid)
+                        O.gelu_split_bf16(mid, m3[:, :M], m3[:, M:2 * M])
+                        m3[:, 2 * M:].copy_(m3[:, :M])
+                    O.gemm16(m3, None, blk["fc2"].w3, blk["fc2"].bias, C, O.EPI_RESID, c=h, resid=h)
+                    continue
                 a_hi, a_lo = self._planes("act", rows, C)
                 O.layernorm_bf16(h, blk["ln1"][0], blk["ln1"][1], d.ln_eps, a_hi, a_lo)
                 qkv = self._linear(a_hi, a_lo, blk["qkv"], self._ws("qkv", (rows, 3 * C), torch.float32))
                 O.clap_window_attn(qkv, B, H, W, C, heads, d.window, shift, blk["bias_table"], a_hi, a_lo)     # planes reused for the context
                 self._linear(a_hi, a_lo, blk["proj"], h, resid=h)
                 O.layernorm_bf16(h, blk["ln2"][0], blk["ln2"][1], d.ln_eps, a_hi, a_lo)
-                mid = self._linear(a_hi, a_lo, blk["fc1"], self._ws("mid", (rows, blk["fc1"].n), torch.float32))
-                m_hi, m_lo = self._planes("mlp", rows, blk["fc1"].n)
-                O.gelu_split_bf16(mid, m_hi, m_lo)
+                m_hi, m_lo = self._planes("mlp", rows, M)
+                if self.fuse_gelu and not self.fp32:
+                    O.gemm16_act(a_hi, None, blk["fc1"].hi, blk["fc1"].bias, M, m_hi, act=2)
+                else:
+                    mid = self._linear(a_hi, a_lo, blk["fc1"], self._ws("mid", (rows, M), torch.float32))
+                    O.gelu_split_bf16(mid, m_hi, m_lo)
                 self._linear(m_hi, m_lo, blk["fc2"], h, resid=h)
             if down is not None:
                 merged = self._ws("qkv", (rows // 4, 4 * C), torch.float32)               # the qkv buffer is free between blocks
                 O.clap_patch_merge(h, B, H, W, merged)
                 rows, H, W = rows // 4, H // 2, W // 2
-                g_hi, g_lo = self._planes("act", rows, 4 * C)
-                O.layernorm_bf16(merged, down["norm"][0], down["norm"][1], d.ln_eps, g_hi, g_lo)
-                C *= 2
-                h = self._linear(g_hi, g_lo, down["red"], self._ws(f"h{(s + 1) % 2}", (rows, C), torch.float32))
+                h_new = self._ws(f"h{(s + 1) % 2}", (rows, 2 * C), torch.float32)
+                if self.kcat:
+                    g3 = self._ws("act3", (rows, 12 * C), torch.bfloat16)
+                    O.layernorm_bf16_dup(merged, down["norm"][0], down["norm"][1], d.ln_eps, g3[:, :4 * C], g3[:, 4 * C:8 * C], g3[:, 8 * C:])
+                    O.gemm16(g3, None, down["red"].w3, None, 2 * C, O.EPI_F32, c=h_new)
+                else:
+                    g_hi, g_lo = self._planes("act", rows, 4 * C)
+                    O.layernorm_bf16(merged, down["norm"][0], down["norm"][1], d.ln_eps, g_hi, g_lo)
+                    self._linear(g_hi, g_lo, down["red"], h_new)
+                h, C = h_new, 2 * C
         O.layernorm_f32_(h, self.norm[0], self.norm[1], d.ln_eps)
         pooled = self._ws("pooled", (B, C), torch.float32)
         O.mean_rows_f32(h, B, pooled)

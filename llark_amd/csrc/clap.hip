@@ -42,8 +42,8 @@ __global__ void clap_patchify_kernel(const float* __restrict__ x, int T, int mel
 template <int HD>
 __global__ __launch_bounds__(256) void clap_window_attn_kernel(const float* __restrict__ qkv, int ldq, int C, int heads, int H, int W,
                                                                int shift, const float* __restrict__ bias_table,
-                                                               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo, int ldo,
-                                                               int units) {
+                                                               bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                               bf16_t* __restrict__ out_hi2, int ldo, int units) {
     __shared__ float sk[4][64 * HD];
     __shared__ float sv[4][64 * HD];
     __shared__ float sb[4][232];
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void clap_window_attn_kernel(const float* __re
         }
         *(bf16x4_t*)(out_hi + mytok * ldo + head * HD + c4 * 4) = h;
         if (out_lo) *(bf16x4_t*)(out_lo + mytok * ldo + head * HD + c4 * 4) = l;
+        if (out_hi2) *(bf16x4_t*)(out_hi2 + mytok * ldo + head * HD + c4 * 4) = h;
     }
 }
 
@@ -255,7 +256,8 @@ extern "C" int llark_clap_patchify(const float* x, int batch, int frames, int me
 }
 
 extern "C" int llark_clap_window_attn(const float* qkv, int ldq, int batch, int H, int W, int C, int heads, int window, int shift,
-                                      const float* bias_table, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+                                      const float* bias_table, void* out_hi, void* out_lo, void* out_hi_dup, int ldo,
+                                      llark_stream_t stream) {
     LLARK_REQUIRE(qkv && bias_table && out_hi, "clap_window_attn: null pointer");
     LLARK_REQUIRE(window == 8, "clap_window_attn: window %d unsupported (the kernel maps one 8x8 window to one 64-lane wave)", window);
     LLARK_REQUIRE(batch > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0 && heads > 0 && C % heads == 0 && ldq >= 3 * C && ldq % 4 == 0 &&
@@ -268,7 +270,7 @@ extern "C" int llark_clap_window_attn(const float* qkv, int ldq, int batch, int 
     const int units = (int)units_l;
     dim3 grid(cdiv(units, 4));
     hipStream_t s = (hipStream_t)stream;
-#define WA_CASE(HD) clap_window_attn_kernel<HD><<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo, units)
+#define WA_CASE(HD) clap_window_attn_kernel<HD><<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo, (bf16_t*)out_hi_dup, ldo, units)
     if (hd == 32) WA_CASE(32);
     else if (hd == 16) WA_CASE(16);
     else {

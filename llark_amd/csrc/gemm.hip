@@ -67,6 +67,8 @@ struct GemmParams {
     void* Ohi;         // 16-bit outputs
     void* Olo;
     int ldo;
+    void* Ohi2;        // EPI_SPLIT16 only: optional second copy of the hi plane (K-concatenated [hi | lo | hi] operands)
+    int act;           // EPI_SPLIT16 / EPI_OUT16: 0 = none, 2 = exact (erf) GELU applied to acc + bias before the split
     int tiles_m, tiles_n;
     // batched mode (grid.y = batch): element strides added per batch index; 0 = operand shared by all batches
     int batch;
@@ -135,6 +137,7 @@ __device__ __forceinline__ float fast_sigmoid_mul(float x, float a) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float quick_gelu(float x) { return fast_sigmoid_mul(x, 1.702f); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
 
 // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Shared by every main-loop variant.
@@ -167,6 +170,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     }
     if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
         rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t rH2;
+    const bool dup_hi = EPI == EPI_SPLIT16 && p.Ohi2 != nullptr;
+    if (EPI == EPI_SPLIT16)
+        rH2 = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)(dup_hi ? p.Ohi2 : p.Ohi) + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const bool act_erf = (EPI == EPI_SPLIT16 || EPI == EPI_OUT16) && p.act == 2;
 
     auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -209,12 +217,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[tn][r] + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
                     } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
                         if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
+                        if (EPI == EPI_SPLIT16 && act_erf) v = gelu_erf(v);
                         const T hi = Mfma<T>::cvt(v);
                         const T lo = Mfma<T>::cvt(v - Mfma<T>::back(hi));
                         const int so = (ml * p.ldo + ocl) * 2;
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
+                        if (EPI == EPI_SPLIT16 && dup_hi) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH2, vO, so, 0);
                     } else if (EPI == EPI_OUT16) {
+                        if (act_erf) v = gelu_erf(v);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
                                                               (ml * p.ldo + ocl) * 2, 0);
                     } else if (EPI == EPI_SWIGLU16) {
@@ -972,7 +983,8 @@ static int pick_variant(int split, int m, int n, int kp) {
 static int gemm16_impl(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
                        const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, int batch, long long sa,
-                       long long sw, long long sc, long long sr, long long so, llark_stream_t stream) {
+                       long long sw, long long sc, long long sr, long long so, llark_stream_t stream, void* out_hi2 = nullptr,
+                       int act = 0) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
     LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant < 10),
                   "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
@@ -989,11 +1001,11 @@ static int gemm16_impl(int variant, int dtype, int split, int epilogue, const vo
     GemmParams p = {};
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
-    p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo; p.Ohi2 = out_hi2; p.act = act;
     p.tiles_m = p.tiles_n = 0;
     p.batch = batch; p.sA = sa; p.sW = sw; p.sC = sc; p.sR = sr; p.sO = so;
     hipStream_t s = (hipStream_t)stream;
-    if (variant < 0 && m <= 16 && batch <= 1) {   // decode: HBM-bound skinny kernel
+    if (variant < 0 && m <= 16 && batch <= 1 && act == 0 && !out_hi2) {   // decode: HBM-bound skinny kernel
         int rc = 1;
         if (dtype == LLARK_F16) rc = dispatch_skinny<half_t>(p, split != 0, epilogue, s);
         else if (dtype == LLARK_BF16) rc = dispatch_skinny<bf16_t>(p, split != 0, epilogue, s);
@@ -1012,6 +1024,19 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
                                llark_stream_t stream) {
     return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
                        out_lo, ldo, 0, 0, 0, 0, 0, 0, stream);
+}
+
+// acc + bias -> (exact GELU) -> 16-bit planes, optionally with a second copy of the hi plane: the producer side of a
+// K-concatenated [hi | lo | hi] operand (A.W for fp32-class W = W_hi + W_lo as ONE non-split product against
+// [W_hi | W_hi | W_lo]: the HTSAT linears of csrc/clap.hip's callers).
+extern "C" int llark_gemm16_act(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                                const void* wt, int ldw, const float* bias, int m, int n, int kp, void* out_hi, void* out_lo,
+                                void* out_hi_dup, int ldo, int act, llark_stream_t stream) {
+    LLARK_REQUIRE(epilogue == EPI_SPLIT16 || epilogue == EPI_OUT16, "gemm16_act: epilogue must be SPLIT16 or OUT16");
+    LLARK_REQUIRE(act == 0 || act == 2, "gemm16_act: act must be 0 (none) or 2 (exact GELU)");
+    LLARK_REQUIRE(!out_hi_dup || epilogue == EPI_SPLIT16, "gemm16_act: the duplicate hi plane belongs to the SPLIT16 epilogue");
+    return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, nullptr, 0, nullptr, 0, out_hi,
+                       out_lo, ldo, 0, 0, 0, 0, 0, 0, stream, out_hi_dup, act);
 }
 
 extern "C" int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, llark_stream_t stream) {

@@ -14,7 +14,7 @@ template <int NV, bool OUT16>
 __global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restrict__ x, int ldx, int rows, int width,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
-                                                            float* __restrict__ y32, int ldo) {
+                                                            float* __restrict__ y32, int ldo, bf16_t* __restrict__ hi2 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restr
                 }
                 ((bf16x4_t*)(hi + (size_t)row * ldo))[c] = h;
                 if (lo) ((bf16x4_t*)(lo + (size_t)row * ldo))[c] = l;
+                if (hi2) ((bf16x4_t*)(hi2 + (size_t)row * ldo))[c] = h;
             } else {
                 ((float4*)(y32 + (size_t)row * ldo))[c] = make_float4(y[0], y[1], y[2], y[3]);
             }
@@ -208,10 +209,10 @@ using namespace llark;
 
 template <bool OUT16>
 static int launch_mpt_ln(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps, void* hi,
-                         void* lo, float* y32, int ldo, hipStream_t s) {
+                         void* lo, float* y32, int ldo, hipStream_t s, void* hi2 = nullptr) {
     const int w4 = width / 4;
     dim3 grid(cdiv(rows, 4));
-#define LN_CASE(NV) mpt_layernorm_kernel<NV, OUT16><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (bf16_t*)hi, (bf16_t*)lo, y32, ldo)
+#define LN_CASE(NV) mpt_layernorm_kernel<NV, OUT16><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (bf16_t*)hi, (bf16_t*)lo, y32, ldo, (bf16_t*)hi2)
     if (w4 <= 64) LN_CASE(1);
     else if (w4 <= 256) LN_CASE(4);
     else if (w4 <= 512) LN_CASE(8);
@@ -231,6 +232,15 @@ extern "C" int llark_layernorm_bf16(const float* x, int ldx, int rows, int width
     LLARK_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width && ldx >= width,
                   "layernorm_bf16: bad shape rows=%d width=%d ldx=%d ldo=%d", rows, width, ldx, ldo);
     return launch_mpt_ln<true>(x, ldx, rows, width, gamma, beta, eps, out_hi, out_lo, nullptr, ldo, (hipStream_t)stream);
+}
+
+// LayerNorm to a K-concatenated [hi | lo | hi] operand (see llark_gemm16_act): out_hi_dup receives a second copy of hi.
+extern "C" int llark_layernorm_bf16_dup(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                                        void* out_hi, void* out_lo, void* out_hi_dup, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && gamma && out_hi && out_lo && out_hi_dup, "layernorm_bf16_dup: null pointer");
+    LLARK_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width && ldx >= width,
+                  "layernorm_bf16_dup: bad shape rows=%d width=%d ldx=%d ldo=%d", rows, width, ldx, ldo);
+    return launch_mpt_ln<true>(x, ldx, rows, width, gamma, beta, eps, out_hi, out_lo, nullptr, ldo, (hipStream_t)stream, out_hi_dup);
 }
 
 extern "C" int llark_layernorm_f32(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,

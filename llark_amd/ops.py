@@ -510,8 +510,8 @@ def scale_f32_(x: torch.Tensor, a: float) -> None:
 def gelu_split_bf16(x: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None) -> None:
     rows, width = x.shape
     bf = torch.bfloat16
-    check(_lib.lib().llark_gelu_split_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(out_hi, "out_hi", bf),
-                                           _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "gelu_split_bf16")
+    check(_lib.lib().llark_gelu_split_bf16(_dev(x, "x", torch.float32), x.stride(0), rows, width, _plane(out_hi, "out_hi"),
+                                           _plane(out_lo, "out_lo", out_hi), out_hi.stride(0), _stream()), "gelu_split_bf16")
 
 
 def cross_entropy_shifted(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
@@ -659,15 +659,54 @@ def clap_patchify(x: torch.Tensor, bn_mean: torch.Tensor, bn_scale: torch.Tensor
           "clap_patchify")
 
 
+def _plane(t: Optional[torch.Tensor], name: str, like: Optional[torch.Tensor] = None):
+    """Pointer of a 2-D bf16 plane that may be a column block of a wider buffer (unit column stride, any row stride)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.LlarkHipError(f"{name}: tensor must live on the GPU (there is no CPU fallback)")
+    if t.dtype != torch.bfloat16 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError(f"{name}: expected a 2-D bf16 plane with unit column stride")
+    if like is not None and (t.stride(0) != like.stride(0) or t.shape != like.shape):
+        raise ValueError(f"{name}: planes of one operand must share shape and row stride")
+    return t.data_ptr()
+
+
 def clap_window_attn(qkv: torch.Tensor, batch: int, H: int, W: int, C: int, heads: int, window: int, shift: int,
-                     bias_table: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor]) -> None:
+                     bias_table: torch.Tensor, out_hi: torch.Tensor, out_lo: Optional[torch.Tensor],
+                     out_hi_dup: Optional[torch.Tensor] = None) -> None:
     """Swin window attention on a (batch, H, W) token map; qkv fp32 [batch*H*W][3C] in token order."""
-    assert qkv.shape == (batch * H * W, 3 * C) and bias_table.shape == ((2 * window - 1) ** 2, heads) and out_hi.shape[0] == batch * H * W
-    bf = torch.bfloat16
+    assert qkv.shape == (batch * H * W, 3 * C) and bias_table.shape == ((2 * window - 1) ** 2, heads) and out_hi.shape == (batch * H * W, C)
     with _timed("clap_window_attn", 4.0 * batch * H * W * window * window * C):
         check(_lib.lib().llark_clap_window_attn(_dev(qkv, "qkv", torch.float32), qkv.stride(0), batch, H, W, C, heads, window, shift,
-                                                _dev(bias_table, "bias_table", torch.float32), _dev(out_hi, "out_hi", bf),
-                                                _opt(out_lo, "out_lo", bf), out_hi.stride(0), _stream()), "clap_window_attn")
+                                                _dev(bias_table, "bias_table", torch.float32), _plane(out_hi, "out_hi"),
+                                                _plane(out_lo, "out_lo", out_hi), _plane(out_hi_dup, "out_hi_dup", out_hi),
+                                                out_hi.stride(0), _stream()), "clap_window_attn")
+
+
+def layernorm_bf16_dup(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float, out_hi: torch.Tensor,
+                       out_lo: torch.Tensor, out_hi_dup: torch.Tensor) -> None:
+    """LayerNorm -> the three column blocks [hi | lo | hi] of a K-concatenated operand (see gemm16_act)."""
+    rows, width = x.shape
+    check(_lib.lib().llark_layernorm_bf16_dup(_dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(gamma, "gamma", torch.float32),
+                                              _opt(beta, "beta", torch.float32), float(eps), _plane(out_hi, "out_hi"),
+                                              _plane(out_lo, "out_lo", out_hi), _plane(out_hi_dup, "out_hi_dup", out_hi),
+                                              out_hi.stride(0), _stream()), "layernorm_bf16_dup")
+
+
+def gemm16_act(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], n: int,
+               out_hi: torch.Tensor, out_lo: Optional[torch.Tensor] = None, out_hi_dup: Optional[torch.Tensor] = None,
+               act: int = 0, variant: int = -1) -> None:
+    """(a_hi [+ a_lo]) . wt^T + bias -> optional exact GELU (act=2) -> bf16 planes (hi, or hi + lo [+ a second hi])."""
+    bf = torch.bfloat16
+    m, kp = a_hi.shape[0], wt.shape[1]
+    assert a_hi.shape[1] >= kp and wt.shape[0] >= n and out_hi.shape == (m, n)
+    epi = EPI_SPLIT16 if out_lo is not None else EPI_OUT16
+    with _timed("gemm_split_bf16" if a_lo is not None else "gemm_bf16", 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_act(variant, BF16, int(a_lo is not None), epi, _dev(a_hi, "a_hi", bf), _opt(a_lo, "a_lo", bf),
+                                          a_hi.stride(0), _dev(wt, "wt", bf), wt.stride(0), _opt(bias, "bias", torch.float32), m, n, kp,
+                                          _plane(out_hi, "out_hi"), _plane(out_lo, "out_lo", out_hi),
+                                          _plane(out_hi_dup, "out_hi_dup", out_hi), out_hi.stride(0), act, _stream()), "gemm16_act")
 
 
 def clap_patch_merge(x: torch.Tensor, batch: int, H: int, W: int, out: torch.Tensor) -> None:

@@ -252,3 +252,42 @@ def test_recorded_launch_list_replay_is_bit_identical_and_survives_shape_changes
     assert torch.equal(eng.embed(xa).cpu(), first) and torch.equal(eng.embed(x5).cpu(), r5)
     eng.replay = False
     assert torch.equal(eng.embed(xa).cpu(), first)                # the plain layer loop gives the same bits
+
+
+def test_gemm_act_epilogue_and_duplicate_plane():
+    """llark_gemm16_act: acc + bias -> exact GELU -> bf16 hi / lo (+ second hi copy written into a wider buffer) against
+    torch fp32, both the split (hi + lo) and the single-plane (OUT16) forms; M large enough for the persistent tile path too."""
+    from llark_amd import ops as O
+    g = torch.Generator().manual_seed(1)
+    for m, n, k in ((300, 96, 64), (20000, 256, 128)):
+        a = torch.randn(m, k, generator=g).cuda()
+        w = (torch.randn(n, k, generator=g) * 0.2).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        a_hi, a_lo = O.split16(a, torch.bfloat16)
+        wt = O.pack_weight16(w, False, torch.bfloat16)
+        ref = torch.nn.functional.gelu((a_hi.float() + a_lo.float()).double() @ wt.float().double().t() + bias.double())
+        out3 = torch.zeros(m, 3 * n, dtype=torch.bfloat16, device="cuda")
+        O.gemm16_act(a_hi, a_lo, wt, bias, n, out3[:, :n], out3[:, n:2 * n], out3[:, 2 * n:], act=2)
+        got = out3[:, :n].float() + out3[:, n:2 * n].float()
+        assert torch.equal(out3[:, 2 * n:], out3[:, :n])
+        assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        one = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+        O.gemm16_act(a_hi, None, wt, bias, n, one, act=2)
+        ref1 = torch.nn.functional.gelu(a_hi.float().double() @ wt.float().double().t() + bias.double())
+        assert (one.double() - ref1).abs().max().item() <= 6e-3 * ref1.abs().max().item()
+        plain = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+        O.gemm16_act(a_hi, None, wt, bias, n, plain, act=0)
+        assert (plain.double() - (a_hi.float().double() @ wt.float().double().t() + bias.double())).abs().max().item() <= 6e-3 * ref1.abs().max().item() + 0.05
+
+
+@pytest.mark.parametrize("kcat,fuse", [("0", "1"), ("1", "0"), ("1", "1")])
+def test_linear_forms_agree_with_oracle(monkeypatch, kcat, fuse):
+    """The two-launch (split + W_lo correction) and one-launch (K-concatenated) linears, with and without the fused GELU
+    epilogue, all meet the fp32-class bar."""
+    monkeypatch.setenv("LLARK_CLAP_KCAT", kcat)
+    monkeypatch.setenv("LLARK_CLAP_FUSE_GELU", fuse)
+    spec, w, eng = _engine(TINY, 5)
+    assert eng.kcat == (kcat == "1")
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 1, 1001, 64, generator=g) * 20 - 30
+    assert _rel(eng.embed(x.cuda()).cpu(), CR.forward(w, spec, x)) <= 1e-4
