@@ -8,6 +8,8 @@
 //     kernel, so q/k/v are read straight from the fused-qkv GEMM output in token order and nothing is permuted in HBM;
 //   * patch merging gather, token mean, ReLU -> planes and the final L2 normalisation.
 // All of it is HBM-bound gather / row work (a few MB per clip); the kernels keep accesses 16-byte wide and coalesced.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace llark {
@@ -194,6 +196,130 @@ __global__ __launch_bounds__(256) void clap_logmel_kernel(const float* __restric
     }
 }
 
+// MFMA form of the same attention (head_dim 32): still one wave per (clip, window, head), but both products run on the fp32
+// matrix pipe (v_mfma_f32_32x32x2f32: exact fp32 products, no operand split) and nothing but the bias table and the 64
+// token indices goes through LDS.  S^T = K . Q^T is computed instead of S so that the accumulator layout (lane = query,
+// registers = keys) is already the A-operand layout of P . V: the k index of an MFMA may be permuted freely as long as both
+// operands agree, so the key order the accumulators happen to hold (4g + (r & 3) + 8 (r >> 2)) is simply the order in which
+// V rows are fetched.  Per unit: 128 MFMAs (8192 cycles), 24 KB of q/k/v read with 128-byte row segments, 12 KB written.
+__global__ __launch_bounds__(256) void clap_window_attn_mfma_kernel(const float* __restrict__ qkv, int ldq, int C, int heads, int H, int W,
+                                                                    int shift, const float* __restrict__ bias_table,
+                                                                    bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                                    bf16_t* __restrict__ out_hi2, int ldo, int units) {
+    constexpr int HD = 32;
+    __shared__ float sb[4][232];
+    __shared__ int stok[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l32 = lane & 31, g = lane >> 5;
+    const int unit_raw = blockIdx.x * 4 + wv;
+    const bool live = unit_raw < units;
+    const int unit = live ? unit_raw : units - 1;
+    const int nWw = W >> 3, nW = (H >> 3) * nWw;
+    const int head = unit % heads, win = (unit / heads) % nW, b = unit / (heads * nW);
+    const int wh = win / nWw, ww = win % nWw;
+    {
+        int ho = wh * 8 + (lane >> 3) + shift, wo = ww * 8 + (lane & 7) + shift;
+        if (ho >= H) ho -= H;
+        if (wo >= W) wo -= W;
+        stok[wv][lane] = (b * H + ho) * W + wo;
+    }
+    for (int i = lane; i < 225; i += 64) sb[wv][i] = bias_table[i * heads + head];
+    __syncthreads();
+    // operand fragments: lane (l32, g) holds d = 16 g .. 16 g + 15 of token 32 t + l32 (k index of MFMA step s = d 16 g + s)
+    float kf[2][16], qf[2][16];
+    const float qs = 1.0f / sqrtf((float)HD);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* base = qkv + (size_t)stok[wv][t * 32 + l32] * ldq + head * HD + 16 * g;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 q4 = *(const float4*)(base + c4 * 4);
+            const float4 k4 = *(const float4*)(base + C + c4 * 4);
+            qf[t][c4 * 4] = q4.x * qs, qf[t][c4 * 4 + 1] = q4.y * qs, qf[t][c4 * 4 + 2] = q4.z * qs, qf[t][c4 * 4 + 3] = q4.w * qs;
+            kf[t][c4 * 4] = k4.x, kf[t][c4 * 4 + 1] = k4.y, kf[t][c4 * 4 + 2] = k4.z, kf[t][c4 * 4 + 3] = k4.w;
+        }
+    }
+    // V rows in the key order of the accumulators: vf[kt][r] = V[key 32 kt + 4 g + (r & 3) + 8 (r >> 2)][d = l32]
+    float vf[2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            vf[kt][r] = qkv[(size_t)stok[wv][kt * 32 + 4 * g + (r & 3) + 8 * (r >> 2)] * ldq + 2 * C + head * HD + l32];
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kt][qt][r] = 0.0f;
+#pragma unroll
+            for (int st = 0; st < 16; ++st) acc[kt][qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][st], qf[qt][st], acc[kt][qt], 0, 0, 0);
+        }
+    // acc[kt][qt][r] = S[query 32 qt + l32][key 32 kt + 4 g + (r & 3) + 8 (r >> 2)]; the other 32 keys of the query sit in lane ^ 32
+    const bool border = shift != 0 && (wh == (H >> 3) - 1 || ww == nWw - 1);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = qt * 32 + l32, ri = qi >> 3, ci = qi & 7;
+        int qreg = 0;
+        if (border) {
+            const int hs = wh * 8 + ri, wsf = ww * 8 + ci;
+            qreg = ((hs >= H - 8) + (hs >= H - shift)) * 3 + ((wsf >= W - 8) + (wsf >= W - shift));
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rj = kt * 4 + (r >> 2), cj = 4 * g + (r & 3);
+                float a = acc[kt][qt][r] + sb[wv][(ri - rj + 7) * 15 + (ci - cj + 7)];
+                if (border) {
+                    const int hs = wh * 8 + rj, wsf = ww * 8 + cj;
+                    const int kreg = ((hs >= H - 8) + (hs >= H - shift)) * 3 + ((wsf >= W - 8) + (wsf >= W - shift));
+                    if (kreg != qreg) a += -100.0f;
+                }
+                acc[kt][qt][r] = a;
+                mx = fmaxf(mx, a);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(acc[kt][qt][r] - mx);
+                acc[kt][qt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[kt][qt][r] *= inv;
+    }
+    if (!live) return;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        f32x16_t o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[kt][qt][r], vf[kt][r], o, 0, 0, 0);
+        // o[r] = O[query 32 qt + 4 g + (r & 3) + 8 (r >> 2)][d = l32]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const size_t off = (size_t)stok[wv][qt * 32 + 4 * g + (r & 3) + 8 * (r >> 2)] * ldo + head * HD + l32;
+            const bf16_t h = (bf16_t)o[r];
+            out_hi[off] = h;
+            if (out_lo) out_lo[off] = (bf16_t)(o[r] - (float)h);
+            if (out_hi2) out_hi2[off] = h;
+        }
+    }
+}
+
 // Swin patch merging gather: out[(b, h/2, w/2)][q*C + c] = x[(b, 2 h2 + (q & 1), 2 w2 + (q >> 1))][c]
 __global__ void clap_patch_merge_kernel(const float* __restrict__ x, int ldx, int H, int W, int C, float* __restrict__ out, int ldo,
                                         long long total4) {
@@ -271,7 +397,12 @@ extern "C" int llark_clap_window_attn(const float* qkv, int ldq, int batch, int 
     dim3 grid(cdiv(units, 4));
     hipStream_t s = (hipStream_t)stream;
 #define WA_CASE(HD) clap_window_attn_kernel<HD><<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo, (bf16_t*)out_hi_dup, ldo, units)
-    if (hd == 32) WA_CASE(32);
+    static const bool valu_only = [] { const char* e = getenv("LLARK_CLAP_ATTN_VALU"); return e && e[0] == '1'; }();
+    if (hd == 32 && !valu_only) {
+        LLARK_REQUIRE((long long)batch * H * W < (1LL << 31), "clap_window_attn: token count overflows int");
+        clap_window_attn_mfma_kernel<<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo,
+                                                          (bf16_t*)out_hi_dup, ldo, units);
+    } else if (hd == 32) WA_CASE(32);
     else if (hd == 16) WA_CASE(16);
     else {
         set_error("clap_window_attn: head_dim %d unsupported (16 or 32)", hd);

@@ -970,7 +970,12 @@ using namespace llark;
 // winners are the shapes that move the fewest bytes per flop in FULL 128-B lines: BK = 64 (8 rows x 128 B per
 // DMA instruction), 64x128 per wave, single LDS stage with 2 blocks per CU overlapping each other.
 static int pick_variant(int split, int m, int n, int kp) {
-    if (m <= 128 || n < 256) return 0;
+    if (m <= 128) return 0;
+    // plain 16-bit products: 128x128x64 tiles at 3 workgroups per CU win or tie on every HTSAT linear (M = 4096 .. 262144,
+    // N = 128 .. 4096, K = 384 .. 12288; profiles/r01_clap_gemm_sweep.txt: 8.8 ms per forward vs 9.8 ms with the rules
+    // below, which were swept on the split-mode prior shapes) as they already did on the Llama prefill shapes.
+    if (!split && kp % 64 == 0 && n < 16384) return 11;
+    if (n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
     if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
                                                   // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
