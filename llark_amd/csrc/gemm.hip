@@ -740,6 +740,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     const T* Alo = (const T*)p.Alo;
     const T* Wt = (const T*)p.Wt;
     const int arow = c < p.M ? c : p.M - 1;
+    const bool a_live = c < p.M;
     const T* ah_p = Ahi ? Ahi + (size_t)arow * p.lda + g * 8 : nullptr;
     const T* al_p = (SPLIT && Alo) ? Alo + (size_t)arow * p.lda + g * 8 : nullptr;
     const T* w_p[NT];
@@ -775,8 +776,18 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     }
     auto load_a = [&](int kstep, frag& hi, frag& lo) __attribute__((always_inline)) {
         if (!norm_a) {
-            hi = *(const frag*)(ah_p + kstep * 32);
-            if (SPLIT) lo = *(const frag*)(al_p + kstep * 32);
+            // Rows >= M of the 16-row MFMA tile are never stored: their lanes load nothing (zero fragments) instead of
+            // re-reading row M-1 -- at M = 1 that was 16 copies of the same activation row per k-step through L2.
+            if (a_live) {
+                hi = *(const frag*)(ah_p + kstep * 32);
+                if (SPLIT) lo = *(const frag*)(al_p + kstep * 32);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi[e] = (T)0.0f;
+                    if (SPLIT) lo[e] = (T)0.0f;
+                }
+            }
         } else {
             const float4 x0 = *(const float4*)(xn_p + kstep * 32), x1 = *(const float4*)(xn_p + kstep * 32 + 4);
             const float4 g0 = *(const float4*)(p.xg + kstep * 32 + g * 8), g1 = *(const float4*)(p.xg + kstep * 32 + g * 8 + 4);

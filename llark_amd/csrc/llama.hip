@@ -10,6 +10,8 @@
 // dtype flow: residual stream fp32; every Linear input and q/k/v are bf16 (rounding points of the
 // reference's bf16 run); softmax probabilities are kept at >= 16 bits (bf16 hi+lo planes in the MFMA
 // path, fp32 in the decode path) -- finer than the reference's bf16 probabilities; accumulation fp32.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace llark {
@@ -326,17 +328,24 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 // Decode attention (one new token per sequence): one block per (batch, head).
 //   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
-                                                          const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
-                                                          bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
-                                                          int nh, int total, int smax, float scale,
-                                                          const int* __restrict__ pos_dev, const float* __restrict__ alibi) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                              const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
+                                                              const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
+                                                              bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
+                                                              int nh, int total, int smax, float scale,
+                                                              const int* __restrict__ pos_dev, const float* __restrict__ alibi) {
+    // NW waves per (batch, head).  A single sequence has only nh blocks (32 of 256 CUs busy): there the block is 16 waves
+    // wide so that the whole K pass and the whole V pass are each ONE round of loads in flight (the kernel is a chain of
+    // memory latencies, not bandwidth); batched decode keeps 4 waves per block.
+    constexpr int NT = NW * 64;
+    constexpr int UB = NW >= 16 ? 4 : 8;          // loads in flight per lane
+    constexpr int PARTS = NT / 128;               // threads sharing one output dim in the PV pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (pos_dev) total = *pos_dev + 1;            // graph-captured decode: keys 0..pos are visible
     float* sp = (float*)smem;                    // [total] scores / probabilities
     __shared__ float sq[128];
-    __shared__ float red[8];
+    __shared__ float red[2 * NW];
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * nh + h;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -351,19 +360,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = sq[chunk * 8 + e];
     float lmax = -INFINITY;
-    constexpr int UB = 8;                                          // loads in flight per lane: the loop is a latency chain otherwise
-    for (int jb = wv * 4 + sub; jb < total + 15; jb += 16 * UB) {  // uniform trip count per 16-lane group (shuffles stay inside it)
+    constexpr int KSTEP = NW * 4;                                  // keys per block and load slot
+    for (int jb = wv * 4 + sub; jb < total + KSTEP - 1; jb += KSTEP * UB) {  // uniform trip count per 16-lane group (shuffles stay inside it)
         bf16x8_t kv[UB], kl[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            int j = jb + 16 * u;
+            int j = jb + KSTEP * u;
             j = j < total ? j : total - 1;
             kv[u] = *(const bf16x8_t*)(kb + (size_t)j * 128 + chunk * 8);
             if (kbl) kl[u] = *(const bf16x8_t*)(kbl + (size_t)j * 128 + chunk * 8);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int j = jb + 16 * u;
+            const int j = jb + KSTEP * u;
             float s = 0.0f;
             if (kbl) {
 #pragma unroll
@@ -387,10 +396,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     lmax = wave_max(lmax);
     if (lane == 0) red[wv] = lmax;
     __syncthreads();
-    const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float mx = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) mx = fmaxf(mx, red[i]);
     float lsum = 0.0f;
     const int tpad = (total + 7) & ~7;
-    for (int j = tid; j < tpad; j += 256) {
+    for (int j = tid; j < tpad; j += NT) {
         float p = 0.0f;                                       // keys total..tpad-1 only pad the 8-key PV chunks
         if (j < total) {
             p = expf(sp[j] - mx);                             // fp32 probabilities (PV below is an fp32 fma chain)
@@ -400,26 +411,29 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
     lsum = wave_sum(lsum);
     __syncthreads();
-    if (lane == 0) red[4 + wv] = lsum;
+    if (lane == 0) red[NW + wv] = lsum;
     __syncthreads();
-    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
-    // ---- O[d] = sum_j p_j V[j][d]: V^T rows are contiguous in j; 2 threads per d, each walking 16-B chunks of 8 keys
-    const int d = tid >> 1, half = tid & 1;
+    float tot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tot += red[NW + i];
+    const float inv = 1.0f / tot;
+    // ---- O[d] = sum_j p_j V[j][d]: V^T rows are contiguous in j; PARTS threads per d, each walking 16-B chunks of 8 keys
+    const int d = tid / PARTS, part = tid % PARTS;
     const bf16_t* vr = vtc + (bh * 128 + d) * (size_t)smax;
     const bf16_t* vrl = vtc_lo ? vtc_lo + (bh * 128 + d) * (size_t)smax : nullptr;
     float acc = 0.0f;
-    for (int cb = half * 8; cb < tpad; cb += 16 * UB) {
+    for (int cb = part * 8; cb < tpad; cb += 8 * PARTS * UB) {
         bf16x8_t vv[UB], vl[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            int c8 = cb + 16 * u;
+            int c8 = cb + 8 * PARTS * u;
             c8 = c8 < tpad ? c8 : tpad - 8;                        // clamped re-load; its probabilities are skipped below
             vv[u] = *(const bf16x8_t*)(vr + c8);
             if (vrl) vl[u] = *(const bf16x8_t*)(vrl + c8);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int c8 = cb + 16 * u;
+            const int c8 = cb + 8 * PARTS * u;
             if (c8 < tpad) {
                 if (vrl) {
 #pragma unroll
@@ -431,8 +445,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             }
         }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    if (half == 0) store_split(out, out_lo, (size_t)b * (nh * 128) + h * 128 + d, acc * inv);
+#pragma unroll
+    for (int o = 1; o < PARTS; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (part == 0) store_split(out, out_lo, (size_t)b * (nh * 128) + h * 128 + d, acc * inv);
+}
+
+// 16 waves per block while the grid is smaller than the chip, 4 otherwise
+template <typename... Args>
+static void launch_attn_decode(int nh, int batch, size_t lds, hipStream_t s, Args... args) {
+    dim3 grid(nh, batch);
+    static const int force = [] { const char* e = getenv("LLARK_ATTN_DECODE_NW"); return e ? atoi(e) : 0; }();
+    if (force ? force == 16 : (long)nh * batch < 256) attn_decode_kernel<16><<<grid, 1024, lds, s>>>(args...);
+    else attn_decode_kernel<4><<<grid, 256, lds, s>>>(args...);
+}
+
+static void attn_decode_lds_limit(int lds) {
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 
@@ -617,14 +646,10 @@ extern "C" int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, 
     const float scale = (float)(1.0 / sqrt((double)hd));
     const size_t lds = (size_t)((total + 7) & ~7) * sizeof(float);
     LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode: context %d too long for the LDS score buffer", total);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(nh, batch);
-    attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
-                                                                (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
-                                                                (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
-                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax, scale, nullptr,
-                                                                alibi_slopes);
+    if (lds > 48 * 1024) attn_decode_lds_limit((int)lds);
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
+                       (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh,
+                       total, smax, scale, (const int*)nullptr, alibi_slopes);
     return check_launch("attn_decode");
 }
 
@@ -646,13 +671,11 @@ extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, c
     LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode_dpos: cache length %d too long for the LDS score buffer", smax);
     static int attr_lds = 0;                                      // not a stream op: raise the limit outside any capture
     if ((int)lds > 48 * 1024 && (int)lds > attr_lds) {
-        (void)hipFuncSetAttribute((const void*)attn_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attn_decode_lds_limit((int)lds);
         attr_lds = (int)lds;
     }
-    dim3 grid(nh, batch);
-    attn_decode_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k_cache,
-                                                                (const bf16_t*)vt_cache, (const bf16_t*)q_lo,
-                                                                (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo,
-                                                                (bf16_t*)out, (bf16_t*)out_lo, nh, 1, smax, scale, pos_dev, nullptr);
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
+                       (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, 1,
+                       smax, scale, pos_dev, (const float*)nullptr);
     return check_launch("attn_decode_dpos");
 }

@@ -95,10 +95,15 @@ class HipLlamaEngine:
         self.fuse_decode_norm = os.environ.get("LLARK_DECODE_FUSE_NORM", "0") == "1"
         # RMSNorm fused INTO the consuming decode GEMM (each workgroup re-derives the row scales): bit-identical, saves
         # two launches per layer (+ the final norm before lm_head).  Measured: B = 8 split 5.89 vs 6.04 ms per step, but
-        # B = 8 single-pass 5.26 vs 4.85 ms and B = 1 split 492 vs 480 ms per 64-token generate -- the on-the-fly
-        # normalisation of fp32 rows costs about what the launches save.  Opt-in (LLARK_DECODE_FUSE_NORM_A=1).
+        # B = 8 single-pass 5.26 vs 4.85 ms and B = 1 split 492 vs 480 ms per 64-token generate.  Why it cannot win: every
+        # one of the ~768 workgroups of a decode GEMM re-normalises and re-splits its activation fragments (~50 VALU
+        # instructions per k-step and wave), so the fused kernel turns VALU-bound (+15 us per launch, more than the
+        # rmsnorm launch it removes); hoisting the weight loads above the scale derivation and batching the raw loads
+        # before the conversions (tried, round 1) changed nothing.  Opt-in (LLARK_DECODE_FUSE_NORM_A=1).
         self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "0") == "1"
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
+        # decode step as a recorded host launch list over static buffers (ops.LaunchList): removes the per-launch Python cost
+        self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
         self._dec: Dict[int, dict] = {}
 
     # ---- weights -------------------------------------------------------------------------------
@@ -298,7 +303,14 @@ class HipLlamaEngine:
             self._dec[B] = st
         st["ids"].copy_(input_ids)
         st["pos"].fill_(pos0)
-        if st["graph"] is not None:
+        if self.decode_replay and not self.decode_graph:
+            if st.get("list") is None:
+                with ops.LaunchList.record() as ll:
+                    self._decode_body(st)
+                st["list"] = ll
+            else:
+                st["list"].replay()
+        elif st["graph"] is not None:
             st["graph"].replay()
         elif st["calls"] == 0:
             self._decode_body(st)
@@ -334,8 +346,8 @@ class HipLlamaEngine:
         assert B == self.cur_batch and pos0 == self.cur_len, "KV cache is out of sync with the requested positions"
         if pos0 + S > self.smax:
             raise ValueError(f"sequence of {pos0 + S} exceeds the engine's max_seq {self.smax}")
-        if (S == 1 and pos0 > 0 and self.decode_graph and not audio_segments and num_layers is None and not return_hidden
-                and not ops.kernel_timing_active()):
+        if (S == 1 and pos0 > 0 and (self.decode_graph or self.decode_replay) and not audio_segments and num_layers is None
+                and not return_hidden and (self.decode_replay or not ops.kernel_timing_active())):
             return self._decode_step_graph(input_ids, pos0)
         ws = self._workspace(B, S)
         h = ws["h"]

@@ -60,8 +60,9 @@ if "decode" in which:
         tok = torch.randint(3, 32000, (8, 1), device=dev)
         import time
         wbytes = 32 * (4 * 4096 * 4096 + 3 * 4096 * 11008) * 2 + 32004 * 4096 * 2
-        for graph in (False, True):
-            eng.decode_graph = graph
+        for graph in (False, "list", True):
+            eng.decode_graph = graph is True
+            eng.decode_replay = graph == "list"
             for _ in range(3):                                  # graph mode: eager, capture, first replay
                 eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
             torch.cuda.synchronize()
@@ -71,7 +72,7 @@ if "decode" in which:
                 eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / n
-            print(f"decode step B=8 ({prec}, {'hipGraph replay' if graph else 'eager launches'}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
+            print(f"decode step B=8 ({prec}, {'hipGraph replay' if graph is True else ('host launch-list replay' if graph else 'eager launches')}): {dt*1e3:.2f} ms/token-step  ({wbytes/dt/1e12:.2f} TB/s of weight bytes)", flush=True)
         del wl, eng
         torch.cuda.empty_cache()
 if "vqvae" in which:

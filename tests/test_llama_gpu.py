@@ -385,8 +385,8 @@ def test_audio_tokenizer_init_and_infer_with_prompt():
 @pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["split", "bf16"])
 def test_decode_graph_replay_matches_eager(precision):
-    """The hipGraph-captured decode step (position read from device memory) is the same arithmetic as the eager
-    per-kernel launches: logits bit-identical over 6 generated positions, KV cache identical afterwards."""
+    """The hipGraph-captured decode step and the host launch-list replay of it (position read from device memory) are the
+    same arithmetic as the eager per-kernel launches: logits bit-identical over 6 generated positions, KV cache identical afterwards."""
     from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
     from oracle import llama_ref as LR
     spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=320,
@@ -398,25 +398,26 @@ def test_decode_graph_replay_matches_eager(precision):
     ids = torch.randint(3, 300, (3, 17), generator=g).cuda()
     toks = torch.randint(3, 300, (6, 3, 1), generator=g).cuda()
     outs = []
-    for graph in (False, True):
+    for graph in (False, True, "list"):
         eng = HipLlamaEngine(dims, "cuda", 3, 64, precision=precision)
         eng.load_state_dict(w)
-        eng.decode_graph = graph
+        eng.decode_graph, eng.decode_replay = graph is True, graph == "list"
         eng.forward_tokens(ids)
         step = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(6)]
         assert eng.cur_len == 17 + 6
         outs.append((torch.stack(step), eng.k_cache.clone(), eng.vt_cache.clone()))
         if graph:
-            assert eng._dec[3]["graph"] is not None, "the decode step was not captured"
-            # a new prompt on the same engine re-uses the captured graph at other positions
+            assert eng._dec[3]["graph" if graph is True else "list"] is not None, "the decode step was not captured / recorded"
+            # a new prompt on the same engine re-uses the captured graph / recorded launch list at other positions
             eng.forward_tokens(ids[:, :9])
             a = eng.forward_tokens(toks[0], (), pos0=9)
-            eng.decode_graph = False
+            eng.decode_graph = eng.decode_replay = False
             eng.forward_tokens(ids[:, :9])
             b = eng.forward_tokens(toks[0], (), pos0=9)
             assert torch.equal(a, b)
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0])
+        assert torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2])
 
 
 @pytest.mark.gpu
