@@ -252,8 +252,9 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
-    ap.add_argument("--grad-comm", dest="grad_comm", default="fp32", choices=["fp32", "bf16"],
-                    help="train: transport dtype of the gradient all-reduce (bf16 = what the reference's bf16 DDP buckets send)")
+    ap.add_argument("--grad-comm", dest="grad_comm", default="bf16", choices=["fp32", "bf16"],
+                    help="train: transport dtype of the gradient all-reduce (bf16 = what the reference's DDP sends after model.to(bfloat16): "
+                         "13.5 GB per step, SURVEY section 8(e); fp32 = 27 GB); accumulation and AdamW stay fp32 either way")
     ap.add_argument("--llm-layers", type=int, default=0, help="debug: override the number of Llama layers (train stage)")
     ap.add_argument("--depth", type=int, default=0, help="debug: override prior depth (result is then NOT the headline)")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
