@@ -43,28 +43,34 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     if (row >= rows) return;
     const int w4 = width >> 2;
     const float4* xr = (const float4*)(x + (size_t)row * ldx);
-    float4 v[NV];
-    float s = 0.0f;
+    const float4* w4p = (const float4*)w;
+    float4 v[NV], gw[NV];
+    // all loads of the row AND of the norm weights are issued before the reduction: a decode step runs this kernel on
+    // 1 .. 16 rows, where it is nothing but memory latency, and fetching the weights after the reduction was a second
+    // full round trip
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < w4) {
             v[k] = xr[c];
-            s += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+            gw[k] = w4p[c];
         } else {
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k] = gw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < w4) s += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
     const float var = wave_sum(s) / (float)width;
     const float rstd = 1.0f / sqrtf(var + eps);
-    const float4* w4p = (const float4*)w;
     bf16x4_t* hr = (bf16x4_t*)(hi + (size_t)row * ldo);
     bf16x4_t* lr = lo ? (bf16x4_t*)(lo + (size_t)row * ldo) : nullptr;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < w4) {
-            const float4 g = w4p[c];
+            const float4 g = gw[k];
             float y[4] = {g.x * (v[k].x * rstd), g.y * (v[k].y * rstd), g.z * (v[k].z * rstd), g.w * (v[k].w * rstd)};
             bf16x4_t h, l;
 #pragma unroll

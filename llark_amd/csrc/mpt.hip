@@ -20,18 +20,26 @@ __global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restr
     if (row >= rows) return;
     const int w4 = width >> 2;
     const float4* xr = (const float4*)(x + (size_t)row * ldx);
-    float4 v[NV];
+    const float4* g4 = (const float4*)gamma;
+    const float4* b4 = (const float4*)beta;
+    float4 v[NV], gg[NV], bb[NV];
     float s = 0.0f;
+    // gamma / beta are requested together with the row (before the two reductions): on the 1 .. 16 rows of a decode step
+    // the kernel is pure latency, and fetching them afterwards was a third memory round trip
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < w4) {
             v[k] = xr[c];
-            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+            gg[k] = g4[c];
+            bb[k] = beta ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k] = gg[k] = bb[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        if (lane + 64 * k < w4) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     const float mean = wave_sum(s) / (float)width;
     float q = 0.0f;
 #pragma unroll
@@ -43,14 +51,12 @@ __global__ __launch_bounds__(256) void mpt_layernorm_kernel(const float* __restr
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)width + eps);
-    const float4* g4 = (const float4*)gamma;
-    const float4* b4 = (const float4*)beta;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < w4) {
-            const float4 g = g4[c];
-            const float4 b = beta ? b4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g = gg[k];
+            const float4 b = bb[k];
             float y[4];
             y[0] = (v[k].x - mean) * rstd * g.x + b.x;
             y[1] = (v[k].y - mean) * rstd * g.y + b.y;
