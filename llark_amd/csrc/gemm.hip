@@ -805,6 +805,16 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
     f32x4_t acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // residual values of the epilogue are requested now, not after the K loop: at M <= 16 the kernel is a chain of memory
+    // latencies and this one can hide behind the weight stream (R may alias C: nothing has been stored yet)
+    float rpre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_RESID && w == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 4 * g + r, n = ocol + c;
+            if (m < p.M && n < p.N) rpre[r] = p.R[(size_t)m * p.ldr + n];
+        }
+    }
     int ks = ks0;
     for (; ks + 4 <= ks1; ks += 4) {            // 4 k-steps in flight: 256 contiguous bytes per weight row
         frag bw[NT][4], ah[4], al[4];
@@ -860,7 +870,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         if (EPI == EPI_F32) {
             p.C[(size_t)m * p.ldc + n] = v[0] + (p.bias ? p.bias[n] : 0.0f);
         } else if (EPI == EPI_RESID) {
-            p.C[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
+            p.C[(size_t)m * p.ldc + n] = rpre[r] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
         } else if (IS_SWIGLU(EPI)) {
             const float a = silu(v[0]) * v[NT - 1];
             const T hi = Mfma<T>::cvt(a);
