@@ -4,7 +4,7 @@
 argument meaning; the compute is the HIP front end + HTSAT engine, and there is no CPU path."""
 from __future__ import annotations
 
-from typing import Any, Dict, List, Optional, Sequence
+from typing import Any, Dict, Optional, Sequence
 
 import numpy as np
 import torch

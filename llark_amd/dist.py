@@ -6,7 +6,7 @@ max-over-ranks of the elapsed time; the backend is RCCL ("nccl") on GPUs and glo
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 

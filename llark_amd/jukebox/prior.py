@@ -16,7 +16,6 @@ Data layout in HBM (per batch of N clips, M = N*n_ctx rows):
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional
 
 import numpy as np

@@ -2,8 +2,6 @@
 generated on the GPU layer by layer and packed straight into kernel layout)."""
 from __future__ import annotations
 
-import time
-
 import math
 
 import torch

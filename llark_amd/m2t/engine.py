@@ -15,7 +15,6 @@ HBM layout:
 """
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass
 import os
 from typing import Dict, List, Optional, Sequence, Tuple

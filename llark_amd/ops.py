@@ -6,7 +6,6 @@ stream to the library.  There is no fallback: a missing library or a non-GPU ten
 """
 from __future__ import annotations
 
-import math
 import os
 from typing import Optional, Tuple
 

@@ -55,3 +55,25 @@ def test_product_package_never_imports_the_oracle():
     mk = root / "csrc" / "Makefile"
     assert "oracle" not in mk.read_text()
     assert not offenders, offenders
+
+
+def test_launch_list_records_and_replays_c_abi_calls():
+    """ops.LaunchList mechanics without a GPU: calls made through _lib.lib() while recording are kept in order with their
+    arguments, replay re-issues them and surfaces a failing return code as LlarkHipError; recording does not nest."""
+    import pytest
+    from llark_amd import _lib as LB
+    from llark_amd import ops as O
+    O._stream = lambda: 0                                     # no device here; restored below
+    try:
+        with O.LaunchList.record() as ll:
+            rc = LB.lib().llark_prior_attn(None, 0, 1, 64, 48, 2, 8, 1, None, None, 0, None)     # rejected before any HIP call
+            assert rc == -1
+            with pytest.raises(RuntimeError, match="does not nest"):
+                O.LaunchList.record().__enter__()
+        assert [c[1] for c in ll.calls] == ["llark_prior_attn"] and ll.calls[0][2][2:5] == (1, 64, 48)
+        assert LB._recorder is None and not isinstance(LB.lib(), LB._RecordingProxy)
+        with pytest.raises(LB.LlarkHipError, match="llark_prior_attn"):
+            ll.replay()
+    finally:
+        import torch
+        O._stream = lambda: torch.cuda.current_stream().cuda_stream

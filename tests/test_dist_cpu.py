@@ -3,7 +3,6 @@ import os
 import socket
 import sys
 
-import pytest
 import torch
 import torch.multiprocessing as mp
 

@@ -1,5 +1,4 @@
 """GPU parity: the drop-in function set of jukebox/main.py end to end (audio -> pooled embedding)."""
-import math
 
 import numpy as np
 import pytest

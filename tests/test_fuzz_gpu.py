@@ -2,7 +2,6 @@
 dtype / main loop, the attention kernels with and without ALiBi and lo planes, the row-norm kernels, and the VQ-VAE
 conv / residual kernels (bit-exact vs the C oracle).  These complement the fixed-shape tests with ragged sizes around every
 tile boundary (128 / 256 rows and columns, 64-key attention tiles, 256-sample conv tiles)."""
-import math
 import random
 
 import numpy as np
