@@ -242,6 +242,12 @@ int llark_mean_rows_f32(const float* x, int ldx, int batch, int L, int C, float*
 int llark_relu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
 int llark_l2_normalize_rows(float* x, int ldx, int rows, int width, float eps, llark_stream_t stream);
 
+/* Decode step, fused: RoPE of the new token (qkv fp32 [batch][3 * nh * 128]) + append to the KV caches + attention over the
+ * cache, one launch (m2t/models/llamav2.py:339-365 decode loop; replaces rope_split_heads + attn_decode).  Position = pos,
+ * or *pos_dev when pos_dev != NULL.  lo planes: all or none.  alibi_slopes may be NULL. */
+int llark_attn_decode_rope_bf16(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo, void* vt_cache_lo,
+                                int smax, void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream);
 /* Decode-step forms with the sequence position in DEVICE memory (*pos_dev = tokens already cached = position of the
  * new token; s = 1): lets ONE captured hipGraph of the whole decode step serve every generated token of
  * m2t/models/llamav2.py:339-365 / m2t/infer.py:137-148. */

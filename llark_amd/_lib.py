@@ -92,6 +92,7 @@ _SIGS = {
     "llark_mean_rows_f32": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_relu_split_bf16": [_P, c_int, c_int, c_int, _P, _P, c_int, _P],
     "llark_l2_normalize_rows": [_P, c_int, c_int, c_int, c_float, _P],
+    "llark_attn_decode_rope_bf16": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P],
     "llark_rope_split_heads_dpos": [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P],
     "llark_attn_decode_bf16_dpos": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P],
     "llark_rope_split_heads": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P],

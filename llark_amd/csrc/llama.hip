@@ -335,12 +335,13 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
 //   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                              const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
-                                                              const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
+__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vtc,
+                                                              const bf16_t* __restrict__ q_lo, bf16_t* kc_lo, bf16_t* vtc_lo,
                                                               bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                               int nh, int total, int smax, float scale,
-                                                              const int* __restrict__ pos_dev, const float* __restrict__ alibi) {
+                                                              const int* __restrict__ pos_dev, const float* __restrict__ alibi,
+                                                              const float* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                              const float* __restrict__ sin_t) {
     // NW waves per (batch, head).  A single sequence has only nh blocks (32 of 256 CUs busy): there the block is 16 waves
     // wide so that the whole K pass and the whole V pass are each ONE round of loads in flight (the kernel is a chain of
     // memory latencies, not bandwidth); batched decode keeps 4 waves per block.
@@ -355,7 +356,35 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
     const int h = blockIdx.x, b = blockIdx.y;
     const size_t bh = (size_t)b * nh + h;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < 128) sq[tid] = (float)q[bh * 128 + tid] + (q_lo ? (float)q_lo[bh * 128 + tid] : 0.0f);
+    if (qkv) {
+        // Fused RoPE + cache write of the new token (decode): this block owns (batch b, head h), so it rotates its own q / k,
+        // appends k and v to the caches with exactly the arithmetic and rounding of rope_split_kernel, keeps q in LDS (the
+        // bf16 q planes are never materialised) and only then -- after the barrier that makes its own global writes visible
+        // to the whole block -- walks the cache including the row it just wrote.  Saves one launch per layer and token.
+        const int pos = total - 1, H = nh * 128;
+        const float* row = qkv + (size_t)b * 3 * H + h * 128;
+        const bool split = kc_lo != nullptr;
+        if (tid < 64) {
+            const int d = tid;
+            const float c = cos_t[(size_t)pos * 64 + d], sn = sin_t[(size_t)pos * 64 + d];
+            const float q1 = row[d], q2 = row[d + 64], k1 = row[H + d], k2 = row[H + d + 64];
+            const float qa = __fadd_rn(__fmul_rn(q1, c), __fmul_rn(-q2, sn));
+            const float qb = __fadd_rn(__fmul_rn(q2, c), __fmul_rn(q1, sn));
+            const float ka = __fadd_rn(__fmul_rn(k1, c), __fmul_rn(-k2, sn));
+            const float kb2 = __fadd_rn(__fmul_rn(k2, c), __fmul_rn(k1, sn));
+            const bf16_t ha = (bf16_t)qa, hb = (bf16_t)qb;
+            sq[d] = (float)ha + (split ? (float)(bf16_t)(qa - (float)ha) : 0.0f);
+            sq[d + 64] = (float)hb + (split ? (float)(bf16_t)(qb - (float)hb) : 0.0f);
+            const size_t ko = (bh * (size_t)smax + pos) * 128;
+            store_split(kc, kc_lo, ko + d, ka);
+            store_split(kc, kc_lo, ko + d + 64, kb2);
+        } else if (tid >= 128 && tid < 256) {
+            const int d = tid - 128;
+            store_split(vtc, vtc_lo, (bh * 128 + d) * (size_t)smax + pos, row[2 * H + d]);
+        }
+    } else if (tid < 128) {
+        sq[tid] = (float)q[bh * 128 + tid] + (q_lo ? (float)q_lo[bh * 128 + tid] : 0.0f);
+    }
     __syncthreads();
     // ---- scores: 16 lanes per key (16 B each = one 256-B cache row per 16-lane group, 1 KiB per wave instruction),
     //      4 keys per wave and iteration; the 16 partial dot products meet in a shuffle tree
@@ -653,9 +682,10 @@ extern "C" int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, 
     const size_t lds = (size_t)((total + 7) & ~7) * sizeof(float);
     LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode: context %d too long for the LDS score buffer", total);
     if (lds > 48 * 1024) attn_decode_lds_limit((int)lds);
-    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
-                       (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh,
-                       total, smax, scale, (const int*)nullptr, alibi_slopes);
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+                       (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh,
+                       total, smax, scale, (const int*)nullptr, alibi_slopes, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr);
     return check_launch("attn_decode");
 }
 
@@ -680,8 +710,36 @@ extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, c
         attn_decode_lds_limit((int)lds);
         attr_lds = (int)lds;
     }
-    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
-                       (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, 1,
-                       smax, scale, pos_dev, (const float*)nullptr);
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+                       (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, 1,
+                       smax, scale, pos_dev, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     return check_launch("attn_decode_dpos");
+}
+
+// Decode step: RoPE of the new token + KV-cache append + attention over the cache in ONE launch per layer (replaces
+// llark_rope_split_heads[_dpos] followed by llark_attn_decode_bf16[_alibi|_dpos]; m2t/models/llamav2.py:339-365 decode loop).
+// qkv fp32 [batch][3 * nh * 128] of the new token; position = pos (host int) or *pos_dev when pos_dev != NULL.
+extern "C" int llark_attn_decode_rope_bf16(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                           const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo,
+                                           void* vt_cache_lo, int smax, void* out, void* out_lo, const float* alibi_slopes,
+                                           llark_stream_t stream) {
+    LLARK_REQUIRE(qkv && cos_t && sin_t && k_cache && vt_cache && out, "attn_decode_rope: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_decode_rope: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE((k_cache_lo == nullptr) == (vt_cache_lo == nullptr) && (k_cache_lo == nullptr) == (out_lo == nullptr),
+                  "attn_decode_rope: give all lo planes (fp32-class mode) or none");
+    LLARK_REQUIRE(batch > 0 && nh > 0 && smax % 8 == 0 && (pos_dev || (pos >= 0 && pos < smax && pos < max_pos)),
+                  "attn_decode_rope: bad shape batch=%d pos=%d smax=%d max_pos=%d", batch, pos, smax, max_pos);
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    const int total = pos_dev ? 1 : pos + 1;
+    const size_t lds = pos_dev ? (size_t)smax * sizeof(float) : (size_t)((total + 7) & ~7) * sizeof(float);
+    LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode_rope: context too long for the LDS score buffer");
+    static int attr_lds = 0;
+    if ((int)lds > 48 * 1024 && (int)lds > attr_lds) {
+        attn_decode_lds_limit((int)lds);
+        attr_lds = (int)lds;
+    }
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)nullptr, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+                       (const bf16_t*)nullptr, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax,
+                       scale, pos_dev, alibi_slopes, qkv, cos_t, sin_t);
+    return check_launch("attn_decode_rope");
 }

@@ -103,6 +103,8 @@ class HipLlamaEngine:
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         # decode step as a recorded host launch list over static buffers (ops.LaunchList): removes the per-launch Python cost
         self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
+        # decode: RoPE + KV-cache append inside the attention launch (one launch per layer fewer); LLARK_DECODE_FUSE_ROPE=0 = two launches
+        self.fuse_decode_rope = os.environ.get("LLARK_DECODE_FUSE_ROPE", "1") != "0"
         self._dec: Dict[int, dict] = {}
 
     # ---- weights -------------------------------------------------------------------------------
@@ -243,7 +245,10 @@ class HipLlamaEngine:
                 if not fused:
                     ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
                 ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
-            if pos_dev is not None:                 # decode step, position in device memory (graph-capturable)
+            if s == 1 and self.fuse_decode_rope:
+                ops.attn_decode_rope(ws["qkv"], batch, nh, hd, pos_dev if pos_dev is not None else pos0, self.cos, self.sin, kc, vc,
+                                     ws["att"], kcl, vcl, ws["att_lo"])
+            elif pos_dev is not None:               # decode step, position in device memory (graph-capturable)
                 ops.rope_split_heads_dpos(ws["qkv"], batch, nh, hd, pos_dev, self.cos, self.sin, ws["q"], kc, vc,
                                           ws["q_lo"], kcl, vcl)
                 ops.attn_decode_dpos(ws["q"], kc, vc, batch, nh, hd, pos_dev, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])

@@ -14,6 +14,7 @@ path) and "bf16" (single pass).  Weights are bf16 like ``model.to(bf16)`` of the
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -70,6 +71,7 @@ class HipMptEngine:
         self.blocks: List[Optional[_Block]] = [None] * dims.n_layers
         self.wte = self.normf_w = self.normf_b = self.proj_w = self.proj_b = None
         self.slopes = alibi_slopes(dims.n_heads, dims.alibi_bias_max).to(self.device)
+        self.fuse_decode_rope = os.environ.get("LLARK_DECODE_FUSE_ROPE", "1") != "0"      # head split + cache append inside the decode attention launch
         # identity rotation: the RoPE kernel then only splits heads, rounds to bf16 (hi/lo) and writes the KV cache
         self.cos = torch.ones((self.smax, 64), dtype=torch.float32, device=self.device)
         self.sin = torch.zeros((self.smax, 64), dtype=torch.float32, device=self.device)
@@ -172,8 +174,14 @@ class HipMptEngine:
             if d.qk_ln:
                 ops.layernorm_f32_(ws["qkv"][:, :D], Bk.qlw, Bk.qlb, d.ln_eps)
                 ops.layernorm_f32_(ws["qkv"][:, D: 2 * D], Bk.klw, Bk.klb, d.ln_eps)
-            ops.rope_split_heads(ws["qkv"], B, S, nh, 128, pos0, self.cos, self.sin, ws["q"], kc, vc, ws["q_lo"], kcl, vcl)
-            if S == 1:
+            if S == 1 and self.fuse_decode_rope:
+                ops.attn_decode_rope(ws["qkv"], B, nh, 128, pos0, self.cos, self.sin, kc, vc, ws["att"], kcl, vcl, ws["att_lo"],
+                                     alibi_slopes=self.slopes)
+            else:
+                ops.rope_split_heads(ws["qkv"], B, S, nh, 128, pos0, self.cos, self.sin, ws["q"], kc, vc, ws["q_lo"], kcl, vcl)
+            if S == 1 and self.fuse_decode_rope:
+                pass
+            elif S == 1:
                 ops.attn_decode(ws["q"], kc, vc, B, nh, 128, pos0 + 1, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"], alibi_slopes=self.slopes)
             else:
                 ops.attn_prefill(ws["q"], kc, vc, B, S, nh, 128, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"], alibi_slopes=self.slopes)

@@ -451,6 +451,22 @@ def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, 
                                                   _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_decode")
 
 
+def attn_decode_rope(qkv: torch.Tensor, batch: int, nh: int, hd: int, pos, cos_t, sin_t, k_cache, vt_cache, out,
+                     k_cache_lo=None, vt_cache_lo=None, out_lo=None, alibi_slopes=None) -> None:
+    """Decode step in one launch: RoPE of the new token + KV-cache append + attention.  `pos` is an int or an int32 scalar
+    device tensor (position read on the device: replayable launch lists / captured graphs)."""
+    smax = k_cache.shape[-2]
+    bf = torch.bfloat16
+    dpos = isinstance(pos, torch.Tensor)
+    assert qkv.shape == (batch, 3 * nh * hd)
+    check(_lib.lib().llark_attn_decode_rope_bf16(_dev(qkv, "qkv", torch.float32), batch, nh, hd, 0 if dpos else int(pos),
+                                                 _dev(pos, "pos", torch.int32) if dpos else None, _dev(cos_t, "cos", torch.float32),
+                                                 _dev(sin_t, "sin", torch.float32), cos_t.shape[0], _dev(k_cache, "k_cache", bf),
+                                                 _dev(vt_cache, "vt_cache", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+                                                 _opt(vt_cache_lo, "vt_cache_lo", bf), smax, _dev(out, "out", bf), _opt(out_lo, "out_lo", bf),
+                                                 _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_decode_rope")
+
+
 # ------------------------------------------------------------------------------------------------
 # MPT
 # ------------------------------------------------------------------------------------------------
