@@ -85,3 +85,33 @@ def test_embed_cli_host_side(tmp_path):
     assert read_wav_48k(paths[3]).shape == (2400,) and read_wav_48k(paths[2]).shape == (4800,)
     got = list(iter_batches(paths, 2))
     assert [len(n) for n, _ in got] == [2, 1] and got[0][0] == [paths[0], paths[2]]          # broken.wav skipped
+
+
+def test_synthetic_weights_and_flop_accounting_match_the_oracle_model():
+    """llark_amd.clap.random_state_dict (bench / smoke weights) has exactly the oracle's parameter names and shapes, and the
+    algorithmic FLOP count bench.py's roofline uses equals a direct count over those shapes."""
+    from llark_amd.clap import ClapDims, algorithmic_flops_per_clip, random_state_dict
+    for kw in (dict(embed_dim=32, depths=[2, 2, 2, 1], heads=[1, 2, 4, 8], proj_dim=64), {}):
+        sd = random_state_dict(ClapDims(**kw), seed=1)
+        ref = CR.make_weights(CR.ClapSpec(**kw), seed=1)
+        assert sorted(sd) == sorted(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+        assert all(torch.isfinite(v).all() for v in sd.values()) and (sd["audio_model.audio_encoder.batch_norm.running_var"] > 0).all()
+        d = ClapDims(**kw)
+        L, gemm = (d.spec_size // d.patch) ** 2, 0.0
+        tokens = {}
+        for s in range(len(d.depths)):
+            tokens[s] = L // 4 ** s
+        for k, v in ref.items():
+            if not k.endswith(".weight") or v.dim() < 2:
+                continue
+            if ".layers." in k:
+                s = int(k.split(".layers.")[1].split(".")[0])
+                rows = tokens[s] // 4 if ".downsample." in k else tokens[s]
+            elif "patch_embed.proj" in k:
+                rows, v = L, v.reshape(v.shape[0], -1)
+            else:
+                rows = 1                                       # projection head: one pooled row per clip
+            gemm += 2.0 * rows * v.shape[0] * v.shape[1]
+        fl = algorithmic_flops_per_clip(d)
+        assert abs(fl["gemm"] - gemm) <= 1e-9 * gemm, (fl["gemm"], gemm)
+    assert abs(algorithmic_flops_per_clip()["gemm"] / 1e9 - 29.81) < 0.01
