@@ -2,7 +2,9 @@
 """Headline benchmark: clips/sec of LLark's audio-encoder -> LLM forward on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 works both ways: started plainly (no WORLD_SIZE in the environment) it launches its own N ranks, one per GPU,
+  under torch.distributed.run (like scripts/training/train_llark.sh:20-22 of the reference); started BY
+  ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` it is one of those ranks.
 
 One "step" = one pass of the hot path over one batch of B synthetic clips per GPU
 (25 s @ 44.1 kHz audio, truncated to 1 048 576 samples as jukebox/main.py:59 does, + a 128-token
@@ -31,20 +33,56 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROAR
 PEAK_HBM_GBS = 8000.0
 
 
-def _dist_setup(n_gpus: int):
+def _dist_setup(n_gpus: int, backend: str = "nccl"):
     from llark_amd import dist as D
 
     rank, world, local = D.env_rank_world()
-    torch.cuda.set_device(local)
-    D.init(backend="nccl", device=torch.device("cuda", local))      # "nccl" IS RCCL on ROCm; only barrier + max-reduce use it
-    assert world == n_gpus, f"--gpus {n_gpus} but WORLD_SIZE={world}"
+    if world != n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {n_gpus}, "
+                         "or start bench.py plainly and it spawns its own ranks)")
+    if backend == "nccl":
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} needs cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible")
+        torch.cuda.set_device(local)                 # one process per GPU
+        D.init(backend="nccl", device=torch.device("cuda", local))      # "nccl" IS RCCL on ROCm; only barrier + max-reduce use it
+    else:
+        D.init(backend=backend)
     return rank, world, local
 
 
-def _barrier(world):
+def _barrier(world, cuda=True):
     from llark_amd import dist as D
 
-    D.barrier(world, cuda=True)
+    D.barrier(world, cuda=cuda)
+
+
+def dist_check(args):
+    """--stages dist-check: the launcher + rendezvous + barrier + max-over-ranks + gather of bench.py with NO kernel
+    work (each rank sleeps rank-dependent milliseconds).  Runs on CPU over gloo (tests/test_dist_cpu.py drives the
+    self-launch path through it) and on GPUs over RCCL."""
+    from llark_amd import dist as D
+
+    rank, world, local = _dist_setup(args.gpus, args.backend)
+    cuda = args.backend == "nccl"
+    device = torch.device("cuda", local) if cuda else "cpu"
+    _barrier(world, cuda)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    mine = time.perf_counter() - t0
+    _barrier(world, cuda)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, world, device=device)
+    per_rank = D.gather_floats(mine / args.steps * 1e3, world, device=device)
+    if rank == 0:
+        import torch.distributed as dist
+
+        print(json.dumps({"metric": "dist-check (no kernel work)", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "backend": args.backend,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                          "clips_by_rank": [D.clip_indices(r, 2) for r in range(world)],
+                          "per_rank_ms_per_step": [round(v, 3) for v in per_rank]}), flush=True)
+    D.shutdown(world)
 
 
 def _prior_gemm_flops(hps, rows):
@@ -247,7 +285,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU per step (default 8 = BASELINE configs[1]; 4 for --stages train = configs[3]: 32 clips over 8 GPUs)")
-    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt", "mpt-train", "clap"])
+    ap.add_argument("--stages", default="e2e", choices=["e2e", "jukebox", "llama", "train", "generate", "mpt", "mpt-train", "clap", "dist-check"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only for --stages dist-check on CPU)")
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
@@ -264,6 +303,16 @@ def main():
     args = ap.parse_args()
     if not args.batch:
         args.batch = {"train": 4, "mpt-train": 4, "generate": 1, "clap": 64}.get(args.stages, 8)
+
+    from llark_amd import dist as D
+
+    if D.needs_self_launch(args.gpus):
+        # started plainly with --gpus N > 1: become the launcher of N ranks (one per GPU) and relay their exit code
+        sys.exit(D.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.stages == "dist-check":
+        return dist_check(args)
+    if args.backend != "nccl":
+        raise SystemExit("bench.py: --backend gloo is only valid with --stages dist-check (the hot path runs on GPUs over RCCL)")
 
     rank, world, local = _dist_setup(args.gpus)
     device = torch.device("cuda", local)
@@ -295,13 +344,19 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0               # this rank's own K steps (before waiting for the others)
         _barrier(world)
         elapsed = time.perf_counter() - t0
         timers = ops.stop_kernel_timing()
 
-    from llark_amd import dist as D
-
     elapsed = D.max_over_ranks(elapsed, world, device=device)
+    per_rank_ms = D.gather_floats(mine / args.steps * 1e3, world, device=device)
+    rccl_ranks = 1
+    if world > 1:
+        import torch.distributed as tdist
+
+        rccl_ranks = tdist.get_world_size()
 
     if rank == 0:
         clips = args.batch * world * args.steps
@@ -354,6 +409,7 @@ def main():
                        "mpt-train": "clips/sec MPT-1B instruction-tuning step (fwd+bwd+all-reduce+AdamW)"}.get(args.stages, "clips/sec (25 s audio + 128-tok prompt) end-to-end fwd"),
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
             "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "jukebox": "fp16x2-split(fp32-class)",
                                            "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",

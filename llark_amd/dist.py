@@ -31,6 +31,50 @@ def init(backend: str = "nccl", device: torch.device = None) -> Tuple[int, int, 
     return rank, world, local
 
 
+def free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def needs_self_launch(n_procs: int) -> bool:
+    """True when N > 1 ranks were requested but this process was NOT started by torch.distributed.run (no WORLD_SIZE
+    in the environment): the caller must spawn its own ranks, like the reference's launcher does
+    (scripts/training/train_llark.sh:20-22: ``python -m torch.distributed.launch --nproc_per_node=8 -m m2t.train``)."""
+    return n_procs > 1 and "WORLD_SIZE" not in os.environ
+
+
+def self_launch(n_procs: int, script: str, argv: List[str], timeout: Optional[float] = None) -> int:
+    """Re-executes ``script argv`` as ``n_procs`` ranks of one node under ``python -m torch.distributed.run`` (one
+    process per GPU, rendezvous on 127.0.0.1 and a free port).  torchrun sets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*; each rank binds ``cuda:LOCAL_RANK``.  Returns the launcher's exit code (non-zero if any rank failed)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_procs)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env, timeout=timeout)
+
+
+def gather_floats(value: float, world: int, device="cpu") -> List[float]:
+    """Every rank's ``value`` on every rank (one small all_gather; off the timed path)."""
+    if world <= 1:
+        return [float(value)]
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous shard of ``n_items`` for ``rank`` (sizes differ by at most one; covers every item once)."""
     base, rem = divmod(n_items, world)

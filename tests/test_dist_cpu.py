@@ -116,3 +116,34 @@ def test_gradient_allreduce_two_ranks():
     expect = torch.arange(1000, dtype=torch.float32) * 3          # (1 + 2) x
     for _, gsum in res:
         assert torch.equal(gsum, expect)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` started plainly (no WORLD_SIZE) must spawn its own two ranks under
+    torch.distributed.run (reference launcher: scripts/training/train_llark.sh:20-22).  The
+    dist-check stage runs bench.py's launcher / rendezvous / barrier / max-over-ranks / gather over gloo on CPU."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stages", "dist-check",
+                          "--backend", "gloo", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                               # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 2
+    assert d["clips_by_rank"] == [[0, 1], [2, 3]]
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["per_rank_ms_per_step"][1] > d["per_rank_ms_per_step"][0]
+    assert d["ms_per_step"] >= max(d["per_rank_ms_per_step"]) - 0.5  # the slowest rank defines the step
+
+
+def test_bench_rejects_world_size_mismatch():
+    """Started as ONE rank of a 1-rank world but asked for --gpus 2: a clear error, not a hang."""
+    import subprocess
+
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stages", "dist-check",
+                          "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr
