@@ -19,8 +19,6 @@
 // fragment reads are bank-conflict free; one barrier per K-step; 48 KiB LDS -> 3 blocks/CU.
 // blockIdx is remapped XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and
 // grouped over M so that co-resident blocks share A and W panels.
-#include <cstdlib>
-#include <type_traits>
 
 // Profiling-only compile-time ablations (results invalid): 1 = no DMA in the K loop, 2 = no LDS fragment
 // reads, 3 = no MFMA.  Built into separate libraries by scripts/build_ablations.sh; never set in the product.
@@ -28,227 +26,9 @@
 #define GEMM_ABLATE 0
 #endif
 
-#include "common.h"
+#include "gemm_core.h"
 
 namespace llark {
-
-// Tile configuration: WM x WN waves, each owning TM x TN MFMA tiles of 32x32; K-step BK (32 or 64).
-template <int WM_, int WN_, int TM_, int TN_, int BK_, int MINW_, int NSTAGE_ = 2>
-struct Cfg {
-    static constexpr int MINW = MINW_;             // __launch_bounds__ waves/SIMD the register allocator must allow
-    static constexpr int NSTAGE = NSTAGE_;         // 1 = single LDS stage (overlap comes from the co-resident workgroup), 2 = double buffer
-    static_assert(NSTAGE_ == 1 || NSTAGE_ == 2, "a 3-deep LDS-DMA ring was measured (round 1): no gain over 2 stages, removed");
-    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_, BK = BK_;
-    static constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    static constexpr int NW = WM * WN, THREADS = NW * 64;
-    static constexpr int ROWB = BK * 2;            // bytes per tile row (16-bit elements)
-    static constexpr int CH = ROWB / 16;           // 16-B chunks per row
-    static constexpr int RPI = 64 / CH;            // rows covered by one wave-wide 1 KiB DMA instruction
-    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    static_assert(BK == 32 || BK == 64, "BK must be 32 or 64");
-    static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "DMA instructions must divide evenly over the waves");
-    // XOR swizzle of the 16-B chunk index so that ds_read_b128 fragment reads are conflict free
-    static __device__ __forceinline__ int swz(int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
-    static __device__ __forceinline__ int off(int row, int c) { return row * ROWB + ((c ^ swz(row)) << 4); }
-};
-
-struct GemmParams {
-    const void* Ahi;
-    const void* Alo;
-    int lda;
-    const void* Wt;
-    int ldw;
-    const float* bias;
-    int M, N, Kp;
-    float* C;          // fp32 output (EPI_F32 / EPI_RESID)
-    int ldc;
-    const float* R;    // residual input (EPI_RESID); may alias C
-    int ldr;
-    void* Ohi;         // 16-bit outputs
-    void* Olo;
-    int ldo;
-    void* Ohi2;        // EPI_SPLIT16 only: optional second copy of the hi plane (K-concatenated [hi | lo | hi] operands)
-    int act;           // EPI_SPLIT16 / EPI_OUT16: 0 = none, 2 = exact (erf) GELU applied to acc + bias before the split
-    int tiles_m, tiles_n;
-    // batched mode (grid.y = batch): element strides added per batch index; 0 = operand shared by all batches
-    int batch;
-    long long sA, sW, sC, sR, sO;
-    // persistent mode: resident workgroups per XCD and this launch's per-XCD chunk counters
-    int slots;
-    int* sync;
-    // skinny kernel, EPI_RESID only: fused RMSNorm of the COMPLETE output rows by the last workgroup to finish
-    const float* nw;   // norm weight [N] (nullptr = off)
-    float neps;
-    void* nhi;         // bf16 [M][ldn] normalised rows (hi plane), optional lo plane
-    void* nlo;
-    int ldn;
-    int* ncnt;         // arrival counter (self-resetting)
-    // skinny kernel: A operand = RMSNorm(xn) computed on the fly (decode: norm fused INTO the consuming GEMM)
-    const float* xn;   // fp32 [M][ldxn] un-normalised rows (nullptr = A comes from Ahi / Alo)
-    const float* xg;   // norm weight [Kp]
-    int ldxn;
-    float xeps;
-};
-
-enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
-#define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
-
-template <typename T>
-struct Mfma;
-template <>
-struct Mfma<half_t> {
-    typedef half8_t frag;
-    static __device__ __forceinline__ f32x16_t run(frag a, frag b, f32x16_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ half_t cvt(float v) { return (half_t)v; }
-    static __device__ __forceinline__ float back(half_t v) { return (float)v; }
-};
-template <>
-struct Mfma<bf16_t> {
-    typedef bf16x8_t frag;
-    static __device__ __forceinline__ f32x16_t run(frag a, frag b, f32x16_t c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ bf16_t cvt(float v) { return (bf16_t)v; }
-    static __device__ __forceinline__ float back(bf16_t v) { return (float)v; }
-};
-
-// One wave-instruction of LDS-DMA: 64 lanes x 16 B -> 1 KiB = RPI tile rows at `lds_dst` (lane-linear
-// destination).  Lane i lands on (row i/CH, slot i%CH) and FETCHES chunk slot ^ swz(row), so that the
-// LDS image is the swizzled one the fragment reads expect (swizzle on the SOURCE address).
-template <typename T, typename C>
-__device__ __forceinline__ void dma_rows(const T* __restrict__ g, int ld, int grow0, int rows_valid, int k0, int trow0,
-                                         char* lds_dst, int lane) {
-    const int rl = lane / C::CH, p = lane % C::CH;
-    int r = grow0 + rl;
-    r = r < rows_valid ? r : rows_valid - 1;
-    const int chunk = p ^ C::swz(trow0 + rl);
-    const T* src = g + (size_t)r * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// x * sigmoid(a x) with the hardware exp2 / rcp (each <= 1 ulp): ~1e-7 relative, far inside the tolerance
-// of activations whose reference (cuDNN/ATen on another GPU) is not bit-defined either; keeps the epilogue
-// at a handful of VALU ops per element instead of IEEE division + range-reduced expf.
-__device__ __forceinline__ float fast_sigmoid_mul(float x, float a) {
-    const float e = __builtin_amdgcn_exp2f(-a * 1.44269504088896341f * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-__device__ __forceinline__ float quick_gelu(float x) { return fast_sigmoid_mul(x, 1.702f); }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
-
-// C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Shared by every main-loop variant.
-template <typename T, bool SPLIT, int EPI, typename C>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                              const int wm, const int wn, const int lane, const long long bz) {
-    // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
-    // `buffer_store v, voff, rsrc, soff` with ONE per-lane byte offset (same for all tiles/registers) and a
-    // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
-    const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
-    const int mrow0 = m0 + wm * C::TM * 32;                      // uniform
-    const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
-    const int ocol0 = IS_SWIGLU(EPI) ? (ncol0 >> 1) : ncol0;
-    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
-    const int lr = 4 * (lane >> 5), lc = lane & 31;
-    constexpr unsigned RSRC_FLAGS = 0x00020000u;
-    __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
-    int vC = 0, vR = 0, vO = 0;
-    if (EPI == EPI_F32 || EPI == EPI_RESID) {
-        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + bz * p.sC + (size_t)mrow0 * p.ldc + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vC = (lr * p.ldc + lc) * 4;
-    }
-    if (EPI == EPI_RESID) {
-        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + bz * p.sR + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vR = (lr * p.ldr + lc) * 4;
-    }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
-        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vO = (lr * p.ldo + lc) * 2;
-    }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
-        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-    __amdgpu_buffer_rsrc_t rH2;
-    const bool dup_hi = EPI == EPI_SPLIT16 && p.Ohi2 != nullptr;
-    if (EPI == EPI_SPLIT16)
-        rH2 = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)(dup_hi ? p.Ohi2 : p.Ohi) + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-    const bool act_erf = (EPI == EPI_SPLIT16 || EPI == EPI_OUT16) && p.act == 2;
-
-    auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            // Residual epilogue: R may alias C (in-place h += ...), so a load placed after a store can never be
-            // hoisted above it -- interleaved load/add/store degenerates into one full memory round trip per
-            // element (measured: +0.8 ms on the 65536 x 4800 products).  Fetch the residuals of this whole tile
-            // row (TN x 16 values per lane) first, all loads in flight together, then add and store.
-            float res[C::TN][16];
-            if (EPI == EPI_RESID) {
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) {
-                    const bool col_ok = FULL || (ocol0 + tn * 32 + lc < nlim);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);
-                        res[tn][r] = (col_ok && (FULL || mrow0 + ml + lr < p.M))
-                                         ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + tn * 32) * 4, 0))
-                                         : 0.0f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn) {
-                if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
-                // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
-                // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
-                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : tn * 32;                 // compile-time
-                if (!FULL && ocol0 + ocl + lc >= nlim) continue;
-                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = tm * 32 + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
-                    if (!FULL && mrow0 + ml + lr >= p.M) continue;
-                    float v = acc[tm][tn][r] + bv;
-                    if (EPI == EPI_F32) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
-                    } else if (EPI == EPI_RESID) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[tn][r] + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
-                    } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
-                        if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
-                        if (EPI == EPI_SPLIT16 && act_erf) v = gelu_erf(v);
-                        const T hi = Mfma<T>::cvt(v);
-                        const T lo = Mfma<T>::cvt(v - Mfma<T>::back(hi));
-                        const int so = (ml * p.ldo + ocl) * 2;
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
-                        if (EPI == EPI_SPLIT16 && dup_hi) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH2, vO, so, 0);
-                    } else if (EPI == EPI_OUT16) {
-                        if (act_erf) v = gelu_erf(v);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
-                                                              (ml * p.ldo + ocl) * 2, 0);
-                    } else if (EPI == EPI_SWIGLU16) {
-                        constexpr int tu = (C::TN > 1) ? 1 : 0;
-                        const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
-                                                              vO, (ml * p.ldo + ocl) * 2, 0);
-                    } else if (EPI == EPI_SWIGLU_SPLIT) {
-                        constexpr int tu = (C::TN > 1) ? 1 : 0;
-                        const float a = silu(acc[tm][tn][r]) * acc[tm][(tn + tu) % C::TN][r];
-                        const T hi = Mfma<T>::cvt(a);
-                        const T lo = Mfma<T>::cvt(a - Mfma<T>::back(hi));
-                        const int so = (ml * p.ldo + ocl) * 2;
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
-                    }
-                }
-            }
-        }
-    };
-    if (full) epilogue(std::true_type{});      // interior tile: no per-element bounds checks
-    else epilogue(std::false_type{});
-}
 
 // One output tile (linear tile index `bid` in the M-grouped order) computed by the calling workgroup.
 template <typename T, bool SPLIT, int EPI, typename C>
@@ -358,14 +138,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, int bid, char* sm
     }
 
     gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
-}
-
-// XCD-aware remap of the hardware block index: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets the
-// contiguous band [base, base + count) of the linear tile order and its private L2 sees neighbouring tiles.
-__device__ __forceinline__ void xcd_band(int nwg, int xcd, int& base, int& count) {
-    const int q = nwg >> 3, r = nwg & 7;
-    base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    count = q + (xcd < r ? 1 : 0);
 }
 
 template <typename T, bool SPLIT, int EPI, typename C>
@@ -969,6 +741,16 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 2: return dispatch<T, Cfg2>(p, split, epi, s);
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
+        case 30: {                                                  // 256x256x64 split tile with the counted-vmcnt LDS ring (gemm256.hip), else 20
+            if (split) {
+                GemmParams q = p;
+                q.sync = persist_sync_slot(s);
+                const int dt = std::is_same<T, half_t>::value ? LLARK_F16 : LLARK_BF16;
+                const int rc = q.sync ? launch_gemm256(q, dt, epi, s) : -1000;
+                if (rc != -1000) return rc;
+            }
+        }
+        [[fallthrough]];
         case 20: {                                                  // persistent 128x256x64 (large grids), else plain variant 12
             const int rc = dispatch_persist<T, Cfg12>(p, split, epi, s);
             return rc == -1000 ? dispatch<T, Cfg12>(p, split, epi, s) : rc;
@@ -998,10 +780,14 @@ static int pick_variant(int split, int m, int n, int kp) {
     if (!split && kp % 64 == 0 && n < 16384) return 11;
     if (n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
+    static const bool persist = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
+    static const bool big = [] { const char* e = getenv("LLARK_GEMM_256"); return !e || e[0] != '0'; }();
+    // the prior (M = clips x 8192, split fp16): 256x256x64 tile with the counted-vmcnt LDS ring (gemm256.hip) as soon as the
+    // problem has two tiles per CU -- also at B = 1 (608 tiles), so a clip's result does not depend on the batch it rides in
+    if (split && big && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 30;
     if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
                                                   // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
-    static const bool persist = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
-    if (m >= 16384 && persist) return 20;                    // very tall products (the prior, M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
+    if (m >= 16384 && persist) return 20;                    // very tall products (M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
     if (!split && n < 16384) return 11;           // plain 16-bit, mid-size N (Llama q/k/v/o, down): 128x128x64, 3 blocks/CU
     return 12;                                    // 128x256x64
 }

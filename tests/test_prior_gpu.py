@@ -81,6 +81,50 @@ def test_gemm_tile_variants(variant):
     assert worst < 6e-7, worst
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640)])
+def test_gemm256_ring_tile_bit_identical(m, n, k):
+    """csrc/gemm256.hip (256x256x64 split tile, counted-vmcnt LDS-DMA ring, persistent chunk-synchronous walk) accumulates
+    every output element in the same order as the 128x256 LDS-staged kernel (k16 steps ascending, hi pass then lo pass):
+    the two must agree BIT FOR BIT on ragged M / N (row clamping, masked stores), 2 .. 75 K-steps (ring wrap, tail waits),
+    every epilogue the prior uses, fp16 and bf16 -- and against an fp64 reference within the split scheme's bound."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = torch.randn(m, n, generator=g).cuda()
+    for dt in (torch.float16, torch.bfloat16):
+        hi, lo = ops.split16(a.cuda(), dt, kmult=64)
+        wt = ops.pack_weight16(w.cuda(), True, dt, kmult=64)
+        c0 = torch.full((m, n), float("nan"), device="cuda")
+        c1 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c0, variant=12)
+        for rep in range(3):                                             # repeated launches: a race in the ring would come and go
+            c1.fill_(float("nan"))
+            ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c1, variant=30)
+            assert torch.equal(c0, c1), f"F32 {dt} rep {rep}: {int((c0 != c1).sum())} elements differ, max diff {(c0 - c1).abs().nan_to_num(1e9).max().item():.3e}"
+        a16 = hi.float().cpu()[:, :k].double() + lo.float().cpu()[:, :k].double()
+        w16 = wt.float().cpu()[:n, :k].double()
+        ref = a16 @ w16.t() + b.cpu().double()
+        bound = 2e-6 * (a16.abs() @ w16.abs().t()) + 1e-6
+        assert bool(((c1.cpu().double() - ref).abs() <= bound).all()), "gemm256 vs fp64 reference out of the split-scheme bound"
+        c0, c1 = r.clone(), r.clone()
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c0, resid=c0, variant=12)
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c1, resid=c1, variant=30)
+        assert torch.equal(c0, c1), "RESID epilogue differs"
+        o0 = [torch.zeros((m, n), dtype=dt, device="cuda") for _ in range(2)]
+        o1 = [torch.zeros((m, n), dtype=dt, device="cuda") for _ in range(2)]
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o0[0], out_lo=o0[1], variant=12)
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o1[0], out_lo=o1[1], variant=30)
+        assert torch.equal(o0[0], o1[0]) and torch.equal(o0[1], o1[1]), "QGELU_SPLIT epilogue differs"
+    # non-split operands are not this kernel's: variant 30 must fall back (and still be right), not fail
+    c2 = torch.full((m, n), float("nan"), device="cuda")
+    c3 = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16(hi, None, wt, b, n, ops.EPI_F32, c=c2, variant=30)
+    ops.gemm16(hi, None, wt, b, n, ops.EPI_F32, c=c3, variant=12)
+    assert torch.equal(c2, c3)
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
