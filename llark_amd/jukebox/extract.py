@@ -199,22 +199,39 @@ def get_acts_from_audio_batch(audios: Sequence[np.ndarray], hps, vqvae, top_prio
     return [_postprocess(acts[i], lens[i], meanpool, pool_frames_per_second, acts_rate) for i in range(len(audios))]
 
 
-def load_model(model="5b", weights=None, hps: Optional[JukeboxHParams] = None, device="cuda", depth=None):
+def load_model(model="5b", weights=None, hps: Optional[JukeboxHParams] = None, device="cuda", depth=None,
+               restore_vqvae: Optional[str] = None, restore_prior: Optional[str] = None):
     """Builds (hps, vqvae, top_prior) like jukebox/main.py:176-200.
 
-    ``weights`` is a state-dict-like mapping with upstream key names (see
-    ``llark_amd.jukebox.synthetic``); without it, seeded synthetic weights are generated (there are
-    no checkpoints offline).  ``setup_dist_from_mpi`` of the reference initialises a world-size-1
-    NCCL group that no collective ever uses; nothing is initialised here.
+    ``weights=None`` (the reference's call, ``load_model()``): read upstream's ``5b/vqvae.pth.tar`` and
+    ``<model>/prior_level_2.pth.tar`` from the local mirror ``~/.cache/jukebox/models`` (``$JUKEBOX_CACHE``) or from
+    ``restore_vqvae`` / ``restore_prior``, with the reference's ``strict=False`` semantics: the checkpoint's prior layers
+    >= 36 are dropped (jukebox/main.py:196, make_models.py.patch:7-8) -- see ``llark_amd/jukebox/checkpoint.py``.  A
+    missing file raises ``FileNotFoundError`` (the reference would download it).
+    ``weights`` = a state-dict-like mapping with upstream key names: used as given (extra keys ignored the same way).
+    ``weights="synthetic"``: seeded synthetic weights (``llark_amd.jukebox.synthetic``; bench / tests, no checkpoint).
+    ``setup_dist_from_mpi`` of the reference initialises a world-size-1 NCCL group that no collective ever uses
+    (SURVEY 2b); nothing is initialised here.
     """
     if model not in ("5b", "5b_lyrics"):
         raise ValueError(f"unknown model {model!r}")
     hps = hparams_5b() if hps is None else hps
     hps.n_samples = 3 if model == "5b_lyrics" else 8
-    if weights is None:
+    d = hps.prior_depth if depth is None else depth
+    if isinstance(weights, str):
+        if weights != "synthetic":
+            raise ValueError(f"weights must be a mapping, None or 'synthetic', got {weights!r}")
         from .synthetic import make_jukebox_weights
 
         weights = make_jukebox_weights(hps, seed=0, depth=depth)
+    elif weights is None:
+        from .checkpoint import load_checkpoint_weights
+
+        weights, _unexpected = load_checkpoint_weights(model, hps, d, restore_vqvae, restore_prior)
+    else:
+        from .checkpoint import select_weights
+
+        weights, _unexpected = select_weights([weights], hps, d, origin="weights mapping")
     vqvae = VQVAE(hps, weights, device)
     top_prior = TopPrior(hps, weights, device, depth=depth)
     return hps, vqvae, top_prior
@@ -273,6 +290,9 @@ def main(argv=None):
     ap.add_argument("--output_dir", default="/output", help="path to outputs")
     ap.add_argument("--pool-frames-per-second", default=10, type=int,
                     help="Frames per second for pooling. Set to zero to pool over all timesteps.")
+    ap.add_argument("--synthetic-weights", action="store_true",
+                    help="NEW: seeded synthetic weights instead of the 5b checkpoint files (there are none offline)")
+    ap.add_argument("--model", default="5b", choices=["5b", "5b_lyrics"], help="NEW: the reference hard-codes load_model()'s default")
     args = ap.parse_args(argv)
 
     out_dir = pathlib.Path(args.output_dir)
@@ -281,7 +301,7 @@ def main(argv=None):
     model = None
     for path in paths:
         if model is None:
-            model = load_model()
+            model = load_model(args.model, weights="synthetic" if args.synthetic_weights else None)
         hps, vqvae, top_prior = model
         with torch.no_grad():
             rep = get_acts_from_file(path, hps, vqvae, top_prior, meanpool=True,

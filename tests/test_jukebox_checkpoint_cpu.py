@@ -1,0 +1,89 @@
+"""Checkpoint ingestion of ``load_model``: upstream ``.pth.tar`` format, DDP ``module.`` prefix,
+``strict=False`` layer dropping (jukebox/main.py:176-200, jukebox/make_models.py.patch:7-8).  CPU: file format and
+name filtering only; tests/test_extract_gpu.py loads such files through the HIP path."""
+import io
+import os
+
+import pytest
+import torch
+
+from llark_amd.jukebox import checkpoint as CK
+from llark_amd.jukebox.hparams import hparams_tiny
+from llark_amd.jukebox.synthetic import make_jukebox_weights
+
+
+def upstream_style_checkpoints(hps, ckpt_depth, seed=0, prefix="module."):
+    """What upstream's two files hold for a model of this shape: the VQ-VAE file carries ALL levels (encoders, decoders,
+    three codebooks + their EMA statistics), the prior file carries ``ckpt_depth`` layers (72 for 5b) plus the
+    tensors the only_encode path never touches (x_out, start_token ...), keys under DDP's ``module.`` prefix."""
+    w = make_jukebox_weights(hps, seed=seed, depth=ckpt_depth)
+    vq = {k: v for k, v in w.items() if k.startswith(("encoders.", "bottleneck."))}
+    g = torch.Generator().manual_seed(99)
+    for lvl in (0, 1):
+        vq[f"encoders.{lvl}.level_blocks.0.model.0.0.weight"] = torch.randn(4, 1, 4, generator=g)
+        vq[f"decoders.{lvl}.level_blocks.0.model.0.weight"] = torch.randn(4, 4, 3, generator=g)
+        vq[f"bottleneck.level_blocks.{lvl}.k"] = torch.randn(hps.l_bins, hps.emb_width, generator=g)
+    vq["bottleneck.level_blocks.2.k_sum"] = torch.randn(hps.l_bins, hps.emb_width, generator=g)
+    vq["bottleneck.level_blocks.2.k_elem"] = torch.ones(hps.l_bins)
+    vq["decoders.2.out.weight"] = torch.randn(1, 4, 3, generator=g)
+    pr = {k: v for k, v in w.items() if k.startswith(("prior.", "y_emb."))}
+    pr["prior.x_out.weight"] = torch.randn(hps.l_bins, hps.prior_width, generator=g)
+    pr["prior.start_token"] = torch.randn(1, hps.prior_width, generator=g)
+    return ({"model": {prefix + k: v for k, v in vq.items()}, "step": 12345, "hps": {"sr": 44100}},
+            {"model": {prefix + k: v for k, v in pr.items()}, "step": 777}, w)
+
+
+def test_pth_tar_roundtrip_drops_layers_beyond_depth(tmp_path):
+    hps = hparams_tiny()
+    depth = hps.prior_depth
+    vq_ck, pr_ck, w = upstream_style_checkpoints(hps, ckpt_depth=2 * depth)       # 5b: 72 layers on disk, 36 built
+    pv, pp = tmp_path / "vqvae.pth.tar", tmp_path / "prior_level_2.pth.tar"
+    torch.save(vq_ck, pv)
+    torch.save(pr_ck, pp)
+    got, unexpected = CK.load_checkpoint_weights("5b", hps, depth, str(pv), str(pp))
+    assert sorted(got) == sorted(CK.vqvae_names(hps) + CK.prior_names(hps, depth))
+    for k, v in got.items():
+        assert torch.equal(v, w[k]), k
+    dropped = {int(k.split(".")[3]) for k in unexpected if k.startswith("prior.transformer._attn_mods.")}
+    assert dropped == set(range(depth, 2 * depth))
+    for k in ("prior.x_out.weight", "prior.start_token", "decoders.2.out.weight", "bottleneck.level_blocks.0.k",
+              "bottleneck.level_blocks.2.k_sum"):
+        assert k in unexpected
+    assert not any(k.startswith("module.") for k in unexpected)
+
+
+def test_file_objects_and_plain_keys():
+    hps = hparams_tiny()
+    vq_ck, pr_ck, w = upstream_style_checkpoints(hps, ckpt_depth=hps.prior_depth, prefix="")
+    buf = io.BytesIO()
+    torch.save(pr_ck, buf)
+    buf.seek(0)
+    sd = CK.read_pth_tar(buf)
+    assert torch.equal(sd["prior.x_emb.weight"], w["prior.x_emb.weight"])
+
+
+def test_missing_tensor_is_an_error_not_a_silent_random_init(tmp_path):
+    hps = hparams_tiny()
+    vq_ck, pr_ck, _ = upstream_style_checkpoints(hps, ckpt_depth=hps.prior_depth - 1)     # one layer short
+    with pytest.raises(KeyError, match=r"_attn_mods"):
+        CK.select_weights([CK.read_pth_tar(_save(vq_ck)), CK.read_pth_tar(_save(pr_ck))], hps)
+    with pytest.raises(ValueError, match="not a Jukebox checkpoint"):
+        CK.read_pth_tar(_save({"state_dict": {}}))
+
+
+def _save(obj):
+    buf = io.BytesIO()
+    torch.save(obj, buf)
+    buf.seek(0)
+    return buf
+
+
+def test_default_paths_and_absent_files(tmp_path, monkeypatch):
+    monkeypatch.setenv(CK.CACHE_ENV, str(tmp_path))
+    pv, pp = CK.default_checkpoint_paths("5b_lyrics")
+    assert pv == os.path.join(str(tmp_path), "jukebox", "models", "5b", "vqvae.pth.tar")
+    assert pp == os.path.join(str(tmp_path), "jukebox", "models", "5b_lyrics", "prior_level_2.pth.tar")
+    with pytest.raises(FileNotFoundError, match="vqvae.pth.tar"):
+        CK.load_checkpoint_weights("5b", hparams_tiny())
+    with pytest.raises(ValueError):
+        CK.default_checkpoint_paths("1b_lyrics")
