@@ -7,10 +7,16 @@
  * reference's own Python module interfaces.  Each entry point names the reference call site it
  * replaces.  Conventions:
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
- *   - every function returns LLARK_OK (0) or a negative error code, never throws, never
- *     allocates, and enqueues its work on `stream` (a hipStream_t passed as void*);
+ *   - every function returns LLARK_OK (0) or a negative error code, never throws, and enqueues its
+ *     work on `stream` (a hipStream_t passed as void*);
+ *   - compute entry points never allocate and keep no hidden device state: the only functions that
+ *     allocate are the two object constructors llark_workspace_create (1 KiB of device counters the
+ *     persistent GEMM kernels synchronise through) and llark_vqvae_plan_create (a host-side launch
+ *     list); both objects are owned, passed in and destroyed by the caller;
  *   - llark_last_error() returns a thread-local human-readable message for the last failure;
- *   - re-entrant per stream; no global state.
+ *   - re-entrant per stream: a workspace serves ONE stream at a time (launches that share it are
+ *     ordered on that stream); create one per (device, stream).  The remaining process-level state is
+ *     immutable once set: per-kernel "dynamic LDS size raised" flags of the code object.
  */
 #ifndef LLARK_HIP_H
 #define LLARK_HIP_H
@@ -40,8 +46,15 @@ enum {
     LLARK_EPI_OUT16 = 3,       /* out = 16-bit(acc + bias)                                       */
     LLARK_EPI_SWIGLU16 = 4,    /* out = 16-bit(silu(gate) * up), W rows interleaved [32 gate|32 up] */
     LLARK_EPI_SPLIT16 = 5,     /* acc + bias -> hi/lo 16-bit planes                              */
-    LLARK_EPI_SWIGLU_SPLIT = 6 /* silu(gate)*up -> hi/lo 16-bit planes (fp32-class Llama mode)        */
+    LLARK_EPI_SWIGLU_SPLIT = 6, /* silu(gate)*up -> hi/lo 16-bit planes (fp32-class Llama mode)       */
+    LLARK_EPI_QGELU_SPLIT8 = 7 /* llark_gemm16_lo8 only: g -> fp16 hi plane + e4m3 low plane          */
 };
+
+/* Caller-owned workspace of the persistent GEMM kernels (per-XCD chunk counters; see the conventions
+ * above).  create() binds to the CURRENT device; returns NULL on failure (llark_last_error()). */
+typedef struct llark_workspace* llark_workspace_t;
+llark_workspace_t llark_workspace_create(void);
+int llark_workspace_destroy(llark_workspace_t ws);
 
 int llark_version(void);
 const char* llark_last_error(void);
@@ -88,6 +101,12 @@ int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, cons
 /* FactoredAttention core (pattern 1 block, 2 transpose-block, 3 previous-block) on qkv [n*t][ldq]. */
 int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks, int pattern,
                      void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* The same two producers in "lo8" mode (see llark_gemm16_lo8): fp16 hi plane [rows][ldo] + E4M3 low plane
+ * [rows][ldo8] = fp8(sat((y - hi) * 2^sa)) in MFMA slot order; ldo8 in bytes, a multiple of 64 covering the width. */
+int llark_layernorm_split_lo8(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta,
+                              float eps, void* out_hi, int ldo, void* out_lo8, int ldo8, int sa, llark_stream_t stream);
+int llark_prior_attn_lo8(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks, int pattern,
+                         void* out_hi, int ldo, void* out_lo8, int ldo8, int sa, llark_stream_t stream);
 /* AvgPool1d(frame_len, stride=frame_len, ceil_mode=False) over time: h [n][t][width] -> out [n][frames][width] */
 int llark_pool_window(const float* h, int n, int t, int width, int frame_len, float* out, int frames,
                       llark_stream_t stream);
@@ -108,6 +127,23 @@ int llark_gemm16(int dtype, int split, int epilogue, const void* a_hi, const voi
 int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* llark_gemm16_ex plus a workspace: only with one are the persistent, chunk-synchronous variants (20 = 128x256x64,
+ * 30 = the 256x256x64 LDS-DMA ring of csrc/gemm256.hip) chosen or honoured; without, such requests run variant 12. */
+int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                    const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
+                    int ldr, void* out_hi, void* out_lo, int ldo, llark_workspace_t ws, llark_stream_t stream);
+/* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8.hip): same call site, upstream Conv1D.forward reached from
+ * jukebox/main.py:108 with fp16=False.  The activation is a_hi = fp16(a) plus an E4M3 low plane
+ * a_lo8[m][lda8] = fp8(sat((a - a_hi) * 2^sa)) whose 64-element k blocks are stored in MFMA slot order
+ * (byte 32*(k/8 % 2) + 8*(k/16 % 4) + k % 8 of the block holds element k); the fp8 weight plane fp8(W * 2^sw) is derived
+ * from wt inside the kernel (choose sw with max|W| * 2^sw <= 448).  C = a_hi.W^T + 2^-(sa+sw) a_lo8.W8^T (+ bias):
+ * one v_mfma_scale_f32_32x32x64_f8f6f4 replaces the four fp16 MFMAs of the second pass.  Accuracy: the activation
+ * carries 15-16 significant bits instead of 22 (measured end to end in tests/test_fulldepth_gpu.py).
+ * epilogue: LLARK_EPI_F32, LLARK_EPI_RESID, LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo] + out_lo8 [m][ldo8], same format).
+ * kp % 64 == 0, kp >= 128; lda8 / ldo8 in bytes, multiples of 64. */
+int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
+                     const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid, int ldr,
+                     void* out_hi, void* out_lo8, int ldo, int ldo8, llark_workspace_t ws, llark_stream_t stream);
 /* Fragment-major weights for the "B-direct" GEMM: wt [n][ldw] (16-bit, K-contiguous, kp % 64 == 0) -> dst of
  * ceil(n/32)*32 * kp elements laid out as 1-KiB chunks [row tile][k16 step][lane 0..63][8 elements] = one MFMA
  * B fragment per chunk (rows >= n are zero).  llark_gemm16_fragw computes the same product as llark_gemm16 but

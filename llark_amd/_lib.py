@@ -60,6 +60,13 @@ _SIGS = {
                      _P, _P, c_int, _P],
     "llark_gemm16_ex": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                         _P, _P, c_int, _P],
+    "llark_gemm16_ws": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                        _P, _P, c_int, _P, _P],
+    "llark_gemm16_lo8": [c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                         _P, _P, c_int, c_int, _P, _P],
+    "llark_workspace_destroy": [_P],
+    "llark_layernorm_split_lo8": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, c_int, _P, c_int, c_int, _P],
+    "llark_prior_attn_lo8": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P],
     "llark_pack_weight16_frag": [_P, c_int, c_int, c_int, _P, _P],
     "llark_gemm16_fragw": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                            _P, _P, c_int, _P],
@@ -117,7 +124,7 @@ _SIGS = {
 
 def declared_symbols():
     """Every symbol ``include/llark_hip.h`` declares (kept in sync by tests/test_abi.py)."""
-    return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy"])
+    return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy", "llark_workspace_create"])
 
 
 # ---- host-side launch lists -------------------------------------------------------------------------------------------
@@ -178,6 +185,8 @@ def _real_lib():
         L.llark_vqvae_plan_create.restype = c_void_p
         L.llark_vqvae_plan_destroy.argtypes = [c_void_p]
         L.llark_vqvae_plan_destroy.restype = None
+        L.llark_workspace_create.argtypes = []
+        L.llark_workspace_create.restype = c_void_p
         _lib = L
     return _lib
 

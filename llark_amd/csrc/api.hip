@@ -1,5 +1,6 @@
 // Library plumbing of libllark_hip.so: error reporting, device probe, and the layout/precision
 // conversion kernels (weight packing, fp32 -> 16-bit hi/lo split) used at load time.
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -43,9 +44,34 @@ __global__ void split16_kernel(const float* __restrict__ x, int ldx, int rows, i
     }
 }
 
+// fp16 weight rows -> E4M3 plane fp8(W * 2^sw) in MFMA slot order (lo8_pos): the B operand of the low-plane product
+__global__ void pack_weight_lo8_kernel(const half_t* __restrict__ wt, int ldw, int n, int kp, float mul, unsigned char* __restrict__ out, int ldo) {
+    const size_t total = (size_t)n * (kp >> 2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i % (kp >> 2)) << 2;
+        const size_t r = i / (kp >> 2);
+        const half4_t v = *(const half4_t*)(wt + r * ldw + k4);
+        unsigned q = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q |= fp8_e4m3_sat((float)v[e] * mul) << (8 * e);
+        *(unsigned*)(out + r * ldo + lo8_pos(k4)) = q;
+    }
+}
+
 }  // namespace llark
 
 using namespace llark;
+
+extern "C" int llark_pack_weight_lo8(const void* wt, int ldw, int n, int kp, int sw, void* out, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(wt && out && n > 0 && kp > 0 && kp % 64 == 0 && ldw >= kp && ldw % 4 == 0 && ldo >= kp && ldo % 16 == 0,
+                  "pack_weight_lo8: bad arguments (kp=%d must be a multiple of 64; ldw=%d, ldo=%d)", kp, ldw, ldo);
+    LLARK_REQUIRE(sw >= -40 && sw <= 40 && ((uintptr_t)wt & 7) == 0 && ((uintptr_t)out & 3) == 0, "pack_weight_lo8: bad scale exponent or alignment");
+    const size_t total = (size_t)n * (kp / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    pack_weight_lo8_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const half_t*)wt, ldw, n, kp, ldexpf(1.0f, sw), (unsigned char*)out, ldo);
+    return check_launch("pack_weight_lo8");
+}
 
 extern "C" int llark_version(void) { return 100; }
 

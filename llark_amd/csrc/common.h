@@ -53,4 +53,17 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// Byte position of element k inside its 64-element block of an fp8 low plane: a lane of v_mfma_scale_f32_32x32x64_f8f6f4
+// (row = lane % 32, half h = lane / 32) owns the k set {16 s + 8 h + j} of the block -- the k its four fp16 fragments
+// cover -- and reads them as 32 contiguous bytes: p = 32 h + 8 s + j.  Groups of 8 consecutive k stay contiguous.
+__host__ __device__ __forceinline__ int lo8_pos(int k) {
+    const int r = k & 63;
+    return (k & ~63) + (((r >> 3) & 1) << 5) + ((r >> 4) << 3) + (r & 7);
+}
+// e4m3 byte of x (round to nearest even; the conversion has no saturation -- |x| > 464 would become NaN -- so clamp first)
+__device__ __forceinline__ unsigned fp8_e4m3_sat(float x) {
+    x = __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xffu;
+}
+
 }  // namespace llark

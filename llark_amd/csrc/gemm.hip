@@ -26,6 +26,8 @@
 #define GEMM_ABLATE 0
 #endif
 
+#include <new>
+
 #include "gemm_core.h"
 
 namespace llark {
@@ -154,8 +156,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_kernel(const GemmPar
 // 4 MiB L2 of their XCD can bridge.  Here exactly `p.slots` workgroups per XCD stay resident and walk that XCD's
 // band of tiles in CHUNKS of `slots` neighbouring tiles (8 tile rows x 8 tile columns for the default order),
 // with a barrier among the XCD's workgroups between chunks: every chunk starts at K = 0 together and streams its
-// shared panels through L2 in lock-step.  The barrier is a monotonically increasing counter per XCD (zeroed by
-// the host before the launch); all workgroups of the grid are co-resident by construction (grid = occupancy x
+// shared panels through L2 in lock-step.  The barrier is a monotonically increasing counter per XCD (owned by
+// the workspace and advanced by the host per launch: p.sync_base); all workgroups of the grid are co-resident by construction (grid = occupancy x
 // CUs) and the spin is bounded anyway: the barrier is a locality aid, never a correctness dependency.
 template <typename T, bool SPLIT, int EPI, typename C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_persist_kernel(const GemmParams p) {
@@ -173,10 +175,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_persist_kernel(const
             __syncthreads();                                       // also: everyone is done reading LDS of this tile
             if (threadIdx.x == 0) {
                 __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int target = (ch + 1) * p.slots;
+                const int target = p.sync_base + (ch + 1) * p.slots;
                 // bounded spin (~30 ms): the barrier only aligns the chunk starts for L2 locality, results never
                 // depend on it, so a workgroup that is (unexpectedly) not co-resident cannot hang the kernel
-                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
+                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
                     __builtin_amdgcn_s_sleep(8);
             }
             __syncthreads();
@@ -184,37 +186,47 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_persist_kernel(const
     }
 }
 
-static int* persist_sync_slot(hipStream_t s) {
-    // ring of counter blocks so that GEMMs in flight on different streams never share one
-    constexpr int RING = 64, BYTES = 8 * 32 * sizeof(int);
-    static int* buf = nullptr;
-    static unsigned next = 0;
-    if (!buf && hipMalloc((void**)&buf, (size_t)RING * BYTES) != hipSuccess) return nullptr;
-    int* slot = buf + (size_t)(next++ % RING) * (BYTES / sizeof(int));
-    if (hipMemsetAsync(slot, 0, BYTES, s) != hipSuccess) return nullptr;
-    return slot;
+// Chunk barriers every workgroup of a persistent launch takes (same formula as the kernels' `nchunks - 1`).
+static int persist_chunk_barriers(int nwg, int slots) {
+    const int nchunks = ((nwg >> 3) + ((nwg & 7) ? 1 : 0) + slots - 1) / slots;
+    return nchunks > 0 ? nchunks - 1 : 0;
 }
 
+// The per-XCD chunk counters live in a caller-owned workspace (include/llark_hip.h: llark_workspace_create) and are
+// MONOTONIC: a launch starts at `base`, every workgroup of an XCD arrives once per chunk barrier, so the host advances
+// `base` by slots x barriers after enqueueing -- no memset per launch.  Launches that share a workspace must be ordered
+// on one stream; the counters are re-zeroed (stream-ordered) long before the 32-bit base can wrap.
+static int ws_begin(llark_workspace* ws, GemmParams& p, hipStream_t s) {
+    if (!ws || !ws->counters) return -1;
+    if (ws->base > (1 << 30)) {
+        if (hipMemsetAsync(ws->counters, 0, LLARK_WS_BYTES, s) != hipSuccess) return -1;
+        ws->base = 0;
+    }
+    p.sync = ws->counters;
+    p.sync_base = ws->base;
+    return 0;
+}
+static void ws_end(llark_workspace* ws, int nwg, int slots) { ws->base += slots * persist_chunk_barriers(nwg, slots); }
+
 template <typename T, bool SPLIT, int EPI, typename C>
-static int launch_gemm_persist(GemmParams p, hipStream_t s) {
+static int launch_gemm_persist(GemmParams p, hipStream_t s, llark_workspace* ws) {
     constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
     auto kern = gemm_persist_kernel<T, SPLIT, EPI, C>;
-    static int grid = -1;                                          // resident workgroups of THIS instantiation (0 = unusable)
-    if (grid < 0) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, C::THREADS, LDS) != hipSuccess) per_cu = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        grid = per_cu * cus;
-        if (grid % 8) grid = 0;
+    static int per_cu = -1;                                        // resident workgroups per CU of THIS instantiation: a property of
+    if (per_cu < 0) {                                              // the code object (same on every gfx950 device), 0 = unusable
+        int n = 0;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, C::THREADS, LDS) != hipSuccess) n = 0;
+        per_cu = n;
     }
+    if (!ws || ws->cus % 8) return -1000;
+    const int grid = per_cu * ws->cus;
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
     if (grid <= 0 || p.batch > 1 || p.tiles_m * p.tiles_n < 4 * grid) return -1000;      // caller falls back to one workgroup per tile
     p.slots = grid / 8;
-    p.sync = persist_sync_slot(s);
-    if (!p.sync) return -1000;
+    if (ws_begin(ws, p, s)) return -1000;
+    ws_end(ws, p.tiles_m * p.tiles_n, p.slots);
     kern<<<dim3(grid), C::THREADS, LDS, s>>>(p);
     return check_launch("gemm_persist");
 }
@@ -236,10 +248,10 @@ static int launch_gemm(GemmParams p, hipStream_t s) {
 }
 
 template <typename T, typename C>
-static int dispatch_persist(const GemmParams& p, bool split, int epi, hipStream_t s) {
+static int dispatch_persist(const GemmParams& p, bool split, int epi, hipStream_t s, llark_workspace* ws) {
 #define CASE(E)                                                      \
     case E:                                                          \
-        return split ? launch_gemm_persist<T, true, E, C>(p, s) : launch_gemm_persist<T, false, E, C>(p, s);
+        return split ? launch_gemm_persist<T, true, E, C>(p, s, ws) : launch_gemm_persist<T, false, E, C>(p, s, ws);
     switch (epi) {
         CASE(EPI_F32)
         CASE(EPI_RESID)
@@ -734,7 +746,7 @@ typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBD0;  // 128x256x64, wave 128x64, A double-
 typedef Cfg<1, 4, 4, 1, 64, 3, 2> CfgBD1;  // 128x128x64, wave 128x32, 32 KiB (plain) / 64 KiB (split)       : 3 / 2 blocks/CU
 
 template <typename T>
-static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s) {
+static int dispatch_variant(int variant, const GemmParams& p, bool split, int epi, hipStream_t s, llark_workspace* ws) {
     switch (variant) {
         case 0: return dispatch<T, Cfg0>(p, split, epi, s);
         case 1: return dispatch<T, Cfg1>(p, split, epi, s);
@@ -742,17 +754,21 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
         case 30: {                                                  // 256x256x64 split tile with the counted-vmcnt LDS ring (gemm256.hip), else 20
-            if (split) {
+            if (split && ws && ws->cus % 8 == 0) {
                 GemmParams q = p;
-                q.sync = persist_sync_slot(s);
                 const int dt = std::is_same<T, half_t>::value ? LLARK_F16 : LLARK_BF16;
-                const int rc = q.sync ? launch_gemm256(q, dt, epi, s) : -1000;
-                if (rc != -1000) return rc;
+                if (ws_begin(ws, q, s) == 0) {
+                    const int rc = launch_gemm256(q, dt, epi, s, ws->cus);
+                    if (rc != -1000) {
+                        ws_end(ws, cdiv(p.M, 256) * cdiv(p.N, 256), ws->cus / 8);
+                        return rc;
+                    }
+                }
             }
         }
         [[fallthrough]];
         case 20: {                                                  // persistent 128x256x64 (large grids), else plain variant 12
-            const int rc = dispatch_persist<T, Cfg12>(p, split, epi, s);
+            const int rc = dispatch_persist<T, Cfg12>(p, split, epi, s, ws);
             return rc == -1000 ? dispatch<T, Cfg12>(p, split, epi, s) : rc;
         }
     }
@@ -772,7 +788,7 @@ using namespace llark;
 // loop (profiles/r01_gemm_ablation.txt) shows the L2->LDS DMA stream, not the MFMAs, is the long pole, so the
 // winners are the shapes that move the fewest bytes per flop in FULL 128-B lines: BK = 64 (8 rows x 128 B per
 // DMA instruction), 64x128 per wave, single LDS stage with 2 blocks per CU overlapping each other.
-static int pick_variant(int split, int m, int n, int kp) {
+static int pick_variant(int split, int m, int n, int kp, bool has_ws) {
     if (m <= 128) return 0;
     // plain 16-bit products: 128x128x64 tiles at 3 workgroups per CU win or tie on every HTSAT linear (M = 4096 .. 262144,
     // N = 128 .. 4096, K = 384 .. 12288; profiles/r01_clap_gemm_sweep.txt: 8.8 ms per forward vs 9.8 ms with the rules
@@ -780,7 +796,8 @@ static int pick_variant(int split, int m, int n, int kp) {
     if (!split && kp % 64 == 0 && n < 16384) return 11;
     if (n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
-    static const bool persist = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
+    static const bool persist_env = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
+    const bool persist = persist_env && has_ws;   // the persistent kernels keep their chunk counters in the caller's workspace
     static const bool big = [] { const char* e = getenv("LLARK_GEMM_256"); return !e || e[0] != '0'; }();
     // the prior (M = clips x 8192, split fp16): 256x256x64 tile with the counted-vmcnt LDS ring (gemm256.hip) as soon as the
     // problem has two tiles per CU -- also at B = 1 (608 tiles), so a clip's result does not depend on the batch it rides in
@@ -796,7 +813,7 @@ static int gemm16_impl(int variant, int dtype, int split, int epilogue, const vo
                        const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
                        const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, int batch, long long sa,
                        long long sw, long long sc, long long sr, long long so, llark_stream_t stream, void* out_hi2 = nullptr,
-                       int act = 0) {
+                       int act = 0, llark_workspace* ws = nullptr) {
     LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemm16: null pointer or empty problem");
     LLARK_REQUIRE(kp % 64 == 0 || (kp % 32 == 0 && variant < 10),
                   "gemm16: kp=%d must be a multiple of the K-step (zero-pad K)", kp);
@@ -823,9 +840,9 @@ static int gemm16_impl(int variant, int dtype, int split, int epilogue, const vo
         else if (dtype == LLARK_BF16) rc = dispatch_skinny<bf16_t>(p, split != 0, epilogue, s);
         if (rc != 1) return rc;
     }
-    if (variant < 0) variant = pick_variant(split, m, n, kp);
-    if (dtype == LLARK_F16) return dispatch_variant<half_t>(variant, p, split != 0, epilogue, s);
-    if (dtype == LLARK_BF16) return dispatch_variant<bf16_t>(variant, p, split != 0, epilogue, s);
+    if (variant < 0) variant = pick_variant(split, m, n, kp, ws != nullptr);
+    if (dtype == LLARK_F16) return dispatch_variant<half_t>(variant, p, split != 0, epilogue, s, ws);
+    if (dtype == LLARK_BF16) return dispatch_variant<bf16_t>(variant, p, split != 0, epilogue, s, ws);
     set_error("gemm16: unknown dtype %d", dtype);
     return LLARK_ERR_INVALID;
 }
@@ -836,6 +853,77 @@ extern "C" int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, 
                                llark_stream_t stream) {
     return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
                        out_lo, ldo, 0, 0, 0, 0, 0, 0, stream);
+}
+
+// llark_gemm16_ex with a caller-owned workspace: enables the persistent, chunk-synchronous tile variants (20, 30), whose
+// per-XCD chunk counters live in the workspace.  Without one (llark_gemm16 / llark_gemm16_ex) those variants are never
+// chosen and a request for them runs the per-tile 128x256x64 kernel: no entry point allocates or keeps hidden state.
+extern "C" int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                               const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc,
+                               const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, llark_workspace_t ws,
+                               llark_stream_t stream) {
+    return gemm16_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi,
+                       out_lo, ldo, 0, 0, 0, 0, 0, 0, stream, nullptr, 0, ws);
+}
+
+extern "C" llark_workspace_t llark_workspace_create(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        set_error("workspace_create: cannot query the current device");
+        return nullptr;
+    }
+    llark_workspace* ws = new (std::nothrow) llark_workspace();
+    if (!ws) { set_error("workspace_create: out of host memory"); return nullptr; }
+    ws->device = dev; ws->cus = cus; ws->base = 0; ws->counters = nullptr;
+    if (hipMalloc((void**)&ws->counters, LLARK_WS_BYTES) != hipSuccess || hipMemset(ws->counters, 0, LLARK_WS_BYTES) != hipSuccess) {
+        set_error("workspace_create: cannot allocate %d bytes of device memory", LLARK_WS_BYTES);
+        if (ws->counters) (void)hipFree(ws->counters);
+        delete ws;
+        return nullptr;
+    }
+    return ws;
+}
+
+extern "C" int llark_workspace_destroy(llark_workspace_t ws) {
+    if (!ws) return LLARK_OK;
+    if (ws->counters) (void)hipFree(ws->counters);
+    delete ws;
+    return LLARK_OK;
+}
+
+// Split GEMM with an e4m3 low plane (csrc/gemm256_lo8.hip): the prior's Conv1D products in "lo8" mode.
+//   a_hi  fp16 [m][lda]            = fp16(a)
+//   a_lo8 e4m3 [m][lda8] (bytes)   = fp8(sat((a - a_hi) * 2^sa)), every 64-k block in the slot order of lo8_pos()
+//   wt    fp16 [n][ldw]; sw such that max|W| * 2^sw <= 448 (the kernel derives W8 = fp8(W * 2^sw) in registers)
+// epilogue: LLARK_EPI_F32 / LLARK_EPI_RESID / LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo], out_lo8 e4m3 [m][ldo8]).
+extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
+                                const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid,
+                                int ldr, void* out_hi, void* out_lo8, int ldo, int ldo8, llark_workspace_t ws,
+                                llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && a_lo8 && wt && ws && m > 0 && n > 0, "gemm16_lo8: null pointer or empty problem");
+    LLARK_REQUIRE(kp % 64 == 0 && kp >= 128, "gemm16_lo8: kp=%d must be a multiple of 64 and >= 128 (zero-pad K)", kp);
+    LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp && lda8 >= kp && lda8 % 16 == 0,
+                  "gemm16_lo8: lda/ldw/lda8 must be >= kp, lda/ldw multiples of 8, lda8 a multiple of 16");
+    LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && ((uintptr_t)a_lo8 & 15) == 0,
+                  "gemm16_lo8: operands must be 16-byte aligned");
+    LLARK_REQUIRE(sa >= 0 && sa <= 40 && sw >= -40 && sw <= 40, "gemm16_lo8: scale exponents out of range (sa=%d sw=%d)", sa, sw);
+    if (epilogue == EPI_F32 || epilogue == EPI_RESID) LLARK_REQUIRE(c && ldc >= n, "gemm16_lo8: fp32 output missing");
+    if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16_lo8: residual missing");
+    if (epilogue == EPI_QGELU_SPLIT8)
+        LLARK_REQUIRE(out_hi && out_lo8 && ldo >= n && ldo8 >= ((n + 63) & ~63) && ldo8 % 64 == 0,
+                      "gemm16_lo8: split outputs missing (ldo8 must cover n rounded up to 64 and be a multiple of 64)");
+    LLARK_REQUIRE(epilogue == EPI_F32 || epilogue == EPI_RESID || epilogue == EPI_QGELU_SPLIT8, "gemm16_lo8: unsupported epilogue %d", epilogue);
+    LLARK_REQUIRE(ws->cus > 0 && ws->cus % 8 == 0, "gemm16_lo8: device with %d CUs is not supported (needs a multiple of 8)", ws->cus);
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo8; p.lda = lda; p.lda8 = lda8; p.Wt = wt; p.ldw = ldw; p.bias = bias;
+    p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    p.Ohi = out_hi; p.Olo = out_lo8; p.ldo = ldo; p.ldo8 = ldo8; p.lo8_sa = sa; p.lo8_sw = sw;
+    hipStream_t s = (hipStream_t)stream;
+    if (ws_begin(ws, p, s)) { set_error("gemm16_lo8: workspace unusable"); return LLARK_ERR_LAUNCH; }
+    const int rc = launch_gemm256_lo8(p, epilogue, s, ws->cus);
+    if (rc == -1000) { set_error("gemm16_lo8: problem outside the kernel's range (32-bit operand offsets)"); return LLARK_ERR_UNSUPPORTED; }
+    ws_end(ws, cdiv(m, 256) * cdiv(n, 256), ws->cus / 8);
+    return rc;
 }
 
 // acc + bias -> (exact GELU) -> 16-bit planes, optionally with a second copy of the hi plane: the producer side of a

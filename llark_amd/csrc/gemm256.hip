@@ -38,6 +38,17 @@ struct Cfg256 {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): the same per-wave cycle counters as gemm256_lo8.hip.
+#ifdef LLARK_LO8_PROF
+#define PROF_DECL long long pt0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0
+#define PROF_T0() pt0 = __builtin_readcyclecounter()
+#define PROF_ADD(ACC) do { const long long t_ = __builtin_readcyclecounter(); ACC += t_ - pt0; pt0 = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_T0()
+#define PROF_ADD(ACC)
+#endif
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(Cfg256::THREADS, Cfg256::MINW) void gemm256_kernel(const GemmParams p) {
     typedef Cfg256 C;
@@ -165,30 +176,48 @@ __global__ __launch_bounds__(Cfg256::THREADS, Cfg256::MINW) void gemm256_kernel(
             issue_TW(1, 6);
             VMCNT(12);
             __builtin_amdgcn_s_barrier();
+            PROF_DECL;
+            PROF_T0();
             int u0 = 0;                                                    // ring slot of unit 0 of K-step k
             for (int k = 0; k < nk; ++k) {
                 const int u2 = wrap2(u0), u4 = wrap2(u2), n0 = wrap2(u4);  // n0 = slot of unit 0 of K-step k+1
                 const bool more = k + 1 < nk;
                 // ---- phase T(k): reads AT_k, W_k; requests AT_{k+1}, W_{k+1} (slots freed by the barrier that ended B(k-1)) ----
                 phase(std::integral_constant<int, 0>{}, u0, u2 + wn, [&]() __attribute__((always_inline)) { if (k > 0 && more) issue_TW(k + 1, n0); });
+                PROF_ADD(pacc0);
                 if (more) VMCNT(8); else VMCNT(0);                         // this wave's share of AB_k has landed
+                PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
                 // ---- phase B(k): reads AB_k, W_k; requests AB_{k+1} (the slots of AT_k, freed by the barrier above) ----
                 phase(std::integral_constant<int, 1>{}, u4, u2 + wn, [&]() __attribute__((always_inline)) { if (more) issue_B(k + 1, n0); });
+                PROF_ADD(pacc0);
                 VMCNT(4);                                                  // this wave's share of AT_{k+1}, W_{k+1} has landed
+                PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
                 u0 = n0;
             }
             VMCNT(0);
+#ifdef LLARK_LO8_PROF
+            if (p.prof && lane == 0) {
+                long long* q = p.prof + ((size_t)blockIdx.x * 8 + w) * 4;
+                q[0] += pacc0; q[1] += pacc1; q[2] += pacc2; q[3] += 2 * nk;
+            }
+            PROF_T0();
+#endif
             gemm_epilogue<T, true, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+#ifdef LLARK_LO8_PROF
+            if (p.prof && lane == 0) { long long* q = p.prof + ((size_t)(blockIdx.x + 256) * 8 + w) * 4; q[0] += __builtin_readcyclecounter() - pt0; q[3] += 1; }
+#endif
         }
         if (ch + 1 < nchunks) {
             __syncthreads();
             if (threadIdx.x == 0) {
                 __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int target = (ch + 1) * p.slots;
+                const int target = p.sync_base + (ch + 1) * p.slots;
                 // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
-                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++it)
+                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
                     __builtin_amdgcn_s_sleep(8);
             }
             __syncthreads();
@@ -197,45 +226,42 @@ __global__ __launch_bounds__(Cfg256::THREADS, Cfg256::MINW) void gemm256_kernel(
 }
 
 template <typename T, int EPI>
-static int launch256(GemmParams p, hipStream_t s) {
+static int launch256(GemmParams p, hipStream_t s, int cus) {
     typedef Cfg256 C;
     auto kern = gemm256_kernel<T, EPI>;
-    static int cus = -1;
-    if (cus < 0) {
-        int dev = 0, n = 0, per_cu = 0;
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) n = 0;
-        else {
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, C::THREADS, C::LDS) != hipSuccess || per_cu < 1) n = 0;
-        }
-        cus = (n % 8 == 0) ? n : 0;
+    static bool attr_set = false;                // a property of the code object, not of a device or a stream
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
+        attr_set = true;
     }
-    if (cus <= 0) return -1000;
+    if (cus <= 0 || cus % 8) return -1000;
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
     p.slots = cus / 8;
+#ifdef LLARK_LO8_PROF
+    if (const char* e = getenv("LLARK_LO8_PROF_BUF")) p.prof = (long long*)strtoull(e, nullptr, 0);
+#endif
     kern<<<dim3(cus), C::THREADS, C::LDS, s>>>(p);
     return check_launch("gemm256");
 }
 
 template <typename T>
-static int dispatch256(const GemmParams& p, int epi, hipStream_t s) {
+static int dispatch256(const GemmParams& p, int epi, hipStream_t s, int cus) {
     switch (epi) {
-        case EPI_F32: return launch256<T, EPI_F32>(p, s);
-        case EPI_RESID: return launch256<T, EPI_RESID>(p, s);
-        case EPI_QGELU_SPLIT: return launch256<T, EPI_QGELU_SPLIT>(p, s);
-        case EPI_SPLIT16: return launch256<T, EPI_SPLIT16>(p, s);
+        case EPI_F32: return launch256<T, EPI_F32>(p, s, cus);
+        case EPI_RESID: return launch256<T, EPI_RESID>(p, s, cus);
+        case EPI_QGELU_SPLIT: return launch256<T, EPI_QGELU_SPLIT>(p, s, cus);
+        case EPI_SPLIT16: return launch256<T, EPI_SPLIT16>(p, s, cus);
     }
     return -1000;
 }
 
-int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s) {
+int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus) {
     // split mode only; needs >= 2 K-steps of 64, operands addressable with 32-bit byte offsets, a sync block, no batch
     if (!p.Alo || p.Kp % 64 != 0 || p.Kp < 128 || p.batch > 1 || !p.sync) return -1000;
     if ((long long)p.M * p.lda * 2 >= (1ll << 31) || (long long)p.N * p.ldw * 2 >= (1ll << 31)) return -1000;
-    if (dtype == LLARK_F16) return dispatch256<half_t>(p, epi, s);
-    if (dtype == LLARK_BF16) return dispatch256<bf16_t>(p, epi, s);
+    if (dtype == LLARK_F16) return dispatch256<half_t>(p, epi, s, cus);
+    if (dtype == LLARK_BF16) return dispatch256<bf16_t>(p, epi, s, cus);
     return -1000;
 }
 

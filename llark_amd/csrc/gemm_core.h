@@ -7,6 +7,17 @@
 
 #include "common.h"
 
+// The object behind llark_workspace_t (include/llark_hip.h): device memory the persistent GEMM kernels need between
+// workgroups -- one 128-B line of chunk counters per XCD -- owned by the CALLER, plus the host-side running base of those
+// monotonic counters.  One workspace serves one stream at a time.
+#define LLARK_WS_BYTES (8 * 32 * (int)sizeof(int))
+struct llark_workspace {
+    int device;
+    int cus;          // CUs of `device`
+    int* counters;    // [8 XCDs][32] ints, device memory
+    int base;         // value every XCD counter will have when the next launch starts
+};
+
 namespace llark {
 
 // Tile configuration: WM x WN waves, each owning TM x TN MFMA tiles of 32x32; K-step BK (32 or 64).
@@ -67,9 +78,16 @@ struct GemmParams {
     const float* xg;   // norm weight [Kp]
     int ldxn;
     float xeps;
+    // lo8 mode (gemm256_lo8.hip): Alo is an e4m3 plane [M][lda8] = fp8(sat((a - Ahi) * 2^lo8_sa)) in the slot order of
+    // lo8_pos(); W8 = e4m3(W * 2^lo8_sw) is derived from Wt in registers.  EPI_QGELU_SPLIT8 writes Olo as such a plane.
+    int lda8, ldo8;
+    int lo8_sa, lo8_sw;
+    int sync_base;     // persistent kernels: value of the (monotonic) chunk counters when this launch starts
+    long long* prof;   // profiling builds only (-DLLARK_LO8_PROF): per-wave cycle counters, nullptr otherwise
 };
 
-enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6 };
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
+       EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8.hip only) */ };
 #define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
 
 template <typename T>
@@ -143,12 +161,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + bz * p.sR + (size_t)mrow0 * p.ldr + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vR = (lr * p.ldr + lc) * 4;
     }
-    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI)) {
+    if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_OUT16 || IS_SWIGLU(EPI) || EPI == EPI_QGELU_SPLIT8) {
         rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
         vO = (lr * p.ldo + lc) * 2;
     }
     if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
         rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+    int v8 = 0;
+    float sa_mul = 1.0f;
+    if (EPI == EPI_QGELU_SPLIT8) {     // e4m3 low plane: byte rows of ldo8, this wave's 128 columns = two 64-k blocks
+        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)p.Olo + (size_t)mrow0 * p.ldo8 + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        v8 = lr * p.ldo8 + (((lc >> 3) & 1) << 5) + ((lc >> 4) << 3) + (lc & 7);       // lo8_pos of column lc inside a 32-column MFMA tile
+        sa_mul = __builtin_ldexpf(1.0f, p.lo8_sa);
+    }
     __amdgpu_buffer_rsrc_t rH2;
     const bool dup_hi = EPI == EPI_SPLIT16 && p.Ohi2 != nullptr;
     if (EPI == EPI_SPLIT16)
@@ -203,6 +228,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, so, 0);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), rL, vO, so, 0);
                         if (EPI == EPI_SPLIT16 && dup_hi) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH2, vO, so, 0);
+                    } else if (EPI == EPI_QGELU_SPLIT8) {
+                        v = quick_gelu(v);
+                        const T hi = Mfma<T>::cvt(v);
+                        const unsigned lo8 = fp8_e4m3_sat((v - Mfma<T>::back(hi)) * sa_mul);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, (ml * p.ldo + ocl) * 2, 0);
+                        // tile tn covers k = (tn & 1) * 32 + lc of 64-block tn / 2: sub-steps s = 2 (tn & 1) + lc / 16
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lo8, rL, v8, ml * p.ldo8 + (tn >> 1) * 64 + (tn & 1) * 16, 0);
                     } else if (EPI == EPI_OUT16) {
                         if (act_erf) v = gelu_erf(v);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
@@ -240,6 +272,10 @@ __device__ __forceinline__ void xcd_band(int nwg, int xcd, int& base, int& count
 
 // gemm256.hip: 256x256x64 split-mode tile (8 waves, counted-vmcnt LDS-DMA ring of 10 x 16 KiB).  dtype LLARK_F16 / LLARK_BF16.
 // Returns -1000 when the problem is not one it handles (caller falls back to another variant).
-int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s);
+int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
+// gemm256_lo8.hip: the same tile with an e4m3 low plane (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of
+// the stream's device (8 | cus).  Returns -1000 when the problem is not one it handles.
+int launch_gemm256_lo8(const GemmParams& p, int epi, hipStream_t s, int cus);
+int gemm256_lo8_chunk_barriers(int M, int N, int cus);
 
 }  // namespace llark

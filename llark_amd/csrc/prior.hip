@@ -47,12 +47,14 @@ __global__ void prior_embed_kernel(const long long* __restrict__ z, const float4
 // LayerNorm (fp32, eps inside the sqrt, two-pass variance) -> fp16 hi/lo planes for the split GEMM.
 // One wave per row; the row lives in registers (NV float4 per lane), so HBM sees 1 read + 1 write.
 // ------------------------------------------------------------------------------------------
-template <int NV>
+// LO8: the low plane is an e4m3 byte plane [rows][ldo8] = fp8(sat((y - hi) * 2^sa)) in the slot order of lo8_pos()
+// (gemm_core.h; consumed by gemm256_lo8.hip) instead of an fp16 plane.
+template <int NV, bool LO8>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, int ldx, int rows, int width,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
-                                                              half_t* __restrict__ hi, half_t* __restrict__ lo,
-                                                              int ldo) {
+                                                              half_t* __restrict__ hi, void* __restrict__ lo_plane,
+                                                              int ldo, int ldo8, int sa) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     const float4* g4 = (const float4*)gamma;
     const float4* b4 = (const float4*)beta;
     half4_t* hr = (half4_t*)(hi + (size_t)row * ldo);
-    half4_t* lr = (half4_t*)(lo + (size_t)row * ldo);
+    half4_t* lr = LO8 ? nullptr : (half4_t*)((half_t*)lo_plane + (size_t)row * ldo);
+    unsigned char* l8 = LO8 ? (unsigned char*)lo_plane + (size_t)row * ldo8 : nullptr;
+    const float sa_mul = __builtin_ldexpf(1.0f, sa);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
@@ -97,13 +101,16 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
             y[2] = (v[k].z - mean) * rstd * g.z + b.z;
             y[3] = (v[k].w - mean) * rstd * g.w + b.w;
             half4_t h, l;
+            unsigned q = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 h[e] = (half_t)y[e];
-                l[e] = (half_t)(y[e] - (float)h[e]);
+                if (LO8) q |= fp8_e4m3_sat((y[e] - (float)h[e]) * sa_mul) << (8 * e);
+                else l[e] = (half_t)(y[e] - (float)h[e]);
             }
             hr[c] = h;
-            lr[c] = l;
+            if (LO8) *(unsigned*)(l8 + lo8_pos(4 * c)) = q;       // 4 consecutive k stay contiguous in the slot order
+            else lr[c] = l;
         }
     }
 }
@@ -119,8 +126,9 @@ struct AttnParams {
     const float* qkv;   // [n*T][ldq]: q | k | v column blocks of n_state each
     int ldq;
     half_t* ohi;        // [n*T][ldo]
-    half_t* olo;
+    half_t* olo;        // fp16 low plane, or (lo8 != 0) the e4m3 byte plane [n*T][ldo8] in the slot order of lo8_pos()
     int ldo;
+    int lo8, ldo8, sa;
     int T, n_state, hd, heads;
     int block_ctx, blocks;
     int pattern;        // 1 block, 2 transpose-block, 3 previous-block
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
             const int r = i / hd, d = i - r * hd;
             const size_t o = (rowbase + q0 + (size_t)r * qs) * p.ldo + hcol + d;
             p.ohi[o] = (half_t)0.0f;
-            p.olo[o] = (half_t)0.0f;
+            if (p.lo8) ((unsigned char*)p.olo)[(rowbase + q0 + (size_t)r * qs) * p.ldo8 + lo8_pos(hcol + d)] = 0;   // e4m3 0x00 = +0
+            else p.olo[o] = (half_t)0.0f;
         }
         return;
     }
@@ -342,10 +351,18 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
                             half2_t h, l;
                             h[0] = (half_t)o[dt][2 * e];
                             h[1] = (half_t)o[dt][2 * e + 1];
-                            l[0] = (half_t)(o[dt][2 * e] - (float)h[0]);
-                            l[1] = (half_t)(o[dt][2 * e + 1] - (float)h[1]);
                             *(half2_t*)(p.ohi + ob + d + 2 * e) = h;
-                            *(half2_t*)(p.olo + ob + d + 2 * e) = l;
+                            if (p.lo8) {
+                                const float sm = __builtin_ldexpf(1.0f, p.sa);
+                                const unsigned q = fp8_e4m3_sat((o[dt][2 * e] - (float)h[0]) * sm) |
+                                                   (fp8_e4m3_sat((o[dt][2 * e + 1] - (float)h[1]) * sm) << 8);
+                                unsigned char* l8 = (unsigned char*)p.olo + (rowbase + q0 + (size_t)i * qs) * p.ldo8;
+                                *(unsigned short*)(l8 + lo8_pos(hcol + d + 2 * e)) = (unsigned short)q;    // even k: the pair stays contiguous
+                            } else {
+                                l[0] = (half_t)(o[dt][2 * e] - (float)h[0]);
+                                l[1] = (half_t)(o[dt][2 * e + 1] - (float)h[1]);
+                                *(half2_t*)(p.olo + ob + d + 2 * e) = l;
+                            }
                         }
                     }
                 }
@@ -411,18 +428,21 @@ extern "C" int llark_prior_embed(const int64_t* z, int n, int t, int width, int 
     return check_launch("prior_embed");
 }
 
-extern "C" int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, const float* gamma,
-                                         const float* beta, float eps, void* out_hi, void* out_lo, int ldo,
-                                         llark_stream_t stream) {
+static int layernorm_split_impl(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
+                                void* out_hi, void* out_lo, int ldo, int lo8, int ldo8, int sa, llark_stream_t stream) {
     LLARK_REQUIRE(x && gamma && beta && out_hi && out_lo, "layernorm_split: null pointer");
     LLARK_REQUIRE(rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= width && ldx >= width,
                   "layernorm_split: bad shape rows=%d width=%d ldx=%d ldo=%d", rows, width, ldx, ldo);
+    if (lo8) LLARK_REQUIRE(ldo8 % 64 == 0 && ldo8 >= ((width + 63) & ~63) && sa >= 0 && sa <= 40 && ((uintptr_t)out_lo & 3) == 0,
+                           "layernorm_split_lo8: ldo8=%d must be a multiple of 64 covering width=%d; sa=%d in [0,40]", ldo8, width, sa);
     const int w4 = width / 4;
     dim3 grid(cdiv(rows, 4));
     hipStream_t s = (hipStream_t)stream;
-#define LN_CASE(NV)                                                                                             \
-    layernorm_split_kernel<NV><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (half_t*)out_hi, \
-                                                     (half_t*)out_lo, ldo)
+#define LN_CASE(NV)                                                                                                              \
+    do {                                                                                                                         \
+        if (lo8) layernorm_split_kernel<NV, true><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (half_t*)out_hi, out_lo, ldo, ldo8, sa); \
+        else layernorm_split_kernel<NV, false><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (half_t*)out_hi, out_lo, ldo, 0, 0);   \
+    } while (0)
     if (w4 <= 64) LN_CASE(1);
     else if (w4 <= 256) LN_CASE(4);
     else if (w4 <= 1024) LN_CASE(16);
@@ -436,8 +456,20 @@ extern "C" int llark_layernorm_split_f16(const float* x, int ldx, int rows, int 
     return check_launch("layernorm_split");
 }
 
-extern "C" int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks,
-                                int pattern, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+extern "C" int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, const float* gamma,
+                                         const float* beta, float eps, void* out_hi, void* out_lo, int ldo,
+                                         llark_stream_t stream) {
+    return layernorm_split_impl(x, ldx, rows, width, gamma, beta, eps, out_hi, out_lo, ldo, 0, 0, 0, stream);
+}
+
+extern "C" int llark_layernorm_split_lo8(const float* x, int ldx, int rows, int width, const float* gamma,
+                                         const float* beta, float eps, void* out_hi, int ldo, void* out_lo8, int ldo8, int sa,
+                                         llark_stream_t stream) {
+    return layernorm_split_impl(x, ldx, rows, width, gamma, beta, eps, out_hi, out_lo8, ldo, 1, ldo8, sa, stream);
+}
+
+static int prior_attn_impl(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks,
+                           int pattern, void* out_hi, void* out_lo, int ldo, int lo8, int ldo8, int sa, llark_stream_t stream) {
     LLARK_REQUIRE(qkv && out_hi && out_lo, "prior_attn: null pointer");
     LLARK_REQUIRE(n > 0 && t > 0 && heads > 0 && n_state % heads == 0 && blocks > 0 && t % blocks == 0,
                   "prior_attn: bad shape");
@@ -448,6 +480,9 @@ extern "C" int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_s
     LLARK_REQUIRE(ldq >= 3 * n_state && ldo >= n_state, "prior_attn: leading dimensions too small");
     AttnParams p;
     p.qkv = qkv; p.ldq = ldq; p.ohi = (half_t*)out_hi; p.olo = (half_t*)out_lo; p.ldo = ldo;
+    p.lo8 = lo8; p.ldo8 = ldo8; p.sa = sa;
+    if (lo8) LLARK_REQUIRE(ldo8 % 64 == 0 && ldo8 >= ((n_state + 63) & ~63) && sa >= 0 && sa <= 40 && ((uintptr_t)out_lo & 1) == 0,
+                           "prior_attn_lo8: ldo8=%d must be a multiple of 64 covering n_state=%d; sa=%d in [0,40]", ldo8, n_state, sa);
     p.T = t; p.n_state = n_state; p.hd = hd; p.heads = heads; p.block_ctx = bc; p.blocks = blocks; p.pattern = pattern;
     p.qc = blocks < 64 ? blocks : 64;
     LLARK_REQUIRE(blocks % p.qc == 0 && blocks <= 128, "prior_attn: blocks=%d must be <=128 and a multiple of %d", blocks, p.qc);
@@ -476,6 +511,16 @@ extern "C" int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_s
     else ATT_LAUNCH(10);
 #undef ATT_LAUNCH
     return check_launch("prior_attn");
+}
+
+extern "C" int llark_prior_attn(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks,
+                                int pattern, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    return prior_attn_impl(qkv, ldq, n, t, n_state, heads, blocks, pattern, out_hi, out_lo, ldo, 0, 0, 0, stream);
+}
+
+extern "C" int llark_prior_attn_lo8(const float* qkv, int ldq, int n, int t, int n_state, int heads, int blocks,
+                                    int pattern, void* out_hi, int ldo, void* out_lo8, int ldo8, int sa, llark_stream_t stream) {
+    return prior_attn_impl(qkv, ldq, n, t, n_state, heads, blocks, pattern, out_hi, out_lo8, ldo, 1, ldo8, sa, stream);
 }
 
 extern "C" int llark_pool_window(const float* h, int n, int t, int width, int frame_len, float* out, int frames,

@@ -55,9 +55,13 @@ def _normalize(audio: np.ndarray) -> np.ndarray:
 def load_audio_from_file(fpath) -> np.ndarray:
     """Reads a wav file, resamples to 44.1 kHz, converts to mono, peak-normalises.
 
-    The reference calls ``librosa.load(fpath, sr=44100)`` (not installed here); wav decoding uses
-    ``scipy.io.wavfile`` and polyphase resampling -- resampled clips therefore differ from librosa's
-    soxr output at rounding level; 44.1 kHz files are bit-identical after the int->float scaling.
+    ``fpath``: a path or a binary file object (the Beam worker passes ``io.BytesIO(wav_bytes)``,
+    jukebox/dataflow_inference.py:101-103).  The reference calls ``librosa.load(fpath, sr=44100)`` (librosa / soundfile /
+    soxr are not installed here): wav decoding uses ``scipy.io.wavfile`` with soundfile's integer scaling (int16 / 2^15,
+    int32 and 24-bit-in-int32 / 2^31, uint8 -> (x - 128) / 2^7), mono = channel mean BEFORE resampling like
+    ``librosa.load``, and polyphase resampling -- resampled clips therefore differ from librosa's ``soxr_hq`` output at
+    filter-design level; 44.1 kHz files are bit-identical.  Formats other than wav (librosa's audioread fallback) are
+    not decoded.
     """
     from scipy.io import wavfile
 
@@ -67,7 +71,9 @@ def load_audio_from_file(fpath) -> np.ndarray:
             raise ValueError("empty wav")
     except ValueError as ve:
         raise EmptyFileError(f"file {fpath} failed to read with exception {ve!r}; it is probably empty.")
-    if np.issubdtype(data.dtype, np.integer):
+    if data.dtype == np.uint8:
+        data = (data.astype(np.float32) - 128.0) / 128.0
+    elif np.issubdtype(data.dtype, np.integer):
         data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
     data = data.astype(np.float32)
     audio = data.T if data.ndim == 2 else data            # (channels, samples) like librosa mono=False
@@ -200,8 +206,11 @@ def get_acts_from_audio_batch(audios: Sequence[np.ndarray], hps, vqvae, top_prio
 
 
 def load_model(model="5b", weights=None, hps: Optional[JukeboxHParams] = None, device="cuda", depth=None,
-               restore_vqvae: Optional[str] = None, restore_prior: Optional[str] = None):
+               restore_vqvae: Optional[str] = None, restore_prior: Optional[str] = None, precision: Optional[str] = None):
     """Builds (hps, vqvae, top_prior) like jukebox/main.py:176-200.
+
+    ``precision`` (NEW): how the prior's Conv1D products carry the fp32 activation -- "f16x2" or "lo8", see
+    ``llark_amd.jukebox.prior.PriorTransformer``; default ``$LLARK_PRIOR_PRECISION`` / the library default.
 
     ``weights=None`` (the reference's call, ``load_model()``): read upstream's ``5b/vqvae.pth.tar`` and
     ``<model>/prior_level_2.pth.tar`` from the local mirror ``~/.cache/jukebox/models`` (``$JUKEBOX_CACHE``) or from
@@ -233,7 +242,7 @@ def load_model(model="5b", weights=None, hps: Optional[JukeboxHParams] = None, d
 
         weights, _unexpected = select_weights([weights], hps, d, origin="weights mapping")
     vqvae = VQVAE(hps, weights, device)
-    top_prior = TopPrior(hps, weights, device, depth=depth)
+    top_prior = TopPrior(hps, weights, device, depth=depth, precision=precision)
     return hps, vqvae, top_prior
 
 
@@ -242,9 +251,10 @@ class WrappedAudioEncoder(torch.nn.Module):
     wrapping get_z -> get_cond -> get_final_activations -> windowed pooling (10 fps => 240 frames for
     >= 23.8 s clips).  Clips are independent: this is the unit that shards across GPUs."""
 
-    def __init__(self, hps=None, weights=None, device="cuda", pool_frames_per_second: int = 10, depth=None):
+    def __init__(self, hps=None, weights=None, device="cuda", pool_frames_per_second: int = 10, depth=None,
+                 precision: Optional[str] = None):
         super().__init__()
-        self.hps, self.vqvae, self.top_prior = load_model("5b", weights, hps, device, depth)
+        self.hps, self.vqvae, self.top_prior = load_model("5b", weights, hps, device, depth, precision=precision)
         self.pool_frames_per_second = pool_frames_per_second
         self._cond = None
 

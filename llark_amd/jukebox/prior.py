@@ -13,9 +13,11 @@ Data layout in HBM (per batch of N clips, M = N*n_ctx rows):
   att_hi/lo fp16 [M][Sp]   (Sp = S rounded up to 32, pad columns stay zero)
   g_hi/lo  fp16 [M][Mp]                     QuickGELU output
   weights  fp16 [N_out][Kp]                 transposed (K-contiguous) copies of upstream Conv1D.w
+In "lo8" precision the three lo planes are E4M3 byte planes (uint8 [M][K rounded up to 64], MFMA slot order, scale 2^12).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -23,6 +25,9 @@ import torch
 
 from .. import ops
 from .hparams import JukeboxHParams
+
+
+DEFAULT_PRECISION = "f16x2"     # see PriorTransformer.__init__; LLARK_PRIOR_PRECISION overrides
 
 
 class Labeller:
@@ -48,16 +53,24 @@ class Labeller:
 
 class _LayerWeights:
     __slots__ = ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "w_attn", "b_attn", "w_proj", "b_proj", "w_fc", "b_fc", "w_proj2",
-                 "b_proj2")
+                 "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2")
 
 
 class PriorTransformer:
     """``top_prior.prior``: the ConditionalAutoregressive2D forward in ``only_encode`` mode."""
 
-    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device, depth: Optional[int] = None):
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device, depth: Optional[int] = None,
+                 precision: Optional[str] = None):
         self.hps = hps
         self.device = torch.device(device)
         self.only_encode = False
+        # How the Conv1D products carry the fp32 activation (the reference runs them in fp32, jukebox/main.py:108):
+        #   "f16x2": fp16 hi + fp16 lo planes, two fp16 MFMA passes (22 significant bits; csrc/gemm256.hip)
+        #   "lo8"  : fp16 hi + E4M3 lo plane, one fp16 pass + one MX-fp8 MFMA (15-16 bits; csrc/gemm256_lo8.hip)
+        precision = precision or os.environ.get("LLARK_PRIOR_PRECISION", DEFAULT_PRECISION)
+        if precision not in ("f16x2", "lo8"):
+            raise ValueError(f"prior precision must be 'f16x2' or 'lo8', got {precision!r}")
+        self.precision = precision
         self.width = hps.prior_width
         self.depth = hps.prior_depth if depth is None else depth
         dev = self.device
@@ -73,7 +86,10 @@ class PriorTransformer:
             # (no fragment-major twin here: measured in situ on MI355X, the B-direct GEMM is within +-4 % of the
             #  LDS-staged kernel on the prior's M = 65536 shapes -- both sit at the L2->CU limit -- so the prior
             #  keeps the single weight copy; the Llama engine, M = 2968, gains 8-13 % and attaches one)
-            return ops.pack_weight16(w.contiguous(), transpose=True, dst_dtype=torch.float16)
+            wt = ops.pack_weight16(w.contiguous(), transpose=True, dst_dtype=torch.float16, kmult=64 if precision == "lo8" else 32)
+            if precision == "lo8" and wt.shape[1] < 128:          # tiny test configs: zero-pad K to two K-steps
+                wt = torch.nn.functional.pad(wt, (0, 128 - wt.shape[1])).contiguous()
+            return wt
 
         self.x_emb = f32("prior.x_emb.weight")
         self.pos_emb = f32("prior.pos_emb.pos_emb")
@@ -87,6 +103,9 @@ class PriorTransformer:
             L.w_proj, L.b_proj = w16(f"{p}.attn.c_proj.w"), f32(f"{p}.attn.c_proj.b")
             L.w_fc, L.b_fc = w16(f"{p}.mlp.c_fc.w"), f32(f"{p}.mlp.c_fc.b")
             L.w_proj2, L.b_proj2 = w16(f"{p}.mlp.c_proj.w"), f32(f"{p}.mlp.c_proj.b")
+            if precision == "lo8":      # per-matrix exponent of the in-kernel fp8 weight plane: max|W| * 2^sw <= 448
+                L.sw_attn, L.sw_proj = ops.lo8_weight_exponent(L.w_attn), ops.lo8_weight_exponent(L.w_proj)
+                L.sw_fc, L.sw_proj2 = ops.lo8_weight_exponent(L.w_fc), ops.lo8_weight_exponent(L.w_proj2)
             self.layers.append(L)
         self._ws: Dict[str, torch.Tensor] = {}
         self._ws_rows = 0
@@ -96,15 +115,19 @@ class PriorTransformer:
         if self._ws_rows != rows:
             hps, dev = self.hps, self.device
             W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
-            Sp, Mp, Wp = ops.round_up(S, 32), ops.round_up(Mw, 32), ops.round_up(W, 32)
+            if self.precision == "lo8":       # K-steps of 64, at least two of them (the kernel's double-buffered prologue)
+                Sp, Mp, Wp = (max(128, ops.round_up(v, 64)) for v in (S, Mw, W))
+            else:
+                Sp, Mp, Wp = ops.round_up(S, 32), ops.round_up(Mw, 32), ops.round_up(W, 32)
+            lo_dt = torch.uint8 if self.precision == "lo8" else torch.float16       # E4M3 bytes (0x00 = 0.0) / fp16
             ws = {}
             ws["ln_hi"] = torch.zeros((rows, Wp), dtype=torch.float16, device=dev)
-            ws["ln_lo"] = torch.zeros((rows, Wp), dtype=torch.float16, device=dev)
+            ws["ln_lo"] = torch.zeros((rows, Wp), dtype=lo_dt, device=dev)
             ws["qkv"] = torch.empty((rows, 3 * S), dtype=torch.float32, device=dev)
             ws["att_hi"] = torch.zeros((rows, Sp), dtype=torch.float16, device=dev)   # pad columns stay 0
-            ws["att_lo"] = torch.zeros((rows, Sp), dtype=torch.float16, device=dev)
+            ws["att_lo"] = torch.zeros((rows, Sp), dtype=lo_dt, device=dev)
             ws["g_hi"] = torch.zeros((rows, Mp), dtype=torch.float16, device=dev)
-            ws["g_lo"] = torch.zeros((rows, Mp), dtype=torch.float16, device=dev)
+            ws["g_lo"] = torch.zeros((rows, Mp), dtype=lo_dt, device=dev)
             self._ws, self._ws_rows = ws, rows
         return self._ws
 
@@ -116,6 +139,8 @@ class PriorTransformer:
         rows = h2.shape[0]
         ws = self._workspace(rows)
         W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
+        if self.precision == "lo8":
+            return self._layer_forward_lo8(h2, L, d, n, ws, taps)
         ops.layernorm_split(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
         ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
         ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
@@ -132,6 +157,32 @@ class PriorTransformer:
             taps["ln1"] = ws["ln_hi"].float() + ws["ln_lo"].float()
             taps["g"] = (ws["g_hi"].float() + ws["g_lo"].float())[:, :Mw]
         ops.gemm16(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
+
+    def _layer_forward_lo8(self, h2, L, d: int, n: int, ws, taps) -> None:
+        """The same block with E4M3 low planes: every producer (LayerNorm, attention, the c_fc epilogue) writes
+        fp16(a) + fp8((a - fp16(a)) 2^12), every Conv1D product is one llark_gemm16_lo8."""
+        hps = self.hps
+        W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
+
+        def full(hi, lo8, width):
+            return hi.float()[:, :width] + ops.lo8_decode(lo8, width)
+
+        ops.layernorm_split_lo8(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
+        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.sw_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
+        ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
+        if taps is not None:
+            taps["ln0"] = full(ws["ln_hi"], ws["ln_lo"], W)
+            taps["qkv"] = ws["qkv"].clone()
+            taps["att"] = full(ws["att_hi"], ws["att_lo"], S)
+        ops.gemm16_lo8(ws["att_hi"], ws["att_lo"], L.w_proj, L.sw_proj, L.b_proj, W, ops.EPI_RESID, c=h2, resid=h2)
+        if taps is not None:
+            taps["xa"] = h2.clone()
+        ops.layernorm_split_lo8(h2, L.ln1_g, L.ln1_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
+        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.sw_fc, L.b_fc, Mw, ops.EPI_QGELU_SPLIT8, out_hi=ws["g_hi"], out_lo8=ws["g_lo"])
+        if taps is not None:
+            taps["ln1"] = full(ws["ln_hi"], ws["ln_lo"], W)
+            taps["g"] = full(ws["g_hi"], ws["g_lo"], Mw)
+        ops.gemm16_lo8(ws["g_hi"], ws["g_lo"], L.w_proj2, L.sw_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
 
     def embed(self, x: torch.Tensor, x_cond: torch.Tensor, y_cond: torch.Tensor) -> torch.Tensor:
         n, t = x.shape
@@ -163,14 +214,15 @@ class PriorTransformer:
 class TopPrior:
     """``top_prior``: conditioning tables + the transformer (upstream SimplePrior, level = top)."""
 
-    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", depth: Optional[int] = None):
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", depth: Optional[int] = None,
+                 precision: Optional[str] = None):
         hps.check()
         self.hps = hps
         self.device = torch.device(device)
         self.raw_to_tokens = hps.raw_to_tokens
         self.n_ctx = hps.n_ctx
         self.labeller = Labeller(hps)
-        self.prior = PriorTransformer(hps, weights, device, depth)
+        self.prior = PriorTransformer(hps, weights, device, depth, precision)
         dev = self.device
         self._y_emb = {k.split(".")[1]: v.detach().to(device=dev, dtype=torch.float32).contiguous()
                        for k, v in weights.items() if k.startswith("y_emb.")}

@@ -46,8 +46,15 @@ def adapter_state(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor
     return {k: v for k, v in state_dict.items() if any(m in k for m in ADAPTER_KEYS)}
 
 
-def save_checkpoint(trainer, output_dir: str, save_total_limit: Optional[int] = 1, rank: int = 0) -> Optional[str]:
-    """Writes ``checkpoint-<trainer.step_count>`` (+ the adapter side-file) from rank 0; other ranks return None."""
+def save_checkpoint(trainer, output_dir: str, save_total_limit: Optional[int] = 1, rank: int = 0, hf_config=None,
+                    tokenizer=None) -> Optional[str]:
+    """Writes ``checkpoint-<trainer.step_count>`` (+ the adapter side-file) from rank 0; other ranks return None.
+
+    ``hf_config`` / ``tokenizer``: what HF ``Trainer._save`` puts next to the weights and what the inference entry
+    needs to open the folder -- ``m2t/models/utils.py:132-172`` (``load_pretrained_model``) calls
+    ``AutoTokenizer.from_pretrained(ckpt_dir)`` and ``WrappedLlamav2ForCausalLM.from_pretrained(ckpt_dir)``: ``config.json``
+    (resized ``vocab_size``, ``mm_hidden_size``, ``tune_mm_mlp_adapter``, ``mm_use_audio_start_end``) and the tokenizer
+    files with the added ``[PAD]`` / audio tokens."""
     if rank != 0:
         return None
     step = trainer.step_count
@@ -59,6 +66,11 @@ def save_checkpoint(trainer, output_dir: str, save_total_limit: Optional[int] = 
     torch.save({"step": step, "lr": trainer.lr, "betas": trainer.betas, "eps": trainer.eps, "weight_decay": trainer.wd,
                 "exp_avg": trainer.flat_m.cpu(), "exp_avg_sq": trainer.flat_v.cpu(),
                 "param_order": [n for n, _ in trainer.params]}, os.path.join(tmp, "trainer_state.pt"))
+    if hf_config is not None:
+        hf_config.vocab_size = int(sd["model.embed_tokens.weight"].shape[0])
+        hf_config.save_pretrained(tmp)
+    if tokenizer is not None:
+        tokenizer.save_pretrained(tmp)
     if os.path.isdir(folder):
         shutil.rmtree(folder)
     os.replace(tmp, folder)                                   # a crash never leaves a half-written checkpoint-N

@@ -107,24 +107,57 @@ def element_to_conversations(elem: Dict[str, Any], rng: random.Random) -> Iterat
                                  {"from": "gpt", "value": resp["answer"]}]}
 
 
+SHUFFLE_BUFFER = 100          # m2t/data_modules.py: dataset.shuffle(100) after webdataset_element_to_conversation
+
+
+def _shuffled(items: Iterator[Dict[str, Any]], rng: random.Random, size: int) -> Iterator[Dict[str, Any]]:
+    """webdataset's bounded shuffle: keep ``size`` items, emit a random one as each new item arrives, drain at the end."""
+    buf: List[Dict[str, Any]] = []
+    for it in items:
+        if len(buf) < size:
+            buf.append(it)
+            continue
+        j = rng.randrange(size)
+        buf[j], it = it, buf[j]
+        yield it
+    rng.shuffle(buf)
+    yield from buf
+
+
 def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any], batch_size: int, model_max_length: int,
-                  rank: int = 0, world: int = 1, seed: int = 0, epochs: Optional[int] = None, allow_pickle: bool = False):
+                  rank: int = 0, world: int = 1, seed: int = 0, epochs: Optional[int] = None, allow_pickle: bool = False,
+                  shuffle_buffer: int = SHUFFLE_BUFFER, skip_micro_batches: int = 0):
     """Collated micro-batches (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``) of THIS rank, forever
-    (``epochs=None``, like the reference's ``repeat()``) or for a number of passes over its shards."""
+    (``epochs=None``, like the reference's ``repeat()``) or for a number of passes over its shards.
+
+    Order (m2t/data_modules.py:560-640): shards shuffled per epoch, then the (question, answer) examples go through a
+    bounded shuffle buffer of ``shuffle_buffer`` conversations so that the pairs of one clip are not emitted back to back;
+    both generators are seeded per rank AND per epoch.  ``skip_micro_batches`` fast-forwards the stream (resume: the
+    trainer passes ``step * gradient_accumulation_steps``) so a resumed run continues where the interrupted one stopped
+    instead of replaying its first samples."""
     shards = split_by_rank(expand_urls(train_data_path), rank, world)
     collate = DataCollatorForSupervisedDataset(tokenizer)
-    rng = random.Random(seed * 1000003 + rank)
     epoch = 0
+    skipped = 0
     while epochs is None or epoch < epochs:
+        rng = random.Random((seed * 1000003 + rank) * 7919 + epoch)
         order = list(shards)
         rng.shuffle(order)                                            # shardshuffle
+
+        def conversations():
+            for elem in iter_tar_samples(order, allow_pickle):
+                yield from element_to_conversations(elem, rng)
+
+        stream = _shuffled(conversations(), rng, shuffle_buffer) if shuffle_buffer and shuffle_buffer > 1 else conversations()
         pending: List[Dict[str, Any]] = []
-        for elem in iter_tar_samples(order, allow_pickle):
-            for conv in element_to_conversations(elem, rng):
-                ex = preprocess_for_lm_mappable(preprocess_multimodal_mappable(conv, multimodal_cfg), tokenizer=tokenizer)
-                ex["input_ids"], ex["labels"] = ex["input_ids"][:model_max_length], ex["labels"][:model_max_length]
-                pending.append(ex)
-                if len(pending) == batch_size:
-                    yield collate(pending)
-                    pending = []
+        for conv in stream:
+            if skipped < skip_micro_batches * batch_size:             # fast-forward without tokenising
+                skipped += 1
+                continue
+            ex = preprocess_for_lm_mappable(preprocess_multimodal_mappable(conv, multimodal_cfg), tokenizer=tokenizer)
+            ex["input_ids"], ex["labels"] = ex["input_ids"][:model_max_length], ex["labels"][:model_max_length]
+            pending.append(ex)
+            if len(pending) == batch_size:
+                yield collate(pending)
+                pending = []
         epoch += 1

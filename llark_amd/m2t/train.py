@@ -45,11 +45,14 @@ def lr_at(step: int, cfg: TrainConfig) -> float:
 
 def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainConfig(), world: int = 1,
           max_optimizer_steps: Optional[int] = None, log=None, output_dir: Optional[str] = None, save_steps: int = 5000,
-          save_total_limit: Optional[int] = 1, rank: int = 0):
+          save_total_limit: Optional[int] = 1, rank: int = 0, hf_config=None, tokenizer=None):
     """engine: a bf16 ``HipLlamaEngine`` holding the weights; batches: collated micro-batches of THIS rank
     (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``).  Returns the list of logged losses.
     With ``output_dir``: resumes from the newest ``checkpoint-*`` there (m2t/train.py:257-260), saves every
-    ``save_steps`` optimizer steps (train_llark.sh:31,41-42) and once more at the end."""
+    ``save_steps`` optimizer steps (train_llark.sh:31,41-42) and once more at the end; ``hf_config`` / ``tokenizer`` are
+    written into every checkpoint folder so that ``from_pretrained`` / ``load_pretrained_model`` can open it.
+    ``batches`` may be a callable ``skip_micro_batches -> iterable``: it is then called with the number of micro-batches
+    the resumed run has already consumed (``step * gradient_accumulation_steps``) so the data stream continues."""
     toks = [t for t in (audio_cfg.audio_start_token, audio_cfg.audio_end_token) if isinstance(t, int)]
     tr = HipLlamaTrainer(engine, lr=cfg.learning_rate, betas=(cfg.adam_beta1, cfg.adam_beta2), eps=cfg.adam_epsilon,
                          weight_decay=cfg.weight_decay, embed_grad_tokens=toks,
@@ -58,6 +61,10 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
 
     if output_dir:
         CK.maybe_resume(tr, output_dir)
+    if callable(batches):
+        batches = batches(tr.step_count * cfg.gradient_accumulation_steps)
+    if max_optimizer_steps and tr.step_count >= max_optimizer_steps:
+        return []
     losses, acc, micro = [], 0.0, 0
     for batch in batches:
         ids = batch["input_ids"].to(engine.device)
@@ -81,12 +88,33 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
                 log(dict(step=tr.step_count, loss=mean_loss, lr=tr.lr))
             acc = 0.0
             if output_dir and tr.step_count % save_steps == 0:
-                CK.save_checkpoint(tr, output_dir, save_total_limit, rank)
+                CK.save_checkpoint(tr, output_dir, save_total_limit, rank, hf_config, tokenizer)
             if max_optimizer_steps and tr.step_count >= max_optimizer_steps:
                 break
     if output_dir:
-        CK.save_checkpoint(tr, output_dir, save_total_limit, rank)
+        CK.save_checkpoint(tr, output_dir, save_total_limit, rank, hf_config, tokenizer)
     return losses
+
+
+def check_supported_recipe(args) -> None:
+    """Flags whose reference meaning the native loop does NOT implement must not be swallowed: a run that silently
+    trains something else than asked is worse than no run.
+      --freeze_backbone True  : m2t/train.py:150-151 ``model.requires_grad_(False)`` (adapter pre-training) -- the HIP
+                                trainer always updates the backbone;
+      --tune_mm_mlp_adapter False: the reference then leaves EVERY embedding row and lm_head trainable
+                                (llamav2.py:395-419); the HIP trainer trains the two audio-token rows and freezes lm_head;
+      --lr_scheduler_type     : only HF's cosine-with-warmup is implemented (train_llark.sh:35);
+      --bf16 False            : the HIP training step is the bf16 flow."""
+    if getattr(args, "freeze_backbone", False):
+        raise NotImplementedError("--freeze_backbone True (adapter-only pre-training) is not implemented by the HIP trainer; "
+                                  "it would fine-tune all backbone weights")
+    if not getattr(args, "tune_mm_mlp_adapter", True):
+        raise NotImplementedError("--tune_mm_mlp_adapter False (all embedding rows + lm_head trainable) is not implemented: the HIP "
+                                  "trainer updates the audio-token embedding rows only and keeps lm_head frozen")
+    if getattr(args, "lr_scheduler_type", "cosine") != "cosine":
+        raise NotImplementedError(f"--lr_scheduler_type {args.lr_scheduler_type!r}: only 'cosine' (with warm-up) is implemented")
+    if not getattr(args, "bf16", True):
+        raise NotImplementedError("--bf16 False: the HIP training step computes in the bf16 flow of the reference recipe")
 
 
 def main(argv=None):
@@ -125,11 +153,15 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--grad_comm", default="bf16", choices=["fp32", "bf16"], help="transport dtype of the gradient all-reduce (reference: bf16)")
     ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
-    for ignored in ("--bf16", "--tf32", "--report_to", "--logging_steps", "--lr_scheduler_type", "--evaluation_strategy", "--save_strategy",
-                    "--freeze_backbone", "--ddp_find_unused_parameters", "--dataloader_num_workers", "--num_train_epochs"):
-        ap.add_argument(ignored, default=None, help="accepted for script compatibility (fixed by the native loop)")
+    ap.add_argument("--freeze_backbone", type=boolean, default=False)
+    ap.add_argument("--lr_scheduler_type", default="cosine")
+    ap.add_argument("--bf16", type=boolean, default=True)
+    for ignored in ("--tf32", "--report_to", "--logging_steps", "--evaluation_strategy", "--save_strategy",
+                    "--ddp_find_unused_parameters", "--dataloader_num_workers", "--num_train_epochs"):
+        ap.add_argument(ignored, default=None, help="accepted for script compatibility (no effect on the arithmetic of the native loop)")
     args = ap.parse_args(argv)
 
+    check_supported_recipe(args)
     rank, world, local = D.env_rank_world()
     _torch.cuda.set_device(local)
     dev = _torch.device("cuda", local)
@@ -150,15 +182,22 @@ def main(argv=None):
     eng = HipLlamaEngine(dims, dev, max_batch=args.per_device_train_batch_size, max_seq=args.model_max_length, precision="bf16", frag_weights=False)
     eng.load_state_dict(model.state_dict())
     audio_cfg = model.get_model().audio_encoder_config
+    hf_config = model.config                                              # written into every checkpoint-N (with the tokenizer)
+    hf_config.mm_hidden_size = args.mm_hidden_size
+    hf_config.tune_mm_mlp_adapter = args.tune_mm_mlp_adapter
+    hf_config.mm_use_audio_start_end = args.mm_use_audio_start_end
+    hf_config.vocab_size = len(tok)
     del model
     mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
                       max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm)
-    batches = micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
-                            seed=args.seed, allow_pickle=args.allow_pickle)
+    def batches(skip_micro_batches: int):
+        return micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
+                             seed=args.seed, allow_pickle=args.allow_pickle, skip_micro_batches=skip_micro_batches)
+
     log = (lambda rec: print(rec, flush=True)) if rank == 0 else None
     train(eng, batches, audio_cfg, cfg, world=world, max_optimizer_steps=args.max_steps, log=log, output_dir=args.output_dir,
-          save_steps=args.save_steps, save_total_limit=args.save_total_limit, rank=rank)
+          save_steps=args.save_steps, save_total_limit=args.save_total_limit, rank=rank, hf_config=hf_config, tokenizer=tok)
     D.shutdown(world)
 
 

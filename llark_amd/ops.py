@@ -15,7 +15,8 @@ from . import _lib
 from ._lib import check
 
 F16, BF16, F32SRC = 0, 1, 2
-EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16, EPI_SWIGLU_SPLIT = 0, 1, 2, 3, 4, 5, 6
+EPI_F32, EPI_RESID, EPI_QGELU_SPLIT, EPI_OUT16, EPI_SWIGLU16, EPI_SPLIT16, EPI_SWIGLU_SPLIT, EPI_QGELU_SPLIT8 = 0, 1, 2, 3, 4, 5, 6, 7
+LO8_SA = 12      # 2^12: exponent of the activation low plane in lo8 mode (|a - fp16(a)| <= 2^-11 |a|; covers |a| < 2^8 unsaturated)
 
 _DT = {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32SRC}
 
@@ -121,6 +122,22 @@ def _dev(t: torch.Tensor, name: str, dtype=None, contiguous=True) -> int:
     return t.data_ptr()
 
 
+# Caller-owned workspaces of the persistent GEMM kernels (include/llark_hip.h: llark_workspace_create): one per
+# (device, stream), created on first use, destroyed with the process.  The C library itself keeps no such state.
+_workspaces = {}
+
+
+def workspace() -> int:
+    key = (torch.cuda.current_device(), _stream())
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _lib._real_lib().llark_workspace_create()
+        if not ws:
+            check(-3, "workspace_create")
+        _workspaces[key] = ws
+    return ws
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -210,9 +227,38 @@ def layernorm_split(x: torch.Tensor, gamma, beta, eps: float, out_hi: torch.Tens
           "layernorm_split")
 
 
+def layernorm_split_lo8(x: torch.Tensor, gamma, beta, eps: float, out_hi: torch.Tensor, out_lo8: torch.Tensor, sa: int = LO8_SA) -> None:
+    """x [rows][width] fp32 -> fp16 hi plane [rows][ldo] + E4M3 low plane [rows][ldo8] (uint8, MFMA slot order)."""
+    rows, width = x.shape
+    assert out_hi.shape[0] == rows and out_lo8.shape[0] == rows and out_hi.shape[1] >= width and out_lo8.dtype == torch.uint8
+    check(_lib.lib().llark_layernorm_split_lo8(_dev(x, "x", torch.float32), x.stride(0), rows, width,
+                                               _dev(gamma, "gamma", torch.float32), _dev(beta, "beta", torch.float32),
+                                               float(eps), _dev(out_hi, "out_hi", torch.float16), out_hi.stride(0),
+                                               _dev(out_lo8, "out_lo8", torch.uint8), out_lo8.stride(0), int(sa), _stream()),
+          "layernorm_split_lo8")
+
+
+def lo8_decode(lo8: torch.Tensor, width: int, sa: int = LO8_SA) -> torch.Tensor:
+    """Host-side view of an E4M3 low plane (tests / taps): undo the slot order and the 2^sa scale -> fp32 [rows][width]."""
+    rows, ld = lo8.shape
+    k = torch.arange(ld, device=lo8.device)
+    r = k & 63
+    pos = (k & ~63) + (((r >> 3) & 1) << 5) + ((r >> 4) << 3) + (r & 7)
+    b = lo8[:, pos][:, :width].to(torch.int32)
+    e, mnt = (b >> 3) & 15, (b & 7).float()
+    mag = torch.where(e == 0, mnt * 2.0 ** -9, (1.0 + mnt * 0.125) * torch.exp2(e.float() - 7.0))     # E4M3: bias 7, subnormal step 2^-9
+    return torch.where((b & 128) != 0, -mag, mag) * (2.0 ** -sa)
+
+
 def prior_attn(qkv: torch.Tensor, n: int, t: int, n_state: int, heads: int, blocks: int, pattern: int,
-               out_hi: torch.Tensor, out_lo: torch.Tensor) -> None:
+               out_hi: torch.Tensor, out_lo: torch.Tensor, lo8_sa: Optional[int] = None) -> None:
     assert qkv.shape[0] == n * t and qkv.shape[1] >= 3 * n_state
+    if out_lo.dtype == torch.uint8:
+        check(_lib.lib().llark_prior_attn_lo8(_dev(qkv, "qkv", torch.float32), qkv.stride(0), n, t, n_state, heads, blocks,
+                                              pattern, _dev(out_hi, "out_hi", torch.float16), out_hi.stride(0),
+                                              _dev(out_lo, "out_lo8", torch.uint8), out_lo.stride(0),
+                                              LO8_SA if lo8_sa is None else int(lo8_sa), _stream()), "prior_attn_lo8")
+        return
     check(_lib.lib().llark_prior_attn(_dev(qkv, "qkv", torch.float32), qkv.stride(0), n, t, n_state, heads, blocks,
                                       pattern, _dev(out_hi, "out_hi", torch.float16), _dev(out_lo, "out_lo", torch.float16),
                                       out_hi.stride(0), _stream()), "prior_attn")
@@ -301,14 +347,45 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         if fr is not None and fr[1] == n and fr[2] == kp:
             return gemm16_fragw(a_hi, a_lo, fr[0], bias, n, kp, epilogue, c=c, resid=resid, out_hi=out_hi, out_lo=out_lo, m=m)
     with _timed(name, 2.0 * m * n * kp):
-      check(_lib.lib().llark_gemm16_ex(
+      check(_lib.lib().llark_gemm16_ws(
         variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
         a_hi.stride(0), _dev(wt, "wt"), wt.stride(0), _dev(bias, "bias", torch.float32) if bias is not None else None,
         m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
         _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
         _dev(out_hi, "out_hi", dtype) if out_hi is not None else None,
         _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
-        out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16")
+        out_hi.stride(0) if out_hi is not None else 0, workspace(), _stream()), "gemm16")
+
+
+def lo8_weight_exponent(w: torch.Tensor) -> int:
+    """sw with max|W| * 2^sw <= 448 (the E4M3 maximum): the per-matrix scale of the in-kernel fp8 weight plane."""
+    amax = float(w.detach().abs().max().float())
+    if not (amax > 0.0) or amax != amax:
+        return 0
+    import math
+
+    return max(-40, min(40, math.floor(math.log2(448.0 / amax))))
+
+
+def gemm16_lo8(a_hi: torch.Tensor, a_lo8: torch.Tensor, wt: torch.Tensor, sw: int, bias: Optional[torch.Tensor], n: int, epilogue: int,
+               c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None,
+               out_lo8: Optional[torch.Tensor] = None, m: Optional[int] = None, sa: int = LO8_SA) -> None:
+    """C[m,n] = a_hi . wt^T + 2^-(sa+sw) a_lo8 . fp8(wt 2^sw)^T (+bias): the prior's split GEMM with an E4M3 low plane
+    (csrc/gemm256_lo8.hip; include/llark_hip.h: llark_gemm16_lo8)."""
+    assert a_hi.dtype == torch.float16 and wt.dtype == torch.float16 and a_lo8.dtype == torch.uint8
+    m = a_hi.shape[0] if m is None else m
+    kp = wt.shape[1]
+    assert a_hi.shape[1] >= kp and a_lo8.shape[1] >= kp and wt.shape[0] >= n
+    with _timed("gemm_lo8_f16", 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_lo8(
+            epilogue, _dev(a_hi, "a_hi"), _dev(a_lo8, "a_lo8"), a_hi.stride(0), a_lo8.stride(0), _dev(wt, "wt"), wt.stride(0),
+            _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp, int(sa), int(sw),
+            _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
+            _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+            _dev(out_hi, "out_hi", torch.float16) if out_hi is not None else None,
+            _dev(out_lo8, "out_lo8", torch.uint8) if out_lo8 is not None else None,
+            out_hi.stride(0) if out_hi is not None else 0, out_lo8.stride(0) if out_lo8 is not None else 0, workspace(), _stream()),
+            "gemm16_lo8")
 
 
 def gemm16_resid_rmsnorm(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, h: torch.Tensor, norm_w: torch.Tensor,

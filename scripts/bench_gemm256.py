@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Interleaved A/B timing of the prior's four GEMM shapes (M = 65536, split fp16): variants 12 / 20 (round-1 kernels) vs 30
-(csrc/gemm256.hip).  Rounds are interleaved inside one process and the median / min per variant is reported
+(csrc/gemm256.hip) vs 40 (csrc/gemm256_lo8.hip, fp8 low plane).  Rounds are interleaved inside one process and the median / min per variant is reported
 (MI355X guide rule 24); operands are random (rule 25).  Run on the GPU box:  python scripts/bench_gemm256.py [variants] [M]"""
 import json
 import os
@@ -34,7 +34,19 @@ def main():
         bias = torch.zeros(n, device=dev)
         a_hi, a_lo = hi[:, :k].contiguous(), lo[:, :k].contiguous()
 
+        a_lo8 = torch.randint(0, 120, (M, a_hi.shape[1]), device=dev, dtype=torch.uint8)      # finite positive E4M3 codes
+        olo8 = torch.zeros(M, 4800, dtype=torch.uint8, device=dev)
+        sw = ops.lo8_weight_exponent(wt)
+
         def fn(v):
+            if v == 40:                                   # csrc/gemm256_lo8.hip: fp16 hi pass + one MX-fp8 MFMA for the low plane
+                if epi == ops.EPI_QGELU_SPLIT:
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, ops.EPI_QGELU_SPLIT8, out_hi=ohi, out_lo8=olo8)
+                elif epi == ops.EPI_RESID:
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=c, resid=c)
+                else:
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=cq)
+                return
             if epi == ops.EPI_QGELU_SPLIT:
                 ops.gemm16(a_hi, a_lo, wt, bias, n, epi, out_hi=ohi, out_lo=olo, variant=v)
             elif epi == ops.EPI_RESID:

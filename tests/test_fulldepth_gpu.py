@@ -20,14 +20,17 @@ from conftest import report_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def jb():
+@pytest.fixture(scope="module", params=["f16x2", "lo8"])
+def jb(request):
+    """Both precisions of the prior's Conv1D products (llark_amd/jukebox/prior.py): "f16x2" = fp16 hi + fp16 lo planes
+    (22 significant bits), "lo8" = fp16 hi + E4M3 lo plane (15-16 bits, one MX-fp8 MFMA instead of the second fp16 pass)."""
     from llark_amd.jukebox import extract as E
 
     z = np.load(FD.JUKEBOX_NPZ)
     hps = FD.jukebox_hps()
     w = FD.jukebox_weights_cpu(hps)
-    enc = E.WrappedAudioEncoder(hps=hps, weights=w, device="cuda")
+    enc = E.WrappedAudioEncoder(hps=hps, weights=w, device="cuda", precision=request.param)
+    assert enc.top_prior.prior.precision == request.param
     # data-dependent codebook from the calibration clip through the HIP encoder; its checksum equals the one the C
     # oracle produced in the build container <=> the full-size encoder output is bit-exact
     cal = torch.from_numpy(FD.jukebox_clip(FD.CAL_CLIP, hps)).cuda()[None, None, :]
@@ -54,7 +57,7 @@ def test_jukebox_36_layers_batch8_vs_oracle(jb):
     assert emb.shape == (8, 240, hps.prior_width)
     scale = float(z["acts_maxabs"])
     err = report_close("36-layer B=8 embedding (240,4800) vs CPU oracle", emb[row].cpu(), z["emb_f10"], 1e-4 * scale)
-    print(f"\n[fulldepth] jukebox 36 layers x B=8: embedding max|err| {err:.3e} = {err / scale:.2e} of max|acts| {scale:.2f} "
+    print(f"\n[fulldepth] jukebox 36 layers x B=8 ({enc.top_prior.prior.precision}): embedding max|err| {err:.3e} = {err / scale:.2e} of max|acts| {scale:.2f} "
           f"({err / np.abs(z['emb_f10']).max():.2e} of max|emb|)")
     # batch invariance: the same clip alone (B = 1) gives bit-identical codes and embedding
     one = torch.from_numpy(a0).cuda()[None]
@@ -88,7 +91,7 @@ def test_jukebox_36_layers_error_growth_and_global_mean(jb):
             scale = float(z["maxabs"][i])
             err = report_close(f"probe rows after layer {d + 1}", h2[rows].cpu(), z["probes"][i], 1e-4 * scale)
             report.append((d + 1, err / scale))
-    print("\n[fulldepth] prior error growth (max|err| / max|h| at the probe rows): " + ", ".join(f"L{l}: {e:.2e}" for l, e in report))
+    print(f"\n[fulldepth] prior error growth, {tp.prior.precision} (max|err| / max|h| at the probe rows): " + ", ".join(f"L{l}: {e:.2e}" for l, e in report))
     mean = ops.pool_mean(h2.contiguous()[None])[0]
     report_close("36-layer global mean (f=0)", mean.cpu(), z["emb_f0"], 1e-4 * float(z["acts_maxabs"]))
 
