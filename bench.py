@@ -118,7 +118,8 @@ def build_workload(args, device):
     if args.depth:
         hps.prior_depth = args.depth
     weights = make_jukebox_weights(hps, seed=0, device=device)
-    enc = E.WrappedAudioEncoder(hps=hps, weights=weights, device=device)
+    enc = E.WrappedAudioEncoder(hps=hps, weights=weights, device=device, precision=args.prior_precision)
+    args.prior_precision = enc.top_prior.prior.precision
     seconds = 25.0 if not args.tiny else 1.6
     rank = int(os.environ.get("RANK", "0"))
 
@@ -239,6 +240,9 @@ def cpu_baseline_train(args):
             "sample": f"1 clip fwd+bwd S={args.train_seq} fp32 torch-autograd oracle: head {t_head:.2f}s + {layers} of 32 layers {t_layers:.2f}s extrapolated to 32"}
 
 
+PRIOR_DT = {"f16x2": "fp16x2-split(fp32-class)", "lo8": "fp16+e4m3-split(fp32 accumulate, 15-bit activations)"}
+
+
 def roofline_clap(timers, args, wl):
     """HTSAT's matrix products on the 16-bit MFMA GEMM: algorithmic 2*M*N*K of one step / HIP-event time of the GEMM launches
     (fp32 mode issues 3 bf16 MFMA passes per product: A_hi.W_hi + A_lo.W_hi + A_hi.W_lo)."""
@@ -298,6 +302,10 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2)
+    ap.add_argument("--prior-precision", default=None, choices=["lo8", "f16x2"],
+                    help="how the prior's Conv1D products carry the fp32 activation: lo8 = fp16 hi plane + E4M3 low plane (one fp16 MFMA pass + "
+                         "one MX-fp8 MFMA; 15-16 significant bits, embeddings 3e-5 of max|acts| after 36 layers), f16x2 = fp16 hi + fp16 lo "
+                         "(two fp16 passes, 22 bits, 3e-6).  Default: the library default (llark_amd/jukebox/prior.py)")
     ap.add_argument("--llm-precision", default="split", choices=["split", "bf16"],
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
@@ -364,22 +372,29 @@ def main():
         # dominant kernel: the split-fp16 MFMA GEMM of the prior.  Algorithmic flops (2*M*N*K of the
         # fp32-equivalent product; the hi/lo second pass is NOT counted) / HIP-event time of its launches.
         roof = None
-        if "gemm_split_f16" in timers and args.stages != "llama":
-            launches, ms, _ = timers["gemm_split_f16"]
+        gname = "gemm_lo8_f16" if "gemm_lo8_f16" in timers else "gemm_split_f16"
+        if gname in timers and args.stages != "llama":
+            launches, ms, _ = timers[gname]
             flops = _prior_gemm_flops(hps, args.batch * hps.n_ctx) * args.steps
             achieved = flops / (ms * 1e-3) / 1e12
+            lo8 = gname == "gemm_lo8_f16"
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")      # separate --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+            # separate --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), one json per kernel form
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_lo8.json" if lo8 else "r01_pmc_gemm.json")
             if os.path.exists(pmc):
                 d = json.load(open(pmc))
                 traffic = d["traffic_bytes_per_launch"]
                 traffic_note = ("memory-side bytes of ONE launch of %s (algorithmic %.2f GB; includes Infinity-Cache hits, see %s)"
-                                % (d["kernel"], d["algorithmic_bytes_per_launch"] / 1e9, "profiles/r01_pmc_gemm.json"))
-            roof = {"bound": "mfma", "kernel": "gemm_kernel<f16,split>", "achieved": round(achieved, 2),
+                                % (d["kernel"], d["algorithmic_bytes_per_launch"] / 1e9, "profiles/" + os.path.basename(pmc)))
+            # issued matrix work per algorithmic flop, in units of the fp16 MFMA rate: f16x2 = two fp16 passes; lo8 = one fp16 pass +
+            # one MX-fp8 MFMA per 64 k (64 cycles against the 128 of four fp16 MFMAs) = 1.5
+            passes = 1.5 if lo8 else 2
+            roof = {"bound": "mfma", "kernel": "gemm256_lo8s_kernel (fp16 hi pass + MX-fp8 low plane)" if lo8 else "gemm256_kernel<f16,split> (two fp16 passes)",
+                    "achieved": round(achieved, 2),
                     "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
                     "traffic": traffic, "traffic_note": traffic_note, "launches": launches,
                     "avg_launch_ms": round(ms / launches, 4),
-                    "mfma_passes": 2, "frac_of_issued_mfma": round(2 * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+                    "mfma_passes": passes, "frac_of_issued_mfma": round(passes * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
         elif args.stages == "clap":
             roof = roofline_clap(timers, args, llm)
         elif llm is not None and args.stages not in ("mpt", "mpt-train"):
@@ -410,10 +425,10 @@ def main():
             "value": round(value, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
-            "vs_baseline": None, "dtype": {"e2e": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
-                                           "jukebox": "fp16x2-split(fp32-class)",
+            "vs_baseline": None, "dtype": {"e2e": PRIOR_DT[args.prior_precision or "f16x2"] + " prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
+                                           "jukebox": PRIOR_DT[args.prior_precision or "f16x2"],
                                            "llama": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
-                                           "generate": "fp16x2-split(fp32-class) prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
+                                           "generate": PRIOR_DT[args.prior_precision or "f16x2"] + " prior + " + ("bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16") + " llm",
                                            "mpt": "bf16x2-split(fp32-class)" if args.llm_precision == "split" else "bf16",
                                            "clap": "bf16x2-split activations x bf16x2-split weights (fp32-class)" if args.llm_precision == "split" else "bf16",
                                            "mpt-train": "bf16 (fp32 accumulate, fp32 grads + AdamW moments)",
@@ -422,6 +437,7 @@ def main():
             "config": {"workload": workload, "clips_per_gpu": args.batch, "global_batch": args.batch * world,
                        "audio_samples": 480000 if args.stages in ("clap", "mpt") else hps.sample_length, "prompt_tokens": 0 if args.stages == "clap" else 128, "seq_len": {"train": args.train_seq, "mpt-train": args.train_seq, "mpt": 132}.get(args.stages, 371),
                        "prior_depth": None if args.stages in ("clap", "mpt", "mpt-train") else hps.prior_depth,
+                       "prior_precision": getattr(args, "prior_precision", None) if args.stages in ("e2e", "jukebox", "generate") else None,
                        "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients ({args.grad_comm} on the links) once per optimizer step)",
                        "debug_overrides": bool(args.depth or args.tiny)},
             "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train", "clap") else None),

@@ -135,15 +135,18 @@ int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, const void*
 /* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8.hip): same call site, upstream Conv1D.forward reached from
  * jukebox/main.py:108 with fp16=False.  The activation is a_hi = fp16(a) plus an E4M3 low plane
  * a_lo8[m][lda8] = fp8(sat((a - a_hi) * 2^sa)) whose 64-element k blocks are stored in MFMA slot order
- * (byte 32*(k/8 % 2) + 8*(k/16 % 4) + k % 8 of the block holds element k); the fp8 weight plane fp8(W * 2^sw) is derived
- * from wt inside the kernel (choose sw with max|W| * 2^sw <= 448).  C = a_hi.W^T + 2^-(sa+sw) a_lo8.W8^T (+ bias):
+ * (byte 32*(k/8 % 2) + 8*(k/16 % 4) + k % 8 of the block holds element k); the fp8 weight plane w8 = fp8(wt * 2^sw), same
+ * slot order, is packed once by llark_pack_weight_lo8 (choose sw with max|W| * 2^sw <= 448; w8 = NULL: the kernel derives it
+ * from wt in registers -- no extra memory, measured 20 % slower).  C = a_hi.W^T + 2^-(sa+sw) a_lo8.W8^T (+ bias):
  * one v_mfma_scale_f32_32x32x64_f8f6f4 replaces the four fp16 MFMAs of the second pass.  Accuracy: the activation
  * carries 15-16 significant bits instead of 22 (measured end to end in tests/test_fulldepth_gpu.py).
  * epilogue: LLARK_EPI_F32, LLARK_EPI_RESID, LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo] + out_lo8 [m][ldo8], same format).
  * kp % 64 == 0, kp >= 128; lda8 / ldo8 in bytes, multiples of 64. */
 int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
-                     const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid, int ldr,
+                     const void* w8, int ldw8, const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid, int ldr,
                      void* out_hi, void* out_lo8, int ldo, int ldo8, llark_workspace_t ws, llark_stream_t stream);
+/* wt fp16 [n][ldw] -> out e4m3 [n][ldo] = fp8(sat(wt * 2^sw)) in MFMA slot order: the w8 operand of llark_gemm16_lo8. */
+int llark_pack_weight_lo8(const void* wt, int ldw, int n, int kp, int sw, void* out, int ldo, llark_stream_t stream);
 /* Fragment-major weights for the "B-direct" GEMM: wt [n][ldw] (16-bit, K-contiguous, kp % 64 == 0) -> dst of
  * ceil(n/32)*32 * kp elements laid out as 1-KiB chunks [row tile][k16 step][lane 0..63][8 elements] = one MFMA
  * B fragment per chunk (rows >= n are zero).  llark_gemm16_fragw computes the same product as llark_gemm16 but

@@ -62,8 +62,9 @@ _SIGS = {
                         _P, _P, c_int, _P],
     "llark_gemm16_ws": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                         _P, _P, c_int, _P, _P],
-    "llark_gemm16_lo8": [c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int,
+    "llark_gemm16_lo8": [c_int, _P, _P, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int,
                          _P, _P, c_int, c_int, _P, _P],
+    "llark_pack_weight_lo8": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_workspace_destroy": [_P],
     "llark_layernorm_split_lo8": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, c_int, _P, c_int, c_int, _P],
     "llark_prior_attn_lo8": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P],

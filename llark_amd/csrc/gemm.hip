@@ -894,10 +894,12 @@ extern "C" int llark_workspace_destroy(llark_workspace_t ws) {
 // Split GEMM with an e4m3 low plane (csrc/gemm256_lo8.hip): the prior's Conv1D products in "lo8" mode.
 //   a_hi  fp16 [m][lda]            = fp16(a)
 //   a_lo8 e4m3 [m][lda8] (bytes)   = fp8(sat((a - a_hi) * 2^sa)), every 64-k block in the slot order of lo8_pos()
-//   wt    fp16 [n][ldw]; sw such that max|W| * 2^sw <= 448 (the kernel derives W8 = fp8(W * 2^sw) in registers)
+//   wt    fp16 [n][ldw]; sw such that max|W| * 2^sw <= 448
+//   w8    e4m3 [n][ldw8] (bytes) = fp8(wt * 2^sw) in the same slot order (llark_pack_weight_lo8): staged through LDS by
+//         csrc/gemm256_lo8s.hip; NULL -> csrc/gemm256_lo8.hip derives the same plane from wt in registers (slower, no extra memory)
 // epilogue: LLARK_EPI_F32 / LLARK_EPI_RESID / LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo], out_lo8 e4m3 [m][ldo8]).
 extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
-                                const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid,
+                                const void* w8, int ldw8, const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid,
                                 int ldr, void* out_hi, void* out_lo8, int ldo, int ldo8, llark_workspace_t ws,
                                 llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && a_lo8 && wt && ws && m > 0 && n > 0, "gemm16_lo8: null pointer or empty problem");
@@ -907,6 +909,7 @@ extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo
     LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && ((uintptr_t)a_lo8 & 15) == 0,
                   "gemm16_lo8: operands must be 16-byte aligned");
     LLARK_REQUIRE(sa >= 0 && sa <= 40 && sw >= -40 && sw <= 40, "gemm16_lo8: scale exponents out of range (sa=%d sw=%d)", sa, sw);
+    LLARK_REQUIRE(!w8 || (ldw8 >= kp && ldw8 % 16 == 0 && ((uintptr_t)w8 & 15) == 0), "gemm16_lo8: w8 plane needs ldw8 >= kp, ldw8 %% 16 == 0 and 16-byte alignment");
     if (epilogue == EPI_F32 || epilogue == EPI_RESID) LLARK_REQUIRE(c && ldc >= n, "gemm16_lo8: fp32 output missing");
     if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16_lo8: residual missing");
     if (epilogue == EPI_QGELU_SPLIT8)
@@ -917,10 +920,14 @@ extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo
     GemmParams p = {};
     p.Ahi = a_hi; p.Alo = a_lo8; p.lda = lda; p.lda8 = lda8; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
-    p.Ohi = out_hi; p.Olo = out_lo8; p.ldo = ldo; p.ldo8 = ldo8; p.lo8_sa = sa; p.lo8_sw = sw;
+    p.Ohi = out_hi; p.Olo = out_lo8; p.ldo = ldo; p.ldo8 = ldo8; p.lo8_sa = sa; p.lo8_sw = sw; p.W8 = w8; p.ldw8 = ldw8;
     hipStream_t s = (hipStream_t)stream;
     if (ws_begin(ws, p, s)) { set_error("gemm16_lo8: workspace unusable"); return LLARK_ERR_LAUNCH; }
-    const int rc = launch_gemm256_lo8(p, epilogue, s, ws->cus);
+    // form: LLARK_LO8_FORM = q (4 waves, one per SIMD), s (8 waves, staged W8; default), r (W8 derived in registers: also when w8 == NULL)
+    static const char form = [] { const char* e = getenv("LLARK_LO8_FORM"); return e ? e[0] : 's'; }();
+    const int rc = !w8 || form == 'r' ? launch_gemm256_lo8(p, epilogue, s, ws->cus)
+                   : form == 'q'      ? launch_gemm256_lo8q(p, epilogue, s, ws->cus)
+                                      : launch_gemm256_lo8s(p, epilogue, s, ws->cus);
     if (rc == -1000) { set_error("gemm16_lo8: problem outside the kernel's range (32-bit operand offsets)"); return LLARK_ERR_UNSUPPORTED; }
     ws_end(ws, cdiv(m, 256) * cdiv(n, 256), ws->cus / 8);
     return rc;

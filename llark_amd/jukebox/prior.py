@@ -27,7 +27,7 @@ from .. import ops
 from .hparams import JukeboxHParams
 
 
-DEFAULT_PRECISION = "f16x2"     # see PriorTransformer.__init__; LLARK_PRIOR_PRECISION overrides
+DEFAULT_PRECISION = "lo8"       # see PriorTransformer.__init__; LLARK_PRIOR_PRECISION overrides ("f16x2" = the 22-bit form)
 
 
 class Labeller:
@@ -53,7 +53,7 @@ class Labeller:
 
 class _LayerWeights:
     __slots__ = ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "w_attn", "b_attn", "w_proj", "b_proj", "w_fc", "b_fc", "w_proj2",
-                 "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2")
+                 "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2", "w8_attn", "w8_proj", "w8_fc", "w8_proj2")
 
 
 class PriorTransformer:
@@ -106,6 +106,9 @@ class PriorTransformer:
             if precision == "lo8":      # per-matrix exponent of the in-kernel fp8 weight plane: max|W| * 2^sw <= 448
                 L.sw_attn, L.sw_proj = ops.lo8_weight_exponent(L.w_attn), ops.lo8_weight_exponent(L.w_proj)
                 L.sw_fc, L.sw_proj2 = ops.lo8_weight_exponent(L.w_fc), ops.lo8_weight_exponent(L.w_proj2)
+                # the E4M3 weight planes e4m3(W 2^sw), staged through LDS next to W (+50 % weight bytes: 5.5 GB for the 36 layers)
+                L.w8_attn, L.w8_proj = ops.pack_weight_lo8(L.w_attn, L.sw_attn), ops.pack_weight_lo8(L.w_proj, L.sw_proj)
+                L.w8_fc, L.w8_proj2 = ops.pack_weight_lo8(L.w_fc, L.sw_fc), ops.pack_weight_lo8(L.w_proj2, L.sw_proj2)
             self.layers.append(L)
         self._ws: Dict[str, torch.Tensor] = {}
         self._ws_rows = 0
@@ -168,21 +171,21 @@ class PriorTransformer:
             return hi.float()[:, :width] + ops.lo8_decode(lo8, width)
 
         ops.layernorm_split_lo8(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
-        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.sw_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
+        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.sw_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"], w8=L.w8_attn)
         ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
         if taps is not None:
             taps["ln0"] = full(ws["ln_hi"], ws["ln_lo"], W)
             taps["qkv"] = ws["qkv"].clone()
             taps["att"] = full(ws["att_hi"], ws["att_lo"], S)
-        ops.gemm16_lo8(ws["att_hi"], ws["att_lo"], L.w_proj, L.sw_proj, L.b_proj, W, ops.EPI_RESID, c=h2, resid=h2)
+        ops.gemm16_lo8(ws["att_hi"], ws["att_lo"], L.w_proj, L.sw_proj, L.b_proj, W, ops.EPI_RESID, c=h2, resid=h2, w8=L.w8_proj)
         if taps is not None:
             taps["xa"] = h2.clone()
         ops.layernorm_split_lo8(h2, L.ln1_g, L.ln1_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
-        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.sw_fc, L.b_fc, Mw, ops.EPI_QGELU_SPLIT8, out_hi=ws["g_hi"], out_lo8=ws["g_lo"])
+        ops.gemm16_lo8(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.sw_fc, L.b_fc, Mw, ops.EPI_QGELU_SPLIT8, out_hi=ws["g_hi"], out_lo8=ws["g_lo"], w8=L.w8_fc)
         if taps is not None:
             taps["ln1"] = full(ws["ln_hi"], ws["ln_lo"], W)
             taps["g"] = full(ws["g_hi"], ws["g_lo"], Mw)
-        ops.gemm16_lo8(ws["g_hi"], ws["g_lo"], L.w_proj2, L.sw_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
+        ops.gemm16_lo8(ws["g_hi"], ws["g_lo"], L.w_proj2, L.sw_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2, w8=L.w8_proj2)
 
     def embed(self, x: torch.Tensor, x_cond: torch.Tensor, y_cond: torch.Tensor) -> torch.Tensor:
         n, t = x.shape

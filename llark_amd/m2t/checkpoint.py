@@ -83,18 +83,17 @@ def save_checkpoint(trainer, output_dir: str, save_total_limit: Optional[int] = 
     return folder
 
 
-def load_checkpoint(trainer, folder: str) -> int:
-    """Restores weights (kernel layout, in place), AdamW moments and the step counter; returns the step."""
-    sd = torch.load(os.path.join(folder, "pytorch_model.bin"), map_location="cpu")
-    eng = trainer.eng
+def copy_weights_into_engine(eng, sd: Dict[str, torch.Tensor], origin: str = "state dict") -> None:
+    """Copies HF-named weights into the engine's kernel-layout tensors IN PLACE (views from ``state_dict_hf``), so that
+    whatever points at those tensors (a trainer's parameter table, recorded launch lists) stays valid."""
     cur = eng.state_dict_hf()
     missing = [k for k in cur if k not in sd]
     if missing:
-        raise KeyError(f"{folder}: checkpoint lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        raise KeyError(f"{origin}: lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
     for k, dst in cur.items():                                # views into the kernel-layout tensors: copy in place so that
         src = sd[k].to(device=dst.device, dtype=dst.dtype)    # the trainer's parameter table keeps pointing at them
         if dst.shape != src.shape:
-            raise ValueError(f"{folder}: {k} has shape {tuple(src.shape)}, engine expects {tuple(dst.shape)}")
+            raise ValueError(f"{origin}: {k} has shape {tuple(src.shape)}, engine expects {tuple(dst.shape)}")
         if k.endswith("gate_proj.weight") or k.endswith("up_proj.weight"):
             continue                                          # interleaved storage: handled below
         dst.copy_(src)
@@ -104,6 +103,12 @@ def load_checkpoint(trainer, folder: str) -> int:
         gu = L.wgu.view(d.intermediate_size // 32, 2, 32, d.hidden_size)
         gu[:, 0].copy_(gate.to(gu.device, gu.dtype).view(-1, 32, d.hidden_size))
         gu[:, 1].copy_(up.to(gu.device, gu.dtype).view(-1, 32, d.hidden_size))
+
+
+def load_checkpoint(trainer, folder: str) -> int:
+    """Restores weights (kernel layout, in place), AdamW moments and the step counter; returns the step."""
+    sd = torch.load(os.path.join(folder, "pytorch_model.bin"), map_location="cpu")
+    copy_weights_into_engine(trainer.eng, sd, origin=folder)
     st = torch.load(os.path.join(folder, "trainer_state.pt"), map_location="cpu")
     if st["param_order"] != [n for n, _ in trainer.params]:
         raise ValueError(f"{folder}: optimizer state was written for a different parameter table")

@@ -135,26 +135,42 @@ def infer_from_audio(encoder, model, tokenizer, clips: Iterable[Tuple[str, np.nd
                      max_new_tokens: int = 512, audio_first: bool = True) -> List[Dict[str, str]]:
     """Fused driver: ``clips`` yields ``(example_id, mono float32 audio @44.1 kHz)``; ``encoder`` is a
     ``llark_amd.jukebox.extract.WrappedAudioEncoder``.  Audio is normalised / padded / truncated exactly as
-    ``jukebox/main.py:29-59`` does, encoded in batches on the GPU, and the resulting ``(B, frames, 4800)`` tensor is
-    handed to ``generate`` without leaving device memory."""
+    ``jukebox/main.py:29-59`` does, encoded in batches on the GPU, short clips keep only the frames of their own audio
+    (``jukebox/main.py:147``), and the ``(B, frames, 4800)`` tensor is handed to ``generate`` without leaving device memory."""
     from ..jukebox import extract as E
 
     records: List[Dict[str, str]] = []
     buf: List[Tuple[str, np.ndarray]] = []
-    prompt_ids = None
+    prompt_cache: Dict[int, torch.Tensor] = {}
 
     def flush():
-        nonlocal prompt_ids
         if not buf:
             return
-        n = encoder.hps.sample_length
-        audio = np.stack([E.maybe_pad_audio_to_max_len(E._normalize(a), n)[:n].astype(np.float32) for _, a in buf])
+        from math import floor
+
+        hps = encoder.hps
+        n = hps.sample_length
+        norm = [E._normalize(a) for _, a in buf]
+        audio = np.stack([E.maybe_pad_audio_to_max_len(a, n)[:n].astype(np.float32) for a in norm])
         emb = encoder(torch.from_numpy(audio).to(encoder.vqvae.device))                  # (B, frames, 4800) fp32, on device
-        if prompt_ids is None or prompt_ids[1] != emb.shape[1]:
-            prompt_ids = (build_prompt_ids(prompt, emb.shape[1], tokenizer, multimodal_cfg, end_seq, audio_first), emb.shape[1])
-        ids = prompt_ids[0].unsqueeze(0).repeat(len(buf), 1)
-        outs = generate_batch(model, ids, emb, tokenizer, max_new_tokens)
-        records.extend(_rows_to_records([ex for ex, _ in buf], prompt, outs, end_seq, tokenizer))
+        # jukebox/main.py:147: activations are truncated to latent_audio_len = floor(T * len / expected) BEFORE pooling, so a clip
+        # shorter than 23.8 s yields fewer frames (no embeddings of the zero padding).  Group the batch by frame count so that
+        # every generate call shares one prompt length, exactly as the .npy pipeline (infer_from_encodings) does.
+        fl = encoder.frame_len
+        frames = [min(floor(hps.n_ctx * len(a) / n), hps.n_ctx) // fl for a in norm]
+        recs: Dict[int, Dict[str, str]] = {}
+        for f in sorted(set(frames)):
+            if f == 0:
+                raise ValueError("infer_from_audio: a clip is shorter than one pooled frame (%d samples)" % (fl * hps.raw_to_tokens))
+            rows = [i for i, fi in enumerate(frames) if fi == f]
+            if f not in prompt_cache:
+                prompt_cache[f] = build_prompt_ids(prompt, f, tokenizer, multimodal_cfg, end_seq, audio_first)
+            ids = prompt_cache[f].unsqueeze(0).repeat(len(rows), 1)
+            sub = emb[torch.tensor(rows, device=emb.device), :f].contiguous()
+            outs = generate_batch(model, ids, sub, tokenizer, max_new_tokens)
+            for i, rec in zip(rows, _rows_to_records([buf[i][0] for i in rows], prompt, outs, end_seq, tokenizer)):
+                recs[i] = rec
+        records.extend(recs[i] for i in range(len(buf)))
         buf.clear()
 
     for item in clips:

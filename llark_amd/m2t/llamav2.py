@@ -124,6 +124,10 @@ class _HipTrainStep(torch.autograd.Function):
         tr.zero_grad()
         loss = tr.forward_backward(input_ids, segs, labels)
         grads = tr.export_grads_hf()
+        lacking = [n for n in names if n not in grads]
+        if lacking:      # e.g. lm_head when it is not frozen: a silent None gradient would leave the parameter untrained
+            raise NotImplementedError(f"the HIP training step exports no gradient for trainable parameter(s) {lacking[:4]}; freeze them "
+                                      "(requires_grad_(False)) -- the reference recipe trains with lm_head frozen (llamav2.py:395-419)")
         ctx.grads = [grads.get(n) for n in names]
         ctx.dtypes = [p.dtype for p in params]
         return loss.clone()
@@ -264,24 +268,36 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
             cfg = self.model.audio_encoder_config
             toks = [t for t in (cfg.audio_start_token, cfg.audio_end_token) if isinstance(t, int)]
             orig = getattr(self.model, "orig_embeds_params", None)
-            self._trainer = HipLlamaTrainer(self._train_engine, embed_grad_tokens=toks, train_embed_all=orig is None)
+            # the torch optimizer of the caller owns the AdamW state on this path: no moments here
+            self._trainer = HipLlamaTrainer(self._train_engine, embed_grad_tokens=toks, train_embed_all=orig is None,
+                                            optimizer_state=False)
         return self._trainer
 
     def _forward_train(self, input_ids, labels, audio_encodings, attention_mask, return_dict):
-        """Training forward (bf16 flow, like the reference's bf16 recipe).  The kernel-layout weights are re-packed
-        from the nn.Parameters on every call because an external optimizer may have changed them."""
+        """Training forward (bf16 flow, like the reference's bf16 recipe).  The kernel-layout weights are refreshed from the
+        nn.Parameters on every call because an external optimizer may have changed them -- IN PLACE into one cached training
+        engine (and one cached trainer: its flat gradient buffer is allocated once, not per step)."""
         if attention_mask is not None:
             am = attention_mask.to(torch.bool)
             if am.shape[1] > 1 and not bool((am[:, :-1] | ~am[:, 1:]).all()):
                 raise NotImplementedError("only right-padded attention masks are supported")
-        prec = self._engine_precision
-        self._engine_precision = "bf16"
-        try:
-            self._train_engine = self.sync_engine()
-        finally:
-            self._engine_precision = prec
+        eng = getattr(self, "_train_engine", None)
+        shape_key = (self.lm_head.weight.shape[0], self.lm_head.weight.device)
+        if eng is None or getattr(self, "_train_engine_key", None) != shape_key:
+            prec = self._engine_precision
+            self._engine_precision = "bf16"
+            try:
+                self._train_engine = self.sync_engine()
+            finally:
+                self._engine_precision = prec
+            self._train_engine_key = shape_key
+            self._trainer = None
+            eng = self._train_engine
+        else:
+            from .checkpoint import copy_weights_into_engine
+
+            copy_weights_into_engine(eng, self.state_dict(), origin="module parameters")
         self._engine = None                                     # the inference engine is rebuilt lazily in its own mode
-        eng = self._train_engine
         input_ids = input_ids.to(eng.device)
         feats = audio_encodings
         segs = []
@@ -321,6 +337,9 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
         (m2t/generate.py:31-44, m2t/infer.py:146-152)."""
         ids = input_ids.to(self.engine.device)
         eos = eos_token_id if eos_token_id is not None else getattr(self.generation_config, "eos_token_id", None)
+        pad = getattr(self.generation_config, "pad_token_id", None)
+        pad = eos if pad is None else pad
+        unfinished = torch.ones((ids.shape[0], 1), dtype=torch.bool, device=ids.device)      # HF: unfinished_sequences, per row
         past = None
         for _ in range(max_new_tokens):
             inputs = self.prepare_inputs_for_generation(ids, past_key_values=past, audio_encodings=audio_encodings)
@@ -345,8 +364,11 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
                 nxt = torch.multinomial(probs, 1)
             else:
                 nxt = scores.argmax(-1, keepdim=True)
+            if eos is not None and eos >= 0:
+                nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))                 # finished rows emit padding
+                unfinished = unfinished & (nxt != eos)
             ids = torch.cat((ids, nxt), dim=1)
-            if eos is not None and bool((nxt == eos).all()):
+            if eos is not None and eos >= 0 and not bool(unfinished.any()):
                 break
             if stopping_criteria is not None and any(bool(c(ids, scores)) for c in stopping_criteria):
                 break

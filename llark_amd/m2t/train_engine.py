@@ -33,7 +33,7 @@ _BF = torch.bfloat16
 class HipLlamaTrainer:
     def __init__(self, engine: HipLlamaEngine, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, embed_grad_tokens: Sequence[int] = (), train_embed_all: bool = False,
-                 grad_comm: torch.dtype = torch.float32):
+                 grad_comm: torch.dtype = torch.float32, optimizer_state: bool = True):
         if grad_comm not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_comm must be torch.float32 or torch.bfloat16")
         self.grad_comm = grad_comm                   # transport dtype of the gradient all-reduce (the reference's DDP sends bf16)
@@ -56,8 +56,9 @@ class HipLlamaTrainer:
             self.params += [("proj_w", engine.proj_w), ("proj_b", engine.proj_b)]
         total = sum(p.numel() for _, p in self.params)
         self.flat_grad = torch.zeros((total,), dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros_like(self.flat_grad)
-        self.flat_v = torch.zeros_like(self.flat_grad)
+        # AdamW moments (2 x 27 GB at 7B): not allocated on the autograd-bridge path, where a torch optimizer owns the state
+        self.flat_m = torch.zeros_like(self.flat_grad) if optimizer_state else None
+        self.flat_v = torch.zeros_like(self.flat_grad) if optimizer_state else None
         self.grads: Dict[str, torch.Tensor] = {}
         self._slices: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -302,6 +303,8 @@ class HipLlamaTrainer:
 
     def step(self, world: int = 1) -> None:
         """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients."""
+        if self.flat_m is None:
+            raise RuntimeError("this HipLlamaTrainer was built with optimizer_state=False (autograd bridge): use a torch optimizer")
         self._finalize_grads()
         self.step_count += 1
         b1, b2 = self.betas

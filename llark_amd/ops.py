@@ -127,10 +127,14 @@ def _dev(t: torch.Tensor, name: str, dtype=None, contiguous=True) -> int:
 _workspaces = {}
 
 
-def workspace() -> int:
+def workspace() -> Optional[int]:
     key = (torch.cuda.current_device(), _stream())
     ws = _workspaces.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # creating one allocates: not allowed inside a hipGraph capture.  Without a workspace llark_gemm16_ws simply never
+            # picks a persistent tile variant (captured regions are decode steps: M <= 16, skinny kernels, no workspace use).
+            return None
         ws = _lib._real_lib().llark_workspace_create()
         if not ws:
             check(-3, "workspace_create")
@@ -367,11 +371,22 @@ def lo8_weight_exponent(w: torch.Tensor) -> int:
     return max(-40, min(40, math.floor(math.log2(448.0 / amax))))
 
 
+def pack_weight_lo8(wt: torch.Tensor, sw: int) -> torch.Tensor:
+    """wt fp16 [n][kp] -> uint8 [n][kp] = e4m3(wt * 2^sw) in MFMA slot order: the staged B operand of the low-plane product."""
+    n, kp = wt.shape
+    assert wt.dtype == torch.float16 and kp % 64 == 0
+    out = torch.empty((n, kp), dtype=torch.uint8, device=wt.device)
+    check(_lib.lib().llark_pack_weight_lo8(_dev(wt, "wt"), wt.stride(0), n, kp, int(sw), _dev(out, "out"), out.stride(0), _stream()),
+          "pack_weight_lo8")
+    return out
+
+
 def gemm16_lo8(a_hi: torch.Tensor, a_lo8: torch.Tensor, wt: torch.Tensor, sw: int, bias: Optional[torch.Tensor], n: int, epilogue: int,
                c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None,
-               out_lo8: Optional[torch.Tensor] = None, m: Optional[int] = None, sa: int = LO8_SA) -> None:
+               out_lo8: Optional[torch.Tensor] = None, m: Optional[int] = None, sa: int = LO8_SA, w8: Optional[torch.Tensor] = None) -> None:
     """C[m,n] = a_hi . wt^T + 2^-(sa+sw) a_lo8 . fp8(wt 2^sw)^T (+bias): the prior's split GEMM with an E4M3 low plane
-    (csrc/gemm256_lo8.hip; include/llark_hip.h: llark_gemm16_lo8)."""
+    (include/llark_hip.h: llark_gemm16_lo8).  ``w8`` = pack_weight_lo8(wt, sw): the staged kernel csrc/gemm256_lo8s.hip;
+    without it csrc/gemm256_lo8.hip derives the fp8 weight plane in registers."""
     assert a_hi.dtype == torch.float16 and wt.dtype == torch.float16 and a_lo8.dtype == torch.uint8
     m = a_hi.shape[0] if m is None else m
     kp = wt.shape[1]
@@ -379,6 +394,7 @@ def gemm16_lo8(a_hi: torch.Tensor, a_lo8: torch.Tensor, wt: torch.Tensor, sw: in
     with _timed("gemm_lo8_f16", 2.0 * m * n * kp):
         check(_lib.lib().llark_gemm16_lo8(
             epilogue, _dev(a_hi, "a_hi"), _dev(a_lo8, "a_lo8"), a_hi.stride(0), a_lo8.stride(0), _dev(wt, "wt"), wt.stride(0),
+            _dev(w8, "w8", torch.uint8) if w8 is not None else None, w8.stride(0) if w8 is not None else 0,
             _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp, int(sa), int(sw),
             _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
             _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,

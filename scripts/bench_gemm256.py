@@ -37,15 +37,17 @@ def main():
         a_lo8 = torch.randint(0, 120, (M, a_hi.shape[1]), device=dev, dtype=torch.uint8)      # finite positive E4M3 codes
         olo8 = torch.zeros(M, 4800, dtype=torch.uint8, device=dev)
         sw = ops.lo8_weight_exponent(wt)
+        w8p = ops.pack_weight_lo8(wt, sw)
 
         def fn(v):
-            if v == 40:                                   # csrc/gemm256_lo8.hip: fp16 hi pass + one MX-fp8 MFMA for the low plane
+            if v in (40, 41):                             # fp16 hi pass + one MX-fp8 MFMA for the low plane: 40 = W8 in registers
+                w8 = w8p if v == 41 else None             # (csrc/gemm256_lo8.hip), 41 = W8 staged (csrc/gemm256_lo8s.hip)
                 if epi == ops.EPI_QGELU_SPLIT:
-                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, ops.EPI_QGELU_SPLIT8, out_hi=ohi, out_lo8=olo8)
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, ops.EPI_QGELU_SPLIT8, out_hi=ohi, out_lo8=olo8, w8=w8)
                 elif epi == ops.EPI_RESID:
-                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=c, resid=c)
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=c, resid=c, w8=w8)
                 else:
-                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=cq)
+                    ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, epi, c=cq, w8=w8)
                 return
             if epi == ops.EPI_QGELU_SPLIT:
                 ops.gemm16(a_hi, a_lo, wt, bias, n, epi, out_hi=ohi, out_lo=olo, variant=v)

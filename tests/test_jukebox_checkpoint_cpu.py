@@ -12,11 +12,14 @@ from llark_amd.jukebox.hparams import hparams_tiny
 from llark_amd.jukebox.synthetic import make_jukebox_weights
 
 
-def upstream_style_checkpoints(hps, ckpt_depth, seed=0, prefix="module."):
+def upstream_style_checkpoints(hps, ckpt_depth, seed=0, prefix="module.", base=None):
     """What upstream's two files hold for a model of this shape: the VQ-VAE file carries ALL levels (encoders, decoders,
     three codebooks + their EMA statistics), the prior file carries ``ckpt_depth`` layers (72 for 5b) plus the
-    tensors the only_encode path never touches (x_out, start_token ...), keys under DDP's ``module.`` prefix."""
+    tensors the only_encode path never touches (x_out, start_token ...), keys under DDP's ``module.`` prefix.
+    ``base``: weights of the model under test (its layers come first; the extra layers are copies of other seeds)."""
     w = make_jukebox_weights(hps, seed=seed, depth=ckpt_depth)
+    if base is not None:
+        w = {**w, **{k: v.clone() for k, v in base.items()}}
     vq = {k: v for k, v in w.items() if k.startswith(("encoders.", "bottleneck."))}
     g = torch.Generator().manual_seed(99)
     for lvl in (0, 1):

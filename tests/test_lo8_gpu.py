@@ -56,12 +56,20 @@ def operands(m, n, k, seed=0, scale_a=1.0, scale_w=0.02):
     return a, hi, lo8, wt, sw, ref, exact, mag
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640), (300, 4800, 1200)])
-def test_gemm_lo8_matches_its_specification(m, n, k):
+@pytest.mark.parametrize("staged", [True, False], ids=["w8-staged", "w8-in-registers"])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640), (300, 4800, 1200),
+                                   (4096, 512, 192), (700, 700, 448)])
+def test_gemm_lo8_matches_its_specification(m, n, k, staged):
     a, hi, lo8, wt, sw, ref, exact, mag = operands(m, n, k, seed=m + n + k)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(1))
     c = torch.full((m, n), float("nan"), device="cuda")
-    ops.gemm16_lo8(hi.cuda(), lo8.cuda(), wt.cuda(), sw, bias.cuda(), n, ops.EPI_F32, c=c)
+    wt_d = wt.cuda()
+    w8 = ops.pack_weight_lo8(wt_d, sw) if staged else None
+    if staged:      # the packed plane is the slot-ordered E4M3 rounding of W 2^sw
+        want8 = torch.zeros_like(wt, dtype=torch.uint8)
+        want8[:, slot_order(wt.shape[1])] = e4m3(wt.float() * 2.0 ** sw).view(torch.uint8)
+        assert torch.equal(w8.cpu(), want8)
+    ops.gemm16_lo8(hi.cuda(), lo8.cuda(), wt_d, sw, bias.cuda(), n, ops.EPI_F32, c=c, w8=w8)
     torch.cuda.synchronize()
     got = c.cpu().double()
     want = ref + bias.double()
@@ -83,14 +91,15 @@ def test_gemm_lo8_residual_and_repeat_launches_share_a_workspace():
     a, hi, lo8, wt, sw, ref, exact, mag = operands(m, n, k, seed=5)
     h0 = torch.randn(m, n, generator=torch.Generator().manual_seed(2))
     hi_d, lo_d, wt_d = hi.cuda(), lo8.cuda(), wt.cuda()
+    w8 = ops.pack_weight_lo8(wt_d, sw)
     outs = []
     for it in range(6):
         h = h0.clone().cuda()
-        ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=h, resid=h)
+        ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=h, resid=h, w8=w8 if it % 2 == 0 else None)
         outs.append(h)
     torch.cuda.synchronize()
     for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+        assert torch.equal(o, outs[0]), "staged and in-register forms (or repeated launches) differ"
     err = (outs[0].cpu().double() - (h0.double() + ref)).abs()
     assert bool((err <= 3e-7 * mag + 3e-7 * h0.abs().double() + 1e-6).all()), f"max err {err.max():.3e}"
 
@@ -102,7 +111,9 @@ def test_gemm_lo8_qgelu_epilogue_writes_hi_and_e4m3_planes():
     np_ = ops.round_up(n, 64)
     out_hi = torch.zeros((m, np_), dtype=torch.float16, device="cuda")
     out_lo8 = torch.zeros((m, np_), dtype=torch.uint8, device="cuda")
-    ops.gemm16_lo8(hi.cuda(), lo8.cuda(), wt.cuda(), sw, bias.cuda(), n, ops.EPI_QGELU_SPLIT8, out_hi=out_hi, out_lo8=out_lo8)
+    wt_d = wt.cuda()
+    ops.gemm16_lo8(hi.cuda(), lo8.cuda(), wt_d, sw, bias.cuda(), n, ops.EPI_QGELU_SPLIT8, out_hi=out_hi, out_lo8=out_lo8,
+                   w8=ops.pack_weight_lo8(wt_d, sw))
     torch.cuda.synchronize()
     x = ref + bias.double()
     g = x * torch.sigmoid(1.702 * x)
@@ -149,16 +160,7 @@ def test_prior_tiny_and_full_width_depth3_lo8():
     import test_prior_gpu as TP
     from llark_amd.jukebox.hparams import hparams_tiny
 
-    import os
-    old = os.environ.get("LLARK_PRIOR_PRECISION")
-    os.environ["LLARK_PRIOR_PRECISION"] = "lo8"
-    try:
-        rel = TP._run_prior(hparams_tiny(), 3, 2, tap_tol=1e-4)
-        print(f"tiny prior (lo8) rel err {rel:.3e}")
-        rel = TP._run_prior(TP.hparams_5b_depth(3), 3, 1, tap_tol=1e-4)
-        print(f"full-width prior, 3 layers (lo8) rel err {rel:.3e}")
-    finally:
-        if old is None:
-            del os.environ["LLARK_PRIOR_PRECISION"]
-        else:
-            os.environ["LLARK_PRIOR_PRECISION"] = old
+    rel = TP._run_prior(hparams_tiny(), 3, 2, tap_tol=1e-4, precision="lo8")
+    print(f"tiny prior (lo8) rel err {rel:.3e}")
+    rel = TP._run_prior(TP.hparams_5b_depth(3), 3, 1, tap_tol=1e-4, precision="lo8")
+    print(f"full-width prior, 3 layers (lo8) rel err {rel:.3e}")

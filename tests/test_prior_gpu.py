@@ -316,14 +316,14 @@ def test_embed_and_pool():
     report_close("pool_mean", pm[1], acts[1, :100].mean(0), 1e-6)
 
 
-def _run_prior(hps, depth, n, seed=0, tap_tol=2e-5):
+def _run_prior(hps, depth, n, seed=0, tap_tol=2e-5, precision="f16x2"):
     from llark_amd.jukebox.prior import TopPrior
     from llark_amd.jukebox import extract as E
     from oracle import jukebox_ref as R
     w = make_prior_weights(hps, seed + 1, depth=depth)
     z = torch.randint(0, hps.l_bins, (n, hps.n_ctx), generator=torch.Generator().manual_seed(seed))
     x_cond_r, y_cond_r = R.get_cond(w, hps)
-    tp = TopPrior(hps, w, "cuda", depth=depth)
+    tp = TopPrior(hps, w, "cuda", depth=depth, precision=precision)
     x_cond, y_cond = E.get_cond(hps, tp)
     assert torch.equal(x_cond.cpu(), x_cond_r) and torch.equal(y_cond.cpu(), y_cond_r), "conditioning tables differ"
     # layer-by-layer taps (each HIP layer is fed the ORACLE's input so errors do not compound)
