@@ -17,7 +17,7 @@
 //                                        (one phase ahead; everything else is requested two phases ahead)
 //   = 64 + 32 + 48 + 16 = 160 KiB.  Requests per wave: T(k): A8B(k) | AhiT(k+1) x2, W(k+1) x4, W8(k+1) x2  -> wait vmcnt(8);
 //   B(k): A8T(k+1) | AhiB(k+1) x2 -> wait vmcnt(2).  In-order completion of VMEM makes "the oldest 1 (+ everything older)"
-//   exactly the set the next phase reads.  The last K-step requests only its own A8B and drains (vmcnt(0)).
+//   exactly the set the next phase reads.  The last K-step re-requests itself (clamped k) so the counts never change.
 // Everything else as in gemm256_lo8.hip: wave = 64 x 128, tn-major phases, slot order of the fp8 planes, persistent +
 // chunk-synchronous tile order, shared epilogue.
 #include "gemm_core.h"
@@ -211,33 +211,31 @@ __global__ __launch_bounds__(Cfg256S::THREADS, Cfg256S::MINW) void gemm256_lo8s_
                 tn_body(std::integral_constant<int, 2>{});
                 tn_body(std::integral_constant<int, 3>{});
             };
-            // One K-step from W stage ST; aT = ring slot of AhiT(k).  LAST = the tile's last K-step: nothing of a next step is
-            // requested (a trailing request would still be landing in LDS when the epilogue's scratch writes start: measured,
-            // vmcnt retires an LDS-DMA before its LDS write is ordered against a later ds_write of another wave).
-            auto kstep = [&](auto st_tag, auto grp_tag, auto last_tag, int k, int aT) __attribute__((always_inline)) {
+            // One K-step from W stage ST; aT = ring slot of AhiT(k).  Both phases ALWAYS issue their requests (the last step
+            // re-requests itself, clamped k: 96 KiB of L2 hits per tile that nobody reads) so the vmcnt counts and the instruction
+            // stream are the same for every K-step: no branches, one copy of the code.  Measured alternatives: peeling the last
+            // K-step as a template copy, or predicating the requests on a wave-uniform `more`, both made hipcc spill 350-500
+            // registers (+12 % on every shape).
+            auto kstep = [&](auto st_tag, auto grp_tag, int k, int aT) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_tag)::value;
-                constexpr bool last = decltype(last_tag)::value;
+                const int kn = k + 1 < nk ? k + 1 : nk - 1;
                 const int aB = aT + 1 >= 3 ? aT - 2 : aT + 1, aN = aT + 2 >= 3 ? aT - 1 : aT + 2;       // slots of AhiB(k), AhiT(k+1)
                 phase(std::integral_constant<int, 0>{}, st_tag, grp_tag, aT, [&]() __attribute__((always_inline)) {
                     dma(rA8, vo8[1], k << 6, C::O_8B + wb);                // A8B(k): read by the NEXT phase
-                    if (!last) {
-                        issue_AhiT(k + 1, aN);
-                        issue_W(k + 1, st ^ 1);
-                    }
+                    issue_AhiT(kn, aN);
+                    issue_W(kn, st ^ 1);
                 });
                 PROF_ADD(pacc0);
-                if (!last) VMCNT(8); else VMCNT(0);                        // AhiB(k) (requested in B(k-1)) and A8B(k) have landed
+                VMCNT(8);                                                  // AhiB(k) (requested in B(k-1)) and A8B(k) have landed
                 PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
                 phase(std::integral_constant<int, 1>{}, st_tag, grp_tag, aB, [&]() __attribute__((always_inline)) {
-                    if (!last) {
-                        dma(rA8, vo8[0], (k + 1) << 6, C::O_8T + wb);      // A8T(k+1): read by the NEXT phase
-                        issue_AhiB(k + 1, aT);
-                    }
+                    dma(rA8, vo8[0], kn << 6, C::O_8T + wb);               // A8T(k+1): read by the NEXT phase
+                    issue_AhiB(kn, aT);
                 });
                 PROF_ADD(pacc0);
-                if (!last) VMCNT(2);                                       // AhiT / W / W8 (k+1) from T(k) and A8T(k+1) have landed
+                VMCNT(2);                                                  // AhiT / W / W8 (k+1) from T(k) and A8T(k+1) have landed
                 PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
@@ -252,24 +250,14 @@ __global__ __launch_bounds__(Cfg256S::THREADS, Cfg256S::MINW) void gemm256_lo8s_
             __builtin_amdgcn_s_barrier();
             PROF_T0();
             auto kloop = [&](auto grp_tag) __attribute__((always_inline)) {
-                constexpr std::integral_constant<int, 0> S0{};
-                constexpr std::integral_constant<int, 1> S1{};
-                constexpr std::false_type MORE{};
-                constexpr std::true_type LAST{};
-                auto next = [](int a) { return a + 2 >= 3 ? a - 1 : a + 2; };
                 int k = 0, aT = 0;
-                for (; k + 2 < nk; k += 2) {
-                    kstep(S0, grp_tag, MORE, k, aT);
-                    aT = next(aT);
-                    kstep(S1, grp_tag, MORE, k + 1, aT);
-                    aT = next(aT);
+                for (; k + 1 < nk; k += 2) {
+                    kstep(std::integral_constant<int, 0>{}, grp_tag, k, aT);
+                    aT = aT + 2 >= 3 ? aT - 1 : aT + 2;
+                    kstep(std::integral_constant<int, 1>{}, grp_tag, k + 1, aT);
+                    aT = aT + 2 >= 3 ? aT - 1 : aT + 2;
                 }
-                if (k + 2 == nk) {
-                    kstep(S0, grp_tag, MORE, k, aT);
-                    kstep(S1, grp_tag, LAST, k + 1, next(aT));
-                } else {
-                    kstep(S0, grp_tag, LAST, k, aT);
-                }
+                if (k < nk) kstep(std::integral_constant<int, 0>{}, grp_tag, k, aT);
             };
 #if LO8_PRIO_MODE == 1
             if (w >= 4) kloop(std::integral_constant<int, 1>{}); else kloop(std::integral_constant<int, 0>{});   // two copies: s_setprio takes an immediate
@@ -285,13 +273,10 @@ __global__ __launch_bounds__(Cfg256S::THREADS, Cfg256S::MINW) void gemm256_lo8s_
             }
             PROF_T0();
 #endif
-            // interior tiles leave through the LDS transpose (16-B stores); its scratch is W stage 1 -- 8 waves x 4 KiB = 32 KiB that
-            // neither the prologue of the next tile nor any DMA still in flight writes (the trailing re-requests of the last
-            // K-step were drained by the vmcnt(0) above, and every wave passed the last phase's barrier)
-#ifndef LO8_DIRECT_EPILOGUE
-            if (m0 + C::BM <= p.M && n0 + C::BN <= p.N) gemm_epilogue_lds<T, EPI, C>(p, acc, m0, n0, wm, wn, lane, smem + C::O_W + 2 * C::UNIT + w * 4096);
-            else
-#endif
+            // Direct epilogue (4-byte stores straight from the MFMA C layout).  An LDS-transposed epilogue with 16-B stores was
+            // built and measured (profiles/r02_lo8_phase_cycles.txt): 8.6k / 19.3k / 32.0k cycles per wave tile against 9.4k / 21.5k /
+            // 32.5k -- the epilogue is bound by the HBM burst of 256 CUs finishing their tiles together (chunk-synchronous order), not
+            // by store issue -- so it was dropped again.
             gemm_epilogue<T, true, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
 #ifdef LLARK_LO8_PROF
             if (p.prof && lane == 0) { long long* q = p.prof + ((size_t)(blockIdx.x + 256) * 8 + w) * 4; q[0] += __builtin_readcyclecounter() - pt0; q[3] += 1; }

@@ -276,100 +276,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     else epilogue(std::false_type{});
 }
 
-// Epilogue through LDS for full interior tiles (EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8): the MFMA C layout gives a lane ONE
-// column of 16 rows, so the direct epilogue above issues 4-byte (or 2 + 1-byte) stores, two rows x 128 B per wave instruction --
-// measured 9.4k / 21.7k / 32.5k cycles per 64 x 128 wave tile (F32 / QGELU-split / RESID; profiles/r02_lo8_phase_cycles.txt),
-// up to 30 % of a K = 1216 tile.  Here every 32 x 32 accumulator tile goes through a wave-private 4 KiB LDS scratch
-// (16 ds_write_b32 in, 4 ds_read_b128 out, 16-B chunks XOR-swizzled with row % 8: conflict-free both ways) and comes back with
-// lane l holding row 8 j + l / 8, columns 4 (l % 8) .. + 3: stores (and the residual loads) become 16 B per lane, eight full
-// 128-B lines per wave instruction, four times fewer of them.  `scratch` = this wave's 4 KiB; it must not be written by
-// another wave's next-tile prologue DMA (callers place it in a region the prologue does not touch).
-template <typename T, int EPI, typename C>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                                  const int wm, const int wn, const int lane, char* scratch) {
-    static_assert(EPI == EPI_F32 || EPI == EPI_RESID || EPI == EPI_QGELU_SPLIT8, "LDS epilogue: unsupported epilogue");
-    const int mrow0 = m0 + wm * C::WROWS, ncol0 = n0 + wn * C::TN * 32;
-    const int lr = 4 * (lane >> 5), lc = lane & 31;
-    const int orow = lane >> 3, oc4 = lane & 7;                        // after the transpose: row 8 j + orow, columns 4 oc4 ..
-    constexpr unsigned RSRC_FLAGS = 0x00020000u;
-    // write side: element (row, col) -> row * 128 + (((col / 4) ^ (row % 8)) * 16) + (col % 4) * 4;   rows of register r: (r&3) + 8 (r>>2) + lr
-    int wofs[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wofs[i] = (i + lr) * 128 + ((((lc >> 2) ^ ((i + lr) & 7)) << 4) | ((lc & 3) << 2));   // + 8 (r>>2) rows = + 1024 (r>>2)
-    const int rofs = orow * 128 + ((oc4 ^ orow) << 4);                 // + j * 1024   (row % 8 == orow)
-    __amdgpu_buffer_rsrc_t rC, rR, rH, rL;
-    int vC = 0, vR = 0, vH = 0, v8 = 0;
-    float sa_mul = 1.0f;
-    if (EPI == EPI_F32 || EPI == EPI_RESID) {
-        rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)mrow0 * p.ldc + ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vC = (orow * p.ldc + 4 * oc4) * 4;
-    }
-    if (EPI == EPI_RESID) {
-        rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.R + (size_t)mrow0 * p.ldr + ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vR = (orow * p.ldr + 4 * oc4) * 4;
-    }
-    if (EPI == EPI_QGELU_SPLIT8) {
-        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + (size_t)mrow0 * p.ldo + ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        vH = (orow * p.ldo + 4 * oc4) * 2;
-        rL = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned char*)p.Olo + (size_t)mrow0 * p.ldo8 + ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
-        v8 = orow * p.ldo8 + lo8_pos(4 * oc4);                          // columns 4 oc4 .. + 3 of a 32-column tile: 4 contiguous slot bytes
-        sa_mul = __builtin_ldexpf(1.0f, p.lo8_sa);
-    }
-    typedef float f32x4v __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
-        // residuals of this tile row first (R may alias C: loads cannot be hoisted above stores by the compiler)
-        u32x4v res[C::TN][4];
-        if (EPI == EPI_RESID) {
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    res[tn][j] = __builtin_amdgcn_raw_buffer_load_b128(rR, vR, ((C::tile_row(tm) + 8 * j) * p.ldr + tn * 32) * 4, 0);
-        }
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            f32x4v bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr) bv = *(const f32x4v*)(p.bias + ncol0 + tn * 32 + 4 * oc4);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) *(float*)(scratch + wofs[r & 3] + 1024 * (r >> 2)) = acc[tm][tn][r];
-            // compiler barriers: the scalar stores and the vector loads go through differently-typed pointers (type-based alias
-            // analysis may not order them); the hardware executes one wave's LDS operations in order
-            asm volatile("" ::: "memory");
-            f32x4v v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = *(const f32x4v*)(scratch + rofs + 1024 * j);
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4v x = v[j] + bv;
-                const int rowoff = C::tile_row(tm) + 8 * j;
-                if (EPI == EPI_F32) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, x), rC, vC, (rowoff * p.ldc + tn * 32) * 4, 0);
-                } else if (EPI == EPI_RESID) {
-                    x = __builtin_bit_cast(f32x4v, res[tn][j]) + x;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, x), rC, vC, (rowoff * p.ldc + tn * 32) * 4, 0);
-                } else {
-                    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-                    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-                    half4v h;
-                    unsigned q = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gv = quick_gelu(x[e]);
-                        h[e] = (half_t)gv;
-                        q |= fp8_e4m3_sat((gv - (float)h[e]) * sa_mul) << (8 * e);
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, h), rH, vH, (rowoff * p.ldo + tn * 32) * 2, 0);
-                    // tile tn = k block tn / 2, sub-steps 2 (tn & 1) + ..: + 64 (tn >> 1) + 16 (tn & 1) bytes (see gemm_epilogue)
-                    __builtin_amdgcn_raw_buffer_store_b32(q, rL, v8, rowoff * p.ldo8 + (tn >> 1) * 64 + (tn & 1) * 16, 0);
-                }
-            }
-        }
-    }
-}
-
 // XCD-aware remap of the hardware block index: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets the
 // contiguous band [base, base + count) of the linear tile order and its private L2 sees neighbouring tiles.
 __device__ __forceinline__ void xcd_band(int nwg, int xcd, int& base, int& count) {
@@ -388,7 +294,5 @@ int launch_gemm256_lo8(const GemmParams& p, int epi, hipStream_t s, int cus);
 int gemm256_lo8_chunk_barriers(int M, int N, int cus);
 // gemm256_lo8s.hip: the form with the fp8 weight plane pre-packed (p.W8) and staged through LDS: no VALU work in the main loop.
 int launch_gemm256_lo8s(const GemmParams& p, int epi, hipStream_t s, int cus);
-// gemm256_lo8q.hip: the same with 4 waves (one per SIMD, 128 x 128 each), W fragments read once per K-step.
-int launch_gemm256_lo8q(const GemmParams& p, int epi, hipStream_t s, int cus);
 
 }  // namespace llark

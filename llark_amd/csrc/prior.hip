@@ -115,6 +115,75 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     }
 }
 
+// lo8 form with 8 consecutive columns per lane: 32-B row loads, one 16-B store of the fp16 plane and one 8-B store of the
+// E4M3 plane per group (8 consecutive k stay contiguous in the slot order of lo8_pos).  width % 8 == 0.
+template <int NG>
+__global__ __launch_bounds__(256) void layernorm_split8_kernel(const float* __restrict__ x, int ldx, int rows, int width,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                               half_t* __restrict__ hi, unsigned char* __restrict__ lo8, int ldo, int ldo8, int sa) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int w8 = width >> 3;
+    const float4* xr = (const float4*)(x + (size_t)row * ldx);
+    float4 v[NG][2];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w8) {
+            v[k][0] = xr[2 * c];
+            v[k][1] = xr[2 * c + 1];
+            s += ((v[k][0].x + v[k][0].y) + (v[k][0].z + v[k][0].w)) + ((v[k][1].x + v[k][1].y) + (v[k][1].z + v[k][1].w));
+        } else {
+            v[k][0] = v[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)width;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        if (lane + 64 * k < w8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a = v[k][h].x - mean, b = v[k][h].y - mean, cc = v[k][h].z - mean, d = v[k][h].w - mean;
+                q += (a * a + b * b) + (cc * cc + d * d);
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)width;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4* g4 = (const float4*)gamma;
+    const float4* b4 = (const float4*)beta;
+    half_t* hr = hi + (size_t)row * ldo;
+    unsigned char* l8 = lo8 + (size_t)row * ldo8;
+    const float sa_mul = __builtin_ldexpf(1.0f, sa);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int c = lane + 64 * k;
+        if (c < w8) {
+            half8_t h;
+            unsigned qq[2] = {0u, 0u};
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float4 g = g4[2 * c + hf], b = b4[2 * c + hf];
+                float y[4];
+                y[0] = (v[k][hf].x - mean) * rstd * g.x + b.x;
+                y[1] = (v[k][hf].y - mean) * rstd * g.y + b.y;
+                y[2] = (v[k][hf].z - mean) * rstd * g.z + b.z;
+                y[3] = (v[k][hf].w - mean) * rstd * g.w + b.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[4 * hf + e] = (half_t)y[e];
+                    qq[hf] |= fp8_e4m3_sat((y[e] - (float)h[4 * hf + e]) * sa_mul) << (8 * e);
+                }
+            }
+            *(half8_t*)(hr + 8 * c) = h;
+            *(uint2*)(l8 + lo8_pos(8 * c)) = make_uint2(qq[0], qq[1]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Factored attention (block / transpose-block / previous-block), fp32, one workgroup per
 // (64-query group, head, clip).  Q K^T and P V run on the fp32-input matrix cores
@@ -438,6 +507,17 @@ static int layernorm_split_impl(const float* x, int ldx, int rows, int width, co
     const int w4 = width / 4;
     dim3 grid(cdiv(rows, 4));
     hipStream_t s = (hipStream_t)stream;
+    if (lo8 && width % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out_hi & 15) == 0 && ((uintptr_t)out_lo & 7) == 0 && ((uintptr_t)x & 15) == 0) {
+        const int w8 = width / 8;
+#define LN8_CASE(NG) layernorm_split8_kernel<NG><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (half_t*)out_hi, (unsigned char*)out_lo, ldo, ldo8, sa)
+        if (w8 <= 64) LN8_CASE(1);
+        else if (w8 <= 256) LN8_CASE(4);
+        else if (w8 <= 640) LN8_CASE(10);
+        else if (w8 <= 1024) LN8_CASE(16);
+        else { set_error("layernorm_split_lo8: width %d too large (max 8192)", width); return LLARK_ERR_UNSUPPORTED; }
+#undef LN8_CASE
+        return check_launch("layernorm_split_lo8");
+    }
 #define LN_CASE(NV)                                                                                                              \
     do {                                                                                                                         \
         if (lo8) layernorm_split_kernel<NV, true><<<grid, 256, 0, s>>>(x, ldx, rows, width, gamma, beta, eps, (half_t*)out_hi, out_lo, ldo, ldo8, sa); \

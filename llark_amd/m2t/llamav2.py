@@ -124,16 +124,16 @@ class _HipTrainStep(torch.autograd.Function):
         tr.zero_grad()
         loss = tr.forward_backward(input_ids, segs, labels)
         grads = tr.export_grads_hf()
-        lacking = [n for n in names if n not in grads]
-        if lacking:      # e.g. lm_head when it is not frozen: a silent None gradient would leave the parameter untrained
-            raise NotImplementedError(f"the HIP training step exports no gradient for trainable parameter(s) {lacking[:4]}; freeze them "
-                                      "(requires_grad_(False)) -- the reference recipe trains with lm_head frozen (llamav2.py:395-419)")
+        ctx.lacking = [n for n in names if n not in grads]
         ctx.grads = [grads.get(n) for n in names]
         ctx.dtypes = [p.dtype for p in params]
         return loss.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.lacking:  # e.g. lm_head when it is not frozen: a silent None gradient would leave the parameter untrained
+            raise NotImplementedError(f"the HIP training step exports no gradient for trainable parameter(s) {ctx.lacking[:4]}; freeze them "
+                                      "(requires_grad_(False)) -- the reference recipe trains with lm_head frozen (llamav2.py:395-419)")
         outs = []
         for g, dt in zip(ctx.grads, ctx.dtypes):
             outs.append(None if g is None else (g * grad_out).to(dt))

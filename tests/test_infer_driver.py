@@ -105,7 +105,9 @@ def test_infer_from_encodings_batched_equals_per_example(tmp_path, monkeypatch):
 
 @pytest.mark.gpu
 def test_infer_from_audio_fused_equals_two_stage():
-    """audio -> WrappedAudioEncoder -> generate in one process == (encoder per clip -> .npy-style array -> infer_with_prompt)."""
+    """audio -> WrappedAudioEncoder -> generate in one process == the two-stage pipeline per clip: ``get_acts_from_audio`` (what
+    jukebox/main.py writes to ``<name>.npy``: a clip shorter than the window keeps only the frames of its own audio, main.py:147)
+    -> infer_with_prompt."""
     from llark_amd.jukebox import extract as E
     from llark_amd.jukebox.hparams import hparams_tiny
     from llark_amd.jukebox.synthetic import make_jukebox_weights, synthetic_clip
@@ -122,8 +124,8 @@ def test_infer_from_audio_fused_equals_two_stage():
     assert [r["example_id"] for r in recs] == ["clip0", "clip1", "clip2"]
     m.configure_engine(max_batch=1, max_seq=160)
     for (name, audio), r in zip(clips, recs):
-        a = E.maybe_pad_audio_to_max_len(E._normalize(audio), hps.sample_length)[: hps.sample_length].astype(np.float32)
-        rep = enc(torch.from_numpy(a)[None].cuda())[0].cpu()
+        rep = torch.from_numpy(E.get_acts_from_audio(E._normalize(audio).astype(np.float32), hps, enc.vqvae, enc.top_prior, meanpool=True,
+                                                     pool_frames_per_second=enc.pool_frames_per_second))
         one = infer_with_prompt(PROMPT, model=m, audio_encoding=rep, end_seq=end_seq, multimodal_cfg=MM_CFG, tokenizer=tok,
                                 audio_first=True, max_new_tokens=8).cpu()
         assert r["model_completion_text"] == tok.decode(extract_response_tokens(one[0], end_seq)), name

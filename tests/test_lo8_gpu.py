@@ -141,18 +141,19 @@ def test_layernorm_split_lo8(rows, width):
     ops.layernorm_split_lo8(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, hi, lo8)
     ops.layernorm_split(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, hi16, lo16)
     torch.cuda.synchronize()
-    assert torch.equal(hi, hi16), "hi planes of the two LayerNorm forms differ"
-    # the fp16 low plane holds (y - hi) to 11 bits; the e4m3 plane must be its round-to-nearest (3 mantissa bits) at 2^12
-    want = e4m3(lo16.cpu().float() * 2.0 ** SA).float() * 2.0 ** -SA
-    got = ops.lo8_decode(lo8, width).cpu()
-    diff = (got - want[:, :width]).abs()
-    # double rounding (fp32 -> fp16 -> e4m3 in the checker vs fp32 -> e4m3 on the device) may differ by one e4m3 step at ties
-    step = torch.maximum(want[:, :width].abs() * 2.0 ** -3, torch.full_like(diff, 2.0 ** -9 * 2.0 ** -SA))
-    assert bool((diff <= step * 1.0001).all())
-    assert float((diff > 0).float().mean()) < 0.02
     ref = torch.nn.functional.layer_norm(x.double(), (width,), gamma.double(), beta.double(), 1e-5)
-    report_close("hi + lo8 vs LayerNorm", hi.cpu().double()[:, :width] + got.double(), ref, 2.0 ** -15 * ref.abs().max().item() + 1e-6)
-    assert int(lo8.cpu()[:, width:].abs().sum()) == 0 if wp > width and (wp - width) % 64 == 0 else True
+    # the two forms assign columns to lanes differently (mean / variance sums in another order): hi planes agree to one fp16 ulp
+    hd = (hi.cpu().double() - hi16.cpu().double()).abs()[:, :width]
+    assert bool((hd <= 2.0 ** -10 * ref.abs() + 2.0 ** -24).all()) and float((hd > 0).double().mean()) < 1e-3
+    # the e4m3 plane is the round-to-nearest (3 mantissa bits) of (y - hi) at 2^12, in MFMA slot order
+    got = ops.lo8_decode(lo8, width).cpu().double()
+    resid = ref - hi.cpu().double()[:, :width]                    # what the low plane has to carry (up to the kernel's fp32 rounding of y)
+    err = (got - resid).abs()
+    tol = 2.0 ** -4 * resid.abs() + 2.0 ** -9 * 2.0 ** -SA + 3e-7 * ref.abs() + 1e-7
+    assert bool((err <= tol).all()), f"max err {err.max():.3e}; worst ratio {(err / tol).max():.2f}"
+    report_close("hi + lo8 vs LayerNorm", hi.cpu().double()[:, :width] + got, ref, 2.0 ** -15 * ref.abs().max().item() + 1e-6)
+    if wp > width:
+        assert int(hi.cpu()[:, width:].abs().sum()) == 0           # pad columns of the fp16 plane stay zero
 
 
 def test_prior_tiny_and_full_width_depth3_lo8():
