@@ -923,7 +923,10 @@ extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo
     p.Ohi = out_hi; p.Olo = out_lo8; p.ldo = ldo; p.ldo8 = ldo8; p.lo8_sa = sa; p.lo8_sw = sw; p.W8 = w8; p.ldw8 = ldw8;
     hipStream_t s = (hipStream_t)stream;
     if (ws_begin(ws, p, s)) { set_error("gemm16_lo8: workspace unusable"); return LLARK_ERR_LAUNCH; }
-    const int rc = w8 ? launch_gemm256_lo8s(p, epilogue, s, ws->cus) : launch_gemm256_lo8(p, epilogue, s, ws->cus);
+    // staged forms: n = phases over N with resident A fragments (gemm256_lo8n.hip), s = phases over M (gemm256_lo8s.hip); LLARK_LO8_FORM picks
+    static const char form = [] { const char* e = getenv("LLARK_LO8_FORM"); return e ? e[0] : 'n'; }();
+    const int rc = !w8 ? launch_gemm256_lo8(p, epilogue, s, ws->cus)
+                   : form == 's' ? launch_gemm256_lo8s(p, epilogue, s, ws->cus) : launch_gemm256_lo8n(p, epilogue, s, ws->cus);
     if (rc == -1000) { set_error("gemm16_lo8: problem outside the kernel's range (32-bit operand offsets)"); return LLARK_ERR_UNSUPPORTED; }
     ws_end(ws, cdiv(m, 256) * cdiv(n, 256), ws->cus / 8);
     return rc;

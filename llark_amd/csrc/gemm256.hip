@@ -33,6 +33,8 @@ struct Cfg256 {
     static constexpr int BM = 256, BN = 256, NW = 8, THREADS = 512, MINW = 2;
     static constexpr int WROWS = 32, TMS = 128;    // epilogue row mapping: wave wm owns rows wm*32.. of EACH 128-row half
     static constexpr int tile_row(int tm) { return tm * TMS; }
+    static constexpr int WCOLS = TN * 32;
+    static constexpr int tile_col(int tn) { return tn * 32; }
     static constexpr int ROWB = 128, UNIT = 128 * ROWB, NUNITS = 10;
     static constexpr int LDS = UNIT * NUNITS;      // 160 KiB
 };

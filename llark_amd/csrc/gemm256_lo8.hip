@@ -32,6 +32,8 @@ struct Cfg256L {
     static constexpr int BM = 256, BN = 256, NW = 8, THREADS = 512, MINW = 2;
     static constexpr int WROWS = 32, TMS = 128;    // epilogue row mapping: wave wm owns rows wm*32.. of EACH 128-row half
     static constexpr int tile_row(int tm) { return tm * TMS; }
+    static constexpr int WCOLS = TN * 32;
+    static constexpr int tile_col(int tn) { return tn * 32; }
     static constexpr int ROWB = 128, UNIT = 128 * ROWB;          // fp16 unit: 128 rows x 128 B = 16 KiB
     static constexpr int ROWB8 = 64, UNIT8 = 128 * ROWB8;        // fp8 unit : 128 rows x  64 B =  8 KiB
     // stage layout: AhiT | AhiB | Wa | Wb | A8T | A8B

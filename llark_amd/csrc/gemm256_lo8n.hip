@@ -1,0 +1,336 @@
+// 256x256x64 split GEMM tile with an FP8 low plane, phases split over N with the A fragments resident ("lo8" mode, default):
+//     C[M,N] = Ahi[M,K] . W[N,K]^T  +  2^-(SA+SW) . A8[M,K] . W8[N,K]^T          (fp32 accumulate)
+// Same product, operand formats, DMA technique and 160 KiB budget as gemm256_lo8s.hip (read that header first) with the roles of
+// A and W swapped.  Measured on lo8s (profiles/r02_lo8_phase_cycles.txt): a phase takes ~2200 cycles for 1536 cycles of matrix
+// work, the DMA stream is never late, and the LDS is the busiest unit: its two phases split M, so every W fragment is read in
+// BOTH phases by all four wave rows -- 480 ds_read_b128 + 96 KiB of DMA writes per K-step and CU.  Here
+//  * a K-step's two phases split N: phase L multiplies by the left 128 weight rows (units WL, W8L), phase R by the right 128;
+//  * wave (wm, wn) owns rows wm*64 .. +63 (two MFMA row tiles) and, in each phase, columns wn*64 .. +63 of that half (two column
+//    tiles): 16 fp16 + 4 fp8 MFMAs per phase as before;
+//  * its A fragments (8 fp16 + 2 fp8 = 48 registers) are read ONCE per K-step, in phase L, and stay in registers for phase R:
+//    288 ds_read_b128 per K-step and CU (-40 %);
+//  * LDS slots by lifetime: A = Ahi 32 KiB + A8 16 KiB, 2 stages (requested in L(k-1), read in L(k)); W fp16 halves in a 3-slot ring
+//    of 16 KiB (unit i = 2k + {L:0, R:1} in slot i % 3); W8L / W8R single 8-KiB slots, requested one phase ahead.
+//    Requests per wave: L(k): W8R(k) | WL(k+1) x2, Ahi(k+1) x4, A8(k+1) x2 -> wait vmcnt(8); R(k): W8L(k+1) | WR(k+1) x2 -> vmcnt(2).
+//  * inside a phase the MFMAs go k sub-step by k sub-step over the phase's four accumulators: no two consecutive MFMAs share an
+//    accumulator (the dependent-accumulator stall was the ~640 idle pipe cycles per phase of the M-split form).
+// Accumulation order per accumulator unchanged: per K-step four fp16 products (k ascending), then the fp8 product.
+#include "gemm_core.h"
+
+namespace llark {
+
+struct Cfg256N {
+    static constexpr int WM = 4, WN = 2, TM = 2, TN = 4, BK = 64;
+    static constexpr int BM = 256, BN = 256, NW = 8, THREADS = 512, MINW = 2;
+    static constexpr int WROWS = 64, TMS = 32;       // epilogue: wave wm owns rows wm*64 .. +63 (two MFMA row tiles)
+    static constexpr int tile_row(int tm) { return tm * 32; }
+    static constexpr int WCOLS = 64;                 // wave wn owns columns wn*64 .. +63 of EACH 128-column half:
+    static constexpr int tile_col(int tn) { return (tn >> 1) * 128 + (tn & 1) * 32; }   // accumulator column tiles 0,1 -> half L, 2,3 -> half R
+    static constexpr int ROWB = 128, UNIT = 128 * ROWB;          // fp16 unit: 128 rows x 128 B = 16 KiB
+    static constexpr int ROWB8 = 64, UNIT8 = 128 * ROWB8;        // fp8 unit : 128 rows x  64 B =  8 KiB
+    // W8L | W8R | W ring (3 x 16 KiB) | Ahi stages (2 x 32 KiB) | A8 stages (2 x 16 KiB)
+    static constexpr int O_8L = 0, O_8R = UNIT8, O_WR = 2 * UNIT8, O_A = O_WR + 3 * UNIT, O_A8 = O_A + 4 * UNIT;
+    static constexpr int LDS = O_A8 + 4 * UNIT8;                 // 160 KiB
+    static_assert(LDS == 160 * 1024, "LDS map");
+};
+
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+#define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): per-wave cycle counters, see gemm256_lo8.hip.
+#ifdef LLARK_LO8_PROF
+#define PROF_DECL long long pt0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0
+#define PROF_T0() pt0 = __builtin_readcyclecounter()
+#define PROF_ADD(ACC) do { const long long t_ = __builtin_readcyclecounter(); ACC += t_ - pt0; pt0 = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_T0()
+#define PROF_ADD(ACC)
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_kernel(const GemmParams p) {
+    typedef Cfg256N C;
+    typedef half_t T;
+    typedef typename Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- fragment-read offsets (lane-constant; slots, stages and tiles are added as scalars / immediates) ----
+    const int sw = (l31 >> 1) & 7;
+    int rdA[4], rdW[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int rd = l31 * C::ROWB + ((((s << 1) | lhi) ^ sw) << 4);
+        rdA[s] = C::O_A + wm * 8192 + rd;              // rows wm*64.. of the 256-row A stage (+ 4096 for the second row tile)
+        rdW[s] = C::O_WR + wn * 8192 + rd;             // weight rows wn*64.. of a 128-row W half (+ 4096 for the second column tile)
+    }
+    // fp8 units: 32 contiguous bytes (chunks 2 lhi, 2 lhi + 1) of row l31, chunk index XOR (row / 4) % 4
+    const int sw8 = (l31 >> 2) & 3;
+    const int c8a = ((lhi << 1) ^ sw8) << 4, c8b = (((lhi << 1) | 1) ^ sw8) << 4;
+    const int rd8a = C::O_A8 + wm * 4096 + l31 * C::ROWB8 + c8a, rd8b = C::O_A8 + wm * 4096 + l31 * C::ROWB8 + c8b;   // + stage, + 2048 tile
+    const int rdW8a = wn * 4096 + l31 * C::ROWB8 + c8a, rdW8b = wn * 4096 + l31 * C::ROWB8 + c8b;                     // + O_8L / O_8R, + 2048 tile
+
+    // ---- LDS-DMA lane geometry ----
+    const int rl = lane >> 3, pch = lane & 7;                             // fp16: 8 rows x 128 B per wave instruction
+    const int dch = pch ^ ((((w & 1) << 2) + (rl >> 1)) & 7);
+    const int rl8 = lane >> 2;                                            // fp8 : 16 rows x 64 B per wave instruction
+    const int dch8 = (lane & 3) ^ ((lane >> 4) & 3);
+    const unsigned RSRC_FLAGS = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ahi, 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rA8 = __builtin_amdgcn_make_buffer_rsrc((void*)p.Alo, 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rW8 = __builtin_amdgcn_make_buffer_rsrc((void*)p.W8, 0, 0x7FFFFFFF, RSRC_FLAGS);
+
+    // block scales of the MX instruction (E8M0 in byte 0, op_sel 0): 2^-SA for A8, 2^-SW for W8
+    const int scale_a = 127 - p.lo8_sa, scale_b = 127 - p.lo8_sw;
+
+    const int nk = p.Kp >> 6;
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int band0, bandn;
+    xcd_band(nwg, xcd, band0, bandn);
+    const int nchunks = ((nwg >> 3) + ((nwg & 7) ? 1 : 0) + p.slots - 1) / p.slots;
+    int* cnt = p.sync + xcd * 32;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int local = ch * p.slots + slot_id;
+        if (local < bandn) {
+            const int bid = band0 + local;
+            // M-grouped tile order: 4 tile rows, N-major inside a group (a chunk of 32 tiles = 4 x 8 tiles)
+            constexpr int GM = 4;
+            const int gsz = GM * p.tiles_n;
+            const int g = bid / gsz;
+            const int first_m = g * GM;
+            const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+            const int tile_m = first_m + (bid % gsz) % gm;
+            const int tile_n = (bid % gsz) / gm;
+            const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+
+            // per-lane byte offsets of the rows this wave stages (clamped to the last valid row; masked on store)
+            unsigned voA[4], voW[4], vo8[2], voW8[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int ra = m0 + q * 64 + w * 8 + rl;
+                ra = ra < p.M ? ra : p.M - 1;
+                voA[q] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)(dch << 4);
+                int rw = n0 + q * 64 + w * 8 + rl;
+                rw = rw < p.N ? rw : p.N - 1;
+                voW[q] = (unsigned)rw * (unsigned)(p.ldw * 2) + (unsigned)(dch << 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                int ra = m0 + q * 128 + w * 16 + rl8;
+                ra = ra < p.M ? ra : p.M - 1;
+                vo8[q] = (unsigned)ra * (unsigned)p.lda8 + (unsigned)(dch8 << 4);
+                int rw = n0 + q * 128 + w * 16 + rl8;
+                rw = rw < p.N ? rw : p.N - 1;
+                voW8[q] = (unsigned)rw * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
+            }
+            auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + dst_off), 16, vo, soff, 0, 0);
+            };
+            const int wb = w * 1024;                                      // this wave's 1 KiB piece inside every 8 KiB of a unit
+            auto issue_WL = [&](int k, int slot) __attribute__((always_inline)) {         // left 128 weight rows (fp16) into ring slot
+                dma(rW, voW[0], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[1], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
+            };
+            auto issue_WR = [&](int k, int slot) __attribute__((always_inline)) {         // right 128 weight rows
+                dma(rW, voW[2], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[3], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
+            };
+            auto issue_A = [&](int k, int st) __attribute__((always_inline)) {            // Ahi (4) + A8 (2) of K-step k into stage st
+                const int b = C::O_A + st * 2 * C::UNIT + wb;
+                dma(rAh, voA[0], k << 7, b); dma(rAh, voA[1], k << 7, b + 8192);
+                dma(rAh, voA[2], k << 7, b + C::UNIT); dma(rAh, voA[3], k << 7, b + C::UNIT + 8192);
+                const int b8 = C::O_A8 + st * 2 * C::UNIT8 + wb;
+                dma(rA8, vo8[0], k << 6, b8); dma(rA8, vo8[1], k << 6, b8 + C::UNIT8);
+            };
+
+            f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            PROF_DECL;
+
+            auto rd_i32x8 = [&](int off_a, int off_b) __attribute__((always_inline)) {
+                // (read through the fp16 fragment type: int4-typed LDS reads made hipcc 7.2 emit `s_waitcnt vmcnt(0)` in front of
+                //  them -- its LDS-DMA alias tracking -- which drains the DMA queue every phase)
+                const i32x4_t lo = __builtin_bit_cast(i32x4_t, *(const frag*)(smem + off_a)), hi = __builtin_bit_cast(i32x4_t, *(const frag*)(smem + off_b));
+                return i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+
+            // A fragments of the current K-step: read in phase L, reused in phase R
+            frag ah[2][4];
+            i32x8_t a8[2];
+
+            // One phase = 64 rows x 64 columns (2 x 2 MFMA tiles) x 64 k of this wave: 16 fp16 MFMAs + 4 fp8 MFMAs, k sub-step by k
+            // sub-step over the four accumulators of the phase.  All eight waves leave the barrier together and queue their fragment
+            // reads on the one LDS: the reads are therefore issued JUST IN TIME -- only what sub-step 0 multiplies (4 reads in phase L,
+            // 2 in phase R) before the first MFMA, the fragments of sub-step s + 1 (and the fp8 fragments) while sub-step s multiplies.
+            // (Front-loading a phase's A fragments -- 8 reads per wave, 64 per CU ahead of anybody's first W fragment -- left the
+            // matrix pipe idle for the first ~500 cycles of every phase: profiles/r02_lo8_phase_cycles.txt.)  The phase's DMA requests
+            // go out behind the first MFMAs for the same reason.  HALF = 0 (L) / 1 (R).
+            auto phase = [&](auto half_tag, auto st_tag, int wslot, auto&& issue) __attribute__((always_inline)) {
+                constexpr int half = decltype(half_tag)::value, st = decltype(st_tag)::value;
+                constexpr int oA = st * 2 * C::UNIT, oA8 = st * 2 * C::UNIT8, o8 = half ? C::O_8R : C::O_8L;
+                const int oW = wslot * C::UNIT;
+                frag bf[2][2];                     // [buffer][column tile]
+                i32x8_t w8[2];
+                if (half == 0) {
+                    ah[0][0] = *(const frag*)(smem + rdA[0] + oA);
+                    ah[1][0] = *(const frag*)(smem + rdA[0] + oA + 4096);
+                }
+                bf[0][0] = *(const frag*)(smem + rdW[0] + oW);
+                bf[0][1] = *(const frag*)(smem + rdW[0] + oW + 4096);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<4>([&](auto sc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(sc)::value, cur = s & 1;
+                    if constexpr (s < 3) {         // fragments of sub-step s + 1
+                        if (half == 0) {
+                            ah[0][s + 1] = *(const frag*)(smem + rdA[s + 1] + oA);
+                            ah[1][s + 1] = *(const frag*)(smem + rdA[s + 1] + oA + 4096);
+                        }
+                        bf[cur ^ 1][0] = *(const frag*)(smem + rdW[s + 1] + oW);
+                        bf[cur ^ 1][1] = *(const frag*)(smem + rdW[s + 1] + oW + 4096);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][2 * half] = Mfma<T>::run(ah[0][s], bf[cur][0], acc[0][2 * half]);
+                    acc[1][2 * half] = Mfma<T>::run(ah[1][s], bf[cur][0], acc[1][2 * half]);
+                    acc[0][2 * half + 1] = Mfma<T>::run(ah[0][s], bf[cur][1], acc[0][2 * half + 1]);
+                    acc[1][2 * half + 1] = Mfma<T>::run(ah[1][s], bf[cur][1], acc[1][2 * half + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (s == 0) issue();                                         // this phase's DMA requests
+                    if constexpr (s == 1) {                                                // fp8 fragments: needed after sub-step 3
+                        if (half == 0) {
+                            a8[0] = rd_i32x8(rd8a + oA8, rd8b + oA8);
+                            a8[1] = rd_i32x8(rd8a + oA8 + 2048, rd8b + oA8 + 2048);
+                        }
+                        w8[0] = rd_i32x8(rdW8a + o8, rdW8b + o8);
+                        w8[1] = rd_i32x8(rdW8a + o8 + 2048, rdW8b + o8 + 2048);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                acc[0][2 * half] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[0], w8[0], acc[0][2 * half], 0, 0, 0, scale_a, 0, scale_b);
+                acc[1][2 * half] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[1], w8[0], acc[1][2 * half], 0, 0, 0, scale_a, 0, scale_b);
+                acc[0][2 * half + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[0], w8[1], acc[0][2 * half + 1], 0, 0, 0, scale_a, 0, scale_b);
+                acc[1][2 * half + 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[1], w8[1], acc[1][2 * half + 1], 0, 0, 0, scale_a, 0, scale_b);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // One K-step from A stage ST; wL = ring slot of WL(k).  Both phases ALWAYS issue their requests (the last step re-requests
+            // itself, clamped k) so the vmcnt counts and the instruction stream are the same for every K-step (see gemm256_lo8s.hip).
+            auto kstep = [&](auto st_tag, int k, int wL) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_tag)::value;
+                const int kn = k + 1 < nk ? k + 1 : nk - 1;
+                const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // slots of WR(k), WL(k+1)
+                phase(std::integral_constant<int, 0>{}, st_tag, wL, [&]() __attribute__((always_inline)) {
+                    dma(rW8, voW8[1], k << 6, C::O_8R + wb);               // W8R(k): read by the NEXT phase
+                    issue_WL(kn, wN);
+                    issue_A(kn, st ^ 1);
+                });
+                PROF_ADD(pacc0);
+                VMCNT(8);                                                  // WR(k) (requested in R(k-1)) and W8R(k) have landed
+                PROF_ADD(pacc1);
+                __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
+                phase(std::integral_constant<int, 1>{}, st_tag, wR, [&]() __attribute__((always_inline)) {
+                    dma(rW8, voW8[0], kn << 6, C::O_8L + wb);              // W8L(k+1): read by the NEXT phase
+                    issue_WR(kn, wL);
+                });
+                PROF_ADD(pacc0);
+                VMCNT(2);                                                  // WL / Ahi / A8 (k+1) from L(k) and W8L(k+1) have landed
+                PROF_ADD(pacc1);
+                __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
+            };
+
+            // prologue: the L set of K-step 0 (W8L, WL -> slot 0, Ahi / A8 -> stage 0), then WR(0) -> slot 1
+            dma(rW8, voW8[0], 0, C::O_8L + wb);
+            issue_WL(0, 0);
+            issue_A(0, 0);
+            issue_WR(0, 1);
+            VMCNT(2);
+            __builtin_amdgcn_s_barrier();
+            PROF_T0();
+            {
+                int k = 0, wL = 0;
+                for (; k + 1 < nk; k += 2) {
+                    kstep(std::integral_constant<int, 0>{}, k, wL);
+                    wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                    kstep(std::integral_constant<int, 1>{}, k + 1, wL);
+                    wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                }
+                if (k < nk) kstep(std::integral_constant<int, 0>{}, k, wL);
+            }
+            // (alternating s_setprio between the two waves of a SIMD, +4 % on the M-split form, measured -0.7 % here: with just-in-time
+            //  reads both waves already finish their phases together -- profiles/r02_lo8_phase_cycles.txt)
+            VMCNT(0);
+#ifdef LLARK_LO8_PROF
+            if (p.prof && lane == 0) {
+                long long* q = p.prof + ((size_t)blockIdx.x * 8 + w) * 4;
+                q[0] += pacc0; q[1] += pacc1; q[2] += pacc2; q[3] += 2 * nk;
+            }
+            PROF_T0();
+#endif
+            // Direct epilogue (4-byte stores straight from the MFMA C layout).  An LDS-transposed epilogue with 16-B stores was
+            // built and measured (profiles/r02_lo8_phase_cycles.txt): 8.6k / 19.3k / 32.0k cycles per wave tile against 9.4k / 21.5k /
+            // 32.5k -- the epilogue is bound by the HBM burst of 256 CUs finishing their tiles together (chunk-synchronous order), not
+            // by store issue -- so it was dropped again.
+            gemm_epilogue<T, true, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+#ifdef LLARK_LO8_PROF
+            if (p.prof && lane == 0) { long long* q = p.prof + ((size_t)(blockIdx.x + 256) * 8 + w) * 4; q[0] += __builtin_readcyclecounter() - pt0; q[3] += 1; }
+#endif
+        }
+        if (ch + 1 < nchunks) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int target = p.sync_base + (ch + 1) * p.slots;
+                // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
+                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int EPI>
+static int launch256_lo8n(GemmParams p, hipStream_t s, int cus) {
+    typedef Cfg256N C;
+    auto kern = gemm256_lo8n_kernel<EPI>;
+    static bool attr_set = false;                // a property of the code object, not of a device or a stream
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
+        attr_set = true;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    p.slots = cus / 8;
+#ifdef LLARK_LO8_PROF
+    if (const char* e = getenv("LLARK_LO8_PROF_BUF")) p.prof = (long long*)strtoull(e, nullptr, 0);
+#endif
+    kern<<<dim3(cus), C::THREADS, C::LDS, s>>>(p);
+    return check_launch("gemm256_lo8n");
+}
+
+int launch_gemm256_lo8n(const GemmParams& p, int epi, hipStream_t s, int cus) {
+    // needs >= 2 K-steps of 64, operands addressable with 32-bit byte offsets, a sync block, 8 | CUs, the packed W8 plane
+    if (!p.Alo || !p.W8 || p.Kp % 64 != 0 || p.Kp < 128 || p.batch > 1 || !p.sync || cus <= 0 || cus % 8) return -1000;
+    if ((long long)p.M * p.lda * 2 >= (1ll << 31) || (long long)p.N * p.ldw * 2 >= (1ll << 31) || (long long)p.M * p.lda8 >= (1ll << 31)) return -1000;
+    switch (epi) {
+        case EPI_F32: return launch256_lo8n<EPI_F32>(p, s, cus);
+        case EPI_RESID: return launch256_lo8n<EPI_RESID>(p, s, cus);
+        case EPI_QGELU_SPLIT8: return launch256_lo8n<EPI_QGELU_SPLIT8>(p, s, cus);
+    }
+    return -1000;
+}
+
+}  // namespace llark

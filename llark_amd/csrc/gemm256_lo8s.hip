@@ -29,6 +29,8 @@ struct Cfg256S {
     static constexpr int BM = 256, BN = 256, NW = 8, THREADS = 512, MINW = 2;
     static constexpr int WROWS = 32, TMS = 128;    // epilogue row mapping: wave wm owns rows wm*32.. of EACH 128-row half
     static constexpr int tile_row(int tm) { return tm * TMS; }
+    static constexpr int WCOLS = TN * 32;
+    static constexpr int tile_col(int tn) { return tn * 32; }
     static constexpr int ROWB = 128, UNIT = 128 * ROWB;          // fp16 unit: 128 rows x 128 B = 16 KiB
     static constexpr int ROWB8 = 64, UNIT8 = 128 * ROWB8;        // fp8 unit : 128 rows x  64 B =  8 KiB
     static constexpr int O_8T = 0, O_8B = UNIT8, O_AH = 2 * UNIT8, O_W = O_AH + 3 * UNIT, O_W8 = O_W + 4 * UNIT;

@@ -43,6 +43,8 @@ struct Cfg {
     static constexpr int WROWS = TM * 32;          // epilogue row mapping: wave wm's first row is wm * WROWS,
     static constexpr int TMS = 32;                 //   its MFMA tile tm starts TMS rows further down
     static constexpr int tile_row(int tm) { return tm * TMS; }
+    static constexpr int WCOLS = TN * 32;          // column mapping: wave wn's first column is wn * WCOLS, its MFMA tile tn starts
+    static constexpr int tile_col(int tn) { return tn * 32; }      //   tile_col(tn) columns further right
     static constexpr int NW = WM * WN, THREADS = NW * 64;
     static constexpr int ROWB = BK * 2;            // bytes per tile row (16-bit elements)
     static constexpr int CH = ROWB / 16;           // 16-B chunks per row
@@ -161,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     // wave-uniform scalar offset per (tile,row): no vector address arithmetic in the epilogue at all.
     const int nlim = IS_SWIGLU(EPI) ? (p.N >> 1) : p.N;
     const int mrow0 = m0 + wm * C::WROWS;                      // uniform
-    const int ncol0 = n0 + wn * C::TN * 32;                      // uniform (weight-row space)
+    const int ncol0 = n0 + wn * C::WCOLS;                        // uniform (weight-row space)
     const int ocol0 = IS_SWIGLU(EPI) ? (ncol0 >> 1) : ncol0;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
     const int lr = 4 * (lane >> 5), lc = lane & 31;
@@ -207,12 +209,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             if (EPI == EPI_RESID) {
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn) {
-                    const bool col_ok = FULL || (ocol0 + tn * 32 + lc < nlim);
+                    const bool col_ok = FULL || (ocol0 + C::tile_col(tn) + lc < nlim);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);
                         res[tn][r] = (col_ok && (FULL || mrow0 + ml + lr < p.M))
-                                         ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + tn * 32) * 4, 0))
+                                         ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + C::tile_col(tn)) * 4, 0))
                                          : 0.0f;
                     }
                 }
@@ -222,9 +224,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                 if (IS_SWIGLU(EPI) && (tn & 1)) continue;            // even tn holds gate, tn+1 holds up
                 // SwiGLU packing: W rows are interleaved in blocks of 32 ([gate 32 | up 32] per 64 rows), so
                 // the output column block of the (tn, tn+1) pair starts at (64-aligned base)/2.
-                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : tn * 32;                 // compile-time
+                const int ocl = IS_SWIGLU(EPI) ? (tn >> 1) * 32 : C::tile_col(tn);         // compile-time
                 if (!FULL && ocol0 + ocl + lc >= nlim) continue;
-                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + tn * 32 + lc] : 0.0f;
+                const float bv = (p.bias != nullptr && !IS_SWIGLU(EPI)) ? p.bias[ncol0 + C::tile_col(tn) + lc] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);                          // compile-time row in the sub-tile
@@ -248,8 +250,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                         const T hi = Mfma<T>::cvt(v);
                         const unsigned lo8 = fp8_e4m3_sat((v - Mfma<T>::back(hi)) * sa_mul);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), rH, vO, (ml * p.ldo + ocl) * 2, 0);
-                        // tile tn covers k = (tn & 1) * 32 + lc of 64-block tn / 2: sub-steps s = 2 (tn & 1) + lc / 16
-                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lo8, rL, v8, ml * p.ldo8 + (tn >> 1) * 64 + (tn & 1) * 16, 0);
+                        // a tile covers k = 32 (col / 32 % 2) + lc of the 64-block col / 64: sub-steps s = 2 (col / 32 % 2) + lc / 16
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)lo8, rL, v8, ml * p.ldo8 + (C::tile_col(tn) & ~63) + ((C::tile_col(tn) >> 5) & 1) * 16, 0);
                     } else if (EPI == EPI_OUT16) {
                         if (act_erf) v = gelu_erf(v);
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(v)), rH, vO,
@@ -294,5 +296,7 @@ int launch_gemm256_lo8(const GemmParams& p, int epi, hipStream_t s, int cus);
 int gemm256_lo8_chunk_barriers(int M, int N, int cus);
 // gemm256_lo8s.hip: the form with the fp8 weight plane pre-packed (p.W8) and staged through LDS: no VALU work in the main loop.
 int launch_gemm256_lo8s(const GemmParams& p, int epi, hipStream_t s, int cus);
+// gemm256_lo8n.hip: phases split over N, A fragments resident across both (40 % fewer LDS reads).
+int launch_gemm256_lo8n(const GemmParams& p, int epi, hipStream_t s, int cus);
 
 }  // namespace llark

@@ -7,7 +7,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 /opt/rocm/bin/hipcc $FLAGS -DLLARK_LO8_PROF ${EXTRA_DEFS} -c gemm256_lo8.hip -o build_ab/gemm256_lo8_prof.o &
 /opt/rocm/bin/hipcc $FLAGS -DLLARK_LO8_PROF ${EXTRA_DEFS} -c gemm256.hip -o build_ab/gemm256_prof.o &
 /opt/rocm/bin/hipcc $FLAGS -DLLARK_LO8_PROF ${EXTRA_DEFS} -c gemm256_lo8s.hip -o build_ab/gemm256_lo8s_prof.o &
+/opt/rocm/bin/hipcc $FLAGS -DLLARK_LO8_PROF ${EXTRA_DEFS} -c gemm256_lo8n.hip -o build_ab/gemm256_lo8n_prof.o &
 wait
-OBJS=$(ls build/*.o | grep -v "gemm256_lo8.o\|gemm256.o\|gemm256_lo8s.o\|gemm256_lo8q.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libllark_hip_lo8prof.so $OBJS build_ab/gemm256_lo8_prof.o build_ab/gemm256_prof.o build_ab/gemm256_lo8s_prof.o
+OBJS=$(ls build/*.o | grep -v "gemm256_lo8.o\|gemm256.o\|gemm256_lo8s.o\|gemm256_lo8n.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libllark_hip_lo8prof.so $OBJS build_ab/gemm256_lo8_prof.o build_ab/gemm256_prof.o build_ab/gemm256_lo8s_prof.o build_ab/gemm256_lo8n_prof.o
 ls -la ../libllark_hip_lo8prof.so

@@ -77,3 +77,60 @@ def test_launch_list_records_and_replays_c_abi_calls():
     finally:
         import torch
         O._stream = lambda: torch.cuda.current_stream().cuda_stream
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_persistent_gemms_on_two_streams_use_separate_caller_owned_workspaces():
+    """include/llark_hip.h: compute entry points keep no hidden device state -- the persistent GEMM kernels synchronise through
+    a workspace the CALLER creates (llark_workspace_create), one per (device, stream).  Two streams run the persistent kernels
+    (f16x2 variant 30 and the lo8 form) concurrently, each with its own workspace; results equal the single-stream run bit for
+    bit, and the library allocates nothing after the two workspaces exist."""
+    import torch
+
+    from llark_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    m, n, k = 8192, 4800, 1216
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(n, k, generator=g) * 0.02).half().cuda()
+    hi, lo = ops.split16(a.cuda(), torch.float16, kmult=64)
+    wt = torch.zeros((n, hi.shape[1]), dtype=torch.float16, device="cuda")
+    wt[:, :k] = w
+    lo8 = torch.randint(0, 120, (m, hi.shape[1]), dtype=torch.uint8, device="cuda")
+    sw = ops.lo8_weight_exponent(wt)
+    w8 = ops.pack_weight_lo8(wt, sw)
+
+    def run(kind, out):
+        if kind == 0:
+            ops.gemm16(hi, lo, wt, None, n, ops.EPI_F32, c=out, variant=30)
+        else:
+            ops.gemm16_lo8(hi, lo8, wt, sw, None, n, ops.EPI_F32, c=out, w8=w8)
+
+    ref = [torch.empty(m, n, device="cuda") for _ in range(2)]
+    for kind in range(2):
+        run(kind, ref[kind])
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {(i, kind): torch.empty(m, n, device="cuda") for i in range(2) for kind in range(2)}
+    n_before = len(ops._workspaces)
+    for rep in range(3):
+        for i, st in enumerate((s1, s2)):
+            with torch.cuda.stream(st):
+                for kind in range(2):
+                    run(kind, outs[(i, kind)])
+    torch.cuda.synchronize()
+    assert len(ops._workspaces) == n_before + 2                      # one workspace per new stream, created once
+    ws = [ops._workspaces[(torch.cuda.current_device(), st.cuda_stream)] for st in (s1, s2)]
+    assert ws[0] != ws[1]
+    for (i, kind), o in outs.items():
+        assert torch.equal(o, ref[kind]), f"stream {i}, kernel {kind}: result differs from the single-stream run"
+    # without a workspace the plain entry point never runs a persistent variant, and says nothing else changed
+    c = torch.empty(m, n, device="cuda")
+    rc = _lib.lib().llark_gemm16_ex(30, 0, 1, 0, hi.data_ptr(), lo.data_ptr(), hi.stride(0), wt.data_ptr(), wt.stride(0), None, m, n,
+                                    wt.shape[1], c.data_ptr(), c.stride(0), None, 0, None, None, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(c, ref[0])                                    # every tile variant computes the same product
