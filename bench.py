@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only for --stages dist-check on CPU)")
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
+    ap.add_argument("--grad-checkpoint", action="store_true", help="train: per-layer recompute in the backward (train_llark.sh:25 --gradient_checkpointing True)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
     ap.add_argument("--grad-comm", dest="grad_comm", default="bf16", choices=["fp32", "bf16"],
                     help="train: transport dtype of the gradient all-reduce (bf16 = what the reference's DDP sends after model.to(bfloat16): "
@@ -389,7 +390,7 @@ def main():
             # issued matrix work per algorithmic flop, in units of the fp16 MFMA rate: f16x2 = two fp16 passes; lo8 = one fp16 pass +
             # one MX-fp8 MFMA per 64 k (64 cycles against the 128 of four fp16 MFMAs) = 1.5
             passes = 1.5 if lo8 else 2
-            roof = {"bound": "mfma", "kernel": "gemm256_lo8s_kernel (fp16 hi pass + MX-fp8 low plane)" if lo8 else "gemm256_kernel<f16,split> (two fp16 passes)",
+            roof = {"bound": "mfma", "kernel": "gemm256_lo8n_kernel (fp16 hi pass + MX-fp8 low plane)" if lo8 else "gemm256_kernel<f16,split> (two fp16 passes)",
                     "achieved": round(achieved, 2),
                     "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
                     "traffic": traffic, "traffic_note": traffic_note, "launches": launches,

@@ -124,7 +124,8 @@ class TrainWorkload:
         eng.set_globals(n(VOCAB, H), ones, n(VOCAB, H), n(H, dims.mm_hidden_size), torch.zeros(H, device=device))
         self.engine = eng
         self.trainer = HipLlamaTrainer(eng, lr=5e-5, embed_grad_tokens=[START, END],
-                                       grad_comm=torch.bfloat16 if getattr(args, "grad_comm", "fp32") == "bf16" else torch.float32)
+                                       grad_comm=torch.bfloat16 if getattr(args, "grad_comm", "fp32") == "bf16" else torch.float32,
+                                       gradient_checkpointing=bool(getattr(args, "grad_checkpoint", False)))
         gen = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
         self.batches = []
         for k in range(self.accum):

@@ -271,6 +271,8 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
             # the torch optimizer of the caller owns the AdamW state on this path: no moments here
             self._trainer = HipLlamaTrainer(self._train_engine, embed_grad_tokens=toks, train_embed_all=orig is None,
                                             optimizer_state=False)
+        # HF: model.gradient_checkpointing_enable() flips `model.model.gradient_checkpointing` (supports_gradient_checkpointing = True)
+        self._trainer.gradient_checkpointing = bool(getattr(self.model, "gradient_checkpointing", False))
         return self._trainer
 
     def _forward_train(self, input_ids, labels, audio_encodings, attention_mask, return_dict):

@@ -31,6 +31,7 @@ class TrainConfig:
     adam_beta2: float = 0.999
     adam_epsilon: float = 1e-8
     lr_scheduler_type: str = "cosine"           # :35
+    gradient_checkpointing: bool = False        # train_llark.sh:25 (per-layer recompute in the backward; same gradients, less HBM)
     grad_comm: str = "bf16"                     # the reference's DDP buckets are bf16 (m2t/train.py:94-103 casts the model): 13.5 GB/step; "fp32" = 27 GB
 
 
@@ -56,7 +57,8 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
     toks = [t for t in (audio_cfg.audio_start_token, audio_cfg.audio_end_token) if isinstance(t, int)]
     tr = HipLlamaTrainer(engine, lr=cfg.learning_rate, betas=(cfg.adam_beta1, cfg.adam_beta2), eps=cfg.adam_epsilon,
                          weight_decay=cfg.weight_decay, embed_grad_tokens=toks,
-                         grad_comm=torch.bfloat16 if cfg.grad_comm == "bf16" else torch.float32)
+                         grad_comm=torch.bfloat16 if cfg.grad_comm == "bf16" else torch.float32,
+                         gradient_checkpointing=cfg.gradient_checkpointing)
     from . import checkpoint as CK
 
     if output_dir:
@@ -153,6 +155,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--grad_comm", default="bf16", choices=["fp32", "bf16"], help="transport dtype of the gradient all-reduce (reference: bf16)")
     ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
+    ap.add_argument("--gradient_checkpointing", type=boolean, default=False, help="train_llark.sh:25: recompute each decoder layer in the backward")
     ap.add_argument("--freeze_backbone", type=boolean, default=False)
     ap.add_argument("--lr_scheduler_type", default="cosine")
     ap.add_argument("--bf16", type=boolean, default=True)
@@ -190,7 +193,8 @@ def main(argv=None):
     del model
     mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
-                      max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm)
+                      max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm,
+                      gradient_checkpointing=args.gradient_checkpointing)
     def batches(skip_micro_batches: int):
         return micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
                              seed=args.seed, allow_pickle=args.allow_pickle, skip_micro_batches=skip_micro_batches)

@@ -33,10 +33,14 @@ _BF = torch.bfloat16
 class HipLlamaTrainer:
     def __init__(self, engine: HipLlamaEngine, lr: float = 5e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, embed_grad_tokens: Sequence[int] = (), train_embed_all: bool = False,
-                 grad_comm: torch.dtype = torch.float32, optimizer_state: bool = True):
+                 grad_comm: torch.dtype = torch.float32, optimizer_state: bool = True, gradient_checkpointing: bool = False):
         if grad_comm not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_comm must be torch.float32 or torch.bfloat16")
         self.grad_comm = grad_comm                   # transport dtype of the gradient all-reduce (the reference's DDP sends bf16)
+        # train_llark.sh:25 `--gradient_checkpointing True` (HF: one checkpoint per decoder layer): the forward keeps only each
+        # layer's input; the backward re-runs that layer's forward -- same kernels, same order, hence bit-identical gradients --
+        # right before differentiating it.  Activation memory drops from ~0.18 MB to 16 KiB per token and layer at 7B widths.
+        self.gradient_checkpointing = bool(gradient_checkpointing)
         if engine.split:
             raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
         self.eng = engine
@@ -130,8 +134,8 @@ class HipLlamaTrainer:
             seg_rows.append(torch.arange(r0, r0 + F, device=dev))
             seg_a16.append(a16[:, : d.mm_hidden_size])
         # ---------------- forward, saving what the backward needs ----------------
-        saved = []
-        for i, L in enumerate(eng.layers):
+        def layer_forward(i, L, h):
+            """One decoder layer on the residual stream ``h`` (updated in place); returns everything its backward reads."""
             st = {"h_in": h.clone()}
             x1 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x1)
@@ -152,7 +156,13 @@ class HipLlamaTrainer:
             ops.swiglu_fwd(gu, act)
             ops.gemm16(act, None, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
             st.update(x2=x2, gu=gu, act=act)
-            saved.append(st)
+            return st
+
+        saved = []
+        for i, L in enumerate(eng.layers):
+            st = layer_forward(i, L, h)
+            saved.append({"h_in": st["h_in"]} if self.gradient_checkpointing else st)
+            del st
         xf = torch.empty((rows, H), **bf)
         ops.rmsnorm_bf16(h, eng.norm, d.rms_norm_eps, xf)
         logits = torch.empty((rows, V), **f32)
@@ -174,6 +184,9 @@ class HipLlamaTrainer:
         smax = eng.smax
         for i in reversed(range(len(eng.layers))):
             L, st = eng.layers[i], saved[i]
+            if self.gradient_checkpointing:          # recompute this layer's forward from its saved input (K / V caches included)
+                st = layer_forward(i, L, st["h_in"].clone())
+                saved[i] = None
             pre = f"layers.{i}."
             # ---- MLP ----
             dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)

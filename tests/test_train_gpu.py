@@ -116,6 +116,36 @@ def test_accumulation_and_adamw_step():
             assert torch.allclose(tr.grads[name], tr2.grads[name], rtol=1e-5, atol=1e-7), name
 
 
+def test_gradient_checkpointing_gives_identical_gradients_with_less_memory():
+    """train_llark.sh:25 `--gradient_checkpointing True`: only each layer's input is kept, the backward re-runs that layer's
+    forward with the same kernels in the same order -> the same gradients (matrix gradients bit for bit; the RMSNorm gain
+    gradients are fp32 atomic sums), the same loss, and a lower activation peak."""
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    toks = (spec.audio_start_token, spec.audio_end_token)
+    peaks, grads, losses = [], [], []
+    for ckpt in (False, True):
+        tr = HipLlamaTrainer(eng, lr=1e-2, embed_grad_tokens=toks, gradient_checkpointing=ckpt, optimizer_state=False)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        losses.append(float(tr.forward_backward(ids.cuda(), segs, labels.cuda())))
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
+        grads.append({n: tr.grads[n].clone() for n, _ in tr.params})
+        del tr
+    assert losses[0] == losses[1]
+    for (name, prm) in HipLlamaTrainer(eng, embed_grad_tokens=toks, optimizer_state=False).params:
+        a, b = grads[0][name], grads[1][name]
+        if prm.dim() == 2 and name != "embed":
+            assert torch.equal(a, b), name
+        else:
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), name
+    assert peaks[1] < peaks[0], peaks
+    with pytest.raises(RuntimeError, match="optimizer_state=False"):
+        HipLlamaTrainer(eng, embed_grad_tokens=toks, optimizer_state=False).step()
+
+
 def test_training_reduces_loss():
     from llark_amd.m2t.train_engine import HipLlamaTrainer
     spec, w, ids, aud, labels, eng, segs = _setup(B=2)
