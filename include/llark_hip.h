@@ -16,7 +16,9 @@
  *   - llark_last_error() returns a thread-local human-readable message for the last failure;
  *   - re-entrant per stream: a workspace serves ONE stream at a time (launches that share it are
  *     ordered on that stream); create one per (device, stream).  The remaining process-level state is
- *     immutable once set: per-kernel "dynamic LDS size raised" flags of the code object.
+ *     immutable once set: per-kernel "dynamic LDS size raised" flags and occupancy figures of the code
+ *     object, the CU count of each device ordinal.  Scratch memory a kernel needs beyond the workspace is
+ *     passed in by the caller (llark_gemm16_fragw_sk).
  */
 #ifndef LLARK_HIP_H
 #define LLARK_HIP_H
@@ -156,6 +158,21 @@ int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, 
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                        int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* llark_gemm16_fragw with a stream-K decomposition for products whose tile count is not a whole number of rounds of the
+ * resident workgroups (Llama prefill at M = 2968: 384 / 1152 / 2064 tiles of 128x256 against 512 resident workgroups --
+ * m2t/models/llamav2.py:224-234 -> the q/k/v, o, gate/up, down projections of HF LlamaDecoderLayer): the grid is exactly
+ * the resident set, the last tiles of the tile order are cut into equal runs of K-steps, and a tile shared by several
+ * workgroups is finished by the one holding its k = 0 end, which adds the others' fp32 partial tiles from `scratch` in
+ * slot order (deterministic; no atomics on data).  Same product and epilogues as llark_gemm16_fragw (QGELU_SPLIT
+ * excepted, which runs the per-tile kernel), equal up to the fp32 summation order over K.
+ * scratch: caller-owned device memory, >= llark_gemm16_sk_scratch_bytes() bytes (the function returns that size for the
+ * CURRENT device, -1 on error), 16-byte aligned, ZEROED once after allocation; launches sharing it must be ordered on one
+ * stream.  scratch == NULL, or a problem too small to cut -> exactly llark_gemm16_fragw. */
+long long llark_gemm16_sk_scratch_bytes(void);
+int llark_gemm16_fragw_sk(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                          const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
+                          int ldr, void* out_hi, void* out_lo, int ldo, void* scratch, long long scratch_bytes,
+                          llark_stream_t stream);
 /* Decode step (m <= 16 rows, bf16): h[m][n] += a . wt^T and then RMSNorm(h; norm_w, eps) -> bf16 planes x_hi (/x_lo),
  * in one launch (the last workgroup to finish normalises the complete rows; bit-identical to llark_gemm16 +
  * llark_rmsnorm_bf16).  Replaces o_proj / down_proj + the next LlamaRMSNorm of the cached decode path

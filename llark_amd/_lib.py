@@ -71,6 +71,8 @@ _SIGS = {
     "llark_pack_weight16_frag": [_P, c_int, c_int, c_int, _P, _P],
     "llark_gemm16_fragw": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                            _P, _P, c_int, _P],
+    "llark_gemm16_fragw_sk": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
+                              _P, _P, c_int, _P, c_int64, _P],
     "llark_gemm16_resid_rmsnorm": [c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_float, _P, _P,
                                    c_int, _P],
     "llark_gemm16_rmsnorm_a": [c_int, c_int, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P,
@@ -125,7 +127,7 @@ _SIGS = {
 
 def declared_symbols():
     """Every symbol ``include/llark_hip.h`` declares (kept in sync by tests/test_abi.py)."""
-    return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy", "llark_workspace_create"])
+    return sorted(list(_SIGS.keys()) + ["llark_last_error", "llark_vqvae_plan_create", "llark_vqvae_plan_destroy", "llark_workspace_create", "llark_gemm16_sk_scratch_bytes"])
 
 
 # ---- host-side launch lists -------------------------------------------------------------------------------------------
@@ -188,6 +190,8 @@ def _real_lib():
         L.llark_vqvae_plan_destroy.restype = None
         L.llark_workspace_create.argtypes = []
         L.llark_workspace_create.restype = c_void_p
+        L.llark_gemm16_sk_scratch_bytes.argtypes = []
+        L.llark_gemm16_sk_scratch_bytes.restype = c_int64
         _lib = L
     return _lib
 

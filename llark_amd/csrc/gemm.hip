@@ -464,6 +464,281 @@ static int dispatch_bd(const GemmParams& p, bool split, int epi, hipStream_t s) 
     return LLARK_ERR_INVALID;
 }
 
+// ------------------------------------------------------------------------------------------
+// Stream-K form of the B-direct kernel.  The Llama prefill products have M = 2968 rows = 24 row tiles, so the tile count
+// is never a multiple of the 512 resident workgroups: 384 tiles (o_proj / down_proj) leave a quarter of the chip idle,
+// 1152 (qkv) and 2064 (gate_up) pay a whole extra round for 128 and 16 left-over tiles.  Here the grid is exactly the
+// resident set (S workgroups).  The last `sk_tiles` tiles of the linear tile order are cut into S equal runs of
+// K-steps (`sk_per` each, a run may cross a tile boundary), every workgroup takes one run first and then its share of
+// the remaining tiles whole ("data-parallel" rounds).  A tile whose K range is shared by several workgroups is
+// finished by the one that holds its k = 0 end (the OWNER): the others (CONTRIBUTORS; for them the piece is always the
+// first thing they do, so it is ready long before the owner needs it) write their fp32 accumulators to a slab in the
+// caller's scratch with write-through (sc1) 16-byte stores, drain, and raise a flag; the owner polls the flags of the
+// following slots in slot order, adds the slabs in that fixed order (deterministic: no atomics on data) and runs the
+// ordinary fused epilogue.  Hand-off protocol: sc1 payload -> every wave s_waitcnt vmcnt(0) -> barrier -> one relaxed
+// agent-scope flag store; consumer: one lane polls relaxed, one agent-scope acquire, barrier, plain loads.  The owner
+// re-zeroes the flag, so a scratch that starts zeroed stays valid from launch to launch (launches sharing a scratch
+// must be ordered on one stream).  All S workgroups must be resident (the host sizes the grid from the occupancy query).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned sk_flag_t;
+
+template <typename T, bool SPLIT, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const GemmParams p) {
+    typedef typename Mfma<T>::frag frag;
+    static_assert(C::WM == 1 && C::BK == 64, "B-direct layout: waves side by side over N, K-step 64");
+    constexpr int ASTAGE = (SPLIT ? 2 : 1) * C::A_BYTES;
+    constexpr int OFF_L = C::A_BYTES;
+    constexpr int SLAB4 = C::BM * C::BN / 4;                             // float4 per slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 A stages
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = 0, wn = w;
+    const int S = (int)gridDim.x;
+    // an XCD's workgroups hold neighbouring runs / tiles (workgroups are dealt round-robin to the 8 XCDs)
+    const int slot = (S & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3);
+    // slab / flag of the contributor in slot s: stream-K runs: s itself (at most one shared piece per slot, its first);
+    // uniform split (sk_ks pieces per tile, piece 0 = owner): tile * (sk_ks - 1) + piece - 1
+    const int ks = p.sk_ks;
+    auto slab_of = [&](int s) { return ks ? (s / ks) * (ks - 1) + (s % ks) - 1 : s; };
+    const int nk = p.Kp / C::BK;
+    const int nk16 = nk * 4;
+    const int rtiles = (p.N + 31) >> 5;
+    const int sk_units = (p.tiles_m * p.tiles_n - p.sk_dp) * nk;
+    int u0 = slot * p.sk_per;
+    u0 = u0 < sk_units ? u0 : sk_units;
+    const int u1 = (u0 + p.sk_per) < sk_units ? (u0 + p.sk_per) : sk_units;
+    int dp_next = slot;
+
+    const T* Ahi = (const T*)p.Ahi;
+    const T* Alo = SPLIT ? (const T*)p.Alo : nullptr;
+    constexpr int APW = (C::BM / C::RPI) / C::NW;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const int a_rl = lane / C::CH, a_ch = lane % C::CH;
+    float4* const part = (float4*)p.sk_part;
+    sk_flag_t* const flags = (sk_flag_t*)p.sk_flag;
+
+    for (;;) {
+        int L, kt0, kt1;                                                  // next piece of work: tile L, K-steps [kt0, kt1)
+        if (u0 < u1) {
+            const int t = u0 / nk;
+            L = p.sk_dp + t;
+            kt0 = u0 - t * nk;
+            kt1 = (kt0 + (u1 - u0)) < nk ? (kt0 + (u1 - u0)) : nk;
+            u0 += kt1 - kt0;
+        } else if (dp_next < p.sk_dp) {
+            L = dp_next;
+            dp_next += S;
+            kt0 = 0;
+            kt1 = nk;
+        } else {
+            break;
+        }
+        constexpr int GM = 8;
+        const int gsz = GM * p.tiles_n;
+        const int g = L / gsz;
+        const int first_m = g * GM;
+        const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+        const int tile_m = first_m + (L % gsz) % gm;
+        const int tile_n = (L % gsz) / gm;
+        const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+
+        u32x4 areg[(SPLIT ? 2 : 1) * APW];
+        auto loadA = [&](int kt) {
+            const int k0 = kt * C::BK;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                int r = m0 + (w + i * C::NW) * C::RPI + a_rl;
+                r = r < p.M ? r : p.M - 1;
+                areg[i] = *(const u32x4*)(Ahi + (size_t)r * p.lda + k0 + a_ch * 8);
+                if (SPLIT) areg[APW + i] = *(const u32x4*)(Alo + (size_t)r * p.lda + k0 + a_ch * 8);
+            }
+        };
+        auto storeA = [&](int buf) {
+            char* base = smem + buf * ASTAGE;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int row = (w + i * C::NW) * C::RPI + a_rl;
+                *(u32x4*)(base + C::off(row, a_ch)) = areg[i];
+                if (SPLIT) *(u32x4*)(base + OFF_L + C::off(row, a_ch)) = areg[APW + i];
+            }
+        };
+        const frag* wbase[C::TN];
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            int R = (n0 >> 5) + wn * C::TN + tn;
+            R = R < rtiles ? R : rtiles - 1;
+            wbase[tn] = (const frag*)p.Wt + ((size_t)R * nk16) * 64 + lane;
+        }
+        frag ring[4][C::TN];
+        const int qlast = kt1 * 4 - 1;
+        auto loadB = [&](int slot_, int q) {
+            q = q < qlast ? q : qlast;                                     // tail: harmless re-load of the piece's last chunk
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) ring[slot_][tn] = wbase[tn][(size_t)q * 64];
+        };
+
+        f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        loadA(kt0);
+        loadB(0, kt0 * 4);
+        loadB(1, kt0 * 4 + 1);
+        loadB(2, kt0 * 4 + 2);
+        storeA(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            loadA(kt + 1 < kt1 ? kt + 1 : kt);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* sA = smem + ((kt - kt0) & 1) * ASTAGE;
+            const char* sL = sA + OFF_L;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                loadB((s + 3) & 3, kt * 4 + s + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const int c = s * 2 + (lane >> 5);
+                frag ah[C::TM], al[C::TM];
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm) {
+                    ah[tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
+                    if (SPLIT) al[tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
+                }
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < C::TN; ++tn) {
+                        acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
+                        if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kt + 1 < kt1) storeA((kt + 1 - kt0) & 1);
+            __syncthreads();
+        }
+
+        if (kt0 != 0) {
+            // contributor: slab[slot] <- accumulators in register order (thread-contiguous 16-byte pieces), write-through
+            // (buffer stores: one descriptor, one per-lane offset, the slab position as a scalar offset -- no address VGPRs)
+            const int mine = slab_of(slot);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(part + (size_t)mine * SLAB4), 0, SLAB4 * 16, 0x00020000u);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        // (whole-vector bit casts only: hipcc 7.2 miscompiles __builtin_bit_cast of a vector ELEMENT -- it reads element 0)
+                        const f32x4_t f = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), rs, (int)threadIdx.x * 16, ((i * C::TN + j) * 4 + r4) * C::THREADS * 16, /*sc1: write-through*/ 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(flags + mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        int done = kt1;
+        for (int cs = slot + 1; done < nk; ++cs) {                         // owner of a shared tile: add the other pieces in slot order
+            const int theirs = slab_of(cs);
+            if (threadIdx.x == 0) {
+                while (__hip_atomic_load(flags + theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(4);
+                __hip_atomic_store(flags + theirs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(part + (size_t)theirs * SLAB4), 0, SLAB4 * 16, 0x00020000u);
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)threadIdx.x * 16, ((i * C::TN + j) * 4 + r4) * C::THREADS * 16, 0);
+                        const f32x4_t v = __builtin_bit_cast(f32x4_t, u);
+                        acc[i][j][4 * r4] += v[0];
+                        acc[i][j][4 * r4 + 1] += v[1];
+                        acc[i][j][4 * r4 + 2] += v[2];
+                        acc[i][j][4 * r4 + 3] += v[3];
+                    }
+            done += (nk - done) < p.sk_per ? (nk - done) : p.sk_per;
+        }
+        gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+    }
+}
+
+template <typename T, bool SPLIT, int EPI, typename C>
+static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long long scratch_bytes, bool uniform) {
+    constexpr int LDS = 2 * (SPLIT ? 2 : 1) * C::A_BYTES;
+    auto kern = gemm_bd_sk_kernel<T, SPLIT, EPI, C>;
+    static int per_cu = -1;                                        // resident workgroups per CU: a property of the code object
+    if (per_cu < 0) {
+        int n = 0;
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, C::THREADS, LDS) != hipSuccess) n = 0;
+        per_cu = n;
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
+    const int S = per_cu * cus;
+    if (S <= 0 || S % 8) return -1000;
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    const int T_ = p.tiles_m * p.tiles_n, nk = p.Kp / C::BK;
+    const long long slab_bytes = (long long)C::BM * C::BN * 4;
+    if (uniform) {
+        // Uniform split: EVERY tile is cut into the same `ks` K ranges, one workgroup each (grid = ks x tiles, dispatched
+        // dynamically; piece 0 of a tile finishes it).  The summation tree of an output element is then the same wherever its
+        // tile sits, so equal rows of a batch give bit-equal results (stream-K runs cut each tile at a position-dependent k).
+        int ks_ = (4 * T_ <= S && nk % 4 == 0 && nk / 4 >= 12) ? 4 : 2;
+        if (T_ >= S || nk % ks_ || nk / ks_ < 12) return -1000;
+        const long long need_u = (long long)T_ * (ks_ - 1) * (slab_bytes + 4);
+        if (!scratch || scratch_bytes < need_u) return -1000;
+        p.sk_ks = ks_;
+        p.sk_dp = 0;
+        p.sk_per = nk / ks_;
+        p.sk_part = (float*)scratch;
+        p.sk_flag = (unsigned*)((char*)scratch + (long long)T_ * (ks_ - 1) * slab_bytes);
+        kern<<<dim3(T_ * ks_), C::THREADS, LDS, s>>>(p);
+        return check_launch("gemm_bd_sk(uniform)");
+    }
+    p.sk_ks = 0;
+    const int rounds = T_ / S, rem = T_ - rounds * S;
+    if (rem == 0) return -1000;                                    // whole rounds: one workgroup per tile is already balanced
+    const int sk_tiles = rem + (rounds >= 1 ? S : 0);               // with a full round in the pool no run is shorter than a tile
+    static const int per_env = [] { const char* e = getenv("LLARK_SK_PER"); return e ? atoi(e) : 0; }();      // debugging: run length override
+    const int per = per_env > 0 ? per_env : cdiv(sk_tiles * nk, S);
+    if (per < 12 || (long long)per * S < (long long)sk_tiles * nk) return -1000;                                    // pieces too short to pay for their prologue and the slab exchange
+    const long long need = (long long)S * C::BM * C::BN * 4 + (long long)S * 4;
+    if (!scratch || scratch_bytes < need) return -1000;
+    p.sk_dp = T_ - sk_tiles;
+    p.sk_per = per;
+    p.sk_part = (float*)scratch;
+    p.sk_flag = (unsigned*)((char*)scratch + (long long)S * C::BM * C::BN * 4);
+    kern<<<dim3(S), C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm_bd_sk");
+}
+
+template <typename T, typename C>
+static int dispatch_bd_sk(const GemmParams& p, bool split, int epi, hipStream_t s, void* scratch, long long scratch_bytes, bool uniform) {
+#define CASE(E)                                                      \
+    case E:                                                          \
+        return split ? launch_gemm_bd_sk<T, true, E, C>(p, s, scratch, scratch_bytes, uniform) : launch_gemm_bd_sk<T, false, E, C>(p, s, scratch, scratch_bytes, uniform);
+    switch (epi) {
+        CASE(EPI_F32)
+        CASE(EPI_RESID)
+        CASE(EPI_OUT16)
+        CASE(EPI_SPLIT16)
+        CASE(EPI_SWIGLU16)
+        CASE(EPI_SWIGLU_SPLIT)
+    }
+#undef CASE
+    return -1000;
+}
+
 // [N][ld] row-major 16-bit weights -> fragment-major chunks (see gemm_bd_kernel); rows >= n are zero.
 __global__ void pack_frag_kernel(const unsigned short* __restrict__ src, int ld, int n, int kp, uint4* __restrict__ dst, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-B lane slot each
@@ -953,9 +1228,23 @@ extern "C" int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, 
     return check_launch("pack_weight16_frag");
 }
 
-extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
-                                  const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
-                                  const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+// CUs of the current device (cached per device ordinal: a property of the hardware, not state of the library).
+static int llark_device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        cached[dev] = cus;
+    }
+    return cached[dev];
+}
+
+static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                             const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
+                             const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, void* scratch, long long scratch_bytes,
+                             llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wfrag && m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_fragw: null pointer / empty problem / kp not a multiple of 64");
     LLARK_REQUIRE(lda % 8 == 0 && lda >= kp, "gemm16_fragw: lda must be >= kp and a multiple of 8");
     LLARK_REQUIRE(!split || a_lo, "gemm16_fragw: split mode needs the lo plane");
@@ -975,6 +1264,20 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
     // at M = 2968, bf16 (profiles/r01_gemm_variants.txt): it wins only on the narrow outputs -- o_proj 844 vs 798,
     // down_proj 939 vs 903 TFLOP/s (N = 4096: 768 small tiles = exactly one wave) -- and loses on qkv / lm_head
     // (822 vs 865, 852 vs 974), where bytes per flop matter more than wave quantisation.
+    // Stream-K over the resident workgroups (128x256 tiles).  Measured at M = 2968 (profiles/r02_streamk.txt): it pays where
+    // the whole product is less than one round of split-mode tiles (o_proj / down_proj: 384 tiles over 512 workgroups, +7 % /
+    // +6 %); with one or more whole rounds ahead of the remainder the hardware's dynamic dispatch of one workgroup per tile
+    // already hides the ragged last round (qkv, gate/up: +-1 %; lm_head: -6 %), and plain 16-bit operands at N <= 4096 are
+    // better served by the 128x128 tiles below.  variant -1 applies that rule, variant 0 + scratch cuts whenever it can.
+    const long long tiles_bd0 = (long long)cdiv(m, CfgBD0::BM) * cdiv(n, CfgBD0::BN);
+    const bool sk_rule = (split && tiles_bd0 < 2LL * llark_device_cus()) || (!split && 4 * tiles_bd0 <= 2LL * llark_device_cus());
+    if (scratch && (variant == 0 || (variant < 0 && sk_rule)) && epilogue != EPI_QGELU_SPLIT) {
+        int rc = -1000;                                             // -1000 = whole rounds / too small to cut -> the per-tile kernels below
+        const bool uniform = variant < 0;                          // library choice: the position-independent cut
+        if (dtype == LLARK_F16) rc = dispatch_bd_sk<half_t, CfgBD0>(p, split != 0, epilogue, s, scratch, scratch_bytes, uniform);
+        else if (dtype == LLARK_BF16) rc = dispatch_bd_sk<bf16_t, CfgBD0>(p, split != 0, epilogue, s, scratch, scratch_bytes, uniform);
+        if (rc != -1000) return rc;
+    }
     if (variant < 0) variant = (!split && !IS_SWIGLU(epilogue) && n <= 4096) ? 1 : 0;
     if (variant == 1) {
         if (IS_SWIGLU(epilogue)) { set_error("gemm16_fragw: variant 1 (128x128 tiles) has no SwiGLU epilogue"); return LLARK_ERR_UNSUPPORTED; }
@@ -985,6 +1288,36 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
     if (dtype == LLARK_BF16) return dispatch_bd<bf16_t, CfgBD0>(p, split != 0, epilogue, s);
     set_error("gemm16_fragw: unknown dtype %d", dtype);
     return LLARK_ERR_INVALID;
+}
+
+extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                                  const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
+                                  const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream) {
+    return gemm16_fragw_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wfrag, bias, m, n, kp, c, ldc, resid, ldr, out_hi, out_lo,
+                             ldo, nullptr, 0, stream);
+}
+
+// Bytes of scratch llark_gemm16_fragw_sk needs on the current device: one 128 KiB fp32 slab + one flag per resident workgroup.
+extern "C" long long llark_gemm16_sk_scratch_bytes(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        set_error("gemm16_sk_scratch_bytes: cannot query the current device");
+        return -1;
+    }
+    return (long long)cus * 2 * (CfgBD0::BM * CfgBD0::BN * 4 + 4);
+}
+
+// llark_gemm16_fragw with the stream-K decomposition (gemm_bd_sk_kernel) whenever the tile count is not a whole number of
+// rounds of the resident workgroups.  `scratch`: caller-owned device memory of >= llark_gemm16_sk_scratch_bytes() bytes,
+// ZEROED once after allocation; launches that share it must be ordered on one stream.  variant: -1 / 0 = stream-K where it
+// applies, 1 = the plain 128x128 tiles.  Same results as llark_gemm16_fragw up to the fp32 summation order over K.
+extern "C" int llark_gemm16_fragw_sk(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
+                                     const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
+                                     const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, void* scratch,
+                                     long long scratch_bytes, llark_stream_t stream) {
+    LLARK_REQUIRE(!scratch || ((uintptr_t)scratch & 15) == 0, "gemm16_fragw_sk: scratch must be 16-byte aligned");
+    return gemm16_fragw_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wfrag, bias, m, n, kp, c, ldc, resid, ldr, out_hi, out_lo,
+                             ldo, scratch, scratch_bytes, stream);
 }
 
 // Decode-step form of `h += x . W^T` followed by RMSNorm(h) -> bf16 planes, in ONE launch (m <= 16 rows): the skinny

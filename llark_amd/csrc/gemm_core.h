@@ -100,6 +100,12 @@ struct GemmParams {
     const void* W8;    // gemm256_lo8s.hip: pre-packed e4m3(W * 2^lo8_sw) [N][ldw8] bytes in slot order (llark_pack_weight_lo8); nullptr = derive in registers
     int ldw8;
     int sync_base;     // persistent kernels: value of the (monotonic) chunk counters when this launch starts
+    // stream-K form of the B-direct kernel (gemm.hip: gemm_bd_sk_kernel)
+    int sk_dp;         // tiles [0, sk_dp) of the linear order are done whole, the rest are cut into runs of sk_per K-steps
+    int sk_per;
+    int sk_ks;         // 0 = stream-K runs; >= 2 = every tile cut into sk_ks equal K ranges, one workgroup each (grid = sk_ks x tiles)
+    float* sk_part;    // [resident workgroups][BM * BN] fp32 slabs (caller's scratch)
+    unsigned* sk_flag; // [resident workgroups] hand-off flags, zero between launches
     long long* prof;   // profiling builds only (-DLLARK_LO8_PROF): per-wave cycle counters, nullptr otherwise
 };
 

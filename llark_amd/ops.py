@@ -142,6 +142,27 @@ def workspace() -> Optional[int]:
     return ws
 
 
+# Scratch of the stream-K GEMM (llark_gemm16_fragw_sk): fp32 partial tiles + hand-off flags, one per (device, stream), zeroed
+# once.  LLARK_STREAMK=0 turns the decomposition off (every product then runs one workgroup per tile).
+_sk_scratch = {}
+
+
+def sk_scratch() -> Optional[torch.Tensor]:
+    if os.environ.get("LLARK_STREAMK", "1") == "0":
+        return None
+    key = (torch.cuda.current_device(), _stream())
+    t = _sk_scratch.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        nbytes = _lib._real_lib().llark_gemm16_sk_scratch_bytes()
+        if nbytes <= 0:
+            check(-3, "gemm16_sk_scratch_bytes")
+        t = torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device="cuda")
+        _sk_scratch[key] = t
+    return t
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -442,23 +463,29 @@ def pack_weight16_frag(wt: torch.Tensor, n: int) -> torch.Tensor:
 def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.Tensor, bias: Optional[torch.Tensor], n: int, kp: int,
                  epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
                  out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
-                 variant: int = -1) -> None:
+                 variant: int = -1, stream_k: Optional[bool] = None) -> None:
     """Same product / epilogues as gemm16, weights given fragment-major (pack_weight16_frag).
-    variant: -1 library choice, 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogue)."""
+    variant: -1 library choice, 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogue).
+    stream_k: None = library choice (split operands and less than one round of tiles: Llama o_proj / down_proj at M = 2968),
+    True = cut whenever the tile count is not a whole number of rounds (forces the 128x256 tiles), False = off."""
     dtype = a_hi.dtype
     assert dtype in (torch.float16, torch.bfloat16) and wfrag.dtype == dtype and a_hi.shape[1] >= kp
     assert wfrag.numel() == round_up(n, 32) * kp
     m = a_hi.shape[0] if m is None else m
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16")
+    scratch = sk_scratch() if (stream_k is not False and variant <= 0) else None
+    if stream_k and scratch is not None:
+        variant = 0
     with _timed(name, 2.0 * m * n * kp):
-      check(_lib.lib().llark_gemm16_fragw(
+      check(_lib.lib().llark_gemm16_fragw_sk(
         variant, _DT[dtype], int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None,
         a_hi.stride(0), _dev(wfrag, "wfrag"), _dev(bias, "bias", torch.float32) if bias is not None else None,
         m, n, kp, _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
         _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
         _dev(out_hi, "out_hi", dtype) if out_hi is not None else None,
         _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
-        out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemm16_fragw")
+        out_hi.stride(0) if out_hi is not None else 0,
+        scratch.data_ptr() if scratch is not None else None, scratch.numel() * 4 if scratch is not None else 0, _stream()), "gemm16_fragw")
 
 
 # ------------------------------------------------------------------------------------------------

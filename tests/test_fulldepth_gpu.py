@@ -138,9 +138,10 @@ def test_llama7b_32_layers_logits_vs_oracle(llm):
     print(f"\n[fulldepth] llama-2-7B 32 layers S=371: logits max|err| {err:.3e} = {err / scale:.2e} of max|logits| {scale:.3f}")
     # rows of the batch hold the same prompt: bit-identical results (batch invariance of every kernel)
     assert torch.equal(logits[0], logits[7])
-    # B = 1 goes through different tile counts; same values to rounding
+    # B = 1 goes through different tile counts and K cuts (o_proj / down_proj: 4 K ranges per tile instead of 2); same values
+    # to the rounding of the fp32 accumulation and of the bf16 hi/lo operand planes downstream (measured 3.1e-5 of max|logits|)
     l1 = eng.forward_tokens(ids.cuda(), [(0, 1, audc)])
-    report_close("B=1 vs B=8 logits", l1[0][rows].cpu(), logits[0][rows].cpu(), 2e-5 * scale)
+    report_close("B=1 vs B=8 logits", l1[0][rows].cpu(), logits[0][rows].cpu(), 6e-5 * scale)
 
 
 def test_llama7b_64_greedy_tokens_vs_oracle(llm):

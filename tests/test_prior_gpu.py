@@ -182,6 +182,62 @@ def test_gemm_fragment_major_weights_bit_identical(m, n, k):
         assert torch.equal(s0[0], s1[0])
 
 
+@pytest.mark.parametrize("m,n,k,epi,split", [
+    (2968, 4096, 4096, "resid", False),       # o_proj at the benchmarked prefill: 384 tiles over 512 resident workgroups
+    (2968, 4096, 11008, "resid", True),       # down_proj, split operands
+    (2968, 12288, 4096, "f32", True),         # qkv: 1152 tiles = 1 whole round + a 640-tile stream-K pool
+    (2968, 22016, 4096, "swiglu", False),     # gate/up pairs: 2064 tiles = 3 whole rounds + 528
+    (2968, 22016, 4096, "swiglu", True),
+    (371, 12288, 4096, "f32", False),         # one clip: 144 tiles, every tile cut
+    (1500, 4000, 2048, "resid", True),        # ragged M and N
+])
+def test_gemm_stream_k(m, n, k, epi, split):
+    """Stream-K form of the B-direct kernel (llark_gemm16_fragw_sk): tiles shared by several workgroups are finished by a
+    fixed owner that adds the other partial tiles in slot order.  Against the one-workgroup-per-tile kernel the result may
+    differ only by the fp32 summation order over K; it is deterministic (run to run bit-equal), leaves its flags clean for
+    the next launch, and covers every epilogue the Llama prefill uses."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g, device="cuda")
+    w = (torch.randn(n, k, generator=g, device="cuda") * 0.05).bfloat16()
+    r = torch.randn(m, n, generator=g, device="cuda")
+    hi, lo = ops.split16(a, torch.bfloat16, kmult=64)
+    l = lo if split else None
+    wt = ops.pack_weight16(w, False, torch.bfloat16, kmult=64)
+    wf = ops.pack_weight16_frag(wt, n)
+    kp = wt.shape[1]
+    scratch = ops.sk_scratch()
+    assert scratch is not None
+    scratch.zero_()
+
+    def run(stream_k):
+        if epi == "swiglu":
+            o = [torch.zeros((m, n // 2), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+            ops.gemm16_fragw(hi, l, wf, None, n, kp, ops.EPI_SWIGLU_SPLIT if split else ops.EPI_SWIGLU16, out_hi=o[0],
+                             out_lo=o[1] if split else None, stream_k=stream_k)
+            return o[0].float() + (o[1].float() if split else 0.0)
+        c = r.clone() if epi == "resid" else torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16_fragw(hi, l, wf, None, n, kp, ops.EPI_RESID if epi == "resid" else ops.EPI_F32, c=c,
+                         resid=c if epi == "resid" else None, stream_k=stream_k)
+        return c
+
+    ref = run(False)
+    assert int(scratch.ne(0).sum()) == 0, "the per-tile kernel must not touch the stream-K scratch"
+    auto = run(None)                                                     # library choice: stream-K only for split operands, < 1 round
+    assert (int(scratch.ne(0).sum()) > 0) == (split and math.ceil(m / 128) * math.ceil(n / 256) < 512)
+    got = run(True)
+    nflag = scratch.numel() // (128 * 256 + 1) * 128 * 256              # [resident workgroups] slabs of 128x256 fp32, then the flags
+    assert int(scratch[:nflag].ne(0).sum()) > 0, "stream-K did not run (no partial tile was written)"
+    assert int(scratch[nflag:].ne(0).sum()) == 0, "hand-off flags must be zero again after the launch"
+    scale = float(ref.abs().max())
+    tol = 2e-6 * scale * (k / 4096) ** 0.5 if epi != "swiglu" else (2.0 ** -7 if not split else 2.0 ** -14) * scale
+    report_close(f"stream-K {m}x{n}x{k} {epi} split={split}", got.cpu().numpy(), ref.cpu().numpy(), tol)
+    report_close("library choice", auto.cpu().numpy(), ref.cpu().numpy(), tol)
+    for _ in range(3):                                                   # back-to-back launches: flags re-armed, bit-equal
+        again = run(True)
+        assert torch.equal(again, got), "stream-K result changed from run to run"
+
+
 def test_gemm_persistent_chunk_synchronous_bit_identical():
     """M >= 16384 routes to the persistent kernel (resident workgroups walk chunks of neighbouring tiles with a
     per-XCD counter barrier in between).  Same tiles, same k order => bit-identical to one-workgroup-per-tile;
