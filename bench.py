@@ -445,6 +445,24 @@ def main():
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
+        if args.stages in ("e2e", "llama") and llm is not None and world == 1:
+            # the Llama half in the OTHER activation precision (same weights), outside the timed region: both MFMA fractions in one line
+            other = "bf16" if args.llm_precision == "split" else "split"
+            with torch.no_grad():
+                llm.engine.set_precision(other)
+                llm.forward(None)
+                torch.cuda.synchronize()
+                ops.start_kernel_timing()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    llm.forward(None)
+                torch.cuda.synchronize()
+                ms_other = (time.perf_counter() - t1) / args.steps * 1e3
+                roof_other = llm.roofline(ops.stop_kernel_timing(), args)
+                llm.engine.set_precision(args.llm_precision)
+            if roof_other is not None:
+                roof_other.update({"llm_precision": other, "llama_ms_per_step": round(ms_other, 3)})
+            line["roofline_llm_" + other] = roof_other
         if args.stages in ("train", "mpt-train"):
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if args.stages == "generate":

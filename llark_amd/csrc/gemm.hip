@@ -874,17 +874,31 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
             if (m < p.M && n < p.N) rpre[r] = p.R[(size_t)m * p.ldr + n];
         }
     }
+#ifndef SKINNY_DEPTH
+#define SKINNY_DEPTH 4
+#endif
+#ifndef SKINNY_NT
+#define SKINNY_NT 0
+#endif
+    constexpr int DEPTH = SKINNY_DEPTH;
+    auto load_w = [&](const T* ptr) __attribute__((always_inline)) {
+#if SKINNY_NT
+        return __builtin_nontemporal_load((const frag*)ptr);        // streamed once: do not keep the line
+#else
+        return *(const frag*)ptr;
+#endif
+    };
     int ks = ks0;
-    for (; ks + 4 <= ks1; ks += 4) {            // 4 k-steps in flight: 256 contiguous bytes per weight row
-        frag bw[NT][4], ah[4], al[4];
+    for (; ks + DEPTH <= ks1; ks += DEPTH) {            // DEPTH k-steps in flight: DEPTH x 64 contiguous bytes per weight row
+        frag bw[NT][DEPTH], ah[DEPTH], al[DEPTH];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < DEPTH; ++u) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bw[t][u] = *(const frag*)(w_p[t] + (ks + u) * 32);
+            for (int t = 0; t < NT; ++t) bw[t][u] = load_w(w_p[t] + (ks + u) * 32);
             load_a(ks + u, ah[u], al[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < DEPTH; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 acc[t] = Mfma16<T>::run(ah[u], bw[t][u], acc[t]);
@@ -896,7 +910,7 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         load_a(ks, a1, a1l);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const frag bw = *(const frag*)(w_p[t] + ks * 32);
+            const frag bw = load_w(w_p[t] + ks * 32);
             acc[t] = Mfma16<T>::run(a1, bw, acc[t]);
             if (SPLIT) acc[t] = Mfma16<T>::run(a1l, bw, acc[t]);
         }

@@ -207,6 +207,18 @@ class HipLlamaEngine:
             self._ws, self._ws_key = ws, key
         return self._ws
 
+    def set_precision(self, precision: str) -> None:
+        """Switch between the "split" (fp32-class) and "bf16" activation flows.  The weights are the same bf16 values in both;
+        activation planes, the KV cache and captured decode graphs are rebuilt on the next call."""
+        if precision not in ("split", "bf16"):
+            raise ValueError(f"precision must be 'split' or 'bf16', got {precision!r}")
+        if precision == self.precision:
+            return
+        self.precision, self.split = precision, precision == "split"
+        self._ws, self._ws_key = None, None
+        self._dec.clear()
+        self.k_cache = self.vt_cache = self.k_cache_lo = self.vt_cache_lo = None
+
     def _ensure_cache(self, batch: int):
         d = self.dims
         if self.k_cache is None or self.k_cache.shape[1] < batch:
