@@ -99,57 +99,84 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
     const int nchunks = ((nwg >> 3) + ((nwg & 7) ? 1 : 0) + p.slots - 1) / p.slots;
     int* cnt = p.sync + xcd * 32;
 
+    // ---- tile geometry and the DMA requests of the tile whose offsets are loaded (the offsets are switched to the NEXT tile
+    //      before the current tile's epilogue, see below) ----
+    auto tile_of = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        // M-grouped tile order: 4 tile rows, N-major inside a group (a chunk of 32 tiles = 4 x 8 tiles)
+        constexpr int GM = 4;
+        const int gsz = GM * p.tiles_n;
+        const int g = bid / gsz;
+        const int first_m = g * GM;
+        const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+        m0 = (first_m + (bid % gsz) % gm) * C::BM;
+        n0 = ((bid % gsz) / gm) * C::BN;
+    };
+    // per-lane byte offsets of the rows this wave stages (clamped to the last valid row; masked on store)
+    unsigned voA[4], voW[4], vo8[2], voW8[2];
+    auto set_offsets = [&](int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int ra = m0 + q * 64 + w * 8 + rl;
+            ra = ra < p.M ? ra : p.M - 1;
+            voA[q] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)(dch << 4);
+            int rw = n0 + q * 64 + w * 8 + rl;
+            rw = rw < p.N ? rw : p.N - 1;
+            voW[q] = (unsigned)rw * (unsigned)(p.ldw * 2) + (unsigned)(dch << 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            int ra = m0 + q * 128 + w * 16 + rl8;
+            ra = ra < p.M ? ra : p.M - 1;
+            vo8[q] = (unsigned)ra * (unsigned)p.lda8 + (unsigned)(dch8 << 4);
+            int rw = n0 + q * 128 + w * 16 + rl8;
+            rw = rw < p.N ? rw : p.N - 1;
+            voW8[q] = (unsigned)rw * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
+        }
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + dst_off), 16, vo, soff, 0, 0);
+    };
+    const int wb = w * 1024;                                      // this wave's 1 KiB piece inside every 8 KiB of a unit
+    auto issue_WL = [&](int k, int slot) __attribute__((always_inline)) {         // left 128 weight rows (fp16) into ring slot
+        dma(rW, voW[0], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[1], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
+    };
+    auto issue_WR = [&](int k, int slot) __attribute__((always_inline)) {         // right 128 weight rows
+        dma(rW, voW[2], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[3], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
+    };
+    auto issue_A = [&](int k, int st) __attribute__((always_inline)) {            // Ahi (4) + A8 (2) of K-step k into stage st
+        const int b = C::O_A + st * 2 * C::UNIT + wb;
+        dma(rAh, voA[0], k << 7, b); dma(rAh, voA[1], k << 7, b + 8192);
+        dma(rAh, voA[2], k << 7, b + C::UNIT); dma(rAh, voA[3], k << 7, b + C::UNIT + 8192);
+        const int b8 = C::O_A8 + st * 2 * C::UNIT8 + wb;
+        dma(rA8, vo8[0], k << 6, b8); dma(rA8, vo8[1], k << 6, b8 + C::UNIT8);
+    };
+    // prologue of a tile: the L set of K-step 0 (W8L, WL -> slot 0, Ahi / A8 -> stage 0), then WR(0) -> slot 1
+    auto prologue = [&]() __attribute__((always_inline)) {
+        dma(rW8, voW8[0], 0, C::O_8L + wb);
+        issue_WL(0, 0);
+        issue_A(0, 0);
+        issue_WR(0, 1);
+    };
+
+    // Tile-to-tile overlap: once a tile's K loop is done (and every wave's last requests have landed), the workgroup (1) arrives
+    // at the chunk barrier, (2) switches the offsets to its NEXT tile and puts that tile's prologue requests in flight, and only
+    // then (3) runs the epilogue -- the epilogue uses no LDS -- and (4) waits for the chunk barrier.  The first K-step of the next
+    // tile and the other workgroups' skew are then hidden behind the 5-18 us of epilogue memory traffic.
+    bool primed = false;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int local = ch * p.slots + slot_id;
+        bool arrived = false;
         if (local < bandn) {
-            const int bid = band0 + local;
-            // M-grouped tile order: 4 tile rows, N-major inside a group (a chunk of 32 tiles = 4 x 8 tiles)
-            constexpr int GM = 4;
-            const int gsz = GM * p.tiles_n;
-            const int g = bid / gsz;
-            const int first_m = g * GM;
-            const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-            const int tile_m = first_m + (bid % gsz) % gm;
-            const int tile_n = (bid % gsz) / gm;
-            const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
-
-            // per-lane byte offsets of the rows this wave stages (clamped to the last valid row; masked on store)
-            unsigned voA[4], voW[4], vo8[2], voW8[2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int ra = m0 + q * 64 + w * 8 + rl;
-                ra = ra < p.M ? ra : p.M - 1;
-                voA[q] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)(dch << 4);
-                int rw = n0 + q * 64 + w * 8 + rl;
-                rw = rw < p.N ? rw : p.N - 1;
-                voW[q] = (unsigned)rw * (unsigned)(p.ldw * 2) + (unsigned)(dch << 4);
+            int m0, n0;
+            tile_of(band0 + local, m0, n0);
+            if (!primed) {
+                set_offsets(m0, n0);
+                prologue();
+                VMCNT(2);
+            } else {
+                VMCNT(0);                                                  // prologue requests (issued before the last epilogue) + that epilogue's stores
             }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                int ra = m0 + q * 128 + w * 16 + rl8;
-                ra = ra < p.M ? ra : p.M - 1;
-                vo8[q] = (unsigned)ra * (unsigned)p.lda8 + (unsigned)(dch8 << 4);
-                int rw = n0 + q * 128 + w * 16 + rl8;
-                rw = rw < p.N ? rw : p.N - 1;
-                voW8[q] = (unsigned)rw * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
-            }
-            auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + dst_off), 16, vo, soff, 0, 0);
-            };
-            const int wb = w * 1024;                                      // this wave's 1 KiB piece inside every 8 KiB of a unit
-            auto issue_WL = [&](int k, int slot) __attribute__((always_inline)) {         // left 128 weight rows (fp16) into ring slot
-                dma(rW, voW[0], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[1], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
-            };
-            auto issue_WR = [&](int k, int slot) __attribute__((always_inline)) {         // right 128 weight rows
-                dma(rW, voW[2], k << 7, C::O_WR + slot * C::UNIT + wb); dma(rW, voW[3], k << 7, C::O_WR + slot * C::UNIT + 8192 + wb);
-            };
-            auto issue_A = [&](int k, int st) __attribute__((always_inline)) {            // Ahi (4) + A8 (2) of K-step k into stage st
-                const int b = C::O_A + st * 2 * C::UNIT + wb;
-                dma(rAh, voA[0], k << 7, b); dma(rAh, voA[1], k << 7, b + 8192);
-                dma(rAh, voA[2], k << 7, b + C::UNIT); dma(rAh, voA[3], k << 7, b + C::UNIT + 8192);
-                const int b8 = C::O_A8 + st * 2 * C::UNIT8 + wb;
-                dma(rA8, vo8[0], k << 6, b8); dma(rA8, vo8[1], k << 6, b8 + C::UNIT8);
-            };
+            __builtin_amdgcn_s_barrier();
 
             f32x16_t acc[C::TM][C::TN];
 #pragma unroll
@@ -251,13 +278,6 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
                 PROF_ADD(pacc2);
             };
 
-            // prologue: the L set of K-step 0 (W8L, WL -> slot 0, Ahi / A8 -> stage 0), then WR(0) -> slot 1
-            dma(rW8, voW8[0], 0, C::O_8L + wb);
-            issue_WL(0, 0);
-            issue_A(0, 0);
-            issue_WR(0, 1);
-            VMCNT(2);
-            __builtin_amdgcn_s_barrier();
             PROF_T0();
             {
                 int k = 0, wL = 0;
@@ -272,6 +292,19 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             // (alternating s_setprio between the two waves of a SIMD, +4 % on the M-split form, measured -0.7 % here: with just-in-time
             //  reads both waves already finish their phases together -- profiles/r02_lo8_phase_cycles.txt)
             VMCNT(0);
+            __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
+            if (ch + 1 < nchunks) {
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrived = true;
+                const int nl = (ch + 1) * p.slots + slot_id;
+                primed = nl < bandn;
+                if (primed) {
+                    int m1, n1;
+                    tile_of(band0 + nl, m1, n1);
+                    set_offsets(m1, n1);
+                    prologue();
+                }
+            }
 #ifdef LLARK_LO8_PROF
             if (p.prof && lane == 0) {
                 long long* q = p.prof + ((size_t)blockIdx.x * 8 + w) * 4;
@@ -289,15 +322,14 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
 #endif
         }
         if (ch + 1 < nchunks) {
-            __syncthreads();
             if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!arrived) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int target = p.sync_base + (ch + 1) * p.slots;
                 // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
                 for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
                     __builtin_amdgcn_s_sleep(8);
             }
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();                                  // raw: a fence here would drain the next tile's prologue requests
         }
     }
 }
