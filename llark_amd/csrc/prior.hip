@@ -6,6 +6,8 @@
 // (jukebox/main.py:101-110; upstream jukebox/prior/autoregressive.py, transformer/transformer.py,
 // transformer/factored_attention.py, transformer/ops.py) and the pooling at jukebox/main.py:113-167.
 // Residual stream and softmax stay fp32 exactly as the reference runs them (fp16=False).
+#include <type_traits>
+
 #include "common.h"
 
 namespace llark {
@@ -256,6 +258,9 @@ __device__ __forceinline__ void store_rows16(const RowRegs& R, float* __restrict
 // MFMA k-slot convention used below (any consistent A/B assignment is valid): in the j-th of four
 // consecutive v_mfma_f32_16x16x4_f32, lane group g = lane>>4 supplies reduction index 16*ks + 4*g + j,
 // so a row-major operand is fetched as ONE float4 per lane.
+#ifndef ATTN_ABLATE
+#define ATTN_ABLATE 0      // profiling builds only (scripts/build_attn_ablations.sh): 1 no softmax, 2 no PV MFMAs, 3 no QK MFMAs, 4 no output stores
+#endif
 template <int NKS>      // NKS = compile-time number of 16-wide head-dim steps (>= ceil(hd/16)); pad columns are zero
 __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -348,7 +353,11 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int sub = 0; sub < 4; ++sub)      // 4 independent accumulators between dependent MFMAs
+#if ATTN_ABLATE == 3
+                        acc[sub][0] += qf[s][j] * kf[sub][j];
+#else
                         acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s][j], kf[sub][j], acc[sub], 0, 0, 0);
+#endif
             }
         }
         // C layout: col = c (key), rows = 4g + r (query within the wave's 16)
@@ -363,19 +372,47 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
             }
     }
 
-    // ---- fp32 softmax over the wave's own 16 rows (no block barrier needed) ----
+    // ---- fp32 softmax over the wave's own 16 rows (no block barrier needed).  Four lanes per row, each owning a contiguous
+    //      quarter (16 or 32 scores): the row maximum and sum need two cross-lane steps instead of a 64-lane butterfly per row, and
+    //      all 16 rows of the wave are processed at once (the row-at-a-time form was 23 % of the kernel:
+    //      profiles/r02_attn_ablation.txt).  Masked scores are -inf: exp gives 0; a fully masked row cannot occur (key 0 is
+    //      always visible), and a zero sum would still give zeros, not NaN. ----
     const int ncol = ntile * 64;
-    for (int r = wv * 16; r < wv * 16 + 16; ++r) {
-        float v0 = lane < ncol ? sS[r * sp + lane] : -INFINITY;
-        float v1 = (lane + 64) < ncol ? sS[r * sp + lane + 64] : -INFINITY;
-        const float mx = wave_max(fmaxf(v0, v1));
-        const float e0 = (lane < ncol && mx > -INFINITY) ? expf(v0 - mx) : 0.0f;
-        const float e1 = ((lane + 64) < ncol && mx > -INFINITY) ? expf(v1 - mx) : 0.0f;
-        const float sum = wave_sum(e0 + e1);
-        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
-        if (lane < ncol) sS[r * sp + lane] = e0 * inv;
-        if (lane + 64 < ncol) sS[r * sp + lane + 64] = e1 * inv;
+#if ATTN_ABLATE != 1
+    {
+        float* srow = sS + (wv * 16 + (lane >> 2)) * sp + (lane & 3) * (ncol >> 2);
+        auto softmax_quarter = [&](auto nv_tag) __attribute__((always_inline)) {
+            constexpr int NV = decltype(nv_tag)::value;                 // float4 per lane: 4 (64 keys) or 8 (128 keys)
+            f32x4_t v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *(const f32x4_t*)(srow + 4 * i);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])), mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            float sum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ex = mx > -INFINITY ? expf(v[i][e] - mx) : 0.0f;
+                    v[i][e] = ex;
+                    sum += ex;
+                }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                v[i] *= inv;
+                *(f32x4_t*)(srow + 4 * i) = v[i];
+            }
+        };
+        if (ntile == 1) softmax_quarter(std::integral_constant<int, 4>{});
+        else softmax_quarter(std::integral_constant<int, 8>{});
     }
+#endif
 
     // ---- O^T = V^T P^T per 64-key tile: A operand = V^T[d][key] read column-wise from the row-major V
     //      tile, B operand = P^T[key][q] = one float4 of the score row; O^T acc: col = q, rows = d ----
@@ -399,42 +436,51 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
                 for (int dt = 0; dt < NKS; ++dt) vv[dt] = vcol[j * ATT_KP + dt * 16];
 #pragma unroll
                 for (int dt = 0; dt < NKS; ++dt)        // NKS independent accumulators
+#if ATTN_ABLATE == 2
+                    o[dt][0] += vv[dt] * pf[j];
+#else
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[dt], pf[j], o[dt], 0, 0, 0);
+#endif
             }
         }
     }
-    // ---- store hi/lo fp16 (two 4-byte stores per 4 head-dim values): O^T layout col = c (query of this
-    //      wave), rows d = dt*16 + 4g + r ----
+    // ---- output: O^T (col = c = query of this wave, rows d = dt*16 + 4g + r) goes through LDS -- the V tile is dead once every
+    //      wave has left the P V loop -- and leaves row-major: one lane per PAIR of head-dim values, consecutive lanes on consecutive
+    //      pairs of a token row, so a store instruction writes runs of up to 256 contiguous bytes of the hi plane instead of 16 rows x
+    //      4 scattered 4-byte pieces (the scattered form was 24 % of the kernel: profiles/r02_attn_ablation.txt).  A head starts at
+    //      byte 300 * head of a row: 4-byte pieces are the widest store that stays inside the head. ----
+    __syncthreads();
     {
-        const int i = wv * 16 + c;
-        if (i < nq) {
-            const size_t ob = (rowbase + q0 + (size_t)i * qs) * p.ldo + hcol;
+        float* orow = sT + (wv * 16 + c) * ATT_KP + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < NKS; ++dt) {
-                {
-                    const int d = dt * 16 + 4 * g;
-                    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (d + 2 * e < hd) {          // hd is even: a pair is either fully in or fully out
-                            half2_t h, l;
-                            h[0] = (half_t)o[dt][2 * e];
-                            h[1] = (half_t)o[dt][2 * e + 1];
-                            *(half2_t*)(p.ohi + ob + d + 2 * e) = h;
-                            if (p.lo8) {
-                                const float sm = __builtin_ldexpf(1.0f, p.sa);
-                                const unsigned q = fp8_e4m3_sat((o[dt][2 * e] - (float)h[0]) * sm) |
-                                                   (fp8_e4m3_sat((o[dt][2 * e + 1] - (float)h[1]) * sm) << 8);
-                                unsigned char* l8 = (unsigned char*)p.olo + (rowbase + q0 + (size_t)i * qs) * p.ldo8;
-                                *(unsigned short*)(l8 + lo8_pos(hcol + d + 2 * e)) = (unsigned short)q;    // even k: the pair stays contiguous
-                            } else {
-                                l[0] = (half_t)(o[dt][2 * e] - (float)h[0]);
-                                l[1] = (half_t)(o[dt][2 * e + 1] - (float)h[1]);
-                                *(half2_t*)(p.olo + ob + d + 2 * e) = l;
-                            }
-                        }
-                    }
-                }
+        for (int dt = 0; dt < NKS; ++dt) *(f32x4_t*)(orow + dt * 16) = o[dt];
+    }
+    {
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+        const int npair = hd >> 1;                                    // hd is even
+        const float sm8 = __builtin_ldexpf(1.0f, p.sa);
+#if ATTN_ABLATE == 4
+        for (int idx = lane; idx < 16 * npair && o[0][0] == 12345.678f; idx += 64) {
+#else
+        for (int idx = lane; idx < 16 * npair; idx += 64) {           // rows of this wave only: no block barrier needed
+#endif
+            const int rr = idx / npair, pr = idx - rr * npair;
+            const int i = wv * 16 + rr;
+            if (i >= nq) break;
+            const float2 x = *(const float2*)(sT + i * ATT_KP + 2 * pr);
+            const size_t tok = rowbase + q0 + (size_t)i * qs;
+            half2_t h;
+            h[0] = (half_t)x.x;
+            h[1] = (half_t)x.y;
+            *(half2_t*)(p.ohi + tok * p.ldo + hcol + 2 * pr) = h;
+            if (p.lo8) {
+                const unsigned q8 = fp8_e4m3_sat((x.x - (float)h[0]) * sm8) | (fp8_e4m3_sat((x.y - (float)h[1]) * sm8) << 8);
+                *(unsigned short*)((unsigned char*)p.olo + tok * p.ldo8 + lo8_pos(hcol + 2 * pr)) = (unsigned short)q8;   // even k: the pair stays contiguous
+            } else {
+                half2_t l;
+                l[0] = (half_t)(x.x - (float)h[0]);
+                l[1] = (half_t)(x.y - (float)h[1]);
+                *(half2_t*)(p.olo + tok * p.ldo + hcol + 2 * pr) = l;
             }
         }
     }
