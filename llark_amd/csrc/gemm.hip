@@ -1284,7 +1284,10 @@ static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, co
     // already hides the ragged last round (qkv, gate/up: +-1 %; lm_head: -6 %), and plain 16-bit operands at N <= 4096 are
     // better served by the 128x128 tiles below.  variant -1 applies that rule, variant 0 + scratch cuts whenever it can.
     const long long tiles_bd0 = (long long)cdiv(m, CfgBD0::BM) * cdiv(n, CfgBD0::BN);
-    const bool sk_rule = (split && tiles_bd0 < 2LL * llark_device_cus()) || (!split && 4 * tiles_bd0 <= 2LL * llark_device_cus());
+    // plain 16-bit operands at < 1 round: the two-way K cut pays only on a deep K (down_proj, K = 11008: 903 -> 974 TFLOP/s; o_proj,
+    // K = 4096: 866 -> 756 against the 128x128 tiles) -- profiles/r02_streamk.txt
+    const bool sk_rule = (split && tiles_bd0 < 2LL * llark_device_cus()) ||
+                         (!split && (4 * tiles_bd0 <= 2LL * llark_device_cus() || (tiles_bd0 < 2LL * llark_device_cus() && kp >= 8192)));
     if (scratch && (variant == 0 || (variant < 0 && sk_rule)) && epilogue != EPI_QGELU_SPLIT) {
         int rc = -1000;                                             // -1000 = whole rounds / too small to cut -> the per-tile kernels below
         const bool uniform = variant < 0;                          // library choice: the position-independent cut

@@ -224,7 +224,8 @@ def test_gemm_stream_k(m, n, k, epi, split):
     ref = run(False)
     assert int(scratch.ne(0).sum()) == 0, "the per-tile kernel must not touch the stream-K scratch"
     auto = run(None)                                                     # library choice: stream-K only for split operands, < 1 round
-    assert (int(scratch.ne(0).sum()) > 0) == (split and math.ceil(m / 128) * math.ceil(n / 256) < 512)
+    tiles = math.ceil(m / 128) * math.ceil(n / 256)
+    assert (int(scratch.ne(0).sum()) > 0) == (tiles < 512 and (split or 4 * tiles <= 512 or k >= 8192))
     got = run(True)
     nflag = scratch.numel() // (128 * 256 + 1) * 128 * 256              # [resident workgroups] slabs of 128x256 fp32, then the flags
     assert int(scratch[:nflag].ne(0).sum()) > 0, "stream-K did not run (no partial tile was written)"
