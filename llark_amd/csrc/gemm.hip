@@ -693,7 +693,9 @@ static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long lo
         // Uniform split: EVERY tile is cut into the same `ks` K ranges, one workgroup each (grid = ks x tiles, dispatched
         // dynamically; piece 0 of a tile finishes it).  The summation tree of an output element is then the same wherever its
         // tile sits, so equal rows of a batch give bit-equal results (stream-K runs cut each tile at a position-dependent k).
+        static const int ks_env = [] { const char* e = getenv("LLARK_SK_KS"); return e ? atoi(e) : 0; }();        // experiments: force 2 / 4 pieces
         int ks_ = (4 * T_ <= S && nk % 4 == 0 && nk / 4 >= 12) ? 4 : 2;
+        if (ks_env == 2 || (ks_env == 4 && nk % 4 == 0 && nk / 4 >= 12 && (long long)T_ * 3 <= S)) ks_ = ks_env;
         if (T_ >= S || nk % ks_ || nk / ks_ < 12) return -1000;
         const long long need_u = (long long)T_ * (ks_ - 1) * (slab_bytes + 4);
         if (!scratch || scratch_bytes < need_u) return -1000;

@@ -338,7 +338,10 @@ def split16(x: torch.Tensor, dtype: torch.dtype, want_lo: bool = True, kmult: in
 # Fragment-major weight copies for the B-direct kernel live as an attribute ON the row-major tensor object they
 # mirror (same lifetime, no address-keyed registry that could go stale).  Attached explicitly by the inference
 # engines; a training engine whose weights change in place must not attach.
-FRAG_MIN_ROWS = 512
+# From 129 rows (more than one 128-row tile) the B-direct kernels win: with the uniform K split a single clip's prefill (M = 371)
+# runs its four products in 0.47 ms per layer against 0.92 ms through the LDS-staged tiles (bench.py --stages llama --batch 1:
+# 32.9 -> 19.1 ms split, 18.6 -> 13.2 ms bf16; profiles/r02_streamk.txt).
+FRAG_MIN_ROWS = int(os.environ.get("LLARK_FRAG_MIN_ROWS", "129"))
 
 
 def attach_frag(wt: torch.Tensor, n: int) -> None:

@@ -27,7 +27,8 @@ def timeit(fn, iters=20, warm=3):
 def main():
     g = torch.Generator(device=dev).manual_seed(0)
     res = {}
-    for M in ([int(a) for a in sys.argv[1:]] or [2968, 371]):
+    cold = "--cold" in sys.argv                     # rotate over enough weight copies that none survives in L2 / Infinity Cache
+    for M in ([int(a) for a in sys.argv[1:] if a.isdigit()] or [2968, 371]):
         x = torch.randn(M, 11008, generator=g, device=dev)
         h = torch.zeros(M, 4096, device=dev)
         c = torch.zeros(M, 32004, device=dev)
@@ -36,6 +37,8 @@ def main():
                                 ("down", 4096, 11008, "resid"), ("lm_head", 32004, 4096, "f32")]:
             wt = ops.pack_weight16((torch.randn(n, k, generator=g, device=dev) * 0.02).bfloat16(), False, torch.bfloat16, kmult=64)
             wf = ops.pack_weight16_frag(wt, n)
+            copies = [wf] + ([wf.clone() for _ in range(max(1, int(600e6 // (wf.numel() * 2))))] if cold else [])
+            turn = [0]
             hi, lo = ops.split16(x[:, :k].contiguous(), torch.bfloat16, kmult=64)
             for split in (False, True):
                 l = lo if split else None
@@ -45,6 +48,8 @@ def main():
                         continue
 
                     def fn():
+                        turn[0] += 1
+                        wf = copies[turn[0] % len(copies)]
                         if epi == "swiglu":
                             ops.gemm16_fragw(hi, l, wf, None, n, k, ops.EPI_SWIGLU_SPLIT if split else ops.EPI_SWIGLU16, out_hi=o16[0],
                                              out_lo=o16[1] if split else None, **kw)
