@@ -23,6 +23,19 @@ for B in (1, 8):
         eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
     torch.cuda.synchronize()
     n = 48
+    for mode in ("eager", "graph"):                         # wall clock without per-op events
+        eng.decode_graph = mode == "graph"
+        eng.forward_tokens(ids, [(b, 1, emb[b]) for b in range(B)])      # fresh prefill: the cache holds 512 positions
+        for _ in range(4):
+            eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.forward_tokens(tok, (), pos0=eng.cur_len, last_only=True)
+        torch.cuda.synchronize()
+        print(f"decode {prec} B={B} {mode}, no per-op events: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/token", flush=True)
+    eng.decode_graph = False
+    eng.forward_tokens(ids, [(b, 1, emb[b]) for b in range(B)])
     ops.start_kernel_timing()
     t0 = time.perf_counter()
     for _ in range(n):
