@@ -349,11 +349,11 @@ def main():
         for _ in range(args.warmup):
             step()
         _barrier(world)
-        # Per-op HIP events are recorded inside the timed region (they are where `roofline` comes from) -- except for `generate`,
+        # Per-op HIP events are recorded inside the timed region (they are where `roofline` comes from) -- except for `generate` / `mpt`,
         # whose decode steps are ~160 small launches per token: there the events alone cost ~0.8 ms per token (4.8 vs 4.0 ms,
         # scripts/bench_decode.py), so the timed region runs uninstrumented and the per-kernel breakdown comes from a second,
         # identical pass.
-        events_in_timed = args.stages != "generate"
+        events_in_timed = args.stages not in ("generate", "mpt")
         if events_in_timed:
             ops.start_kernel_timing()
         t0 = time.perf_counter()
@@ -457,7 +457,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
-        if args.stages == "generate":
+        if args.stages in ("generate", "mpt"):
             line["kernel_ms_from"] = "second pass with per-op events (the timed region runs without them)"
         if args.stages in ("e2e", "llama") and llm is not None and world == 1:
             # the Llama half in the OTHER activation precision (same weights), outside the timed region: both MFMA fractions in one line
