@@ -34,6 +34,13 @@ struct Cfg256N {
     static_assert(LDS == 160 * 1024, "LDS map");
 };
 
+// LO8N_SKEW: the two waves of every SIMD (w and w ^ 4) run half a phase apart -- waves 4..7 take one extra barrier before the K
+// loop, waves 0..3 one after it, and every phase has a barrier in its middle -- so that one of them is always in the middle of its
+// MFMA stream while the other crosses a phase boundary (first fragment reads, barrier).  What this needs from the DMA protocol is
+// spelled out at kstep() below.
+#ifndef LO8N_SKEW
+#define LO8N_SKEW 1
+#endif
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
@@ -64,18 +71,21 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
 
     // ---- fragment-read offsets (lane-constant; slots, stages and tiles are added as scalars / immediates) ----
     const int sw = (l31 >> 1) & 7;
-    int rdA[4], rdW[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int rd = l31 * C::ROWB + ((((s << 1) | lhi) ^ sw) << 4);
-        rdA[s] = C::O_A + wm * 8192 + rd;              // rows wm*64.. of the 256-row A stage (+ 4096 for the second row tile)
-        rdW[s] = C::O_WR + wn * 8192 + rd;             // weight rows wn*64.. of a 128-row W half (+ 4096 for the second column tile)
-    }
-    // fp8 units: 32 contiguous bytes (chunks 2 lhi, 2 lhi + 1) of row l31, chunk index XOR (row / 4) % 4
+    // Sub-step s reads 16-byte chunk ((2s | lhi) ^ sw) of its row: the s part only flips bits 5-6 of the byte offset, so ONE register
+    // per operand is kept and the other three offsets are re-derived with an XOR where they are used (the `opaque` asm keeps the
+    // compiler from hoisting them back into four loop-invariant registers each: with the skewed loop's extra offsets that cost
+    // spills INSIDE the K loop, and every in-loop reload comes with an `s_waitcnt vmcnt(0)` that drains the DMA queue).
+    const int rd0 = l31 * C::ROWB + ((lhi ^ sw) << 4);
+    const int rdA0 = C::O_A + wm * 8192 + rd0;          // rows wm*64.. of the 256-row A stage (+ 4096 for the second row tile)
+    const int rdW0 = C::O_WR + wn * 8192 + rd0;         // weight rows wn*64.. of a 128-row W half (+ 4096 for the second column tile)
+    auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+    auto rdA = [&](int sub) __attribute__((always_inline)) { return sub ? (opaque(rdA0) ^ (sub << 5)) : rdA0; };
+    auto rdW = [&](int sub) __attribute__((always_inline)) { return sub ? (opaque(rdW0) ^ (sub << 5)) : rdW0; };
+    // fp8 units: 32 contiguous bytes (chunks 2 lhi, 2 lhi + 1) of row l31, chunk index XOR (row / 4) % 4: the second chunk is the first ^ 16
     const int sw8 = (l31 >> 2) & 3;
-    const int c8a = ((lhi << 1) ^ sw8) << 4, c8b = (((lhi << 1) | 1) ^ sw8) << 4;
-    const int rd8a = C::O_A8 + wm * 4096 + l31 * C::ROWB8 + c8a, rd8b = C::O_A8 + wm * 4096 + l31 * C::ROWB8 + c8b;   // + stage, + 2048 tile
-    const int rdW8a = wn * 4096 + l31 * C::ROWB8 + c8a, rdW8b = wn * 4096 + l31 * C::ROWB8 + c8b;                     // + O_8L / O_8R, + 2048 tile
+    const int c8a = ((lhi << 1) ^ sw8) << 4;
+    const int rd8a = C::O_A8 + wm * 4096 + l31 * C::ROWB8 + c8a;    // + stage, + 2048 tile
+    const int rdW8a = wn * 4096 + l31 * C::ROWB8 + c8a;             // + O_8L / O_8R, + 2048 tile
 
     // ---- LDS-DMA lane geometry ----
     const int rl = lane >> 3, pch = lane & 7;                             // fp16: 8 rows x 128 B per wave instruction
@@ -113,6 +123,9 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
     };
     // per-lane byte offsets of the rows this wave stages (clamped to the last valid row; masked on store)
     unsigned voA[4], voW[4], vo8[2], voW8[2];
+#if LO8N_SKEW
+    unsigned voW8p[2];                                            // W8 rows of wave w ^ 4 (requested by the leading wave of the pair)
+#endif
     auto set_offsets = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -131,6 +144,11 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             int rw = n0 + q * 128 + w * 16 + rl8;
             rw = rw < p.N ? rw : p.N - 1;
             voW8[q] = (unsigned)rw * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
+#if LO8N_SKEW
+            int rp = n0 + q * 128 + (w ^ 4) * 16 + rl8;
+            rp = rp < p.N ? rp : p.N - 1;
+            voW8p[q] = (unsigned)rp * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
+#endif
         }
     };
     auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
@@ -150,9 +168,24 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
         const int b8 = C::O_A8 + st * 2 * C::UNIT8 + wb;
         dma(rA8, vo8[0], k << 6, b8); dma(rA8, vo8[1], k << 6, b8 + C::UNIT8);
     };
+    // fp8 weight plane of one half (q = 0: left -> O_8L, 1: right -> O_8R).  LO8N_SKEW: the 8 KiB units are single-buffered, so a
+    // trailing wave's request would always be half a phase late for the leading waves' reads: the LEADING wave of each pair
+    // (w < 4) requests both shares, the trailing wave none.  (The only wave-dependent branch in the loop; wave-dependent
+    // s_waitcnt counts instead cost 40-60 spilled registers, so the request order below is chosen to make the counts equal.)
+    auto issue_W8 = [&](int q, int k) __attribute__((always_inline)) {
+        const int dst = q ? C::O_8R : C::O_8L;
+#if LO8N_SKEW
+        if (w < 4) {
+            dma(rW8, voW8[q], k << 6, dst + wb);
+            dma(rW8, voW8p[q], k << 6, dst + (wb ^ 4096));
+        }
+#else
+        dma(rW8, voW8[q], k << 6, dst + wb);
+#endif
+    };
     // prologue of a tile: the L set of K-step 0 (W8L, WL -> slot 0, Ahi / A8 -> stage 0), then WR(0) -> slot 1
     auto prologue = [&]() __attribute__((always_inline)) {
-        dma(rW8, voW8[0], 0, C::O_8L + wb);
+        issue_W8(0, 0);
         issue_WL(0, 0);
         issue_A(0, 0);
         issue_WR(0, 1);
@@ -205,28 +238,37 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             // (Front-loading a phase's A fragments -- 8 reads per wave, 64 per CU ahead of anybody's first W fragment -- left the
             // matrix pipe idle for the first ~500 cycles of every phase: profiles/r02_lo8_phase_cycles.txt.)  The phase's DMA requests
             // go out behind the first MFMAs for the same reason.  HALF = 0 (L) / 1 (R).
-            auto phase = [&](auto half_tag, auto st_tag, int wslot, auto&& issue) __attribute__((always_inline)) {
+            auto phase = [&](auto half_tag, auto st_tag, int wslot, auto&& issue, auto&& issue_mid) __attribute__((always_inline)) {
                 constexpr int half = decltype(half_tag)::value, st = decltype(st_tag)::value;
                 constexpr int oA = st * 2 * C::UNIT, oA8 = st * 2 * C::UNIT8, o8 = half ? C::O_8R : C::O_8L;
                 const int oW = wslot * C::UNIT;
                 frag bf[2][2];                     // [buffer][column tile]
                 i32x8_t w8[2];
                 if (half == 0) {
-                    ah[0][0] = *(const frag*)(smem + rdA[0] + oA);
-                    ah[1][0] = *(const frag*)(smem + rdA[0] + oA + 4096);
+                    ah[0][0] = *(const frag*)(smem + rdA(0) + oA);
+                    ah[1][0] = *(const frag*)(smem + rdA(0) + oA + 4096);
                 }
-                bf[0][0] = *(const frag*)(smem + rdW[0] + oW);
-                bf[0][1] = *(const frag*)(smem + rdW[0] + oW + 4096);
+                bf[0][0] = *(const frag*)(smem + rdW(0) + oW);
+                bf[0][1] = *(const frag*)(smem + rdW(0) + oW + 4096);
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<4>([&](auto sc) __attribute__((always_inline)) {
                     constexpr int s = decltype(sc)::value, cur = s & 1;
+#if LO8N_SKEW
+                    if constexpr (s == 2) {        // half-phase boundary: the other wave of the pair starts its next phase here
+                        if (half == 0) VMCNT(6);   // WR(k) landed            (newer: Ahi / A8 (k+1) x6)
+                        else VMCNT(0);             // WL / Ahi / A8 (k+1) and W8R(k) landed
+                        __builtin_amdgcn_s_barrier();
+                        issue_mid();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
                     if constexpr (s < 3) {         // fragments of sub-step s + 1
                         if (half == 0) {
-                            ah[0][s + 1] = *(const frag*)(smem + rdA[s + 1] + oA);
-                            ah[1][s + 1] = *(const frag*)(smem + rdA[s + 1] + oA + 4096);
+                            ah[0][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA);
+                            ah[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA + 4096);
                         }
-                        bf[cur ^ 1][0] = *(const frag*)(smem + rdW[s + 1] + oW);
-                        bf[cur ^ 1][1] = *(const frag*)(smem + rdW[s + 1] + oW + 4096);
+                        bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1) + oW);
+                        bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + oW + 4096);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     acc[0][2 * half] = Mfma<T>::run(ah[0][s], bf[cur][0], acc[0][2 * half]);
@@ -234,14 +276,19 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
                     acc[0][2 * half + 1] = Mfma<T>::run(ah[0][s], bf[cur][1], acc[0][2 * half + 1]);
                     acc[1][2 * half + 1] = Mfma<T>::run(ah[1][s], bf[cur][1], acc[1][2 * half + 1]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (s == 0) issue();                                         // this phase's DMA requests
-                    if constexpr (s == 1) {                                                // fp8 fragments: needed after sub-step 3
+                    if constexpr (s == 0) {                                                // this phase's DMA requests
+                        issue();
+#if !LO8N_SKEW
+                        issue_mid();
+#endif
+                    }
+                    if constexpr (s == (LO8N_SKEW ? 2 : 1)) {                              // fp8 fragments: needed after sub-step 3
                         if (half == 0) {
-                            a8[0] = rd_i32x8(rd8a + oA8, rd8b + oA8);
-                            a8[1] = rd_i32x8(rd8a + oA8 + 2048, rd8b + oA8 + 2048);
+                            a8[0] = rd_i32x8(rd8a + oA8, (opaque(rd8a) ^ 16) + oA8);
+                            a8[1] = rd_i32x8(rd8a + oA8 + 2048, (opaque(rd8a) ^ 16) + oA8 + 2048);
                         }
-                        w8[0] = rd_i32x8(rdW8a + o8, rdW8b + o8);
-                        w8[1] = rd_i32x8(rdW8a + o8 + 2048, rdW8b + o8 + 2048);
+                        w8[0] = rd_i32x8(rdW8a + o8, (opaque(rdW8a) ^ 16) + o8);
+                        w8[1] = rd_i32x8(rdW8a + o8 + 2048, (opaque(rdW8a) ^ 16) + o8 + 2048);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -253,32 +300,68 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             };
             // One K-step from A stage ST; wL = ring slot of WL(k).  Both phases ALWAYS issue their requests (the last step re-requests
             // itself, clamped k) so the vmcnt counts and the instruction stream are the same for every K-step (see gemm256_lo8s.hip).
+#if LO8N_SKEW
+            // Skewed form.  Time in half-phases ("slots"): the leading waves run La(k) Lb(k) Ra(k) Rb(k) in slots 4k .. 4k+3, the
+            // trailing waves one slot later; a barrier separates consecutive slots.  Reads: La: A(k), A8(k), WL(k); Lb: WL(k), W8L(k);
+            // Ra: WR(k); Rb: WR(k), W8R(k).  Requests and what they overwrite (last read by the trailing waves in slot ...):
+            //   La start : Ahi / A8 (k+1) -> the other stage        (A(k-1): slot 4k-2)            leading 4k,   trailing 4k+1
+            //   Lb start : WL(k+1) -> slot of WR(k-1)               (slot 4k)                      leading 4k+1, trailing 4k+2
+            //              W8R(k), both shares, leading waves only  (W8R(k-1): slot 4k)            4k+1
+            //   Rb start : WR(k+1) -> slot of WL(k)                 (slot 4k+2)                    leading 4k+3, trailing 4k+4
+            //              W8L(k+1), both shares, leading only      (W8L(k): slot 4k+2)            4k+3
+            // Landing (every wave waits for its own requests before the barrier that precedes the first read by EITHER group):
+            //   before Lb (s_waitcnt vmcnt(6)): WR(k) -- first read Ra(k), leading slot 4k+2, i.e. right after the trailing waves'
+            //     La|Lb barrier -- and W8L(k) (read in Lb); queue at that point: WR(k) x2 [W8L(k) x2] | A(k+1) x6
+            //   before Rb (s_waitcnt vmcnt(0)): A / A8 / WL (k+1) -- first read La(k+1), leading slot 4k+4 -- and W8R(k) (read in Rb)
+            //   phase ends: nothing to wait for.
+            auto kstep = [&](auto st_tag, int k, int wL) __attribute__((always_inline)) {
+                constexpr int st = decltype(st_tag)::value;
+                const int kn = k + 1 < nk ? k + 1 : nk - 1;
+                const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // slots of WR(k), WL(k+1)
+                phase(std::integral_constant<int, 0>{}, st_tag, wL,
+                      [&]() __attribute__((always_inline)) { issue_A(kn, st ^ 1); },
+                      [&]() __attribute__((always_inline)) { issue_WL(kn, wN); issue_W8(1, k); });
+                PROF_ADD(pacc0);
+                __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
+                phase(std::integral_constant<int, 1>{}, st_tag, wR,
+                      [&]() __attribute__((always_inline)) {},
+                      [&]() __attribute__((always_inline)) { issue_WR(kn, wL); issue_W8(0, kn); });
+                PROF_ADD(pacc0);
+                __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
+            };
+#else
             auto kstep = [&](auto st_tag, int k, int wL) __attribute__((always_inline)) {
                 constexpr int st = decltype(st_tag)::value;
                 const int kn = k + 1 < nk ? k + 1 : nk - 1;
                 const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // slots of WR(k), WL(k+1)
                 phase(std::integral_constant<int, 0>{}, st_tag, wL, [&]() __attribute__((always_inline)) {
-                    dma(rW8, voW8[1], k << 6, C::O_8R + wb);               // W8R(k): read by the NEXT phase
+                    issue_W8(1, k);                                        // W8R(k): read by the NEXT phase
                     issue_WL(kn, wN);
                     issue_A(kn, st ^ 1);
-                });
+                }, [&]() __attribute__((always_inline)) {});
                 PROF_ADD(pacc0);
                 VMCNT(8);                                                  // WR(k) (requested in R(k-1)) and W8R(k) have landed
                 PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
                 phase(std::integral_constant<int, 1>{}, st_tag, wR, [&]() __attribute__((always_inline)) {
-                    dma(rW8, voW8[0], kn << 6, C::O_8L + wb);              // W8L(k+1): read by the NEXT phase
+                    issue_W8(0, kn);                                       // W8L(k+1): read by the NEXT phase
                     issue_WR(kn, wL);
-                });
+                }, [&]() __attribute__((always_inline)) {});
                 PROF_ADD(pacc0);
                 VMCNT(2);                                                  // WL / Ahi / A8 (k+1) from L(k) and W8L(k+1) have landed
                 PROF_ADD(pacc1);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
             };
+#endif
 
             PROF_T0();
+#if LO8N_SKEW
+            if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
+#endif
             {
                 int k = 0, wL = 0;
                 for (; k + 1 < nk; k += 2) {
@@ -291,6 +374,9 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             }
             // (alternating s_setprio between the two waves of a SIMD, +4 % on the M-split form, measured -0.7 % here: with just-in-time
             //  reads both waves already finish their phases together -- profiles/r02_lo8_phase_cycles.txt)
+#if LO8N_SKEW
+            if (w < 4) __builtin_amdgcn_s_barrier();                       // the trailing waves' last half-phase
+#endif
             VMCNT(0);
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
             if (ch + 1 < nchunks) {
