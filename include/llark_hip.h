@@ -158,12 +158,14 @@ int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, 
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                        int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
-/* llark_gemm16_fragw with a stream-K decomposition for products whose tile count is not a whole number of rounds of the
- * resident workgroups (Llama prefill at M = 2968: 384 / 1152 / 2064 tiles of 128x256 against 512 resident workgroups --
- * m2t/models/llamav2.py:224-234 -> the q/k/v, o, gate/up, down projections of HF LlamaDecoderLayer): the grid is exactly
- * the resident set, the last tiles of the tile order are cut into equal runs of K-steps, and a tile shared by several
- * workgroups is finished by the one holding its k = 0 end, which adds the others' fp32 partial tiles from `scratch` in
- * slot order (deterministic; no atomics on data).  Same product and epilogues as llark_gemm16_fragw (QGELU_SPLIT
+/* llark_gemm16_fragw with the K range of a tile cut over several workgroups, for products whose tile count is not a whole
+ * number of rounds of the resident workgroups (Llama prefill at M = 2968: 384 / 1152 / 2064 tiles of 128x256 against 512
+ * resident workgroups; one clip, M = 371: 48 .. 258 tiles -- m2t/models/llamav2.py:224-234 -> the q/k/v, o, gate/up, down
+ * projections of HF LlamaDecoderLayer).  variant -1: where the measured rule says it pays (gemm.hip, gemm16_fragw_impl), the
+ * library's choice cuts EVERY tile into the same 2 or 4 K ranges (one workgroup each; the last range finishes the tile and
+ * adds the others' fp32 partial tiles from `scratch` in order: deterministic, no atomics on data, no assumption about how
+ * many workgroups are resident); variant 0 instead cuts the ragged remainder of the tile order into equal runs over exactly
+ * the resident workgroups (stream-K; needs an otherwise idle device).  Same product and epilogues as llark_gemm16_fragw (QGELU_SPLIT
  * excepted, which runs the per-tile kernel), equal up to the fp32 summation order over K.
  * scratch: caller-owned device memory, >= llark_gemm16_sk_scratch_bytes() bytes (the function returns that size for the
  * CURRENT device, -1 on error), 16-byte aligned, ZEROED once after allocation; launches sharing it must be ordered on one

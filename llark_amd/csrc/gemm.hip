@@ -498,9 +498,9 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
     // an XCD's workgroups hold neighbouring runs / tiles (workgroups are dealt round-robin to the 8 XCDs)
     const int slot = (S & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3);
     // slab / flag of the contributor in slot s: stream-K runs: s itself (at most one shared piece per slot, its first);
-    // uniform split (sk_ks pieces per tile, piece 0 = owner): tile * (sk_ks - 1) + piece - 1
+    // uniform split (sk_ks pieces per tile, the LAST piece = owner): tile * (sk_ks - 1) + piece
     const int ks = p.sk_ks;
-    auto slab_of = [&](int s) { return ks ? (s / ks) * (ks - 1) + (s % ks) - 1 : s; };
+    auto slab_of = [&](int s) { return ks ? (s / ks) * (ks - 1) + (s % ks) : s; };
     const int nk = p.Kp / C::BK;
     const int nk16 = nk * 4;
     const int rtiles = (p.N + 31) >> 5;
@@ -621,7 +621,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
             __syncthreads();
         }
 
-        if (kt0 != 0) {
+        // Who finishes a shared tile.  Uniform split: the piece with the LAST K range -- it has the highest block id of its tile, so
+        // it only ever waits for workgroups that were dispatched before it and never wait themselves: no deadlock however few
+        // workgroup slots the device has free (other streams, other processes).  Stream-K runs: the piece with the k = 0 end; the
+        // pieces it waits for sit in the following slots, which is safe only because that form's grid is exactly the resident set
+        // of an otherwise idle device (it is opt-in: variant 0).
+        if (ks ? (kt1 < nk) : (kt0 != 0)) {
             // contributor: slab[slot] <- accumulators in register order (thread-contiguous 16-byte pieces), write-through
             // (buffer stores: one descriptor, one per-lane offset, the slab position as a scalar offset -- no address VGPRs)
             const int mine = slab_of(slot);
@@ -641,8 +646,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
             if (threadIdx.x == 0) __hip_atomic_store(flags + mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        int done = kt1;
-        for (int cs = slot + 1; done < nk; ++cs) {                         // owner of a shared tile: add the other pieces in slot order
+        int done = ks ? 0 : kt1;
+        for (int cs = ks ? slot - (ks - 1) : slot + 1; ks ? (cs < slot) : (done < nk); ++cs) {       // owner: add the other pieces in slot order
             const int theirs = slab_of(cs);
             if (threadIdx.x == 0) {
                 while (__hip_atomic_load(flags + theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(4);
@@ -691,7 +696,7 @@ static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long lo
     const long long slab_bytes = (long long)C::BM * C::BN * 4;
     if (uniform) {
         // Uniform split: EVERY tile is cut into the same `ks` K ranges, one workgroup each (grid = ks x tiles, dispatched
-        // dynamically; piece 0 of a tile finishes it).  The summation tree of an output element is then the same wherever its
+        // dynamically; the LAST piece of a tile finishes it, adding pieces 0 .. ks-2 in that order).  The summation tree of an output element is then the same wherever its
         // tile sits, so equal rows of a batch give bit-equal results (stream-K runs cut each tile at a position-dependent k).
         static const int ks_env = [] { const char* e = getenv("LLARK_SK_KS"); return e ? atoi(e) : 0; }();        // experiments: force 2 / 4 pieces
         int ks_ = (4 * T_ <= S && nk % 4 == 0 && nk / 4 >= 12) ? 4 : 2;
