@@ -950,7 +950,10 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         if (EPI == EPI_F32) {
             p.C[(size_t)m * p.ldc + n] = v[0] + (p.bias ? p.bias[n] : 0.0f);
         } else if (EPI == EPI_RESID) {
-            p.C[(size_t)m * p.ldc + n] = rpre[r] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
+            const float hv = rpre[r] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
+            // fused-norm mode: write-through (sc1) stores, so that the last workgroup can read the rows without any release fence here
+            if (p.nw != nullptr) __hip_atomic_store(p.C + (size_t)m * p.ldc + n, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else p.C[(size_t)m * p.ldc + n] = hv;
         } else if (IS_SWIGLU(EPI)) {
             const float a = silu(v[0]) * v[NT - 1];
             const T hi = Mfma<T>::cvt(a);
@@ -963,14 +966,23 @@ __global__ __launch_bounds__(KW * 64) void gemm_skinny_kernel(const GemmParams p
         // Fused RMSNorm (decode): the workgroup that arrives last owns complete rows of C = h and normalises them
         // with the arithmetic of rmsnorm_kernel (llama.hip) -- same per-lane float4 order, same wave reduction,
         // y = g * (x * rstd), hi = bf16(y), lo = bf16(y - hi) -- so the result is bit-identical to a separate launch.
+        // Hand-off (publish / consume recipe of the CDNA guide): the C stores above are write-through, the storing wave drains
+        // them, ONE lane takes a ticket with a relaxed agent-scope atomic; the last workgroup does ONE agent-scope acquire (drops
+        // its CU's stale L1 lines) and reads the rows with plain loads.  (The first version fenced with __threadfence() in every
+        // workgroup -- an L2 write-back + invalidate each, ~65 us per launch on the 8-XCD part.)
         __shared__ int s_last;
-        __threadfence();                                         // release: this workgroup's C stores
+        if (w == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) s_last = (atomicAdd(p.ncnt, 1) == (int)gridDim.x - 1);
+        if (threadIdx.x == 0) {
+            const int last = __hip_atomic_fetch_add(p.ncnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+            if (last) {
+                __hip_atomic_store(p.ncnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            s_last = last;
+        }
         __syncthreads();
         if (s_last) {
-            if (threadIdx.x == 0) *p.ncnt = 0;                   // ready for the next launch
-            __threadfence();                                     // acquire: drop stale L1 lines of C
             const int w4 = p.N >> 2;
             for (int row = w; row < p.M; row += KW) {
                 const float4* xr = (const float4*)(p.C + (size_t)row * p.ldc);

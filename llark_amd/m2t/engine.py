@@ -89,8 +89,10 @@ class HipLlamaEngine:
         self.cur_batch = 0
         # graph-captured decode step (one hipGraph per batch size; position read from device memory)
         # o_proj / down_proj + following RMSNorm in one launch ("last workgroup done" tail).  Bit-identical, but OFF by
-        # default: on the 8-XCD MI355X the device-scope release/acquire fences it needs write back / invalidate L2
-        # (the XCD L2s are not coherent with each other) and cost ~65 us per launch -- 10.1 vs 5.9 ms per decode step.
+        # default.  Round 1 fenced with __threadfence() in every workgroup (an L2 write-back + invalidate each on the 8-XCD
+        # part: ~65 us per launch, 10.1 vs 5.9 ms per decode step); with write-through stores + a relaxed ticket + ONE
+        # acquire in the last workgroup (round 2) the tail is cheap but still serial: 4.34 vs 3.97 ms per token at B = 1 --
+        # the last workgroup normalises alone while the chip idles, which costs more than the 5 us rmsnorm launch it removes.
         self.fuse_decode_norm = os.environ.get("LLARK_DECODE_FUSE_NORM", "0") == "1"
         # RMSNorm fused INTO the consuming decode GEMM (each workgroup re-derives the row scales): bit-identical, saves
         # two launches per layer (+ the final norm before lm_head).  Measured: B = 8 split 5.89 vs 6.04 ms per step, but
