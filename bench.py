@@ -241,6 +241,49 @@ def cpu_baseline_train(args):
 
 
 PRIOR_DT = {"f16x2": "fp16x2-split(fp32-class)", "lo8": "fp16+e4m3-split(fp32 accumulate, 15-bit activations)"}
+# The prior's Conv1D products per precision: HIP-event timer name, kernel, issued matrix work per algorithmic flop in units of the
+# fp16 MFMA rate (f16x2 = two fp16 passes; lo8 = one fp16 pass + one MX-fp8 MFMA per 64 k, 64 cycles against the 128 of four fp16
+# MFMAs = 1.5), and the committed PMC record of that kernel (separate --pmc passes: FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
+PRIOR_GEMM = {
+    "f16x2": ("gemm_split_f16", "gemm256n_kernel<f16> (two fp16 MFMA passes, fp32 accumulate)", 2.0, "r03_pmc_gemm256n.json"),
+    "lo8": ("gemm_lo8_f16", "gemm256_lo8n_kernel (fp16 hi pass + MX-fp8 low plane)", 1.5, "r02_pmc_gemm_lo8.json"),
+}
+
+
+def prior_roofline(timers, hps, args, precision):
+    """MFMA roofline of the prior's GEMMs from the HIP events of the timed region: ALGORITHMIC flops (2*M*N*K of the
+    fp32-equivalent product; the second pass is not counted) / event time of the launches."""
+    tname, kernel, passes, pmc_name = PRIOR_GEMM[precision]
+    if tname not in timers:
+        return None
+    launches, ms, _ = timers[tname]
+    flops = _prior_gemm_flops(hps, args.batch * hps.n_ctx) * args.steps
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic, traffic_note = None, "no PMC record committed for this kernel version"
+    pmc = os.path.join(ROOT, "profiles", pmc_name)
+    if os.path.exists(pmc):
+        d = json.load(open(pmc))
+        traffic = d["traffic_bytes_per_launch"]
+        traffic_note = ("NOT measured in this run: memory-side bytes of ONE launch of %s from the committed rocprofv3 --pmc passes in "
+                        "profiles/%s (algorithmic %.2f GB; the counter includes Infinity-Cache hits)"
+                        % (d["kernel"], pmc_name, d["algorithmic_bytes_per_launch"] / 1e9))
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "launches": launches, "avg_launch_ms": round(ms / launches, 4), "mfma_passes": passes,
+            "frac_of_issued_mfma": round(passes * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+
+
+def conv_roofline(timers, args):
+    """HBM roofline of the VQ-VAE level-2 encoder + codebook (north_star: >= 50 %): ALGORITHMIC bytes (every layer reads its input
+    once and writes its output once, 1.42 GB per clip -- SURVEY 8(d)) / HIP-event time of the llark_vqvae_encode call."""
+    if "vqvae_encode" not in timers:
+        return None
+    launches, ms, work = timers["vqvae_encode"]
+    gbs = work / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "llark_vqvae_encode (conv / resblock chain + codebook argmin, one event pair per batch)",
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "algorithmic_gb_per_clip": round(work / launches / args.batch / 1e9, 4), "launches": launches,
+            "ms_per_clip": round(ms / launches / args.batch, 4)}
 
 
 def roofline_clap(timers, args, wl):
@@ -302,11 +345,13 @@ def main():
     ap.add_argument("--depth", type=int, default=0, help="debug: override prior depth (result is then NOT the headline)")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny twin model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-precision", action="store_true", help="skip the second pass that times the prior in the other precision")
     ap.add_argument("--cpu-layers", type=int, default=2)
     ap.add_argument("--prior-precision", default=None, choices=["lo8", "f16x2"],
-                    help="how the prior's Conv1D products carry the fp32 activation: lo8 = fp16 hi plane + E4M3 low plane (one fp16 MFMA pass + "
-                         "one MX-fp8 MFMA; 15-16 significant bits, embeddings 3e-5 of max|acts| after 36 layers), f16x2 = fp16 hi + fp16 lo "
-                         "(two fp16 passes, 22 bits, 3e-6).  Default: the library default (llark_amd/jukebox/prior.py)")
+                    help="how the prior's Conv1D products carry the fp32 activation: f16x2 (library default) = fp16 hi + fp16 lo planes, two "
+                         "fp16 MFMA passes, 22 significant bits, 36-layer embedding max-abs-err 5.4e-5; lo8 (opt-in) = fp16 hi plane + E4M3 "
+                         "low plane (one fp16 pass + one MX-fp8 MFMA; 15-16 bits, 5.1e-4).  The default run times BOTH: `value` is the "
+                         "chosen one, `alt_prior_precision` the other")
     ap.add_argument("--llm-precision", default="split", choices=["split", "bf16"],
                     help="Llama half: fp32-class bf16 hi+lo (default, matches the fp32 reference path) or single-pass bf16")
     args = ap.parse_args()
@@ -385,29 +430,8 @@ def main():
         # dominant kernel: the split-fp16 MFMA GEMM of the prior.  Algorithmic flops (2*M*N*K of the
         # fp32-equivalent product; the hi/lo second pass is NOT counted) / HIP-event time of its launches.
         roof = None
-        gname = "gemm_lo8_f16" if "gemm_lo8_f16" in timers else "gemm_split_f16"
-        if gname in timers and args.stages != "llama":
-            launches, ms, _ = timers[gname]
-            flops = _prior_gemm_flops(hps, args.batch * hps.n_ctx) * args.steps
-            achieved = flops / (ms * 1e-3) / 1e12
-            lo8 = gname == "gemm_lo8_f16"
-            traffic, traffic_note = None, None
-            # separate --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), one json per kernel form
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_lo8.json" if lo8 else "r01_pmc_gemm.json")
-            if os.path.exists(pmc):
-                d = json.load(open(pmc))
-                traffic = d["traffic_bytes_per_launch"]
-                traffic_note = ("memory-side bytes of ONE launch of %s (algorithmic %.2f GB; includes Infinity-Cache hits, see %s)"
-                                % (d["kernel"], d["algorithmic_bytes_per_launch"] / 1e9, "profiles/" + os.path.basename(pmc)))
-            # issued matrix work per algorithmic flop, in units of the fp16 MFMA rate: f16x2 = two fp16 passes; lo8 = one fp16 pass +
-            # one MX-fp8 MFMA per 64 k (64 cycles against the 128 of four fp16 MFMAs) = 1.5
-            passes = 1.5 if lo8 else 2
-            roof = {"bound": "mfma", "kernel": "gemm256_lo8n_kernel (fp16 hi pass + MX-fp8 low plane)" if lo8 else "gemm256_kernel<f16,split> (two fp16 passes)",
-                    "achieved": round(achieved, 2),
-                    "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                    "traffic": traffic, "traffic_note": traffic_note, "launches": launches,
-                    "avg_launch_ms": round(ms / launches, 4),
-                    "mfma_passes": passes, "frac_of_issued_mfma": round(passes * achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+        if args.stages != "llama" and enc is not None and prior_roofline(timers, hps, args, args.prior_precision) is not None:
+            roof = prior_roofline(timers, hps, args, args.prior_precision)
         elif args.stages == "clap":
             roof = roofline_clap(timers, args, llm)
         elif llm is not None and args.stages not in ("mpt", "mpt-train"):
@@ -453,7 +477,8 @@ def main():
                        "prior_precision": getattr(args, "prior_precision", None) if args.stages in ("e2e", "jukebox", "generate") else None,
                        "parallelism": f"dp{world} (clip-sharded, no collective)" if args.stages != "train" else f"dp{world} (clip-sharded, RCCL all-reduce of fp32 gradients ({args.grad_comm} on the links) once per optimizer step)",
                        "debug_overrides": bool(args.depth or args.tiny)},
-            "roofline": roof, "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train", "clap") else None),
+            "roofline": roof, "roofline_conv": conv_roofline(timers, args),
+            "roofline_llm": (llm.roofline(timers, args) if llm is not None and args.stages not in ("train", "mpt", "mpt-train", "clap") else None),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
@@ -477,6 +502,36 @@ def main():
             if roof_other is not None:
                 roof_other.update({"llm_precision": other, "llama_ms_per_step": round(ms_other, 3)})
             line["roofline_llm_" + other] = roof_other
+        if args.stages in ("e2e", "jukebox") and enc is not None and world == 1 and not args.no_alt_precision:
+            # The SAME step with the prior in the OTHER precision (same weights, second encoder object), outside the timed region, so
+            # that one driver-recorded line carries both: `value` belongs to the default f16x2 (22-bit activations, full-depth
+            # embedding max-abs-err 5.4e-5 <= 1e-4 = the configs[1] bar); lo8 (15-16 bits, 5.1e-4) is the opt-in speed mode.
+            other = "lo8" if args.prior_precision == "f16x2" else "f16x2"
+            from llark_amd.jukebox import extract as E
+
+            with torch.no_grad():
+                enc_main = enc
+                enc2 = E.WrappedAudioEncoder(hps=hps, weights=weights, device=device, precision=other)
+                enc2.vqvae.set_codebook(enc_main.vqvae.k)
+                enc = enc2
+                for _ in range(max(1, args.warmup)):
+                    step()
+                torch.cuda.synchronize()
+                ops.start_kernel_timing()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                dt_other = time.perf_counter() - t1
+                timers_other = ops.stop_kernel_timing()
+                enc = enc_main
+                del enc2
+            line["alt_prior_precision"] = {
+                "prior_precision": other, "dtype": PRIOR_DT[other], "value": round(args.batch * args.steps / dt_other, 4), "unit": "clips/s",
+                "ms_per_step": round(dt_other / args.steps * 1e3, 3), "roofline": prior_roofline(timers_other, hps, args, other),
+                "note": ("opt-in mode, narrower than the reference's fp32 activations: 36-layer B=8 embedding max-abs-err 5.1e-4 (> the 1e-4 of "
+                         "configs[1]; tests/test_fulldepth_gpu.py) -- reported next to the headline, never as it") if other == "lo8" else
+                        "the library default (22-bit activations; full-depth embedding max-abs-err 5.4e-5 <= 1e-4)"}
         if args.stages in ("train", "mpt-train"):
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if args.stages == "generate":

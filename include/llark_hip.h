@@ -18,7 +18,11 @@
  *     ordered on that stream); create one per (device, stream).  The remaining process-level state is
  *     immutable once set: per-kernel "dynamic LDS size raised" flags and occupancy figures of the code
  *     object, the CU count of each device ordinal.  Scratch memory a kernel needs beyond the workspace is
- *     passed in by the caller (llark_gemm16_fragw_sk).
+ *     passed in by the caller (llark_gemm16_fragw_sk);
+ *   - the library reads NO environment variables: every choice it makes is a function of its arguments (tile variants,
+ *     K-splitting, kernel forms); the only getenv in the sources is LLARK_LO8_PROF_BUF inside `#ifdef LLARK_LO8_PROF`,
+ *     a cycle-counter build (scripts/build_lo8_prof.sh) that is never shipped.  The knobs of the Python host layer
+ *     (LLARK_PRIOR_PRECISION, LLARK_LLM_PRECISION, LLARK_HIP_LIB, ...) are listed in INTEGRATION.md.
  */
 #ifndef LLARK_HIP_H
 #define LLARK_HIP_H
@@ -130,18 +134,23 @@ int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void*
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
 /* llark_gemm16_ex plus a workspace: only with one are the persistent, chunk-synchronous variants (20 = 128x256x64,
- * 30 = the 256x256x64 LDS-DMA ring of csrc/gemm256.hip) chosen or honoured; without, such requests run variant 12. */
+ * 30 = the 256x256x64 LDS-DMA ring of csrc/gemm256.hip, 31 = the 256x256x64 tile with phases over N and resident A
+ * fragments of csrc/gemm256n.hip -- the default for the prior's M = clips x 8192 split-fp16 products) chosen or honoured;
+ * without, such requests run variant 12.  All variants produce bit-identical results. */
 int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_workspace_t ws, llark_stream_t stream);
-/* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8.hip): same call site, upstream Conv1D.forward reached from
+/* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8n.hip; OPT-IN reduced precision, the default is the two-pass fp16
+ * form behind llark_gemm16_ws): same call site, upstream Conv1D.forward reached from
  * jukebox/main.py:108 with fp16=False.  The activation is a_hi = fp16(a) plus an E4M3 low plane
  * a_lo8[m][lda8] = fp8(sat((a - a_hi) * 2^sa)) whose 64-element k blocks are stored in MFMA slot order
  * (byte 32*(k/8 % 2) + 8*(k/16 % 4) + k % 8 of the block holds element k); the fp8 weight plane w8 = fp8(wt * 2^sw), same
- * slot order, is packed once by llark_pack_weight_lo8 (choose sw with max|W| * 2^sw <= 448; w8 = NULL: the kernel derives it
- * from wt in registers -- no extra memory, measured 20 % slower).  C = a_hi.W^T + 2^-(sa+sw) a_lo8.W8^T (+ bias):
+ * slot order, is packed once by llark_pack_weight_lo8 (choose sw with max|W| * 2^sw <= 448; required).  C = a_hi.W^T + 2^-(sa+sw) a_lo8.W8^T (+ bias):
  * one v_mfma_scale_f32_32x32x64_f8f6f4 replaces the four fp16 MFMAs of the second pass.  Accuracy: the activation
- * carries 15-16 significant bits instead of 22 (measured end to end in tests/test_fulldepth_gpu.py).
+ * carries 15-16 significant bits instead of 22 (measured end to end in tests/test_fulldepth_gpu.py: 36-layer embedding
+ * max-abs-err 5.1e-4 against 5.4e-5 for the two-pass form -- above the 1e-4 of BASELINE configs[1], hence opt-in).
+ * Operands are addressed with 32-bit byte offsets: m * lda * 2 and m * lda8 must stay below 2^31 (LLARK_ERR_UNSUPPORTED
+ * otherwise; split the rows over several calls -- rows are independent).
  * epilogue: LLARK_EPI_F32, LLARK_EPI_RESID, LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo] + out_lo8 [m][ldo8], same format).
  * kp % 64 == 0, kp >= 128; lda8 / ldo8 in bytes, multiples of 64. */
 int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
@@ -169,7 +178,9 @@ int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const vo
  * excepted, which runs the per-tile kernel), equal up to the fp32 summation order over K.
  * scratch: caller-owned device memory, >= llark_gemm16_sk_scratch_bytes() bytes (the function returns that size for the
  * CURRENT device, -1 on error), 16-byte aligned, ZEROED once after allocation; launches sharing it must be ordered on one
- * stream.  scratch == NULL, or a problem too small to cut -> exactly llark_gemm16_fragw. */
+ * stream.  The hand-off flags occupy the LAST 64 KiB of [scratch, scratch + scratch_bytes) whatever the shape of a launch (the
+ * fp32 partial tiles grow from the front and are checked never to reach them), so pass the same (scratch, scratch_bytes)
+ * pair on every call that shares a scratch.  scratch == NULL, or a problem too small to cut -> exactly llark_gemm16_fragw. */
 long long llark_gemm16_sk_scratch_bytes(void);
 int llark_gemm16_fragw_sk(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                           const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,

@@ -397,13 +397,11 @@ extern "C" int llark_clap_window_attn(const float* qkv, int ldq, int batch, int 
     dim3 grid(cdiv(units, 4));
     hipStream_t s = (hipStream_t)stream;
 #define WA_CASE(HD) clap_window_attn_kernel<HD><<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo, (bf16_t*)out_hi_dup, ldo, units)
-    static const bool valu_only = [] { const char* e = getenv("LLARK_CLAP_ATTN_VALU"); return e && e[0] == '1'; }();
-    if (hd == 32 && !valu_only) {
+    if (hd == 32) {
         LLARK_REQUIRE((long long)batch * H * W < (1LL << 31), "clap_window_attn: token count overflows int");
         clap_window_attn_mfma_kernel<<<grid, 256, 0, s>>>(qkv, ldq, C, heads, H, W, shift, bias_table, (bf16_t*)out_hi, (bf16_t*)out_lo,
                                                           (bf16_t*)out_hi_dup, ldo, units);
-    } else if (hd == 32) WA_CASE(32);
-    else if (hd == 16) WA_CASE(16);
+    } else if (hd == 16) WA_CASE(16);
     else {
         set_error("clap_window_attn: head_dim %d unsupported (16 or 32)", hd);
         return LLARK_ERR_UNSUPPORTED;

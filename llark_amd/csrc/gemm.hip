@@ -12,13 +12,15 @@
 // fp32-class accuracy at 1/2 of the fp16 matrix rate instead of 1/16 (the f32-input MFMA rate).
 // Single-pass mode (SPLIT=false) is the plain bf16/fp16 GEMM used for Llama.
 //
-// Structure: 128x128x32 block tile, 4 waves (2x2), each wave 64x64 = 2x2 tiles of
-// v_mfma_f32_32x32x16_{f16,bf16}; operands stream HBM/L2 -> LDS with global_load_lds_dwordx4
-// (16 B/lane, no VGPR round trip) into a double-buffered LDS image whose 16-B chunks are XOR
-// swizzled on the SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128
-// fragment reads are bank-conflict free; one barrier per K-step; 48 KiB LDS -> 3 blocks/CU.
-// blockIdx is remapped XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and
-// grouped over M so that co-resident blocks share A and W panels.
+// Structure of the LDS-staged kernels in this file (`gemm_tile`, tile variants 0 / 1 / 2 / 11 / 12 and the persistent form 20;
+// the default for most shapes is 128x256x64 with 4 waves of 64x128, a single 64 KiB stage and two workgroups per CU): waves own
+// TM x TN tiles of v_mfma_f32_32x32x16_{f16,bf16}; operands stream HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B/lane, no
+// VGPR round trip) into an LDS image whose 16-B chunks are XOR swizzled on the SOURCE address (the DMA destination is
+// lane-linear) so that the ds_read_b128 fragment reads are bank-conflict free; one barrier per K-step.  blockIdx is remapped
+// XCD-aware (each XCD's private L2 sees a contiguous band of tiles) and grouped over M so that co-resident blocks share A and
+// W panels.  Also here: the B-direct kernels (weights fragment-major, L2 -> VGPR; the Llama prefill) with their K-splitting
+// forms, and the skinny weight-streaming kernels of the decode step.  The prior's 256x256 tiles live in gemm256n.hip (two-pass
+// fp16, default), gemm256.hip (its predecessor, the M-split LDS ring) and gemm256_lo8n.hip (fp8 low plane, opt-in).
 
 // Profiling-only compile-time ablations (results invalid): 1 = no DMA in the K loop, 2 = no LDS fragment
 // reads, 3 = no MFMA.  Built into separate libraries by scripts/build_ablations.sh; never set in the product.
@@ -481,6 +483,10 @@ static int dispatch_bd(const GemmParams& p, bool split, int epi, hipStream_t s) 
 // must be ordered on one stream).  All S workgroups must be resident (the host sizes the grid from the occupancy query).
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned sk_flag_t;
+// The hand-off flags live in a FIXED region: the last SK_FLAG_BYTES of the caller's scratch, whatever the shape, tile configuration
+// or decomposition of a launch (the fp32 slabs grow from the front and never reach it: launch_gemm_bd_sk checks).  "Zeroed once,
+// every owner re-zeroes what it consumed" therefore holds across launches of different shapes sharing one scratch.
+constexpr long long SK_FLAG_BYTES = 64 * 1024;
 
 template <typename T, bool SPLIT, int EPI, typename C>
 __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const GemmParams p) {
@@ -495,11 +501,22 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = 0, wn = w;
     const int S = (int)gridDim.x;
-    // an XCD's workgroups hold neighbouring runs / tiles (workgroups are dealt round-robin to the 8 XCDs)
-    const int slot = (S & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3);
+    const int ks = p.sk_ks;
+    // Block id -> slot (slot s works on units [s * sk_per, (s + 1) * sk_per) of the cut tiles).  Workgroups are dealt round-robin to
+    // the 8 XCDs, so the map hands every XCD a contiguous band of runs / tiles (speed only).  Uniform split: the block order is
+    // PIECE-major -- blocks [q * T, (q + 1) * T) hold piece q of every tile -- so the owner of a tile (its last piece) has a higher
+    // block id than every piece it waits for WHATEVER the XCD remap does inside a piece plane: it only ever waits for workgroups
+    // dispatched before it (scripts/sim_streamk_plan.py: slot_of_block).
+    int slot;
+    if (ks) {
+        const int T_ = S / ks, piece = (int)blockIdx.x / T_, tb = (int)blockIdx.x - piece * T_;
+        const int tile = (T_ & 7) ? tb : (tb & 7) * (T_ >> 3) + (tb >> 3);
+        slot = tile * ks + piece;
+    } else {
+        slot = (S & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3);
+    }
     // slab / flag of the contributor in slot s: stream-K runs: s itself (at most one shared piece per slot, its first);
     // uniform split (sk_ks pieces per tile, the LAST piece = owner): tile * (sk_ks - 1) + piece
-    const int ks = p.sk_ks;
     auto slab_of = [&](int s) { return ks ? (s / ks) * (ks - 1) + (s % ks) : s; };
     const int nk = p.Kp / C::BK;
     const int nk16 = nk * 4;
@@ -621,9 +638,10 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
             __syncthreads();
         }
 
-        // Who finishes a shared tile.  Uniform split: the piece with the LAST K range -- it has the highest block id of its tile, so
-        // it only ever waits for workgroups that were dispatched before it and never wait themselves: no deadlock however few
-        // workgroup slots the device has free (other streams, other processes).  Stream-K runs: the piece with the k = 0 end; the
+        // Who finishes a shared tile.  Uniform split: the piece with the LAST K range -- the block order is piece-major (see `slot`
+        // above), so it has a higher block id than the other pieces of its tile: it only ever waits for workgroups that were
+        // dispatched before it and never wait themselves: no deadlock however few workgroup slots the device has free (other
+        // streams, other processes).  Stream-K runs: the piece with the k = 0 end; the
         // pieces it waits for sit in the following slots, which is safe only because that form's grid is exactly the resident set
         // of an otherwise idle device (it is opt-in: variant 0).
         if (ks ? (kt1 < nk) : (kt0 != 0)) {
@@ -698,17 +716,15 @@ static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long lo
         // Uniform split: EVERY tile is cut into the same `ks` K ranges, one workgroup each (grid = ks x tiles, dispatched
         // dynamically; the LAST piece of a tile finishes it, adding pieces 0 .. ks-2 in that order).  The summation tree of an output element is then the same wherever its
         // tile sits, so equal rows of a batch give bit-equal results (stream-K runs cut each tile at a position-dependent k).
-        static const int ks_env = [] { const char* e = getenv("LLARK_SK_KS"); return e ? atoi(e) : 0; }();        // experiments: force 2 / 4 pieces
-        int ks_ = (4 * T_ <= S && nk % 4 == 0 && nk / 4 >= 12) ? 4 : 2;
-        if (ks_env == 2 || (ks_env == 4 && nk % 4 == 0 && nk / 4 >= 12 && (long long)T_ * 3 <= S)) ks_ = ks_env;
+        const int ks_ = (4 * T_ <= S && nk % 4 == 0 && nk / 4 >= 12) ? 4 : 2;
         if (T_ >= S || nk % ks_ || nk / ks_ < 12) return -1000;
-        const long long need_u = (long long)T_ * (ks_ - 1) * (slab_bytes + 4);
-        if (!scratch || scratch_bytes < need_u) return -1000;
+        const long long need_u = (long long)T_ * (ks_ - 1) * slab_bytes + SK_FLAG_BYTES;
+        if (!scratch || scratch_bytes < need_u || (long long)T_ * (ks_ - 1) * 4 > SK_FLAG_BYTES) return -1000;
         p.sk_ks = ks_;
         p.sk_dp = 0;
         p.sk_per = nk / ks_;
         p.sk_part = (float*)scratch;
-        p.sk_flag = (unsigned*)((char*)scratch + (long long)T_ * (ks_ - 1) * slab_bytes);
+        p.sk_flag = (unsigned*)((char*)scratch + scratch_bytes - SK_FLAG_BYTES);
         kern<<<dim3(T_ * ks_), C::THREADS, LDS, s>>>(p);
         return check_launch("gemm_bd_sk(uniform)");
     }
@@ -716,15 +732,14 @@ static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long lo
     const int rounds = T_ / S, rem = T_ - rounds * S;
     if (rem == 0) return -1000;                                    // whole rounds: one workgroup per tile is already balanced
     const int sk_tiles = rem + (rounds >= 1 ? S : 0);               // with a full round in the pool no run is shorter than a tile
-    static const int per_env = [] { const char* e = getenv("LLARK_SK_PER"); return e ? atoi(e) : 0; }();      // debugging: run length override
-    const int per = per_env > 0 ? per_env : cdiv(sk_tiles * nk, S);
+    const int per = cdiv(sk_tiles * nk, S);
     if (per < 12 || (long long)per * S < (long long)sk_tiles * nk) return -1000;                                    // pieces too short to pay for their prologue and the slab exchange
-    const long long need = (long long)S * C::BM * C::BN * 4 + (long long)S * 4;
-    if (!scratch || scratch_bytes < need) return -1000;
+    const long long need = (long long)S * C::BM * C::BN * 4 + SK_FLAG_BYTES;
+    if (!scratch || scratch_bytes < need || (long long)S * 4 > SK_FLAG_BYTES) return -1000;
     p.sk_dp = T_ - sk_tiles;
     p.sk_per = per;
     p.sk_part = (float*)scratch;
-    p.sk_flag = (unsigned*)((char*)scratch + (long long)S * C::BM * C::BN * 4);
+    p.sk_flag = (unsigned*)((char*)scratch + scratch_bytes - SK_FLAG_BYTES);
     kern<<<dim3(S), C::THREADS, LDS, s>>>(p);
     return check_launch("gemm_bd_sk");
 }
@@ -1019,8 +1034,7 @@ static int launch_skinny(const GemmParams& p, hipStream_t s) {
     const int blocks = IS_SWIGLU(EPI) ? (p.N / 64) * 2 : cdiv(p.N, 16);
     // K is split over the waves of a block; HBM streaming needs many bytes in flight per CU, so problems with few
     // column tiles (o_proj / down_proj: 256 blocks) or a deep K get 16 waves, the wide ones 8
-    static const int force = [] { const char* e = getenv("LLARK_SKINNY_KW"); return e ? atoi(e) : 0; }();
-    const int kw = force ? force : ((blocks <= 512 || p.Kp >= 8192) ? 16 : 8);
+    const int kw = (blocks <= 512 || p.Kp >= 8192) ? 16 : 8;
     if (kw == 16) gemm_skinny_kernel<T, SPLIT, EPI, 16><<<blocks, 1024, 0, s>>>(p);
     else if (kw == 8) gemm_skinny_kernel<T, SPLIT, EPI, 8><<<blocks, 512, 0, s>>>(p);
     else gemm_skinny_kernel<T, SPLIT, EPI, 4><<<blocks, 256, 0, s>>>(p);
@@ -1061,6 +1075,20 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 2: return dispatch<T, Cfg2>(p, split, epi, s);
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
+        case 31: {                                                  // 256x256x64 split tile, phases over N with resident A fragments (gemm256n.hip), else 30
+            if (split && ws && ws->cus % 8 == 0) {
+                GemmParams q = p;
+                const int dt = std::is_same<T, half_t>::value ? LLARK_F16 : LLARK_BF16;
+                if (ws_begin(ws, q, s) == 0) {
+                    const int rc = launch_gemm256n(q, dt, epi, s, ws->cus);
+                    if (rc != -1000) {
+                        ws_end(ws, cdiv(p.M, 256) * cdiv(p.N, 256), ws->cus / 8);
+                        return rc;
+                    }
+                }
+            }
+        }
+        [[fallthrough]];
         case 30: {                                                  // 256x256x64 split tile with the counted-vmcnt LDS ring (gemm256.hip), else 20
             if (split && ws && ws->cus % 8 == 0) {
                 GemmParams q = p;
@@ -1104,12 +1132,11 @@ static int pick_variant(int split, int m, int n, int kp, bool has_ws) {
     if (!split && kp % 64 == 0 && n < 16384) return 11;
     if (n < 256) return 0;
     if (kp % 64 != 0) return kp < 2048 ? 1 : 2;
-    static const bool persist_env = [] { const char* e = getenv("LLARK_GEMM_PERSIST"); return !e || e[0] != '0'; }();
-    const bool persist = persist_env && has_ws;   // the persistent kernels keep their chunk counters in the caller's workspace
-    static const bool big = [] { const char* e = getenv("LLARK_GEMM_256"); return !e || e[0] != '0'; }();
-    // the prior (M = clips x 8192, split fp16): 256x256x64 tile with the counted-vmcnt LDS ring (gemm256.hip) as soon as the
+    const bool persist = has_ws;                  // the persistent kernels keep their chunk counters in the caller's workspace
+    // the prior (M = clips x 8192, split fp16): 256x256x64 tile, phases over N with resident A fragments (gemm256n.hip; round 2's
+    // M-split LDS ring gemm256.hip = variant 30 stays for A/B) as soon as the
     // problem has two tiles per CU -- also at B = 1 (608 tiles), so a clip's result does not depend on the batch it rides in
-    if (split && big && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 30;
+    if (split && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 31;
     if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
                                                   // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
     if (m >= 16384 && persist) return 20;                    // very tall products (M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
@@ -1199,25 +1226,25 @@ extern "C" int llark_workspace_destroy(llark_workspace_t ws) {
     return LLARK_OK;
 }
 
-// Split GEMM with an e4m3 low plane (csrc/gemm256_lo8.hip): the prior's Conv1D products in "lo8" mode.
+// Split GEMM with an e4m3 low plane (csrc/gemm256_lo8n.hip): the prior's Conv1D products in the opt-in "lo8" mode.
 //   a_hi  fp16 [m][lda]            = fp16(a)
 //   a_lo8 e4m3 [m][lda8] (bytes)   = fp8(sat((a - a_hi) * 2^sa)), every 64-k block in the slot order of lo8_pos()
 //   wt    fp16 [n][ldw]; sw such that max|W| * 2^sw <= 448
-//   w8    e4m3 [n][ldw8] (bytes) = fp8(wt * 2^sw) in the same slot order (llark_pack_weight_lo8): staged through LDS by
-//         csrc/gemm256_lo8s.hip; NULL -> csrc/gemm256_lo8.hip derives the same plane from wt in registers (slower, no extra memory)
+//   w8    e4m3 [n][ldw8] (bytes) = fp8(wt * 2^sw) in the same slot order (llark_pack_weight_lo8), staged through LDS next to wt
+//         (required; the form that derived it from wt in registers lost and lives in scripts/experiments/)
 // epilogue: LLARK_EPI_F32 / LLARK_EPI_RESID / LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo], out_lo8 e4m3 [m][ldo8]).
 extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
                                 const void* w8, int ldw8, const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid,
                                 int ldr, void* out_hi, void* out_lo8, int ldo, int ldo8, llark_workspace_t ws,
                                 llark_stream_t stream) {
-    LLARK_REQUIRE(a_hi && a_lo8 && wt && ws && m > 0 && n > 0, "gemm16_lo8: null pointer or empty problem");
+    LLARK_REQUIRE(a_hi && a_lo8 && wt && w8 && ws && m > 0 && n > 0, "gemm16_lo8: null pointer (a_hi / a_lo8 / wt / w8 / ws) or empty problem");
     LLARK_REQUIRE(kp % 64 == 0 && kp >= 128, "gemm16_lo8: kp=%d must be a multiple of 64 and >= 128 (zero-pad K)", kp);
     LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp && lda8 >= kp && lda8 % 16 == 0,
                   "gemm16_lo8: lda/ldw/lda8 must be >= kp, lda/ldw multiples of 8, lda8 a multiple of 16");
     LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wt & 15) == 0 && ((uintptr_t)a_lo8 & 15) == 0,
                   "gemm16_lo8: operands must be 16-byte aligned");
     LLARK_REQUIRE(sa >= 0 && sa <= 40 && sw >= -40 && sw <= 40, "gemm16_lo8: scale exponents out of range (sa=%d sw=%d)", sa, sw);
-    LLARK_REQUIRE(!w8 || (ldw8 >= kp && ldw8 % 16 == 0 && ((uintptr_t)w8 & 15) == 0), "gemm16_lo8: w8 plane needs ldw8 >= kp, ldw8 %% 16 == 0 and 16-byte alignment");
+    LLARK_REQUIRE(ldw8 >= kp && ldw8 % 16 == 0 && ((uintptr_t)w8 & 15) == 0, "gemm16_lo8: w8 plane needs ldw8 >= kp, ldw8 %% 16 == 0 and 16-byte alignment");
     if (epilogue == EPI_F32 || epilogue == EPI_RESID) LLARK_REQUIRE(c && ldc >= n, "gemm16_lo8: fp32 output missing");
     if (epilogue == EPI_RESID) LLARK_REQUIRE(resid && ldr >= n, "gemm16_lo8: residual missing");
     if (epilogue == EPI_QGELU_SPLIT8)
@@ -1231,10 +1258,7 @@ extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo
     p.Ohi = out_hi; p.Olo = out_lo8; p.ldo = ldo; p.ldo8 = ldo8; p.lo8_sa = sa; p.lo8_sw = sw; p.W8 = w8; p.ldw8 = ldw8;
     hipStream_t s = (hipStream_t)stream;
     if (ws_begin(ws, p, s)) { set_error("gemm16_lo8: workspace unusable"); return LLARK_ERR_LAUNCH; }
-    // staged forms: n = phases over N with resident A fragments (gemm256_lo8n.hip), s = phases over M (gemm256_lo8s.hip); LLARK_LO8_FORM picks
-    static const char form = [] { const char* e = getenv("LLARK_LO8_FORM"); return e ? e[0] : 'n'; }();
-    const int rc = !w8 ? launch_gemm256_lo8(p, epilogue, s, ws->cus)
-                   : form == 's' ? launch_gemm256_lo8s(p, epilogue, s, ws->cus) : launch_gemm256_lo8n(p, epilogue, s, ws->cus);
+    const int rc = launch_gemm256_lo8n(p, epilogue, s, ws->cus);
     if (rc == -1000) { set_error("gemm16_lo8: problem outside the kernel's range (32-bit operand offsets)"); return LLARK_ERR_UNSUPPORTED; }
     ws_end(ws, cdiv(m, 256) * cdiv(n, 256), ws->cus / 8);
     return rc;
@@ -1333,14 +1357,15 @@ extern "C" int llark_gemm16_fragw(int variant, int dtype, int split, int epilogu
                              ldo, nullptr, 0, stream);
 }
 
-// Bytes of scratch llark_gemm16_fragw_sk needs on the current device: one 128 KiB fp32 slab + one flag per resident workgroup.
+// Bytes of scratch llark_gemm16_fragw_sk needs on the current device: one 128 KiB fp32 slab per resident workgroup + the fixed 64 KiB
+// flag region at its end.
 extern "C" long long llark_gemm16_sk_scratch_bytes(void) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         set_error("gemm16_sk_scratch_bytes: cannot query the current device");
         return -1;
     }
-    return (long long)cus * 2 * (CfgBD0::BM * CfgBD0::BN * 4 + 4);
+    return (long long)cus * 2 * (CfgBD0::BM * CfgBD0::BN * 4) + SK_FLAG_BYTES;
 }
 
 // llark_gemm16_fragw with the stream-K decomposition (gemm_bd_sk_kernel) whenever the tile count is not a whole number of

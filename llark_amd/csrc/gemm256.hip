@@ -41,7 +41,7 @@ struct Cfg256 {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): the same per-wave cycle counters as gemm256_lo8.hip.
+// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): the same per-wave cycle counters as gemm256_lo8n.hip.
 #ifdef LLARK_LO8_PROF
 #define PROF_DECL long long pt0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0
 #define PROF_T0() pt0 = __builtin_readcyclecounter()

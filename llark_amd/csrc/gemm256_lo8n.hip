@@ -1,7 +1,15 @@
-// 256x256x64 split GEMM tile with an FP8 low plane, phases split over N with the A fragments resident ("lo8" mode, default):
+// 256x256x64 split GEMM tile with an FP8 low plane, phases split over N with the A fragments resident (the opt-in "lo8" precision
+// of the prior; the default two-pass fp16 form is gemm256n.hip):
 //     C[M,N] = Ahi[M,K] . W[N,K]^T  +  2^-(SA+SW) . A8[M,K] . W8[N,K]^T          (fp32 accumulate)
-// Same product, operand formats, DMA technique and 160 KiB budget as gemm256_lo8s.hip (read that header first) with the roles of
-// A and W swapped.  Measured on lo8s (profiles/r02_lo8_phase_cycles.txt): a phase takes ~2200 cycles for 1536 cycles of matrix
+// Operands: Ahi = fp16(a) [M][lda]; A8 = e4m3(sat((a - Ahi) 2^SA)) [M][lda8] bytes, every 64-k block in the MFMA slot order of
+// lo8_pos() (common.h); W fp16 [N][ldw]; W8 = e4m3(W 2^SW) [N][ldw8] in the same slot order, pre-packed once at load time
+// (llark_pack_weight_lo8).  Per 32x32 tile and 64 k the kernel issues four v_mfma_f32_32x32x16_f16 (Ahi . W) and ONE
+// v_mfma_scale_f32_32x32x64_f8f6f4 (A8 . W8, block scales = the two constant exponents) instead of the four fp16 MFMAs of a second
+// pass.  All four planes stream L2 -> LDS with `buffer_load ... lds` (no VGPR round trip), 16-B chunks XOR-swizzled on the SOURCE
+// address (the DMA destination is lane-linear), counted `s_waitcnt vmcnt(N)` in front of raw `s_barrier`s so the DMA queue never
+// drains; one persistent workgroup of 8 waves per CU (160 KiB of LDS), chunk-synchronous tile order per XCD.  History of the forms
+// that lost (W8 derived in registers; phases split over M) and their sources: DESIGN.md section 4, scripts/experiments/.
+// Measured on the M-split form (profiles/r02_lo8_phase_cycles.txt): a phase takes ~2200 cycles for 1536 cycles of matrix
 // work, the DMA stream is never late, and the LDS is the busiest unit: its two phases split M, so every W fragment is read in
 // BOTH phases by all four wave rows -- 480 ds_read_b128 + 96 KiB of DMA writes per K-step and CU.  Here
 //  * a K-step's two phases split N: phase L multiplies by the left 128 weight rows (units WL, W8L), phase R by the right 128;
@@ -46,7 +54,7 @@ typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): per-wave cycle counters, see gemm256_lo8.hip.
+// Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): per-wave cycle counters (issue / counted-vmcnt wait / barrier per phase, epilogue per tile).
 #ifdef LLARK_LO8_PROF
 #define PROF_DECL long long pt0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0
 #define PROF_T0() pt0 = __builtin_readcyclecounter()
@@ -202,12 +210,15 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
         if (local < bandn) {
             int m0, n0;
             tile_of(band0 + local, m0, n0);
+            // (builtin waits, visible to hipcc's waitcnt pass -- see the same place in gemm256n.hip: with asm waits here the pass kept
+            //  the previous epilogue's load destinations marked pending and put an `s_waitcnt vmcnt(0)` at the head of the K loop)
             if (!primed) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): nothing outstanding
                 set_offsets(m0, n0);
                 prologue();
-                VMCNT(2);
+                __builtin_amdgcn_s_waitcnt(0x0F72);                        // vmcnt(2)
             } else {
-                VMCNT(0);                                                  // prologue requests (issued before the last epilogue) + that epilogue's stores
+                __builtin_amdgcn_s_waitcnt(0x0F70);                        // prologue requests (issued before the last epilogue) + that epilogue's stores
             }
             __builtin_amdgcn_s_barrier();
 
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
                 __builtin_amdgcn_sched_barrier(0);
             };
             // One K-step from A stage ST; wL = ring slot of WL(k).  Both phases ALWAYS issue their requests (the last step re-requests
-            // itself, clamped k) so the vmcnt counts and the instruction stream are the same for every K-step (see gemm256_lo8s.hip).
+            // itself, clamped k) so the vmcnt counts and the instruction stream are the same for every K-step.
 #if LO8N_SKEW
             // Skewed form.  Time in half-phases ("slots"): the leading waves run La(k) Lb(k) Ra(k) Rb(k) in slots 4k .. 4k+3, the
             // trailing waves one slot later; a barrier separates consecutive slots.  Reads: La: A(k), A8(k), WL(k); Lb: WL(k), W8L(k);

@@ -93,11 +93,11 @@ struct GemmParams {
     const float* xg;   // norm weight [Kp]
     int ldxn;
     float xeps;
-    // lo8 mode (gemm256_lo8.hip): Alo is an e4m3 plane [M][lda8] = fp8(sat((a - Ahi) * 2^lo8_sa)) in the slot order of
-    // lo8_pos(); W8 = e4m3(W * 2^lo8_sw) is derived from Wt in registers.  EPI_QGELU_SPLIT8 writes Olo as such a plane.
+    // lo8 mode (gemm256_lo8n.hip): Alo is an e4m3 plane [M][lda8] = fp8(sat((a - Ahi) * 2^lo8_sa)) in the slot order of
+    // lo8_pos(); W8 = e4m3(W * 2^lo8_sw) in the same order.  EPI_QGELU_SPLIT8 writes Olo as such a plane.
     int lda8, ldo8;
     int lo8_sa, lo8_sw;
-    const void* W8;    // gemm256_lo8s.hip: pre-packed e4m3(W * 2^lo8_sw) [N][ldw8] bytes in slot order (llark_pack_weight_lo8); nullptr = derive in registers
+    const void* W8;    // pre-packed e4m3(W * 2^lo8_sw) [N][ldw8] bytes in slot order (llark_pack_weight_lo8)
     int ldw8;
     int sync_base;     // persistent kernels: value of the (monotonic) chunk counters when this launch starts
     // stream-K form of the B-direct kernel (gemm.hip: gemm_bd_sk_kernel)
@@ -110,7 +110,7 @@ struct GemmParams {
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
-       EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8.hip only) */ };
+       EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8n.hip only) */ };
 #define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
 
 template <typename T>
@@ -296,13 +296,13 @@ __device__ __forceinline__ void xcd_band(int nwg, int xcd, int& base, int& count
 // gemm256.hip: 256x256x64 split-mode tile (8 waves, counted-vmcnt LDS-DMA ring of 10 x 16 KiB).  dtype LLARK_F16 / LLARK_BF16.
 // Returns -1000 when the problem is not one it handles (caller falls back to another variant).
 int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
-// gemm256_lo8.hip: the same tile with an e4m3 low plane (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of
-// the stream's device (8 | cus).  Returns -1000 when the problem is not one it handles.
-int launch_gemm256_lo8(const GemmParams& p, int epi, hipStream_t s, int cus);
-int gemm256_lo8_chunk_barriers(int M, int N, int cus);
-// gemm256_lo8s.hip: the form with the fp8 weight plane pre-packed (p.W8) and staged through LDS: no VALU work in the main loop.
-int launch_gemm256_lo8s(const GemmParams& p, int epi, hipStream_t s, int cus);
-// gemm256_lo8n.hip: phases split over N, A fragments resident across both (40 % fewer LDS reads).
+// gemm256n.hip: the same 256x256x64 split-mode product with phases over N, resident A fragments, just-in-time fragment reads,
+// tile-to-tile overlap and the two waves of a SIMD half a phase apart (the main loop of gemm256_lo8n.hip with a second fp16 pass
+// instead of the fp8 MFMA).  Bit-identical to launch_gemm256.  Returns -1000 when the problem is not one it handles.
+int launch_gemm256n(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
+// gemm256_lo8n.hip: the 256x256 tile with an e4m3 low plane staged through LDS (p.W8), phases split over N, A fragments resident
+// across both (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of the stream's device (8 | cus).  Returns -1000
+// when the problem is not one it handles.
 int launch_gemm256_lo8n(const GemmParams& p, int epi, hipStream_t s, int cus);
 
 }  // namespace llark

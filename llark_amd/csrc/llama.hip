@@ -489,8 +489,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
 template <typename... Args>
 static void launch_attn_decode(int nh, int batch, size_t lds, hipStream_t s, Args... args) {
     dim3 grid(nh, batch);
-    static const int force = [] { const char* e = getenv("LLARK_ATTN_DECODE_NW"); return e ? atoi(e) : 0; }();
-    if (force ? force == 16 : (long)nh * batch < 256) attn_decode_kernel<16><<<grid, 1024, lds, s>>>(args...);
+    if ((long)nh * batch < 256) attn_decode_kernel<16><<<grid, 1024, lds, s>>>(args...);
     else attn_decode_kernel<4><<<grid, 256, lds, s>>>(args...);
 }
 

@@ -50,7 +50,7 @@ __global__ void prior_embed_kernel(const long long* __restrict__ z, const float4
 // One wave per row; the row lives in registers (NV float4 per lane), so HBM sees 1 read + 1 write.
 // ------------------------------------------------------------------------------------------
 // LO8: the low plane is an e4m3 byte plane [rows][ldo8] = fp8(sat((y - hi) * 2^sa)) in the slot order of lo8_pos()
-// (gemm_core.h; consumed by gemm256_lo8.hip) instead of an fp16 plane.
+// (gemm_core.h; consumed by gemm256_lo8n.hip) instead of an fp16 plane.
 template <int NV, bool LO8>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, int ldx, int rows, int width,
                                                               const float* __restrict__ gamma,

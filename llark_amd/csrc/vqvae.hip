@@ -92,77 +92,6 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------
-// fused ResConv1DBlock: y = x + W2 * relu(W1 (*)_dil relu(x) + b1) + b2, C = 32.
-// ------------------------------------------------------------------------------------------
-template <int C, int TPT>
-__global__ __launch_bounds__(256) void resblock_kernel(const float* __restrict__ x, const float* __restrict__ w1p,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2p,
-                                                       const float* __restrict__ b2, float* __restrict__ y, int t,
-                                                       int dil) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int TT = 256 * TPT;
-    const int n = blockIdx.y;
-    const int t0 = blockIdx.x * TT;
-    const int span = TT + 2 * dil;
-    const float* xn = x + (size_t)n * C * t;
-    for (int i = threadIdx.x; i < C * span; i += 256) {
-        int ci = i / span, j = i - ci * span;
-        int gi = t0 - dil + j;
-        lds[ci * span + j] = (gi >= 0 && gi < t) ? xn[(size_t)ci * t + gi] : 0.0f;
-    }
-    __syncthreads();
-    float acc[TPT][C];
-#pragma unroll
-    for (int p = 0; p < TPT; ++p)
-#pragma unroll
-        for (int co = 0; co < C; ++co) acc[p][co] = b1[co];
-    for (int tap = 0; tap < 3; ++tap) {
-#pragma unroll 4
-        for (int ci = 0; ci < C; ++ci) {
-            const float* wrow = w1p + ((size_t)tap * C + ci) * C;
-            float xv[TPT];
-#pragma unroll
-            for (int p = 0; p < TPT; ++p) xv[p] = fmaxf(lds[ci * span + threadIdx.x + p * 256 + tap * dil], 0.0f);
-#pragma unroll
-            for (int co = 0; co < C; ++co) {
-                float wv = wrow[co];
-#pragma unroll
-                for (int p = 0; p < TPT; ++p) acc[p][co] = fmaf(wv, xv[p], acc[p][co]);
-            }
-        }
-    }
-    float out[TPT][C];
-#pragma unroll
-    for (int p = 0; p < TPT; ++p)
-#pragma unroll
-        for (int co = 0; co < C; ++co) out[p][co] = b2[co];
-#pragma unroll
-    for (int cs = 0; cs < C; ++cs) {
-        const int ci = ((cs >> 1) & 3) + 8 * (cs >> 3) + 4 * (cs & 1);   // shared 1x1 accumulation order (see oracle)
-        const float* wrow = w2p + (size_t)ci * C;
-        float hv[TPT];
-#pragma unroll
-        for (int p = 0; p < TPT; ++p) hv[p] = fmaxf(acc[p][ci], 0.0f);
-#pragma unroll
-        for (int co = 0; co < C; ++co) {
-            float wv = wrow[co];
-#pragma unroll
-            for (int p = 0; p < TPT; ++p) out[p][co] = fmaf(wv, hv[p], out[p][co]);
-        }
-    }
-    float* yn = y + (size_t)n * C * t;
-#pragma unroll
-    for (int p = 0; p < TPT; ++p) {
-        int tl = threadIdx.x + p * 256;
-        int tg = t0 + tl;
-        if (tg < t) {
-#pragma unroll
-            for (int co = 0; co < C; ++co) yn[(size_t)co * t + tg] = lds[co * span + tl + dil] + out[p][co];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Strided / output convs on the fp32-input matrix cores (same chain order as the oracle: tap-major, ci
 // ascending, two channels per v_mfma_f32_32x32x2_f32).  Wave = 32 output steps x COUT channels
 // (COUT/32 accumulators); weights live in registers; the input tile (with stride and taps) in LDS.
@@ -454,8 +383,7 @@ extern "C" int llark_conv1d_f32(const float* x, int n, int cin, int tin, const f
     LLARK_REQUIRE(expect == tout, "conv1d: tout=%d does not match (tin=%d,k=%d,s=%d,p=%d,d=%d) -> %d", tout, tin, k,
                   stride, pad, dil, expect);
     hipStream_t s = (hipStream_t)stream;
-    static const bool conv_valu = getenv("LLARK_CONV_VALU") != nullptr;         // A/B knob: the fp32 VALU kernels
-    if (!conv_valu && dil == 1) {
+    if (dil == 1) {
 #define CONV_MFMA(CIN, COUT, K, STRIDE, NTILE)                                                                          \
     do {                                                                                                                \
         constexpr int TT_ = 4 * NTILE * 32;                                                                             \
@@ -488,17 +416,6 @@ extern "C" int llark_resblock_f32(const float* x, int n, int c, int t, const flo
     LLARK_REQUIRE(c == 32, "resblock: only width 32 (Jukebox vqvae width) is built, got %d", c);
     LLARK_REQUIRE(dil >= 1 && dil <= 81, "resblock: dilation %d out of range", dil);
     LLARK_REQUIRE(t >= 1, "resblock: empty time axis");
-    static const bool use_valu = getenv("LLARK_RESBLOCK_VALU") != nullptr;      // A/B knob: the fp32 VALU version
-    if (use_valu) {
-        constexpr int TPT = 2;
-        constexpr int TT = 256 * TPT;
-        size_t lds = (size_t)32 * (TT + 2 * dil) * sizeof(float);
-        auto kern = resblock_kernel<32, TPT>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dim3 grid(cdiv(t, TT), n);
-        kern<<<grid, 256, lds, (hipStream_t)stream>>>(x, w1p, b1, w2p, b2, y, t, dil);
-        return check_launch("resblock");
-    }
     LLARK_REQUIRE(dil <= 27, "resblock: the matrix-core path is built for dilation <= 27 (Jukebox: 1,3,9,27), got %d", dil);
     constexpr int NTILE = 2;
     constexpr int TT = 4 * NTILE * 32;

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import logging
 import os
+import pickle
 import re
 from typing import Dict, Iterable, List, Optional, Tuple
 
@@ -39,12 +40,29 @@ def default_checkpoint_paths(model: str = "5b") -> Tuple[str, str]:
     return os.path.join(root, "5b", "vqvae.pth.tar"), os.path.join(root, model, "prior_level_2.pth.tar")
 
 
-def read_pth_tar(path) -> Dict[str, torch.Tensor]:
+UNSAFE_PICKLE_ENV = "LLARK_ALLOW_UNSAFE_CHECKPOINT_PICKLE"
+
+
+def read_pth_tar(path, allow_pickle: Optional[bool] = None) -> Dict[str, torch.Tensor]:
     """``checkpoint["model"]`` of an upstream checkpoint file with DDP's ``module.`` prefix removed
-    (upstream make_models.py ``restore_model``).  Accepts a path or a file object."""
+    (upstream make_models.py ``restore_model``).  Accepts a path or a file object.
+
+    The file is read with ``torch.load(weights_only=True)``: upstream's files are a dict of tensors plus an ``hps`` dict of
+    plain Python values, which the restricted unpickler accepts.  A file it rejects is NOT retried with the full
+    unpickler (that would run whatever code a corrupted or hostile ``.pth.tar`` carries) unless the caller opts in with
+    ``allow_pickle=True`` or ``LLARK_ALLOW_UNSAFE_CHECKPOINT_PICKLE=1`` -- the same gate m2t/data.py puts on ``.pyd``."""
+    if allow_pickle is None:
+        allow_pickle = os.environ.get(UNSAFE_PICKLE_ENV, "0") == "1"
+    pos = path.tell() if hasattr(path, "tell") else None
     try:
         ck = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:                                     # upstream files pickle an hps dict next to the tensors
+    except pickle.UnpicklingError as e:
+        if not allow_pickle:
+            raise ValueError(f"{path}: the restricted (weights_only) loader rejected this checkpoint: {e}.  If the file is trusted, "
+                             f"pass allow_pickle=True or set {UNSAFE_PICKLE_ENV}=1 to read it with the full unpickler.") from e
+        logging.warning("%s: reading with the UNRESTRICTED unpickler (%s)", path, UNSAFE_PICKLE_ENV)
+        if pos is not None:
+            path.seek(pos)
         ck = torch.load(path, map_location="cpu", weights_only=False)
     if not isinstance(ck, dict) or "model" not in ck:
         raise ValueError(f"{path}: not a Jukebox checkpoint (expected a dict with a 'model' entry)")

@@ -117,7 +117,7 @@ class VQVAE:
         (`llark_vqvae_encode`): the ~40 short launches are issued without returning to Python in between."""
         assert audio.dim() == 2 and audio.shape[1] == self.sample_length, (
             f"expected (N,{self.sample_length}) audio, got {tuple(audio.shape)}")
-        if want_dist or ops.kernel_timing_active():            # per-layer path: distances / per-kernel event timers
+        if want_dist:                                          # per-layer path: also returns the distances
             xe = self.encoder_forward(audio.contiguous().view(audio.shape[0], 1, -1))
             return ops.codebook_argmin(xe, self.k, self.kk, want_dist=want_dist)
         n = audio.shape[0]
@@ -128,13 +128,32 @@ class VQVAE:
         import ctypes
 
         t_out = ctypes.c_int(0)
-        ops.check(ops._lib.lib().llark_vqvae_encode(self._plan(), ops._dev(audio, "audio", torch.float32), n, self.sample_length,
-                                                    b0.data_ptr(), b1.data_ptr(), widest, ops._dev(self.k, "k", torch.float32),
-                                                    ops._dev(self.kk, "kk", torch.float32), self.k.shape[0], codes.data_ptr(),
-                                                    ctypes.byref(t_out), ops._stream()), "vqvae_encode")
+        # one HIP-event pair around the whole layer list when bench.py times kernels: work = ALGORITHMIC bytes of the stack
+        with ops._timed("vqvae_encode", float(self.algorithmic_bytes(n))):
+            ops.check(ops._lib.lib().llark_vqvae_encode(self._plan(), ops._dev(audio, "audio", torch.float32), n, self.sample_length,
+                                                        b0.data_ptr(), b1.data_ptr(), widest, ops._dev(self.k, "k", torch.float32),
+                                                        ops._dev(self.kk, "kk", torch.float32), self.k.shape[0], codes.data_ptr(),
+                                                        ctypes.byref(t_out), ops._stream()), "vqvae_encode")
         if t_out.value != self.hps.n_ctx:
             raise ops._lib.LlarkHipError(f"vqvae_encode produced {t_out.value} tokens per clip, hparams say {self.hps.n_ctx}")
         return codes
+
+    def algorithmic_bytes(self, n: int) -> int:
+        """HBM bytes of the level-2 encoder + codebook for n clips with every layer reading its input once and writing its
+        output once ("per-layer-fused", 1.42 GB per 1 048 576-sample clip): the numerator of bench.py's
+        ``roofline_conv``."""
+        total, c, t = 0, 1, self.sample_length
+        for layer in self.layers:
+            if layer[0] == "conv":
+                _, wp, _b, stride, pad = layer
+                k, cin, cout = wp.shape
+                tout = (t + 2 * pad - (k - 1) - 1) // stride + 1
+                total += 4 * (cin * t + cout * tout)
+                c, t = cout, tout
+            else:
+                total += 4 * 2 * c * t
+        total += 4 * c * t + 8 * t                      # codebook: encoder output in, int64 codes out
+        return n * total + self.k.numel() * 4
 
     def encode(self, x: torch.Tensor):
         """Upstream-shaped entry: x (N, T, 1) like ``vqvae.encode(torch.cuda.FloatTensor(audio[None,:,None]))``."""

@@ -138,7 +138,7 @@ def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any
     shards = split_by_rank(expand_urls(train_data_path), rank, world)
     collate = DataCollatorForSupervisedDataset(tokenizer)
     epoch = 0
-    skipped = 0
+    to_skip = max(0, int(skip_micro_batches))                         # whole micro-batches still to fast-forward over
     while epochs is None or epoch < epochs:
         rng = random.Random((seed * 1000003 + rank) * 7919 + epoch)
         order = list(shards)
@@ -150,9 +150,13 @@ def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any
 
         stream = _shuffled(conversations(), rng, shuffle_buffer) if shuffle_buffer and shuffle_buffer > 1 else conversations()
         pending: List[Dict[str, Any]] = []
+        skip_pending = 0      # conversations of the micro-batch being skipped; like `pending`, an epoch's remainder is dropped
         for conv in stream:
-            if skipped < skip_micro_batches * batch_size:             # fast-forward without tokenising
-                skipped += 1
+            if to_skip > 0:                                           # fast-forward without tokenising
+                skip_pending += 1
+                if skip_pending == batch_size:
+                    to_skip -= 1
+                    skip_pending = 0
                 continue
             ex = preprocess_for_lm_mappable(preprocess_multimodal_mappable(conv, multimodal_cfg), tokenizer=tokenizer)
             ex["input_ids"], ex["labels"] = ex["input_ids"][:model_max_length], ex["labels"][:model_max_length]

@@ -8,8 +8,9 @@ the audio splice, the 32 decoder layers, final norm and ``lm_head`` -- runs in
 Weights stay in the HF ``nn.Parameter`` containers (so ``from_pretrained``, ``state_dict``,
 ``resize_token_embeddings`` and checkpoint side-files keep working); the engine holds bf16 copies
 in kernel layout that are (re)built by :meth:`WrappedLlamav2ForCausalLM.sync_engine` after any
-weight change.  Inference only in this round: the training step (backward kernels, RCCL gradient
-all-reduce) is the next row of SURVEY section 8 and raises ``NotImplementedError`` here.
+weight change.  Training: ``model(input_ids, labels=..., audio_encodings=...).loss.backward()`` runs the HIP
+forward / backward of :class:`llark_amd.m2t.train_engine.HipLlamaTrainer` through an autograd bridge that fills the
+``.grad`` of these ``nn.Parameter``s (m2t/train.py:53-277); the RCCL gradient all-reduce lives in ``llark_amd/dist.py``.
 """
 from __future__ import annotations
 

@@ -409,16 +409,27 @@ def gemm16_lo8(a_hi: torch.Tensor, a_lo8: torch.Tensor, wt: torch.Tensor, sw: in
                c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None,
                out_lo8: Optional[torch.Tensor] = None, m: Optional[int] = None, sa: int = LO8_SA, w8: Optional[torch.Tensor] = None) -> None:
     """C[m,n] = a_hi . wt^T + 2^-(sa+sw) a_lo8 . fp8(wt 2^sw)^T (+bias): the prior's split GEMM with an E4M3 low plane
-    (include/llark_hip.h: llark_gemm16_lo8).  ``w8`` = pack_weight_lo8(wt, sw): the staged kernel csrc/gemm256_lo8s.hip;
-    without it csrc/gemm256_lo8.hip derives the fp8 weight plane in registers."""
+    (include/llark_hip.h: llark_gemm16_lo8; csrc/gemm256_lo8n.hip).  ``w8`` = pack_weight_lo8(wt, sw), required.
+    The kernel addresses its operands with 32-bit byte offsets: a product whose A plane reaches 2 GiB (about 28 clips of the
+    5b prior) is issued as several launches over row ranges -- rows are independent, so the result is bit-identical."""
     assert a_hi.dtype == torch.float16 and wt.dtype == torch.float16 and a_lo8.dtype == torch.uint8
+    if w8 is None:
+        raise ValueError("gemm16_lo8: the packed fp8 weight plane w8 = pack_weight_lo8(wt, sw) is required")
     m = a_hi.shape[0] if m is None else m
     kp = wt.shape[1]
     assert a_hi.shape[1] >= kp and a_lo8.shape[1] >= kp and wt.shape[0] >= n
+    max_rows = lo8_max_rows(a_hi.stride(0), a_lo8.stride(0))
+    if m > max_rows:
+        for r0 in range(0, m, max_rows):
+            r1 = min(m, r0 + max_rows)
+            gemm16_lo8(a_hi[r0:r1], a_lo8[r0:r1], wt, sw, bias, n, epilogue, c=c[r0:r1] if c is not None else None,
+                       resid=resid[r0:r1] if resid is not None else None, out_hi=out_hi[r0:r1] if out_hi is not None else None,
+                       out_lo8=out_lo8[r0:r1] if out_lo8 is not None else None, m=r1 - r0, sa=sa, w8=w8)
+        return
     with _timed("gemm_lo8_f16", 2.0 * m * n * kp):
         check(_lib.lib().llark_gemm16_lo8(
             epilogue, _dev(a_hi, "a_hi"), _dev(a_lo8, "a_lo8"), a_hi.stride(0), a_lo8.stride(0), _dev(wt, "wt"), wt.stride(0),
-            _dev(w8, "w8", torch.uint8) if w8 is not None else None, w8.stride(0) if w8 is not None else 0,
+            _dev(w8, "w8", torch.uint8), w8.stride(0),
             _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp, int(sa), int(sw),
             _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
             _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
@@ -426,6 +437,13 @@ def gemm16_lo8(a_hi: torch.Tensor, a_lo8: torch.Tensor, wt: torch.Tensor, sw: in
             _dev(out_lo8, "out_lo8", torch.uint8) if out_lo8 is not None else None,
             out_hi.stride(0) if out_hi is not None else 0, out_lo8.stride(0) if out_lo8 is not None else 0, workspace(), _stream()),
             "gemm16_lo8")
+
+
+def lo8_max_rows(lda: int, lda8: int) -> int:
+    """Largest row count one llark_gemm16_lo8 launch takes (32-bit byte offsets into the fp16 and e4m3 A planes), rounded down
+    to whole 256-row tiles."""
+    rows = min(((1 << 31) - 1) // (2 * lda), ((1 << 31) - 1) // max(1, lda8))
+    return max(256, rows // 256 * 256)
 
 
 def gemm16_resid_rmsnorm(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, h: torch.Tensor, norm_w: torch.Tensor,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Interleaved A/B timing of the prior's four GEMM shapes (M = 65536, split fp16): variants 12 / 20 (round-1 kernels) vs 30
-(csrc/gemm256.hip) vs 40 (csrc/gemm256_lo8.hip, fp8 low plane).  Rounds are interleaved inside one process and the median / min per variant is reported
+"""Interleaved A/B timing of the prior's four GEMM shapes (M = 65536, split fp16): variants 12 / 20 (round-1 kernels), 30
+(csrc/gemm256.hip, the M-split LDS ring), 31 (csrc/gemm256n.hip, phases over N -- the default) and 41 (csrc/gemm256_lo8n.hip, fp8 low
+plane, opt-in).  Variants 12 / 20 / 30 / 31 are also compared bit for bit on every shape.  Rounds are interleaved inside one process and the median / min per variant is reported
 (MI355X guide rule 24); operands are random (rule 25).  Run on the GPU box:  python scripts/bench_gemm256.py [variants] [M]"""
 import json
 import os
@@ -12,7 +13,7 @@ import torch
 
 from llark_amd import ops
 
-VARIANTS = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "12,20,30".split(","))]
+VARIANTS = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "30,31,41".split(","))]
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 ROUNDS, ITERS = 5, 4
 dev = "cuda"
@@ -40,8 +41,8 @@ def main():
         w8p = ops.pack_weight_lo8(wt, sw)
 
         def fn(v):
-            if v in (40, 41):                             # fp16 hi pass + one MX-fp8 MFMA for the low plane: 40 = W8 in registers
-                w8 = w8p if v == 41 else None             # (csrc/gemm256_lo8.hip), 41 = W8 staged (csrc/gemm256_lo8s.hip)
+            if v == 41:                                   # fp16 hi pass + one MX-fp8 MFMA for the low plane (csrc/gemm256_lo8n.hip)
+                w8 = w8p
                 if epi == ops.EPI_QGELU_SPLIT:
                     ops.gemm16_lo8(a_hi, a_lo8, wt, sw, bias, n, ops.EPI_QGELU_SPLIT8, out_hi=ohi, out_lo8=olo8, w8=w8)
                 elif epi == ops.EPI_RESID:
@@ -57,9 +58,21 @@ def main():
                 ops.gemm16(a_hi, a_lo, wt, bias, n, epi, c=cq, variant=v)
 
         times = {v: [] for v in VARIANTS}
+        outs = {}
         for v in VARIANTS:
+            if epi == ops.EPI_RESID:
+                c.zero_()
             fn(v)
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            if v != 41:
+                outs[v] = (ohi.clone(), olo.clone()) if epi == ops.EPI_QGELU_SPLIT else (c.clone() if epi == ops.EPI_RESID else cq.clone())
+        ref_v = min(outs) if outs else None
+        for v, o in outs.items():
+            same = all(torch.equal(a, b) for a, b in zip(o, outs[ref_v])) if isinstance(o, tuple) else torch.equal(o, outs[ref_v])
+            if v != ref_v:
+                print(f"split f16 {name:12s} v{v} vs v{ref_v}: {'bit-identical' if same else 'DIFFERENT'}", flush=True)
+                res[f"{name}_v{v}_equals_v{ref_v}"] = bool(same)
+        del outs
         for _ in range(ROUNDS):
             for v in VARIANTS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -12,6 +12,7 @@ than every slot it waits for (it only waits for workgroups dispatched before it)
 increasing slot order.  The numbers mirror launch_gemm_bd_sk / gemm_bd_sk_kernel; tests/test_streamk_plan_cpu.py sweeps shapes.
 """
 BM, BN, BK = 128, 256, 64
+FLAG_BYTES = 64 * 1024          # SK_FLAG_BYTES: the fixed flag region at the end of the caller's scratch
 
 
 def cdiv(a, b):
@@ -34,6 +35,18 @@ def plan(m, n, kp, S=512, uniform=True):
     if per < 12:
         return None
     return dict(mode="runs", tiles=tiles, nk=nk, ks=0, grid=S, per=per, dp=tiles - sk_tiles, slabs=S)
+
+
+def slot_of_block(p, bid):
+    """gemm_bd_sk_kernel's block id -> slot map.  Uniform split: piece-major block order (blocks [q T, (q + 1) T) hold piece q of
+    every tile) with the XCD band remap applied to the TILE index inside a piece plane; stream-K runs: the band remap on the slot."""
+    grid, ks = p["grid"], p["ks"]
+    if ks:
+        T = grid // ks
+        piece, tb = divmod(bid, T)
+        tile = tb if T & 7 else (tb & 7) * (T >> 3) + (tb >> 3)
+        return tile * ks + piece
+    return bid if grid & 7 else (bid & 7) * (grid >> 3) + (bid >> 3)
 
 
 def pieces(p):
@@ -69,6 +82,10 @@ def check(m, n, kp, S=512, uniform=True):
     if p is None:
         return None
     nk = p["nk"]
+    slots = [slot_of_block(p, b) for b in range(p["grid"])]
+    assert sorted(slots) == list(range(p["grid"])), "block id -> slot is not a permutation"
+    block_of = {s: b for b, s in enumerate(slots)}
+    assert p["slabs"] * 4 <= FLAG_BYTES, "flags outgrow the fixed region at the end of the scratch"
     cover = {}
     by_tile = {}
     slabs = set()
@@ -92,6 +109,8 @@ def check(m, n, kp, S=512, uniform=True):
         assert len(others) == len(ps) - 1
         if p["ks"]:
             assert all(o[0] < fin[0][0] for o in others), "uniform split: the finisher must have the highest slot of its tile"
+            # ... and, what the no-deadlock argument actually needs, the highest BLOCK id: it only waits for workgroups dispatched before it
+            assert all(block_of[o[0]] < block_of[fin[0][0]] for o in others), "uniform split: a finisher waits for a later block"
             assert [o[0] for o in others] == list(range(fin[0][0] - (p["ks"] - 1), fin[0][0]))       # the kernel's wait loop
         else:
             assert [o[0] for o in others] == list(range(fin[0][0] + 1, fin[0][0] + 1 + len(others)))  # following slots, in order

@@ -85,3 +85,21 @@ def test_tar_reader_conversations_and_batches(tmp_path):
     r0 = [x["input_ids"].shape[0] for x in D.micro_batches(pattern, tok, mm, 2, 64, rank=0, world=2, epochs=1, allow_pickle=True)]
     r1 = [x["input_ids"].shape[0] for x in D.micro_batches(pattern, tok, mm, 2, 64, rank=1, world=2, epochs=1, allow_pickle=True)]
     assert sum(r0) == 4 and sum(r1) == 2                                   # rank 0: d-000 (+ the malformed d-002), rank 1: d-001
+
+
+def test_resume_fast_forward_matches_uninterrupted_stream_across_epochs(tmp_path):
+    """an epoch whose conversation count is not a multiple of the batch size drops its remainder; the resume
+    fast-forward must drop it too, or the resumed stream drifts by up to batch_size - 1 conversations per epoch."""
+    _make_shard(tmp_path / "e-000.tar", ["a0", "a1", "a2"])                # 3 clips x 2 QA pairs = 6 conversations / epoch
+    _make_shard(tmp_path / "e-001.tar", ["b0"])                            # + 2 = 8; batch 3 -> 2 batches + remainder 2
+    tok = ToyTokenizer()
+    tok.add_tokens(["<audio_patch>", "<audio_start>", "<audio_end>"], special_tokens=True)
+    mm = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    pattern = str(tmp_path / "e-{000..001}.tar")
+    full = list(D.micro_batches(pattern, tok, mm, batch_size=3, model_max_length=64, epochs=4, seed=5))
+    assert len(full) == 8                                                  # 2 per epoch
+    for skip in (1, 2, 3, 5):                                              # inside epoch 0, at its end, in epoch 1, in epoch 2
+        rest = list(D.micro_batches(pattern, tok, mm, batch_size=3, model_max_length=64, epochs=4, seed=5, skip_micro_batches=skip))
+        assert len(rest) == len(full) - skip
+        for a, b in zip(rest, full[skip:]):
+            assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(a["labels"], b["labels"])

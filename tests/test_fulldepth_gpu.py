@@ -6,8 +6,9 @@ depth / width / batch with the CPU oracle's committed outputs:
   tests/golden/jukebox_full36.npz   <- tests/golden/make_jukebox_full_golden.py   (oracle/jukebox_ref.py + jukebox_ref.c)
   tests/golden/llama7b_full32.npz   <- tests/golden/make_llama7b_golden.py        (oracle/llama_ref.py, fp32)
 
-Bars (BASELINE.json): VQ codes exact; embeddings max|err| <= 1e-4 * max|acts| (configs[1]); logits max|err| <= 1e-3 *
-max|logits| (north_star); 64 greedy tokens equal (configs[2]).  Weights are regenerated from the CPU seeds of
+Bars (BASELINE.json): VQ codes exact; embeddings max-abs-err <= 1e-4 ABSOLUTE for the default precision f16x2 (configs[1],
+SURVEY 8(d); the opt-in lo8 mode only meets 1e-4 * max|acts| and says so); logits max|err| <= 1e-3 * max|logits|
+(north_star); 64 greedy tokens equal (configs[2]).  Weights are regenerated from the CPU seeds of
 tests/fulldepth.py on both sides.  The measured errors are printed (run with -s to see them).
 """
 import numpy as np
@@ -16,6 +17,7 @@ import torch
 
 import fulldepth as FD
 from conftest import report_close
+from llark_amd.jukebox.prior import DEFAULT_PRECISION
 
 pytestmark = pytest.mark.gpu
 
@@ -55,10 +57,22 @@ def test_jukebox_36_layers_batch8_vs_oracle(jb):
     assert np.array_equal(codes[row].cpu().numpy(), z["codes"].astype(np.int64)), "VQ codes differ from the oracle (36-layer fixture)"
     emb = enc(audio)
     assert emb.shape == (8, 240, hps.prior_width)
-    scale = float(z["acts_maxabs"])
-    err = report_close("36-layer B=8 embedding (240,4800) vs CPU oracle", emb[row].cpu(), z["emb_f10"], 1e-4 * scale)
-    print(f"\n[fulldepth] jukebox 36 layers x B=8 ({enc.top_prior.prior.precision}): embedding max|err| {err:.3e} = {err / scale:.2e} of max|acts| {scale:.2f} "
-          f"({err / np.abs(z['emb_f10']).max():.2e} of max|emb|)")
+    prec = enc.top_prior.prior.precision
+    ref = torch.from_numpy(z["emb_f10"]).double()
+    got = emb[row].cpu().double()
+    err = float((got - ref).abs().max())
+    acts_max, emb_max, emb_rms = float(z["acts_maxabs"]), float(ref.abs().max()), float(ref.pow(2).mean().sqrt())
+    # The error three ways: absolute, / max|emb|, / rms|emb| (and / max|un-pooled acts|, round 2's normaliser)
+    print(f"\n[fulldepth] jukebox 36 layers x B=8 ({prec}): embedding max|err| ABS {err:.3e} | / max|emb| {emb_max:.2f} = {err / emb_max:.2e} "
+          f"| / rms|emb| {emb_rms:.2f} = {err / emb_rms:.2e} | / max|acts| {acts_max:.2f} = {err / acts_max:.2e}")
+    if prec == "f16x2":
+        # the library default: BASELINE configs[1] / SURVEY 8(d) read literally -- max-abs-err <= 1e-4, no normaliser
+        assert DEFAULT_PRECISION == "f16x2"
+        assert err <= 1e-4, f"default precision: embedding max-abs-err {err:.3e} > 1e-4"
+    else:
+        # opt-in reduced-precision mode: meets the bar only relative to max|acts| (15-16 bit activations; 5.1e-4 absolute in round 2)
+        assert err <= 1e-4 * acts_max, f"lo8: embedding max|err| {err:.3e} > 1e-4 * max|acts| = {1e-4 * acts_max:.3e}"
+        assert err <= 1e-3, "lo8: error far above its measured level"
     # batch invariance: the same clip alone (B = 1) gives bit-identical codes and embedding
     one = torch.from_numpy(a0).cuda()[None]
     assert torch.equal(enc.vqvae.encode_top(one)[0], codes[row])
@@ -90,10 +104,12 @@ def test_jukebox_36_layers_error_growth_and_global_mean(jb):
             i = layers.index(d + 1)
             scale = float(z["maxabs"][i])
             err = report_close(f"probe rows after layer {d + 1}", h2[rows].cpu(), z["probes"][i], 1e-4 * scale)
-            report.append((d + 1, err / scale))
-    print(f"\n[fulldepth] prior error growth, {tp.prior.precision} (max|err| / max|h| at the probe rows): " + ", ".join(f"L{l}: {e:.2e}" for l, e in report))
+            report.append((d + 1, err, err / scale))
+    print(f"\n[fulldepth] prior error growth, {tp.prior.precision} (un-pooled probe rows: max|err| absolute, and / max|h|): "
+          + ", ".join(f"L{l}: {a:.2e} ({e:.2e})" for l, a, e in report))
     mean = ops.pool_mean(h2.contiguous()[None])[0]
-    report_close("36-layer global mean (f=0)", mean.cpu(), z["emb_f0"], 1e-4 * float(z["acts_maxabs"]))
+    strict = tp.prior.precision == "f16x2"        # default precision: absolute 1e-4 on the pooled outputs
+    report_close("36-layer global mean (f=0)", mean.cpu(), z["emb_f0"], 1e-4 if strict else 1e-4 * float(z["acts_maxabs"]))
 
 
 def test_jukebox_near_tie_audit_fixture():

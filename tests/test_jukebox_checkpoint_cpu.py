@@ -90,3 +90,21 @@ def test_default_paths_and_absent_files(tmp_path, monkeypatch):
         CK.load_checkpoint_weights("5b", hparams_tiny())
     with pytest.raises(ValueError):
         CK.default_checkpoint_paths("1b_lyrics")
+
+
+class _Unsafe:                       # a global the weights_only unpickler refuses (stands in for arbitrary pickled code)
+    def __init__(self):
+        self.x = 1
+
+
+def test_unsafe_pickle_is_opt_in(tmp_path, monkeypatch):
+    """a file the restricted loader rejects is not silently retried with the full unpickler."""
+    hps = hparams_tiny()
+    _, pr_ck, w = upstream_style_checkpoints(hps, ckpt_depth=hps.prior_depth, prefix="")
+    pr_ck = dict(pr_ck, hps=_Unsafe())
+    with pytest.raises(ValueError, match="allow_pickle"):
+        CK.read_pth_tar(_save(pr_ck))
+    sd = CK.read_pth_tar(_save(pr_ck), allow_pickle=True)
+    assert torch.equal(sd["prior.x_emb.weight"], w["prior.x_emb.weight"])
+    monkeypatch.setenv(CK.UNSAFE_PICKLE_ENV, "1")
+    assert "prior.x_emb.weight" in CK.read_pth_tar(_save(pr_ck))

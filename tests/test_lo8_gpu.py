@@ -56,19 +56,18 @@ def operands(m, n, k, seed=0, scale_a=1.0, scale_w=0.02):
     return a, hi, lo8, wt, sw, ref, exact, mag
 
 
-@pytest.mark.parametrize("staged", [True, False], ids=["w8-staged", "w8-in-registers"])
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640), (300, 4800, 1200),
                                    (4096, 512, 192), (700, 700, 448)])
-def test_gemm_lo8_matches_its_specification(m, n, k, staged):
+def test_gemm_lo8_matches_its_specification(m, n, k):
     a, hi, lo8, wt, sw, ref, exact, mag = operands(m, n, k, seed=m + n + k)
     bias = torch.randn(n, generator=torch.Generator().manual_seed(1))
     c = torch.full((m, n), float("nan"), device="cuda")
     wt_d = wt.cuda()
-    w8 = ops.pack_weight_lo8(wt_d, sw) if staged else None
-    if staged:      # the packed plane is the slot-ordered E4M3 rounding of W 2^sw
-        want8 = torch.zeros_like(wt, dtype=torch.uint8)
-        want8[:, slot_order(wt.shape[1])] = e4m3(wt.float() * 2.0 ** sw).view(torch.uint8)
-        assert torch.equal(w8.cpu(), want8)
+    w8 = ops.pack_weight_lo8(wt_d, sw)
+    # the packed plane is the slot-ordered E4M3 rounding of W 2^sw
+    want8 = torch.zeros_like(wt, dtype=torch.uint8)
+    want8[:, slot_order(wt.shape[1])] = e4m3(wt.float() * 2.0 ** sw).view(torch.uint8)
+    assert torch.equal(w8.cpu(), want8)
     ops.gemm16_lo8(hi.cuda(), lo8.cuda(), wt_d, sw, bias.cuda(), n, ops.EPI_F32, c=c, w8=w8)
     torch.cuda.synchronize()
     got = c.cpu().double()
@@ -95,11 +94,11 @@ def test_gemm_lo8_residual_and_repeat_launches_share_a_workspace():
     outs = []
     for it in range(6):
         h = h0.clone().cuda()
-        ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=h, resid=h, w8=w8 if it % 2 == 0 else None)
+        ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=h, resid=h, w8=w8)
         outs.append(h)
     torch.cuda.synchronize()
     for o in outs[1:]:
-        assert torch.equal(o, outs[0]), "staged and in-register forms (or repeated launches) differ"
+        assert torch.equal(o, outs[0]), "repeated launches sharing a workspace differ"
     err = (outs[0].cpu().double() - (h0.double() + ref)).abs()
     assert bool((err <= 3e-7 * mag + 3e-7 * h0.abs().double() + 1e-6).all()), f"max err {err.max():.3e}"
 
@@ -165,3 +164,23 @@ def test_prior_tiny_and_full_width_depth3_lo8():
     print(f"tiny prior (lo8) rel err {rel:.3e}")
     rel = TP._run_prior(TP.hparams_5b_depth(3), 3, 1, tap_tol=1e-4, precision="lo8")
     print(f"full-width prior, 3 layers (lo8) rel err {rel:.3e}")
+
+
+def test_gemm_lo8_row_chunks_when_the_a_plane_outgrows_32bit_offsets(monkeypatch):
+    """llark_gemm16_lo8 addresses A with 32-bit byte offsets (about 28 clips of the 5b prior); ops.gemm16_lo8 then
+    issues row ranges of whole tiles.  Forced here with a tiny limit: bit-identical to the single launch."""
+    assert ops.lo8_max_rows(4800, 4800) == ((1 << 31) - 1) // 9600 // 256 * 256 and ops.lo8_max_rows(4800, 4800) * 9600 < 1 << 31
+    m, n, k = 1000, 520, 448
+    a, hi, lo8, wt, sw, ref, exact, mag = operands(m, n, k, seed=77)
+    hi_d, lo_d, wt_d = hi.cuda(), lo8.cuda(), wt.cuda()
+    w8 = ops.pack_weight_lo8(wt_d, sw)
+    h0 = torch.randn(m, n, generator=torch.Generator().manual_seed(4)).cuda()
+    one = h0.clone()
+    ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=one, resid=one, w8=w8)
+    monkeypatch.setattr(ops, "lo8_max_rows", lambda lda, lda8: 256)
+    many = h0.clone()
+    ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=many, resid=many, w8=w8)
+    torch.cuda.synchronize()
+    assert torch.equal(one, many)
+    with pytest.raises(ValueError, match="w8"):
+        ops.gemm16_lo8(hi_d, lo_d, wt_d, sw, None, n, ops.EPI_RESID, c=many, resid=many)

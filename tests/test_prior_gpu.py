@@ -81,11 +81,15 @@ def test_gemm_tile_variants(variant):
     assert worst < 6e-7, worst
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640)])
-def test_gemm256_ring_tile_bit_identical(m, n, k):
-    """csrc/gemm256.hip (256x256x64 split tile, counted-vmcnt LDS-DMA ring, persistent chunk-synchronous walk) accumulates
-    every output element in the same order as the 128x256 LDS-staged kernel (k16 steps ascending, hi pass then lo pass):
-    the two must agree BIT FOR BIT on ragged M / N (row clamping, masked stores), 2 .. 75 K-steps (ring wrap, tail waits),
+@pytest.mark.parametrize("v256", [31, 30], ids=["v31-phases-over-N", "v30-M-split-ring"])
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 290, 200), (8192, 1200, 640),
+                                   (40000, 600, 448), (70000, 2500, 192)])
+def test_gemm256_ring_tile_bit_identical(m, n, k, v256):
+    """The 256x256x64 split tiles -- csrc/gemm256n.hip (variant 31, the default of the prior: phases over N, resident A fragments,
+    A ring of 7 quarter units, wave pairs half a phase apart) and csrc/gemm256.hip (variant 30: round 2's M-split LDS ring) --
+    accumulate every output element in the same order as the 128x256 LDS-staged kernel (k16 steps ascending, hi pass then lo
+    pass): they must agree BIT FOR BIT on ragged M / N (row clamping, masked stores), 2 .. 75 K-steps (ring wrap, tail waits;
+    3 and 7 K-steps walk the 7-slot ring through every residue), more tiles than CUs (tile-to-tile overlap, chunk barriers),
     every epilogue the prior uses, fp16 and bf16 -- and against an fp64 reference within the split scheme's bound."""
     from llark_amd import ops
     g = torch.Generator().manual_seed(m * 7 + n + k)
@@ -101,7 +105,7 @@ def test_gemm256_ring_tile_bit_identical(m, n, k):
         ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c0, variant=12)
         for rep in range(3):                                             # repeated launches: a race in the ring would come and go
             c1.fill_(float("nan"))
-            ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c1, variant=30)
+            ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c1, variant=v256)
             assert torch.equal(c0, c1), f"F32 {dt} rep {rep}: {int((c0 != c1).sum())} elements differ, max diff {(c0 - c1).abs().nan_to_num(1e9).max().item():.3e}"
         a16 = hi.float().cpu()[:, :k].double() + lo.float().cpu()[:, :k].double()
         w16 = wt.float().cpu()[:n, :k].double()
@@ -110,17 +114,17 @@ def test_gemm256_ring_tile_bit_identical(m, n, k):
         assert bool(((c1.cpu().double() - ref).abs() <= bound).all()), "gemm256 vs fp64 reference out of the split-scheme bound"
         c0, c1 = r.clone(), r.clone()
         ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c0, resid=c0, variant=12)
-        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c1, resid=c1, variant=30)
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c1, resid=c1, variant=v256)
         assert torch.equal(c0, c1), "RESID epilogue differs"
         o0 = [torch.zeros((m, n), dtype=dt, device="cuda") for _ in range(2)]
         o1 = [torch.zeros((m, n), dtype=dt, device="cuda") for _ in range(2)]
         ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o0[0], out_lo=o0[1], variant=12)
-        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o1[0], out_lo=o1[1], variant=30)
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o1[0], out_lo=o1[1], variant=v256)
         assert torch.equal(o0[0], o1[0]) and torch.equal(o0[1], o1[1]), "QGELU_SPLIT epilogue differs"
     # non-split operands are not this kernel's: variant 30 must fall back (and still be right), not fail
     c2 = torch.full((m, n), float("nan"), device="cuda")
     c3 = torch.full((m, n), float("nan"), device="cuda")
-    ops.gemm16(hi, None, wt, b, n, ops.EPI_F32, c=c2, variant=30)
+    ops.gemm16(hi, None, wt, b, n, ops.EPI_F32, c=c2, variant=v256)
     ops.gemm16(hi, None, wt, b, n, ops.EPI_F32, c=c3, variant=12)
     assert torch.equal(c2, c3)
 

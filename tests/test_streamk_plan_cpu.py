@@ -32,8 +32,20 @@ def test_shape_sweep(uniform):
     assert checked > 300
 
 
+def test_uniform_finisher_is_dispatched_last_under_the_xcd_remap():
+    """split gate_up at M in 129..256 gives T = 172 tiles, ks = 2, grid 344 (a multiple of 8, so the XCD remap is
+    active) -- with a slot-major block order the owner of tile 21 was block 1 and its contributor block 336."""
+    for m in (129, 200, 256):
+        p = sim.check(m, 22016, 4096, uniform=True)
+        assert p is not None and p["ks"] == 2 and p["grid"] % 8 == 0
+    p = sim.plan(200, 22016, 4096, uniform=True)
+    owner, contributor = 21 * 2 + 1, 21 * 2
+    blocks = {sim.slot_of_block(p, b): b for b in range(p["grid"])}
+    assert blocks[owner] > blocks[contributor]
+
+
 def test_scratch_is_large_enough():
-    # llark_gemm16_sk_scratch_bytes() = 2 x CUs x (128 KiB slab + 4-byte flag): one slab per resident workgroup of the 128x256 tile
+    # llark_gemm16_sk_scratch_bytes() = 2 x CUs x 128 KiB slab (one per resident workgroup of the 128x256 tile) + the fixed 64 KiB flag region
     for m, n, k in ((2968, 4096, 4096), (371, 4096, 11008), (2968, 22016, 4096), (371, 12288, 4096)):
         for uniform in (True, False):
             p = sim.plan(m, n, k, uniform=uniform)
