@@ -94,6 +94,29 @@ int llark_vqvae_plan_add_conv(void* plan, const float* wp, const float* bias, in
 int llark_vqvae_plan_add_resblock(void* plan, const float* w1p, const float* b1, const float* w2p, const float* b2, int width, int dil);
 int llark_vqvae_encode(void* plan, const float* audio, int n, int t, float* buf0, float* buf1, long long buf_elems,
                        const float* codebook, const float* kk, int bins, int64_t* codes, int* t_out, llark_stream_t stream);
+/* Fused stage of the level encoder on the 16-bit matrix cores (csrc/vqvae_fused.hip): one `down_t` step of upstream
+ * EncoderConvBlock -- Conv1d(cin -> 32, k = 4, stride 2, pad 1), `depth` ResConv1DBlocks (dilations dil[0 .. depth), a HOST array),
+ * optionally the block's output Conv1d(32 -> 64, k = 3, pad 1) -- in ONE launch, activations resident in LDS / registers, every
+ * product as three fp16 MFMA passes over hi / lo splits of BOTH operands (fp32-class; the cin = 1 convolution stays an exact fp32
+ * fmaf chain).  Replaces the same call site as llark_vqvae_encode (jukebox/main.py:61 -> VQVAE.encode); VQ codes equal the fp32
+ * path's on every fixture, activations agree to ~1e-6 relative instead of bit for bit (the exact per-layer kernels stay).
+ *   input : cin == 1: audio fp32 [n][tin];  cin == 32 / 64: planes in_hi / in_lo fp16 [n][tin][cin] (= a previous stage's output)
+ *   weights: w0_f32 (cin == 1) = llark_pack_conv_weight layout [4][1][32]; every other weight operand = the hi / lo outputs of
+ *            llark_vqvae_pack_frag16: w0 (32, cin, 4), wr = depth x [conv3 (32, 32, 3) | 1x1 (32, 32, 1) with perm1x1 = 1] concatenated
+ *            (8 k-steps of 1 KiB per block and plane), wo (64, 32, 3) or NULL;  b0 [32], br [depth][2][32] (b1, b2), bo [64]
+ *   output: planes out_hi / out_lo [n][tin/2][C] and / or out_f32 [n][C][tin/2], C = 64 with the output conv else 32.
+ *   wexp  : HOST array of 2 + 2 depth ints: the exp2 each weight tensor was packed with (strided conv; dilated conv, 1x1 per block;
+ *           output conv; 0 where a tensor is not fragment-packed).
+ * tin even; sum(dil) (+1 with the output conv) <= 48. */
+int llark_vqvae_stage_f16x2(const float* audio, const void* in_hi, const void* in_lo, int n, int cin, int tin, const float* w0_f32,
+                            const void* w0_hi, const void* w0_lo, const float* b0, const void* wr_hi, const void* wr_lo,
+                            const float* br, int depth, const int* dil, const void* wo_hi, const void* wo_lo, const float* bo,
+                            const int* wexp, void* out_hi, void* out_lo, float* out_f32, llark_stream_t stream);
+/* Conv1d.weight fp32 [cout][cin][k] (cout % 32 == 0, cin % 16 == 0) -> MFMA A fragments of w 2^exp2, fp16 hi / lo planes of
+ * (cout / 32) * (k * cin / 16) * 512 elements each; perm1x1 != 0 (k == 1, cin == 32): channels in accumulator-register order.
+ * exp2: choose max|w| 2^exp2 in [2^13, 2^14] so that the low plane is a normal fp16 (unscaled it is subnormal and the pair carries
+ * ~19 bits instead of 22). */
+int llark_vqvae_pack_frag16(const float* w, int cout, int cin, int k, int perm1x1, int exp2, void* hi, void* lo, llark_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Jukebox top prior, only_encode: replaces `top_prior.prior.forward(...)` at jukebox/main.py:108

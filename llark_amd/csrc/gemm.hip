@@ -393,30 +393,42 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
         __builtin_amdgcn_sched_barrier(0);
         const char* sA = smem + (kt & 1) * ASTAGE;
         const char* sL = sA + OFF_L;
+        // A fragments one k sub-step ahead (plain operands; the split form has no registers left for a second set): the reads of
+        // sub-step s + 1 are in flight while sub-step s multiplies, instead of every sub-step starting with an LDS round trip that
+        // only the other workgroups of the CU could cover.  Sub-step 0 follows the K-step's barrier and stays exposed.
+        constexpr int NAB = SPLIT ? 1 : 2;
+        frag ah[NAB][C::TM], al[NAB][C::TM];
+        auto ldA = [&](int buf, int s) __attribute__((always_inline)) {
+            const int c = s * 2 + (lane >> 5);
+#if GEMM_ABLATE == 13 || GEMM_ABLATE == 14
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" : "=v"(ah[buf][tm])); asm volatile("" : "=v"(al[buf][tm])); }
+#else
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                ah[buf][tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
+                if (SPLIT) al[buf][tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
+            }
+#endif
+        };
+        if (!SPLIT) ldA(0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #if GEMM_ABLATE != 11 && GEMM_ABLATE != 14
             loadB((s + 3) & 3, kt * 4 + s + 3);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const int c = s * 2 + (lane >> 5);
-            frag ah[C::TM], al[C::TM];
-#if GEMM_ABLATE == 13 || GEMM_ABLATE == 14
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" : "=v"(ah[tm])); asm volatile("" : "=v"(al[tm])); }
-#else
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) {
-                ah[tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
-                if (SPLIT) al[tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
-            }
-#endif
+            constexpr int dummy = 0;
+            const int cur = SPLIT ? 0 : (s & 1);
+            if (SPLIT) ldA(0, s);
+            else if (s < 3) ldA(cur ^ 1, s + 1);
+            if (!SPLIT) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn) {
-                    acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
-                    if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
+                    acc[tm][tn] = Mfma<T>::run(ah[cur][tm], ring[s][tn], acc[tm][tn]);
+                    if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[cur][tm], ring[s][tn], acc[tm][tn]);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -56,6 +56,14 @@ struct Cfg256NF {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// Instruction placement inside a phase (A/B builds; same arithmetic, same request order within a phase -- see phase()):
+//   0: every sub-step MFMA-first, fragment reads in its first gaps, requests behind them
+//   1: + after the half-phase barrier the first three MFMAs back to back, reads and requests behind them
+//   2: + the A ring's requests balanced over the two phases (Q0, Q1 in L; Q2, Q3 in R)
+#ifndef G256N_SCHED
+#define G256N_SCHED 0
+#endif
+
 // Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): per-wave cycle counters (issue / barrier per phase, epilogue per tile).
 #ifdef LLARK_LO8_PROF
 #define PROF_DECL long long pt0 = 0, pacc0 = 0, pacc1 = 0, pacc2 = 0
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
             // accumulator are four issue slots apart).  HALF = 0 (L) / 1 (R).  aslot / wslot: byte offsets of this wave's A quarter and
             // of the phase's W half.  issue(): the phase's first DMA requests (behind the MFMAs of sub-step 0); issue_mid(): the ones
             // that may only go out after the half-phase barrier.  MIDW: outstanding requests allowed at the half-phase wait.
-            auto phase = [&](auto half_tag, auto midw_tag, int aslot, int wslot, auto&& issue, auto&& issue_mid) __attribute__((always_inline)) {
+            auto phase = [&](auto half_tag, auto midw_tag, int aslot, int wslot, auto&& dmaop, auto&& midop) __attribute__((always_inline)) {
                 constexpr int half = decltype(half_tag)::value, midw = decltype(midw_tag)::value;
                 const int vA = rdA0 + aslot, vW = rdW0 + wslot;
                 auto rdA = [&](int sub) __attribute__((always_inline)) { return sub ? (opaque(vA) ^ (sub << 5)) : vA; };
@@ -220,36 +228,51 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
                     constexpr int s = decltype(sc)::value, cur = s & 1;
                     if constexpr (s == 2) {        // half-phase boundary: the other wave of the pair starts its next phase here
                         if constexpr (midw == 6) VMCNT(6);
+                        else if constexpr (midw == 4) VMCNT(4);
                         else if constexpr (midw == 2) VMCNT(2);
                         else VMCNT(0);
                         __builtin_amdgcn_s_barrier();
-                        issue_mid();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (s < 3) {         // fragments of sub-step s + 1
-                        if (half == 0) {
-                            ah[0][s + 1] = *(const frag*)(smem + rdA(s + 1));
-                            ah[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + 4096);
+                    // The eight MFMAs of the sub-step go FIRST after a barrier (their operands were read during the previous sub-step), and
+                    // everything else the wave has to issue -- the fragment reads of sub-step s + 1, the phase's DMA requests -- is SPREAD
+                    // one item per MFMA gap behind them: an in-order wave that meets a block of LDS-DMA instructions (60 .. 185 cycles of
+                    // issue each) or a burst of reads right after a barrier leaves the matrix pipe idle whenever its partner on the SIMD is
+                    // waiting for its own first fragments (profiles/r03_phase_cycles.txt: 2760 cycles per phase for 2048 of matrix work,
+                    // whatever the loop structure).  Gap g (after MFMA g + 1): L: 0 -> A hi, 1 -> W, 2 -> A lo of sub-step s + 1, then
+                    // requests; R: 0 -> W of sub-step s + 1, then requests.
+                    static_for<8>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value, tm = i & 1, tn = (i >> 1) & 1;
+                        if constexpr (i < 4) acc[tm][2 * half + tn] = Mfma<T>::run(ah[tm][s], bf[cur][tn], acc[tm][2 * half + tn]);
+                        else acc[tm][2 * half + tn] = Mfma<T>::run(al[tm][s], bf[cur][tn], acc[tm][2 * half + tn]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // first gap of the sub-step that carries a fragment read: right after a barrier (s == 2) the wave's first MFMAs go
+                        // out back to back (G256N_SCHED >= 1): its partner on the SIMD is waiting for its first fragments just then
+                        constexpr int r0 = (G256N_SCHED >= 1 && s == 2) ? 2 : 0;
+                        constexpr int nreads = half == 0 ? 3 : 1;
+                        constexpr int first_req = r0 + nreads;                              // first gap that carries a request
+                        if constexpr (s < 3) {
+                            if constexpr (half == 0 && i == r0) {
+                                ah[0][s + 1] = *(const frag*)(smem + rdA(s + 1));
+                                ah[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + 4096);
+                            }
+                            if constexpr (i == r0 + (half == 0 ? 1 : 0)) {
+                                bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1));
+                                bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + 4096);
+                            }
+                            if constexpr (half == 0 && i == r0 + 2) {
+                                al[0][s + 1] = *(const frag*)(smem + rdA(s + 1) + 8192);
+                                al[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + 8192 + 4096);
+                            }
                         }
-                        bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1));
-                        bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + 4096);
-                        if (half == 0) {
-                            al[0][s + 1] = *(const frag*)(smem + rdA(s + 1) + 8192);
-                            al[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + 8192 + 4096);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[0][2 * half] = Mfma<T>::run(ah[0][s], bf[cur][0], acc[0][2 * half]);
-                    acc[1][2 * half] = Mfma<T>::run(ah[1][s], bf[cur][0], acc[1][2 * half]);
-                    acc[0][2 * half + 1] = Mfma<T>::run(ah[0][s], bf[cur][1], acc[0][2 * half + 1]);
-                    acc[1][2 * half + 1] = Mfma<T>::run(ah[1][s], bf[cur][1], acc[1][2 * half + 1]);
-                    acc[0][2 * half] = Mfma<T>::run(al[0][s], bf[cur][0], acc[0][2 * half]);
-                    acc[1][2 * half] = Mfma<T>::run(al[1][s], bf[cur][0], acc[1][2 * half]);
-                    acc[0][2 * half + 1] = Mfma<T>::run(al[0][s], bf[cur][1], acc[0][2 * half + 1]);
-                    acc[1][2 * half + 1] = Mfma<T>::run(al[1][s], bf[cur][1], acc[1][2 * half + 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (s == 0) issue();                                          // this phase's first DMA requests
-                    __builtin_amdgcn_sched_barrier(0);
+                        // requests: NREQ behind sub-step 0 (from gap first_req on; what does not fit there goes behind sub-step 1, gaps 3..);
+                        // the two half-phase requests behind sub-step 2
+                        constexpr int nreq = G256N_SCHED >= 2 ? 4 : (half == 0 ? 6 : 2), fit0 = 8 - first_req < nreq ? 8 - first_req : nreq;
+                        if constexpr (s == 0 && i >= first_req && i - first_req < fit0) dmaop(std::integral_constant<int, i - first_req>{});
+                        if constexpr (s == 1 && i >= first_req && i - first_req < nreq - fit0) dmaop(std::integral_constant<int, i - first_req + fit0>{});
+                        if constexpr (s == 2 && i >= first_req && i - first_req < 2) midop(std::integral_constant<int, i - first_req>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 });
             };
 
@@ -278,19 +301,37 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
                 const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // W slots of WR(k), WL(k+1)
                 const int an = wrap7(aq + 4);                                                            // A slot of Q0(k+1)
                 const int amine = wrap7(aq + wm) * C::UNIT;
+                // single requests, so that phase() can place one per MFMA gap: L: 0,1 Q0 hi/lo  2,3 Q1  4,5 Q2; R: 0,1 Q3 hi/lo
+                auto reqQ = [&](int j, int lo_plane, int slot) __attribute__((always_inline)) {
+                    const unsigned vo = j == 0 ? voA[0] : j == 1 ? voA[1] : j == 2 ? voA[2] : voA[3];
+                    dma(lo_plane ? rAl : rAh, vo, kn << 7, C::O_A + slot * C::UNIT + wb + (lo_plane ? 8192 : 0));
+                };
+                auto reqW = [&](int right, int piece, int slot) __attribute__((always_inline)) {
+                    dma(rW, voW[2 * right + piece], kn << 7, C::O_W + slot * C::UNIT + piece * 8192 + wb);
+                };
+#if G256N_SCHED >= 2
+                // Q2(kn) requested in phase R next to Q3(kn) (its slot, Q3(k-1)'s, has been free since slot 4k-2; first read 4k+5 like Q3):
+                // four requests per phase instead of six and two.  Waits: La|Lb vmcnt(4), Ra|Rb vmcnt(4), end of R vmcnt(2).
+                phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, amine, wL * C::UNIT,
+                      [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(i >> 1, i & 1, wrap7(an + (i >> 1))); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(0, decltype(ic)::value, wN); });
+                PROF_ADD(pacc0);
+                __builtin_amdgcn_s_barrier();
+                PROF_ADD(pacc2);
+                phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, amine, wR * C::UNIT,
+                      [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(2 + (i >> 1), i & 1, wrap7(an + 2 + (i >> 1))); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(1, decltype(ic)::value, wL); });
+#else
                 phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{}, amine, wL * C::UNIT,
-                      [&]() __attribute__((always_inline)) {
-                          issue_Q(std::integral_constant<int, 0>{}, kn, an);
-                          issue_Q(std::integral_constant<int, 1>{}, kn, wrap7(an + 1));
-                          issue_Q(std::integral_constant<int, 2>{}, kn, wrap7(an + 2));
-                      },
-                      [&]() __attribute__((always_inline)) { issue_WL(kn, wN); });
+                      [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(i >> 1, i & 1, wrap7(an + (i >> 1))); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(0, decltype(ic)::value, wN); });
                 PROF_ADD(pacc0);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
                 phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, amine, wR * C::UNIT,
-                      [&]() __attribute__((always_inline)) { issue_Q(std::integral_constant<int, 3>{}, kn, wrap7(an + 3)); },
-                      [&]() __attribute__((always_inline)) { issue_WR(kn, wL); });
+                      [&](auto ic) __attribute__((always_inline)) { reqQ(3, decltype(ic)::value, wrap7(an + 3)); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(1, decltype(ic)::value, wL); });
+#endif
                 PROF_ADD(pacc0);
                 VMCNT(2);                                                  // Q3(kn) landed (newer: WR(kn) x2)
                 PROF_ADD(pacc1);

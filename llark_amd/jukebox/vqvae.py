@@ -19,12 +19,18 @@ from .hparams import JukeboxHParams
 class VQVAE:
     """Level-2 encoder + codebook of the Jukebox VQ-VAE, weights resident in HBM in kernel layout."""
 
-    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda"):
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", exact: bool = False):
+        """exact=False (default): the fused stage kernels on the 16-bit matrix cores (csrc/vqvae_fused.hip: one launch per
+        down-sampling step, activations resident in LDS, split-fp16 products -- fp32-class activations, VQ codes equal to the
+        oracle's).  exact=True: the per-layer fp32 kernels of csrc/vqvae.hip whose activations are BIT-equal to the defined-order C
+        oracle (oracle/jukebox_ref.c); ``encoder_forward(..., taps=)`` and ``encode_top(want_dist=True)`` always use them."""
         hps.check()
         self.hps = hps
         self.device = torch.device(device)
         self.sample_length = hps.sample_length
+        self.exact = bool(exact)
         self.layers: List[tuple] = []          # ("conv", wp, b, stride, pad) | ("res", w1p, b1, w2p, b2, dil)
+        self.stages: List[dict] = []           # fused path: one entry per down-sampling step (see _make_stage)
         dev = self.device
 
         def f32(name):
@@ -43,9 +49,76 @@ class VQVAE:
                                         hps.dilation_growth_rate ** r))
             b = f"{p}.level_blocks.{lb}.model.{down_t}"
             self.layers.append(("conv", ops.pack_conv_weight(f32(f"{b}.weight")), f32(f"{b}.bias"), 1, 1))
+            for i in range(down_t):
+                assert stride_t == 2, "the fused stage kernel is built for stride-2 down-sampling (Jukebox strides_t = (2, 2, 2))"
+                self.stages.append(self._make_stage(f32, f"{p}.level_blocks.{lb}.model", i, hps, out_conv=(i == down_t - 1),
+                                                    down_t=down_t))
         self._plan_handle = None
         self.set_codebook(weights["bottleneck.level_blocks.2.k"])
         self._bufs: Dict[tuple, torch.Tensor] = {}
+
+    @staticmethod
+    def _make_stage(f32, prefix: str, i: int, hps: JukeboxHParams, out_conv: bool, down_t: int) -> dict:
+        """Packed operands of one fused stage (csrc/vqvae_fused.hip): strided conv, `depth` residual blocks, optional output conv."""
+        b = f"{prefix}.{i}"
+        w0 = f32(f"{b}.0.weight")                                  # [32][cin][4]
+        cin = w0.shape[1]
+        st = dict(cin=cin, b0=f32(f"{b}.0.bias"), w0f=None, w0_hi=None, w0_lo=None, wo_hi=None, wo_lo=None, bo=None,
+                  dil=[hps.dilation_growth_rate ** r for r in range(hps.depth)])
+        wexp = [0]
+        if cin == 1:
+            st["w0f"] = ops.pack_conv_weight(w0)                  # [4][1][32]: exact fp32 fmaf chain on the VALU
+        else:
+            wexp[0] = ops.vqvae_weight_exponent(w0)
+            st["w0_hi"], st["w0_lo"] = ops.vqvae_pack_frag16(w0, exp2=wexp[0])
+        hi, lo, br = [], [], []
+        for r in range(hps.depth):
+            rb = f"{b}.1.model.{r}.model"
+            w3, w1 = f32(f"{rb}.1.weight"), f32(f"{rb}.3.weight")
+            e3, e1 = ops.vqvae_weight_exponent(w3), ops.vqvae_weight_exponent(w1)
+            h3, l3 = ops.vqvae_pack_frag16(w3, exp2=e3)                            # dilated k = 3 conv: 6 k-steps
+            h1, l1 = ops.vqvae_pack_frag16(w1, perm1x1=True, exp2=e1)              # 1x1 conv in accumulator-register channel order
+            hi += [h3, h1]
+            lo += [l3, l1]
+            br += [f32(f"{rb}.1.bias"), f32(f"{rb}.3.bias")]
+            wexp += [e3, e1]
+        st["wr_hi"], st["wr_lo"], st["br"] = torch.cat(hi).contiguous(), torch.cat(lo).contiguous(), torch.cat(br).contiguous()
+        wexp.append(0)
+        if out_conv:
+            wo = f32(f"{prefix}.{down_t}.weight")                  # [64][32][3]
+            wexp[-1] = ops.vqvae_weight_exponent(wo)
+            st["wo_hi"], st["wo_lo"] = ops.vqvae_pack_frag16(wo, exp2=wexp[-1])
+            st["bo"] = f32(f"{prefix}.{down_t}.bias")
+        st["wexp"] = wexp
+        return st
+
+    def _planes(self, slot: int, numel: int):
+        """Ping-pong (hi, lo) fp16 plane buffers of the fused path."""
+        key = ("planes", slot)
+        cur = self._bufs.get(key)
+        if cur is None or cur[0].numel() < numel:
+            cur = (torch.empty((numel,), dtype=torch.float16, device=self.device), torch.empty((numel,), dtype=torch.float16, device=self.device))
+            self._bufs[key] = cur
+        return cur
+
+    def encoder_forward_fused(self, audio: torch.Tensor) -> torch.Tensor:
+        """audio (N, T) fp32 on device -> (N, emb_width, T / raw_to_tokens) fp32, one launch per down-sampling step."""
+        n, t = audio.shape
+        x, cin, slot = audio.contiguous(), 1, 0
+        out = None
+        for si, st in enumerate(self.stages):
+            assert st["cin"] == cin, f"stage {si}: expects {st['cin']} input channels, has {cin}"
+            c = 64 if st["wo_hi"] is not None else 32
+            last = si + 1 == len(self.stages)
+            if last:
+                out = torch.empty((n, c, t // 2), dtype=torch.float32, device=self.device)
+                ops.vqvae_stage(x, n, cin, t, st, out_f32=out)
+            else:
+                planes = self._planes(slot, n * (t // 2) * c)
+                ops.vqvae_stage(x, n, cin, t, st, out_planes=planes)
+                x, slot = planes, slot ^ 1
+            cin, t = c, t // 2
+        return out
 
     def set_codebook(self, k: torch.Tensor) -> None:
         self.k = k.detach().to(device=self.device, dtype=torch.float32).contiguous()
@@ -117,18 +190,25 @@ class VQVAE:
         (`llark_vqvae_encode`): the ~40 short launches are issued without returning to Python in between."""
         assert audio.dim() == 2 and audio.shape[1] == self.sample_length, (
             f"expected (N,{self.sample_length}) audio, got {tuple(audio.shape)}")
-        if want_dist:                                          # per-layer path: also returns the distances
+        if want_dist:                                          # per-layer exact path: also returns the distances
             xe = self.encoder_forward(audio.contiguous().view(audio.shape[0], 1, -1))
             return ops.codebook_argmin(xe, self.k, self.kk, want_dist=want_dist)
         n = audio.shape[0]
         audio = audio.contiguous()
+        if not self.exact:
+            # one HIP-event pair around the whole stack when bench.py times kernels: work = ALGORITHMIC bytes of the stack
+            with ops._timed("vqvae_encode", float(self.algorithmic_bytes(n))):
+                xe = self.encoder_forward_fused(audio)
+                codes = ops.codebook_argmin(xe, self.k, self.kk)
+            if codes.shape[1] != self.hps.n_ctx:
+                raise ops._lib.LlarkHipError(f"vqvae_encode produced {codes.shape[1]} tokens per clip, hparams say {self.hps.n_ctx}")
+            return codes
         widest = n * max(layer[1].shape[2] for layer in self.layers) * (self.sample_length // 2 + 1)
         b0, b1 = self._buf(0, (widest,)), self._buf(1, (widest,))
         codes = torch.empty((n, self.hps.n_ctx), dtype=torch.int64, device=self.device)
         import ctypes
 
         t_out = ctypes.c_int(0)
-        # one HIP-event pair around the whole layer list when bench.py times kernels: work = ALGORITHMIC bytes of the stack
         with ops._timed("vqvae_encode", float(self.algorithmic_bytes(n))):
             ops.check(ops._lib.lib().llark_vqvae_encode(self._plan(), ops._dev(audio, "audio", torch.float32), n, self.sample_length,
                                                         b0.data_ptr(), b1.data_ptr(), widest, ops._dev(self.k, "k", torch.float32),

@@ -206,6 +206,61 @@ def resblock(x: torch.Tensor, w1p, b1, w2p, b2, dil: int, out: Optional[torch.Te
     return out
 
 
+def vqvae_weight_exponent(w: torch.Tensor) -> int:
+    """exp2 with max|w| * 2^exp2 in (2^13, 2^14]: the power-of-two scale a weight tensor is fragment-packed with so that its
+    fp16 low plane stays in the normal range (csrc/vqvae_fused.hip)."""
+    import math
+
+    amax = float(w.detach().abs().max().float())
+    if not (amax > 0.0) or amax != amax:
+        return 0
+    return max(-40, min(40, 14 - math.ceil(math.log2(amax))))
+
+
+def vqvae_pack_frag16(w: torch.Tensor, perm1x1: bool = False, exp2: int = 0):
+    """torch Conv1d.weight fp32 [cout][cin][k] -> (hi, lo) fp16 MFMA A fragments of w 2^exp2 for llark_vqvae_stage_f16x2
+    (include/llark_hip.h: llark_vqvae_pack_frag16)."""
+    cout, cin, k = w.shape
+    assert cout % 32 == 0 and cin % 16 == 0
+    numel = (cout // 32) * (k * cin // 16) * 512
+    hi = torch.empty((numel,), dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    check(_lib.lib().llark_vqvae_pack_frag16(_dev(w, "w", torch.float32), cout, cin, k, int(perm1x1), int(exp2), _dev(hi, "hi"), _dev(lo, "lo"),
+                                             _stream()), "vqvae_pack_frag16")
+    return hi, lo
+
+
+def vqvae_stage(x, n: int, cin: int, tin: int, st: dict, out_planes=None, out_f32: Optional[torch.Tensor] = None) -> None:
+    """One fused stage of the level encoder (include/llark_hip.h: llark_vqvae_stage_f16x2).  x: audio fp32 (n, tin) when cin == 1,
+    else the (hi, lo) fp16 planes [n][tin][cin] of the previous stage; st: the stage's packed weights (jukebox/vqvae.py)."""
+    import ctypes
+
+    if cin == 1:
+        audio, in_hi, in_lo = _dev(x, "audio", torch.float32), None, None
+        assert x.numel() >= n * tin
+    else:
+        audio, in_hi, in_lo = None, _dev(x[0], "in_hi", torch.float16), _dev(x[1], "in_lo", torch.float16)
+        assert x[0].numel() >= n * tin * cin and x[1].numel() >= n * tin * cin
+    c = 64 if st["wo_hi"] is not None else 32
+    need = n * (tin // 2) * c
+    if out_planes is not None:
+        assert out_planes[0].numel() >= need and out_planes[1].numel() >= need
+    if out_f32 is not None:
+        assert out_f32.numel() >= need
+    dil = (ctypes.c_int * len(st["dil"]))(*st["dil"])
+    wexp = (ctypes.c_int * len(st["wexp"]))(*st["wexp"])
+    assert len(st["wexp"]) == 2 + 2 * len(st["dil"])
+    opt = lambda t, name, dt: _dev(t, name, dt) if t is not None else None      # noqa: E731
+    check(_lib.lib().llark_vqvae_stage_f16x2(
+        audio, in_hi, in_lo, n, cin, tin, opt(st["w0f"], "w0f", torch.float32), opt(st["w0_hi"], "w0_hi", torch.float16),
+        opt(st["w0_lo"], "w0_lo", torch.float16), _dev(st["b0"], "b0", torch.float32), _dev(st["wr_hi"], "wr_hi", torch.float16),
+        _dev(st["wr_lo"], "wr_lo", torch.float16), _dev(st["br"], "br", torch.float32), len(st["dil"]),
+        ctypes.cast(dil, ctypes.c_void_p), opt(st["wo_hi"], "wo_hi", torch.float16), opt(st["wo_lo"], "wo_lo", torch.float16),
+        opt(st["bo"], "bo", torch.float32), ctypes.cast(wexp, ctypes.c_void_p), out_planes[0].data_ptr() if out_planes is not None else None,
+        out_planes[1].data_ptr() if out_planes is not None else None, out_f32.data_ptr() if out_f32 is not None else None, _stream()),
+        "vqvae_stage")
+
+
 def codebook_norms(k: torch.Tensor) -> torch.Tensor:
     bins, emb = k.shape
     kk = torch.empty((bins,), dtype=torch.float32, device=k.device)

@@ -1,0 +1,41 @@
+#!/bin/bash
+# round 3, GPU run 2: evidence for the two-pass 256x256 tile (variant 31): per-phase cycle profile (profiling build), PMC passes
+# (separate passes, --kernel-trace only), and the new 7B-width training-gradient parity test
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03_pmc
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+( timeout 600 python -m pytest tests/test_train_gpu.py -x -q -s -k "7b_width" 2>&1 | tail -8 ) > gpurun_out/r03_train7b_test.txt; cat gpurun_out/r03_train7b_test.txt
+for k in f16x2n f16x2 lo8; do
+  LLARK_HIP_LIB=$R/llark_amd/libllark_hip_lo8prof.so timeout 300 python scripts/prof_lo8.py $k 2>&1 | grep -v amdgpu.ids
+done > gpurun_out/r03_phase_cycles.txt; cat gpurun_out/r03_phase_cycles.txt
+cd /tmp
+for c in FETCH_SIZE "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_LDS"; do
+  n=$(echo $c | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$n -o a -- python $R/scripts/bench_gemm256.py 31 > $O/$n.log 2>&1; echo "pmc $n exit $?"
+done
+cd $R
+python - <<'PY' | tee gpurun_out/r03_pmc/summary.txt
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/r03_pmc/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(f)):
+        if "gemm256" not in row["Kernel_Name"]:
+            continue
+        k = row["Kernel_Name"][:70] + "|grid" + row["Grid_Size"]
+        agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, cs in agg.items():
+        print(k, {c: (len(v), round(sum(v) / len(v))) for c, v in cs.items()})
+PY
+python - <<'PY' | tee gpurun_out/r03_pmc/kernel_times.txt
+import csv, glob, collections
+for f in sorted(glob.glob("gpurun_out/r03_pmc/GRBM*/**/*kernel_trace.csv", recursive=True)):
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "gemm256" in row["Kernel_Name"]:
+            agg[row["Kernel_Name"][:70]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    for k, v in agg.items():
+        print(k, len(v), "launches, avg ms", round(sum(v) / len(v), 4))
+PY
+rm -rf $O/*/

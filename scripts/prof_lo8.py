@@ -14,7 +14,9 @@ from llark_amd import ops  # noqa: E402
 
 M = 65536
 g = torch.Generator(device="cuda").manual_seed(0)
-KERNEL = sys.argv[1] if len(sys.argv) > 1 else "lo8"      # "lo8" (gemm256_lo8.hip), "lo8s" (gemm256_lo8s.hip) or "f16x2" (gemm256.hip, variant 30)
+KERNEL = sys.argv[1] if len(sys.argv) > 1 else "f16x2n"   # "lo8" (gemm256_lo8n.hip), "f16x2" (gemm256.hip, variant 30) or "f16x2n" (gemm256n.hip, variant 31)
+F16 = KERNEL in ("f16x2", "f16x2n")
+VAR = 31 if KERNEL == "f16x2n" else 30
 for name, n, k, epi in [("qkv_f32", 3600, 4800, ops.EPI_F32), ("fc_qgelu", 4800, 4800, ops.EPI_QGELU_SPLIT8), ("proj_resid", 4800, 1216, ops.EPI_RESID)]:
     hi = torch.randn(M, k, generator=g, device="cuda").half()
     lo8 = torch.randint(0, 120, (M, k), device="cuda", dtype=torch.uint8)
@@ -23,19 +25,19 @@ for name, n, k, epi in [("qkv_f32", 3600, 4800, ops.EPI_F32), ("fc_qgelu", 4800,
     ohi = torch.zeros(M, 4800, dtype=torch.float16, device="cuda")
     olo = torch.zeros(M, 4800, dtype=torch.uint8, device="cuda")
     sw = ops.lo8_weight_exponent(wt)
-    w8 = ops.pack_weight_lo8(wt, sw) if KERNEL == "lo8s" else None
+    w8 = ops.pack_weight_lo8(wt, sw)
 
-    lo16 = (torch.randn(M, k, generator=g, device="cuda") * 1e-3).half() if KERNEL == "f16x2" else None
-    olo16 = torch.zeros(M, 4800, dtype=torch.float16, device="cuda") if KERNEL == "f16x2" else None
+    lo16 = (torch.randn(M, k, generator=g, device="cuda") * 1e-3).half() if F16 else None
+    olo16 = torch.zeros(M, 4800, dtype=torch.float16, device="cuda") if F16 else None
 
     def run():
-        if KERNEL == "f16x2":
+        if F16:
             if epi == ops.EPI_QGELU_SPLIT8:
-                ops.gemm16(hi, lo16, wt, None, n, ops.EPI_QGELU_SPLIT, out_hi=ohi, out_lo=olo16, variant=30)
+                ops.gemm16(hi, lo16, wt, None, n, ops.EPI_QGELU_SPLIT, out_hi=ohi, out_lo=olo16, variant=VAR)
             elif epi == ops.EPI_RESID:
-                ops.gemm16(hi, lo16, wt, None, n, epi, c=c, resid=c, variant=30)
+                ops.gemm16(hi, lo16, wt, None, n, epi, c=c, resid=c, variant=VAR)
             else:
-                ops.gemm16(hi, lo16, wt, None, n, epi, c=c, variant=30)
+                ops.gemm16(hi, lo16, wt, None, n, epi, c=c, variant=VAR)
             return
         if epi == ops.EPI_QGELU_SPLIT8:
             ops.gemm16_lo8(hi, lo8, wt, sw, None, n, epi, out_hi=ohi, out_lo8=olo, w8=w8)

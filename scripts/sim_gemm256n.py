@@ -56,11 +56,12 @@ def program(nk, variant="ok"):
         for j in range(4):
             cur.append(("read",) + q(j, k, aq) + (readers[j],))
         cur.append(("read", f"W{wl}", ("WL", k), "both"))
-        for j in range(3 if variant != "q3_early" else 4):
+        nl = 4 if variant == "q3_early" else (2 if variant == "sched2" else 3)      # A quarters requested in phase L
+        for j in range(nl):
             cur.append(("req",) + q(j, kn, an) + (2,))
         if variant == "wr_early" and k > 0:
             pass
-        cur.append(("wait", 6 if variant != "q3_early" else 8))
+        cur.append(("wait", 8 if variant == "q3_early" else (4 if variant == "sched2" else 6)))
         barrier()
         # Lb(k): WL(kn) right after the barrier; fragments of sub-step 3 of A(k), WL(k)
         cur.append(("req", f"W{wn}", ("WL", kn), 2))
@@ -70,11 +71,13 @@ def program(nk, variant="ok"):
         barrier()
         # Ra(k): WR(k); request Q3(kn) behind sub-step 0; wait vmcnt(2) before the barrier
         cur.append(("read", f"W{wr}", ("WR", k), "both"))
+        if variant == "sched2":
+            cur.append(("req",) + q(2, kn, an) + (2,))
         if variant != "q3_early":
             cur.append(("req",) + q(3, kn, an) + (2,))
         if variant == "wr_early":
             cur.append(("req", f"W{wl}", ("WR", kn), 2))
-        cur.append(("wait", 2 if variant not in ("q3_early",) else 0))
+        cur.append(("wait", 0 if variant == "q3_early" else (4 if variant == "sched2" else 2)))
         barrier()
         # Rb(k): WR(kn) right after the barrier; WR(k); wait vmcnt(2) before the barrier that ends the phase
         if variant != "wr_early":
@@ -126,7 +129,7 @@ def check(nk, variant="ok"):
 
 if __name__ == "__main__":
     for nk in (2, 3, 4, 7, 8, 19, 75):
-        print(f"nk={nk}: {check(nk)} reads checked, protocol ok")
+        print(f"nk={nk}: {check(nk)} reads checked, protocol ok; G256N_SCHED=2 (Q2 requested in phase R): {check(nk, 'sched2')} reads ok")
     for bad in ("q3_early", "no_end_wait", "ring6", "wr_early"):
         try:
             check(9, bad)

@@ -365,3 +365,67 @@ def test_train_cli_end_to_end(tmp_path):
     assert full["model.embed_tokens.weight"].shape[0] == len(vocab) + 1 + 3          # + [PAD] + the three audio tokens
     T.main([("4" if a == "3" else a) for a in argv])                     # --max_steps 4: resumes from checkpoint-3, one more step
     assert os.path.basename(CK.latest_checkpoint(str(out))) == "checkpoint-4"
+
+
+def test_grads_at_7b_width_vs_autograd_fixture():
+    """parity of the training step AT THE WIDTH IT IS BENCHMARKED -- hidden 4096, 32 heads x 128, intermediate
+    11008, vocab 32004, S = 1024, two decoder layers -- against torch autograd over the fp32 CPU oracle in the bf16 flow
+    (tests/golden/train7b_grads.npz <- tests/golden/make_train7b_golden.py; weights regenerated from the same seed on both sides).
+    Per gradient tensor the fixture holds the Frobenius norm, all row sums, all column sums and a fixed 64 x 64 sample of entries
+    (1-D gradients and the two trainable embedding rows whole); each must match like the small-width test's whole tensors:
+    relative error <= 3e-2, cosine >= 0.999."""
+    import importlib.util
+
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sp = importlib.util.spec_from_file_location("make_train7b_golden", os.path.join(here, "golden", "make_train7b_golden.py"))
+    G = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(G)
+    z = np.load(G.NPZ)
+    spec, w, ids, labels, aud = G.train7b_setup()
+    assert int(z["seq"]) == ids.shape[1] and int(z["layers"]) == spec.num_hidden_layers
+    dims = LlamaDims(num_hidden_layers=spec.num_hidden_layers, vocab_size=spec.vocab_size)
+    assert (dims.hidden_size, dims.intermediate_size, dims.num_attention_heads) == (4096, 11008, 32)
+    eng = HipLlamaEngine(dims, "cuda", 1, ids.shape[1], precision="bf16")
+    eng.load_state_dict(w)
+    del w
+    tr = HipLlamaTrainer(eng, embed_grad_tokens=(spec.audio_start_token, spec.audio_end_token))
+    segs = [(0, int((ids[0] == spec.audio_start_token).nonzero()[0, 0]), aud[0].cuda())]
+    loss = tr.forward_backward(ids.cuda(), segs, labels.cuda()).item()
+    ref_loss = float(z["loss"])
+    assert abs(loss - ref_loss) <= 5e-3 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    got = tr.export_grads_hf()
+
+    def close(what, a, b):
+        a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+        rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        assert np.isfinite(rel) and rel <= 3e-2 and cos >= 0.999, f"{what}: rel {rel:.3e} cos {cos:.5f}"
+        return rel
+
+    worst, checked = {}, 0
+    for name, gh in got.items():
+        gh = gh.float().cpu()
+        if name == "model.embed_tokens.weight":
+            rows = [spec.audio_start_token, spec.audio_end_token]
+            mask = torch.ones(gh.shape[0], dtype=torch.bool)
+            mask[rows] = False
+            assert gh[mask].abs().max().item() == 0.0
+            worst[name] = close(name, gh[rows], z[name + "|rows"])
+        elif gh.dim() == 1:
+            worst[name] = close(name, gh, z[name + "|full"])
+        else:
+            r, c = G.sample_index(gh.shape)
+            rels = [close(name + " sample", gh[r][:, c], z[name + "|sample"]),
+                    close(name + " row sums", gh.double().sum(1), z[name + "|rowsum"]),
+                    close(name + " column sums", gh.double().sum(0), z[name + "|colsum"])]
+            nrm = float(gh.double().norm())
+            assert abs(nrm - float(z[name + "|norm"])) <= 3e-2 * float(z[name + "|norm"]), f"{name}: norm {nrm} vs {float(z[name + '|norm'])}"
+            worst[name] = max(rels)
+        checked += 1
+    assert checked == 9 * spec.num_hidden_layers + 4 and "lm_head.weight" not in got
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(f"\n[train7b] loss {loss:.5f} (oracle {ref_loss:.5f}); worst gradient errors at 7B width, S = {ids.shape[1]}: "
+          + ", ".join(f"{k.replace('model.', '')} {v:.2e}" for k, v in top))

@@ -123,3 +123,76 @@ def test_full_size_clip_exact():
     assert np.array_equal(codes.cpu().numpy(), ref), f"{(codes.cpu().numpy() != ref).sum()} / {ref.size} code mismatches"
     assert np.array_equal(dist.cpu().numpy(), ref_d)
     assert len(np.unique(ref)) > 200
+
+
+def test_fused_stage_weight_fragments():
+    """llark_vqvae_pack_frag16: MFMA A fragments (hi / lo fp16) of a Conv1d weight, checked element by element against the layout
+    the header states, including the accumulator-register channel order of the block's 1x1 convolution."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for cout, cin, k, perm, e in ((32, 32, 3, False, 0), (32, 64, 4, False, 9), (64, 32, 3, False, -2), (32, 32, 1, True, 13)):
+        w = torch.randn(cout, cin, k, generator=g) * 0.3
+        hi, lo = ops.vqvae_pack_frag16(w.cuda(), perm1x1=perm, exp2=e)
+        assert 2.0 ** 13 < float(w.abs().max()) * 2.0 ** ops.vqvae_weight_exponent(w) <= 2.0 ** 14
+        w = w * 2.0 ** e                                               # the planes hold w 2^exp2 (power of two: exact)
+        nks = k * cin // 16
+        hi, lo = hi.cpu().view(cout // 32, nks, 64, 8), lo.cpu().view(cout // 32, nks, 64, 8)
+        want = torch.empty(cout // 32, nks, 64, 8)
+        for hb in range(cout // 32):
+            for q in range(nks):
+                tap, s = divmod(q, cin // 16)
+                for lane in range(64):
+                    co, gg = hb * 32 + (lane & 31), lane >> 5
+                    for j in range(8):
+                        c = 16 * s + (j & 3) + 8 * (j >> 2) + 4 * gg if perm else 16 * s + 8 * gg + j
+                        want[hb, q, lane, j] = w[co, c, tap]
+        assert torch.equal(hi.float(), want.half().float())
+        assert torch.equal(lo.float(), (want - want.half().float()).half().float())
+
+
+def test_fused_encoder_matches_exact_path(tiny_model):
+    """The default encoder (csrc/vqvae_fused.hip: one launch per down-sampling step, split-fp16 MFMA products, activations in
+    LDS / registers) against the per-layer fp32 path that is bit-equal to the C oracle: activations fp32-class (printed), VQ
+    codes EQUAL -- for a batch, for a single clip (other window sizes) and for silence."""
+    from oracle import jukebox_c as C
+    hps, w, vq = tiny_model
+    assert vq.exact is False and len(vq.stages) == sum(hps.downs_t)
+    audio = np.stack([_clip(hps, i, 1.6) for i in range(3)])
+    a = torch.from_numpy(audio).cuda()
+    fused = vq.encoder_forward_fused(a)
+    exact = vq.encoder_forward(a[:, None, :])
+    assert fused.shape == exact.shape == (3, hps.emb_width, hps.n_ctx)
+    scale = float(exact.abs().max())
+    err = float((fused - exact).abs().max())
+    print(f"\n[vqvae fused] tiny: max|fused - exact| {err:.3e} = {err / scale:.2e} of max|x| {scale:.3f}")
+    assert err <= 2e-5 * scale, f"fused encoder output differs from the fp32 path by {err:.3e} ({err / scale:.2e} of max)"
+    ref_codes = C.encode_codes(w, audio, hps)
+    assert np.array_equal(vq.encode_top(a).cpu().numpy(), ref_codes)
+    assert np.array_equal(vq.encode_top(a[1:2]).cpu().numpy(), ref_codes[1:2])
+    one = vq.encoder_forward_fused(a[2:3])
+    assert torch.equal(one[0], fused[2]), "a clip's encoding depends on the batch it rides in"
+
+
+def test_fused_encoder_full_size_clip_codes():
+    """BASELINE config size through the fused path: 8192 codes equal the C oracle's; the activation difference to the exact fp32
+    path is orders of magnitude below the smallest best / second-best codebook gap of the clip."""
+    from llark_amd.jukebox.vqvae import VQVAE
+    from oracle import jukebox_c as C
+    hps = hparams_5b()
+    w = make_vqvae_weights(hps, 0)
+    calib = C.encoder_forward(w, _clip(hps, 100, 25.0)[None], hps)
+    w["bottleneck.level_blocks.2.k"] = init_codebook_from_encodings(torch.from_numpy(calib), hps.l_bins)
+    vq = VQVAE(hps, w, "cuda")
+    audio = np.stack([_clip(hps, 0, 25.0), _clip(hps, 7, 25.0)])
+    a = torch.from_numpy(audio).cuda()
+    codes = vq.encode_top(a).cpu().numpy()
+    ref, _, ref_d = C.encode_codes(w, audio[:1], hps, return_all=True)
+    assert np.array_equal(codes[:1], ref), f"{(codes[:1] != ref).sum()} / {ref.size} code mismatches"
+    fused = vq.encoder_forward_fused(a[:1])
+    exact = vq.encoder_forward(a[:1, None, :])
+    scale, err = float(exact.abs().max()), float((fused - exact).abs().max())
+    _, dist = vq.encode_top(a[:1], want_dist=True)
+    print(f"\n[vqvae fused] full-size clip: max|fused - exact| {err:.3e} = {err / scale:.2e} of max|x| {scale:.3f}")
+    assert err <= 2e-5 * scale
+    exact_codes = VQVAE(hps, w, "cuda", exact=True).encode_top(a)
+    assert np.array_equal(exact_codes.cpu().numpy(), codes)
