@@ -60,8 +60,14 @@ struct Cfg256NF {
 //   0: every sub-step MFMA-first, fragment reads in its first gaps, requests behind them
 //   1: + after the half-phase barrier the first three MFMAs back to back, reads and requests behind them
 //   2: + the A ring's requests balanced over the two phases (Q0, Q1 in L; Q2, Q3 in R)
+//   3: like 2, fragment-read offsets of the four sub-steps computed once per phase      4: like 2, s_setprio 1 for waves 4..7
+// Measured (profiles/r03_gemm256n_sched.txt): 0 = 1 = 2 within 0.3 % on all four shapes.
 #ifndef G256N_SCHED
-#define G256N_SCHED 0
+#define G256N_SCHED 3
+#endif
+
+#ifndef G256N_SYNC_MIN_NK
+#define G256N_SYNC_MIN_NK 0
 #endif
 
 // Profiling build only (-DLLARK_LO8_PROF, scripts/build_lo8_prof.sh): per-wave cycle counters (issue / barrier per phase, epilogue per tile).
@@ -210,8 +216,17 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
             auto phase = [&](auto half_tag, auto midw_tag, int aslot, int wslot, auto&& dmaop, auto&& midop) __attribute__((always_inline)) {
                 constexpr int half = decltype(half_tag)::value, midw = decltype(midw_tag)::value;
                 const int vA = rdA0 + aslot, vW = rdW0 + wslot;
+#if G256N_SCHED == 3
+                // the four sub-step offsets of each operand computed ONCE per phase (6 VALU) instead of re-derived in front of every
+                // read (2 VALU x 24 reads): this kernel has the registers for it (239 of 256), gemm256_lo8n.hip did not
+                const int vAs[4] = {vA, opaque(vA) ^ 32, opaque(vA) ^ 64, opaque(vA) ^ 96};
+                const int vWs[4] = {vW, opaque(vW) ^ 32, opaque(vW) ^ 64, opaque(vW) ^ 96};
+                auto rdA = [&](int sub) __attribute__((always_inline)) { return vAs[sub]; };
+                auto rdW = [&](int sub) __attribute__((always_inline)) { return vWs[sub]; };
+#else
                 auto rdA = [&](int sub) __attribute__((always_inline)) { return sub ? (opaque(vA) ^ (sub << 5)) : vA; };
                 auto rdW = [&](int sub) __attribute__((always_inline)) { return sub ? (opaque(vW) ^ (sub << 5)) : vW; };
+#endif
                 frag bf[2][2];                     // [buffer][column tile]
                 if (half == 0) {
                     ah[0][0] = *(const frag*)(smem + rdA(0));
@@ -340,6 +355,9 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
             };
 
             PROF_T0();
+#if G256N_SCHED == 4
+            if (w >= 4) __builtin_amdgcn_s_setprio(1);                     // static priority for the later-dispatched half (guide: +0.8 .. 1.5 %)
+#endif
             if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
             {
                 int aq = 0, wL = 0;
@@ -381,7 +399,9 @@ __global__ __launch_bounds__(Cfg256NF::THREADS, Cfg256NF::MINW) void gemm256n_ke
                 if (!arrived) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int target = p.sync_base + (ch + 1) * p.slots;
                 // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
-                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
+                // (G256N_SYNC_MIN_NK: A/B builds that let short-K products, whose residual epilogue is a quarter of the tile time,
+                //  drift apart instead; the arrival above is still counted, so the host's running base stays right)
+                for (int it = 0; nk >= G256N_SYNC_MIN_NK && it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
                     __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_s_barrier();                                  // raw: a fence here would drain the next tile's prologue requests

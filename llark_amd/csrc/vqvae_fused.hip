@@ -32,7 +32,6 @@ namespace llark {
 
 constexpr int VF_ROW = 144;            // LDS bytes per position
 constexpr int VF_HALO = 48;            // positions of halo on each side of a window (>= 1 + 3 + 9 + 27 + 1)
-constexpr int VF_MAXT = 4;             // 32-position tiles per wave (8 waves): NT <= 32
 constexpr int VF_MAXDEPTH = 4;
 
 struct VqStageParams {
@@ -66,63 +65,101 @@ struct VqStageParams {
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x16_t mfma16(half8_t a, half8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 // row (output channel) of accumulator register r for lane half g
 __device__ __forceinline__ constexpr int vf_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-template <int CIN, bool OUTCONV>
+// (a, b) fp32 -> packed fp16 pairs hi = (fp16(a), fp16(b)), lo = (fp16(a - hi.x), fp16(b - hi.y)) in four VALU instructions: the
+// residuals come from v_fma_mix_f32, which reads the fp16 halves of `hi` directly ((fp16 -> fp32) * -1 + a), instead of two
+// conversions and two subtractions (the split is the bulk of this kernel's VALU work: 32 values per tile and residual block).
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const half2_t h = {(half_t)a, (half_t)b};
+    hi = __builtin_bit_cast(unsigned, h);
+    float la, lb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    const half2_t l = {(half_t)la, (half_t)lb};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// NTW = tiles of 32 positions per wave (2 or 4): the window has 8 NTW tiles.
+template <int CIN, bool OUTCONV, int NTW>
 __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int GUARD = 32;                                       // zero rows on either side of the window: no bounds checks on fragment reads
+    char* const smem = smem_raw + GUARD * VF_ROW;                   // row 0 = window position 0
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tl = lane & 31, g = lane >> 5;
-    const int P = p.nt * 32, TT = P - 2 * VF_HALO;
+    constexpr int P = NTW * 8 * 32, TT = P - 2 * VF_HALO;
     const int n = blockIdx.y;
     const int t0 = (int)blockIdx.x * TT - VF_HALO;                 // stage-rate time of window position 0
     const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // this wave's tiles: j -> window tile w + 8 j (positions 32 (w + 8 j) + tl); the residual stream of those positions lives in acc[j]
-    f32x16_t acc[VF_MAXT];
-    auto tile_on = [&](int j) __attribute__((always_inline)) { return w + 8 * j < p.nt; };
-    auto pos_of = [&](int j) __attribute__((always_inline)) { return (w + 8 * j) * 32 + tl; };
+    for (int i = threadIdx.x; i < 2 * GUARD * VF_ROW / 16; i += 512) {
+        const int row = i / (VF_ROW / 16), c = i % (VF_ROW / 16);
+        *(half8_t*)(smem_raw + (row < GUARD ? row : P + row) * VF_ROW + c * 16) = zero8;
+    }
 
-    // relu(v) (or v) of one accumulator tile -> fp16 hi / lo planes of LDS row `pp`; `keep` = position inside the clip (the padding
-    // of the next convolution is ZERO, not the value a longer signal would have had)
-    auto lds_store = [&](const f32x16_t& a, int pp, bool keep, bool relu) __attribute__((always_inline)) {
+    // this wave's tiles: j -> window tile w + 8 j (positions 32 (w + 8 j) + tl); the residual stream of those positions lives in acc[j]
+    f32x16_t acc[NTW];
+    auto pos_of = [&](int j) __attribute__((always_inline)) { return (w + 8 * j) * 32 + tl; };
+    // a tile lies inside the clip <=> its first and last position do (wave-uniform): only tiles that straddle a clip end mask
+    auto inside = [&](int j) __attribute__((always_inline)) {
+        const int ta = t0 + (w + 8 * j) * 32;
+        return ta >= 0 && ta + 31 < p.t;
+    };
+
+    // relu(v) (or v) of one accumulator tile -> fp16 hi / lo planes of LDS row `pp`.  MASK: zero the positions outside the clip (the
+    // padding of the next convolution is ZERO, not the value a longer signal would have had).
+    auto lds_store = [&](const f32x16_t& a, int pp, auto relu_tag, bool keep) __attribute__((always_inline)) {
+        constexpr bool relu = decltype(relu_tag)::value;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            half4_t h, l;
+            float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v = a[4 * rq + i];
-                if (relu) v = fmaxf(v, 0.0f);
-                v = keep ? v : 0.0f;
-                h[i] = (half_t)v;
-                l[i] = (half_t)(v - (float)h[i]);
+                v[i] = relu ? fmaxf(a[4 * rq + i], 0.0f) : a[4 * rq + i];
+                v[i] = keep ? v[i] : 0.0f;
             }
+            unsigned h0, h1, l0, l1;
+            split2(v[0], v[1], h0, l0);
+            split2(v[2], v[3], h1, l1);
             char* d = smem + pp * VF_ROW + (8 * rq + 4 * g) * 2;
-            *(u32x2_t*)d = __builtin_bit_cast(u32x2_t, h);
-            *(u32x2_t*)(d + 64) = __builtin_bit_cast(u32x2_t, l);
+            *(u32x2_t*)d = (u32x2_t){h0, h1};
+            *(u32x2_t*)(d + 64) = (u32x2_t){l0, l1};
         }
     };
-    // B fragment (16 channels c0 + 8 g .. of window position q) from LDS; positions outside the window read as zero
+    auto store_tiles = [&](auto relu_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int pp = pos_of(j), tg = t0 + pp;
+            if (inside(j)) lds_store(acc[j], pp, relu_tag, true);           // `keep` folds away
+            else lds_store(acc[j], pp, relu_tag, tg >= 0 && tg < p.t);
+        }
+    };
+    // B fragment (16 channels c0 + 8 g .. of window position q) from LDS; the guard rows make q in [-32, P + 32) legal
     auto lds_frag = [&](int q, int c0, int plane) __attribute__((always_inline)) -> half8_t {
-        const bool ok = q >= 0 && q < P;
-        const int qq = ok ? q : 0;
-        const half8_t v = *(const half8_t*)(smem + qq * VF_ROW + plane * 64 + (c0 + 8 * g) * 2);
-        return ok ? v : zero8;
+        return *(const half8_t*)(smem + q * VF_ROW + plane * 64 + (c0 + 8 * g) * 2);
     };
 
     // ---------------------------------------------------------------------------------------------------------------------
     // phase 0: the strided convolution, every position of the window straight from global memory
     // ---------------------------------------------------------------------------------------------------------------------
-    if (CIN == 1) {
+    if constexpr (CIN == 1) {
         // exact fp32 fmaf chain, bias first, taps ascending (= oracle/jukebox_ref.c; zero taps leave the accumulator unchanged)
         const float* a = p.audio + (size_t)n * p.tin;
+        float wv[4][16], bv[16];
 #pragma unroll
-        for (int j = 0; j < VF_MAXT; ++j) {
-            if (!tile_on(j)) continue;
+        for (int r = 0; r < 16; ++r) {
+            bv[r] = p.b0[vf_row(r, g)];
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) wv[tap][r] = p.w0f[tap * 32 + vf_row(r, g)];
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
             const int tg = t0 + pos_of(j);
             float xv[4];
 #pragma unroll
@@ -132,66 +169,70 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = vf_row(r, g);
-                float s = p.b0[co];
+                float s = bv[r];
 #pragma unroll
-                for (int tap = 0; tap < 4; ++tap) s = fmaf(p.w0f[tap * 32 + co], xv[tap], s);
+                for (int tap = 0; tap < 4; ++tap) s = fmaf(wv[tap][r], xv[tap], s);
                 acc[j][r] = s;
             }
         }
     } else {
-        constexpr int KPT = CIN / 16;                                // k-steps per tap
+        constexpr int KPT = CIN / 16, NQ = 4 * KPT;                  // k-steps per tap, k-steps
 #pragma unroll
-        for (int j = 0; j < VF_MAXT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = p.b0[vf_row(r, g)] * p.m0;
         const half_t* ih = p.in_hi + (size_t)n * p.tin * CIN;
         const half_t* il = p.in_lo + (size_t)n * p.tin * CIN;
-        for (int q = 0; q < 4 * KPT; ++q) {
+        // fragments of k-step q + 1 are requested before k-step q multiplies (two register sets): the loads are L2 / HBM round trips
+        half8_t xh[2][NTW], xl[2][NTW], wh[2], wl[2];
+        auto fetch = [&](int buf, int q) __attribute__((always_inline)) {
             const int tap = q / KPT, c0 = (q % KPT) * 16;
-            const half8_t wh = *(const half8_t*)(p.w0_hi + ((size_t)q * 64 + lane) * 8);
-            const half8_t wl = *(const half8_t*)(p.w0_lo + ((size_t)q * 64 + lane) * 8);
-            half8_t xh[VF_MAXT], xl[VF_MAXT];
+            wh[buf] = *(const half8_t*)(p.w0_hi + ((size_t)q * 64 + lane) * 8);
+            wl[buf] = *(const half8_t*)(p.w0_lo + ((size_t)q * 64 + lane) * 8);
 #pragma unroll
-            for (int j = 0; j < VF_MAXT; ++j) {
+            for (int j = 0; j < NTW; ++j) {
                 const long idx = 2l * (t0 + pos_of(j)) - 1 + tap;
-                const bool ok = tile_on(j) && idx >= 0 && idx < p.tin;
+                const bool ok = idx >= 0 && idx < p.tin;
                 const size_t off = (size_t)(ok ? idx : 0) * CIN + c0 + 8 * g;
                 const half8_t vh = *(const half8_t*)(ih + off), vl = *(const half8_t*)(il + off);
-                xh[j] = ok ? vh : zero8;
-                xl[j] = ok ? vl : zero8;
+                xh[buf][j] = ok ? vh : zero8;
+                xl[buf][j] = ok ? vl : zero8;
             }
+        };
+        fetch(0, 0);
 #pragma unroll
-            for (int j = 0; j < VF_MAXT; ++j) acc[j] = mfma16(wh, xh[j], acc[j]);
+        for (int q = 0; q < NQ; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < NQ) fetch(cur ^ 1, q + 1);
 #pragma unroll
-            for (int j = 0; j < VF_MAXT; ++j) acc[j] = mfma16(wh, xl[j], acc[j]);
+            for (int j = 0; j < NTW; ++j) acc[j] = mfma16(wh[cur], xh[cur][j], acc[j]);
 #pragma unroll
-            for (int j = 0; j < VF_MAXT; ++j) acc[j] = mfma16(wl, xh[j], acc[j]);
+            for (int j = 0; j < NTW; ++j) acc[j] = mfma16(wh[cur], xl[cur][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = mfma16(wl[cur], xh[cur][j], acc[j]);
         }
 #pragma unroll
-        for (int j = 0; j < VF_MAXT; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] *= p.i0;
     }
-#pragma unroll
-    for (int j = 0; j < VF_MAXT; ++j) {
-        if (!tile_on(j)) continue;
-        const int pp = pos_of(j), tg = t0 + pp;
-        lds_store(acc[j], pp, tg >= 0 && tg < p.t, true);
-    }
+    store_tiles(std::true_type{});
     __syncthreads();
 
     // ---------------------------------------------------------------------------------------------------------------------
     // the residual blocks: y = x + W2 . relu(W1 (*)_d relu(x) + b1) + b2
     // ---------------------------------------------------------------------------------------------------------------------
-    for (int rb = 0; rb < p.depth; ++rb) {
-        const int d = p.dil[rb];
-        half8_t wh[8], wl[8];
+    half8_t wh[8], wl[8];
+    auto load_block_weights = [&](int rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             wh[q] = *(const half8_t*)(p.wr_hi + (((size_t)rb * 8 + q) * 64 + lane) * 8);
             wl[q] = *(const half8_t*)(p.wr_lo + (((size_t)rb * 8 + q) * 64 + lane) * 8);
         }
+    };
+    load_block_weights(0);
+    for (int rb = 0; rb < p.depth; ++rb) {
+        const int d = p.dil[rb];
         float b1v[16], b2v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -201,9 +242,7 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
         const float i1 = p.ir[rb][0], m2 = p.mr[rb][1], i2 = p.ir[rb][1];
         // two tiles at a time: their MFMA chains interleave, so consecutive MFMAs never share an accumulator
 #pragma unroll
-        for (int jp = 0; jp < VF_MAXT; jp += 2) {
-            if (!tile_on(jp)) continue;
-            const bool two = tile_on(jp + 1);
+        for (int jp = 0; jp < NTW; jp += 2) {
             const int pa = pos_of(jp), pb = pos_of(jp + 1);
             f32x16_t ha, hb;
 #pragma unroll
@@ -212,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
             for (int q = 0; q < 6; ++q) {
                 const int sh = (q / 2 - 1) * d, c0 = (q & 1) * 16;
                 const half8_t xah = lds_frag(pa + sh, c0, 0), xal = lds_frag(pa + sh, c0, 1);
-                const half8_t xbh = two ? lds_frag(pb + sh, c0, 0) : zero8, xbl = two ? lds_frag(pb + sh, c0, 1) : zero8;
+                const half8_t xbh = lds_frag(pb + sh, c0, 0), xbl = lds_frag(pb + sh, c0, 1);
                 ha = mfma16(wh[q], xah, ha);
                 hb = mfma16(wh[q], xbh, hb);
                 ha = mfma16(wh[q], xal, ha);
@@ -224,34 +263,35 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
             for (int r = 0; r < 16; ++r) { acc[jp][r] = (acc[jp][r] + b2v[r]) * m2; acc[jp + 1][r] = (acc[jp + 1][r] + b2v[r]) * m2; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                half8_t hah, hal, hbh, hbl;
+                unsigned hah[4], hal[4], hbh[4], hbl[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float va = fmaxf(ha[8 * s + i], 0.0f) * i1, vb = fmaxf(hb[8 * s + i], 0.0f) * i1;
-                    hah[i] = (half_t)va;
-                    hal[i] = (half_t)(va - (float)hah[i]);
-                    hbh[i] = (half_t)vb;
-                    hbl[i] = (half_t)(vb - (float)hbh[i]);
+                for (int i = 0; i < 4; ++i) {
+                    split2(fmaxf(ha[8 * s + 2 * i], 0.0f) * i1, fmaxf(ha[8 * s + 2 * i + 1], 0.0f) * i1, hah[i], hal[i]);
+                    split2(fmaxf(hb[8 * s + 2 * i], 0.0f) * i1, fmaxf(hb[8 * s + 2 * i + 1], 0.0f) * i1, hbh[i], hbl[i]);
                 }
-                acc[jp] = mfma16(wh[6 + s], hah, acc[jp]);
-                acc[jp + 1] = mfma16(wh[6 + s], hbh, acc[jp + 1]);
-                acc[jp] = mfma16(wh[6 + s], hal, acc[jp]);
-                acc[jp + 1] = mfma16(wh[6 + s], hbl, acc[jp + 1]);
-                acc[jp] = mfma16(wl[6 + s], hah, acc[jp]);
-                acc[jp + 1] = mfma16(wl[6 + s], hbh, acc[jp + 1]);
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const half8_t fah = __builtin_bit_cast(half8_t, (u32x4_t){hah[0], hah[1], hah[2], hah[3]});
+                const half8_t fal = __builtin_bit_cast(half8_t, (u32x4_t){hal[0], hal[1], hal[2], hal[3]});
+                const half8_t fbh = __builtin_bit_cast(half8_t, (u32x4_t){hbh[0], hbh[1], hbh[2], hbh[3]});
+                const half8_t fbl = __builtin_bit_cast(half8_t, (u32x4_t){hbl[0], hbl[1], hbl[2], hbl[3]});
+                acc[jp] = mfma16(wh[6 + s], fah, acc[jp]);
+                acc[jp + 1] = mfma16(wh[6 + s], fbh, acc[jp + 1]);
+                acc[jp] = mfma16(wh[6 + s], fal, acc[jp]);
+                acc[jp + 1] = mfma16(wh[6 + s], fbl, acc[jp + 1]);
+                acc[jp] = mfma16(wl[6 + s], fah, acc[jp]);
+                acc[jp + 1] = mfma16(wl[6 + s], fbh, acc[jp + 1]);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[jp][r] *= i2; acc[jp + 1][r] *= i2; }
         }
-        __syncthreads();                                           // every wave has read relu(x): the window can be overwritten
         const bool last = rb + 1 == p.depth;
-        if (!last || OUTCONV) {
-#pragma unroll
-            for (int j = 0; j < VF_MAXT; ++j) {
-                if (!tile_on(j)) continue;
-                const int pp = pos_of(j), tg = t0 + pp;
-                lds_store(acc[j], pp, tg >= 0 && tg < p.t, !last);    // the output conv takes the RAW block output (no ReLU in front of it)
-            }
+        if (!last) load_block_weights(rb + 1);                     // in flight across the two barriers and the LDS stores
+        __syncthreads();                                           // every wave has read relu(x): the window can be overwritten
+        if (!last) {
+            store_tiles(std::true_type{});
+            __syncthreads();
+        } else if (OUTCONV) {
+            store_tiles(std::false_type{});                        // the output conv takes the RAW block output (no ReLU in front of it)
             __syncthreads();
         }
     }
@@ -269,38 +309,31 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
         if (p.out_hi) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                half4_t h, l;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = a[4 * rq + i];
-                    h[i] = (half_t)v;
-                    l[i] = (half_t)(v - (float)h[i]);
-                }
+                unsigned h0, h1, l0, l1;
+                split2(a[4 * rq], a[4 * rq + 1], h0, l0);
+                split2(a[4 * rq + 2], a[4 * rq + 3], h1, l1);
                 const size_t o = ((size_t)n * p.t + tg) * C + cbase + 8 * rq + 4 * g;
-                *(u32x2_t*)(p.out_hi + o) = __builtin_bit_cast(u32x2_t, h);
-                *(u32x2_t*)(p.out_lo + o) = __builtin_bit_cast(u32x2_t, l);
+                *(u32x2_t*)(p.out_hi + o) = (u32x2_t){h0, h1};
+                *(u32x2_t*)(p.out_lo + o) = (u32x2_t){l0, l1};
             }
         }
     };
     if (!OUTCONV) {
 #pragma unroll
-        for (int j = 0; j < VF_MAXT; ++j)
-            if (tile_on(j)) store_tile(acc[j], pos_of(j), 0, 32);
+        for (int j = 0; j < NTW; ++j) store_tile(acc[j], pos_of(j), 0, 32);
     } else {
         for (int hh = 0; hh < 2; ++hh) {                            // output channels 32 hh .. 32 hh + 31
-            half8_t wh[6], wl[6];
+            half8_t oh[6], ol[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                wh[q] = *(const half8_t*)(p.wo_hi + (((size_t)hh * 6 + q) * 64 + lane) * 8);
-                wl[q] = *(const half8_t*)(p.wo_lo + (((size_t)hh * 6 + q) * 64 + lane) * 8);
+                oh[q] = *(const half8_t*)(p.wo_hi + (((size_t)hh * 6 + q) * 64 + lane) * 8);
+                ol[q] = *(const half8_t*)(p.wo_lo + (((size_t)hh * 6 + q) * 64 + lane) * 8);
             }
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = p.bo[32 * hh + vf_row(r, g)] * p.mo;
 #pragma unroll
-            for (int jp = 0; jp < VF_MAXT; jp += 2) {
-                if (!tile_on(jp)) continue;
-                const bool two = tile_on(jp + 1);
+            for (int jp = 0; jp < NTW; jp += 2) {
                 const int pa = pos_of(jp), pb = pos_of(jp + 1);
                 f32x16_t oa, ob;
 #pragma unroll
@@ -309,39 +342,45 @@ __global__ __launch_bounds__(512, 2) void vq_stage_kernel(const VqStageParams p)
                 for (int q = 0; q < 6; ++q) {
                     const int sh = q / 2 - 1, c0 = (q & 1) * 16;
                     const half8_t xah = lds_frag(pa + sh, c0, 0), xal = lds_frag(pa + sh, c0, 1);
-                    const half8_t xbh = two ? lds_frag(pb + sh, c0, 0) : zero8, xbl = two ? lds_frag(pb + sh, c0, 1) : zero8;
-                    oa = mfma16(wh[q], xah, oa);
-                    ob = mfma16(wh[q], xbh, ob);
-                    oa = mfma16(wh[q], xal, oa);
-                    ob = mfma16(wh[q], xbl, ob);
-                    oa = mfma16(wl[q], xah, oa);
-                    ob = mfma16(wl[q], xbh, ob);
+                    const half8_t xbh = lds_frag(pb + sh, c0, 0), xbl = lds_frag(pb + sh, c0, 1);
+                    oa = mfma16(oh[q], xah, oa);
+                    ob = mfma16(oh[q], xbh, ob);
+                    oa = mfma16(oh[q], xal, oa);
+                    ob = mfma16(oh[q], xbl, ob);
+                    oa = mfma16(ol[q], xah, oa);
+                    ob = mfma16(ol[q], xbh, ob);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { oa[r] *= p.io; ob[r] *= p.io; }
                 store_tile(oa, pa, 32 * hh, 64);
-                if (two) store_tile(ob, pb, 32 * hh, 64);
+                store_tile(ob, pb, 32 * hh, 64);
             }
         }
     }
 }
 
-template <int CIN, bool OUTCONV>
-static int launch_vq_stage(const VqStageParams& p, hipStream_t s) {
-    auto kern = vq_stage_kernel<CIN, OUTCONV>;
-    const int lds = p.nt * 32 * VF_ROW;
+template <int CIN, bool OUTCONV, int NTW>
+static int launch_vq_stage_n(const VqStageParams& p, hipStream_t s) {
+    auto kern = vq_stage_kernel<CIN, OUTCONV, NTW>;
+    constexpr int P = NTW * 8 * 32;
+    constexpr int lds = (P + 64) * VF_ROW;
+    static_assert(lds <= 160 * 1024, "window + guard rows must fit the LDS");
     static bool attr_set = false;                // a property of the code object
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 32 * VF_ROW) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("vqvae_stage: cannot raise the dynamic LDS limit");
             return LLARK_ERR_LAUNCH;
         }
         attr_set = true;
     }
-    const int tt = p.nt * 32 - 2 * VF_HALO;
-    dim3 grid(cdiv(p.t, tt), p.n);
+    dim3 grid(cdiv(p.t, P - 2 * VF_HALO), p.n);
     kern<<<grid, 512, lds, s>>>(p);
     return check_launch("vqvae_stage");
+}
+
+template <int CIN, bool OUTCONV>
+static int launch_vq_stage(const VqStageParams& p, hipStream_t s) {
+    return p.nt == 32 ? launch_vq_stage_n<CIN, OUTCONV, 4>(p, s) : launch_vq_stage_n<CIN, OUTCONV, 2>(p, s);
 }
 
 }  // namespace llark
@@ -385,9 +424,9 @@ extern "C" int llark_vqvae_stage_f16x2(const float* audio, const void* in_hi, co
     p.wr_hi = (const half_t*)wr_hi; p.wr_lo = (const half_t*)wr_lo; p.br = br; p.depth = depth;
     p.wo_hi = (const half_t*)wo_hi; p.wo_lo = (const half_t*)wo_lo; p.bo = bo;
     p.out_hi = (half_t*)out_hi; p.out_lo = (half_t*)out_lo; p.out_f32 = out_f32;
-    // window size: 32 tiles (928 output positions, 10 % halo work) while that still gives every CU two windows, else 16 / 8 tiles
+    // window size: 32 tiles (928 output positions, 10 % halo work) while that still gives every CU two windows, else 16 tiles (416)
     const long work = (long)n * p.t;
-    p.nt = work >= 512l * 928 ? 32 : (work >= 512l * 416 ? 16 : 8);
+    p.nt = work >= 512l * 928 ? 32 : 16;
     hipStream_t s = (hipStream_t)stream;
     const bool oc = wo_hi != nullptr;
     if (cin == 1) return oc ? launch_vq_stage<1, true>(p, s) : launch_vq_stage<1, false>(p, s);
