@@ -534,6 +534,11 @@ def main():
                         "the library default (22-bit activations; full-depth embedding max-abs-err 5.4e-5 <= 1e-4)"}
         if args.stages in ("train", "mpt-train"):
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
+        if args.stages == "train":
+            # MFU = 6 x parameters x tokens / step time / dense bf16 MFMA peak (per GPU); and the part of the gradient exchange the
+            # backward did not hide (HIP events around allreduce_grads on the compute stream; 0 on one GPU) next to the step time
+            line["mfu"] = round(llm.model_flops_per_step() / (elapsed / args.steps) / (PEAK_F16_MFMA_TFLOPS * 1e12), 4)
+            line["allreduce_exposed_ms"] = round(llm.trainer.exposed_exchange_ms() / max(1, args.steps + args.warmup), 3)
         if args.stages == "generate":
             key = "gemm_split_bf16_skinny" if args.llm_precision == "split" else "gemm_bf16_skinny"
             if key in timers:

@@ -140,13 +140,20 @@ class _Exchange:
             self.staged = None
 
 
-def all_reduce_sum_async(buf: torch.Tensor, comm_dtype: torch.dtype = torch.float32) -> _Exchange:
+def all_reduce_sum_async(buf: torch.Tensor, comm_dtype: torch.dtype = torch.float32, stage: Optional[torch.Tensor] = None) -> _Exchange:
     """Asynchronous SUM all-reduce of a slice of the flat fp32 gradient buffer.  ``comm_dtype=torch.bfloat16`` sends
     bf16 over the links, which is what the reference's DDP does (m2t/train.py:94-103 casts the model to bf16, so its
-    gradient buckets are bf16): half the xGMI bytes of the fp32 exchange."""
+    gradient buckets are bf16): half the xGMI bytes of the fp32 exchange.  ``stage``: the caller's PRE-ALLOCATED transport
+    buffer for this slice (same number of elements, ``comm_dtype``) -- the trainer owns one the size of the flat gradient, so the
+    32 per-layer exchanges of a step neither allocate nor return 0.4 GB blocks to the caching allocator while the backward runs."""
     import torch.distributed as dist
 
     if comm_dtype == torch.float32:
         return _Exchange(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf, None)
-    staged = buf.to(comm_dtype)
+    if stage is None:
+        staged = buf.to(comm_dtype)
+    else:
+        assert stage.dtype == comm_dtype and stage.numel() == buf.numel(), "staging slice does not match the gradient slice"
+        staged = stage.view(buf.shape)
+        staged.copy_(buf)
     return _Exchange(dist.all_reduce(staged, op=dist.ReduceOp.SUM, async_op=True), buf, staged)

@@ -126,6 +126,7 @@ class TrainWorkload:
         self.trainer = HipLlamaTrainer(eng, lr=5e-5, embed_grad_tokens=[START, END],
                                        grad_comm=torch.bfloat16 if getattr(args, "grad_comm", "fp32") == "bf16" else torch.float32,
                                        gradient_checkpointing=bool(getattr(args, "grad_checkpoint", False)))
+        self.trainer.time_exchange = True            # HIP events around allreduce_grads(): the exchange the backward did not hide
         gen = torch.Generator().manual_seed(11 + int(__import__("os").environ.get("RANK", "0")))
         self.batches = []
         for k in range(self.accum):
@@ -154,6 +155,13 @@ class TrainWorkload:
         per_layer = 2.0 * rows * (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size)
         # fwd + dX + dW for every layer GEMM; lm_head: fwd + dX only (frozen)
         return 3.0 * per_layer * d.num_hidden_layers + 2.0 * 2.0 * rows * d.hidden_size * d.vocab_size
+
+    def model_flops_per_step(self) -> float:
+        """The usual MFU numerator: 6 x parameters x tokens (fwd + bwd of every weight matrix incl. lm_head, no attention term,
+        no recompute)."""
+        d = self.dims
+        params = d.num_hidden_layers * (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size) + 2 * d.vocab_size * d.hidden_size
+        return 6.0 * params * self.micro * self.accum * self.seq
 
     def roofline(self, timers, args):
         if "gemm_bf16" not in timers:

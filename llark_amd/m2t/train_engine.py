@@ -283,8 +283,20 @@ class HipLlamaTrainer:
         o0, o1 = self._layer_span(i)
         if not hasattr(self, "_inflight"):
             self._inflight, self._reduced = [], []
-        self._inflight.append(D.all_reduce_sum_async(self.flat_grad[o0:o1], getattr(self, "grad_comm", torch.float32)))
+        self._inflight.append(D.all_reduce_sum_async(self.flat_grad[o0:o1], getattr(self, "grad_comm", torch.float32), self._stage(o0, o1)))
         self._reduced.append((o0, o1))
+
+    def _stage(self, o0: int, o1: int):
+        """Slice [o0, o1) of the persistent reduced-precision transport buffer (allocated once, on the first exchange that needs
+        it: 2 bytes per gradient element, 13.5 GB at 7B); None when the gradients travel as fp32."""
+        comm = getattr(self, "grad_comm", torch.float32)
+        if comm == torch.float32:
+            return None
+        st = getattr(self, "_flat_stage", None)
+        if st is None or st.dtype != comm or st.numel() != self.flat_grad.numel():
+            st = torch.empty(self.flat_grad.numel(), dtype=comm, device=self.flat_grad.device)
+            self._flat_stage = st
+        return st[o0:o1]
 
     def _finalize_grads(self) -> None:
         """A matrix whose dW product never ran since zero_grad() (e.g. mm_projector on a text-only batch) still holds the
@@ -301,6 +313,10 @@ class HipLlamaTrainer:
         done = sorted(getattr(self, "_reduced", []))
         works = list(getattr(self, "_inflight", []))
         self._inflight, self._reduced = [], []
+        timed = getattr(self, "time_exchange", False) and self.flat_grad.is_cuda
+        if timed:                                        # everything between these two events is exchange the backward did not hide
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if world > 1:
             from .. import dist as D
 
@@ -309,10 +325,23 @@ class HipLlamaTrainer:
             pos = 0
             for a, b in done + [(n, n)]:                  # the gaps between the spans reduced so far
                 for o in range(pos, a, bucket_elems):
-                    works.append(D.all_reduce_sum_async(self.flat_grad[o: min(o + bucket_elems, a)], comm))
+                    e = min(o + bucket_elems, a)
+                    works.append(D.all_reduce_sum_async(self.flat_grad[o:e], comm, self._stage(o, e)))
                 pos = max(pos, b)
         for w in works:
             w.wait()
+        if timed:
+            ev1.record()
+            self._exchange_events = getattr(self, "_exchange_events", []) + [(ev0, ev1)]
+
+    def exposed_exchange_ms(self) -> float:
+        """Sum over the steps since the last call of the compute-stream time spent in allreduce_grads() -- the part of the
+        gradient exchange the backward did not overlap (0 on one GPU).  Needs ``time_exchange = True``."""
+        evs, self._exchange_events = getattr(self, "_exchange_events", []), []
+        if not evs:
+            return 0.0
+        torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in evs))
 
     def step(self, world: int = 1) -> None:
         """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients."""

@@ -94,6 +94,14 @@ def _grad_worker(rank, world, port, q):
     tr.allreduce_grads(world, bucket_elems=128)
     want = sum((base * (r + 1)).to(torch.bfloat16) for r in range(world)).float()
     assert tr.flat_grad.dtype == torch.float32 and torch.equal(tr.flat_grad, want), "bf16 exchange: every element once, fp32 buffer"
+    # the transport buffer is allocated ONCE (the size of the flat gradient) and sliced per exchange: a second step reuses it
+    stage = tr._flat_stage
+    assert stage.dtype == torch.bfloat16 and stage.numel() == tr.flat_grad.numel()
+    tr.flat_grad = base * (rank + 1)
+    tr._start_layer_allreduce(0)
+    tr._start_layer_allreduce(1)
+    tr.allreduce_grads(world, bucket_elems=64)
+    assert tr._flat_stage is stage and torch.equal(tr.flat_grad, want)
     tr.grad_comm = torch.float32
     tr.flat_grad = first.clone()
     q.put((rank, tr.flat_grad.clone()))
