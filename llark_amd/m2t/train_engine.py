@@ -74,6 +74,15 @@ class HipLlamaTrainer:
         self.micro_batches = 0
         self._matrix_grads = {n for n, p in self.params if p.dim() == 2 and n != "embed"}
         self._fresh = set()                            # flat_grad starts zeroed: accumulate until the first zero_grad()
+        # Operands DERIVED from the weights, valid until the next optimizer step (self._wver): the K-contiguous transpose W^T that
+        # dX = dY . W multiplies by (was re-made by every micro-batch: 4 x 13.5 GB read + written per step at accumulation 4), and --
+        # from the second micro-batch of a step on, when the packing has something to amortise over -- fragment-major twins of W
+        # and W^T, so that the forward and dX products take the B-direct kernel like the inference engine (+8 .. 13 %).  Only when
+        # this object owns the optimizer: on the autograd-bridge path the weights are rebuilt outside (sync_engine).
+        self.derived_operands = bool(optimizer_state)
+        self._wver = 0
+        self._derived: Dict[int, list] = {}
+        self._fwd_uses: Dict[int, list] = {}
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -96,9 +105,42 @@ class HipLlamaTrainer:
         else:
             ops.gemm16(dyT, None, xT, None, k, ops.EPI_RESID, c=grad, resid=grad, m=n)
 
+    def _w_transposed(self, w: torch.Tensor) -> torch.Tensor:
+        if not self.derived_operands:
+            return ops.transposed16(w)
+        ent = self._derived.get(w.data_ptr())
+        if ent is None or ent[0] != self._wver:
+            ent = [self._wver, ops.transposed16(w), 0]
+            self._derived[w.data_ptr()] = ent
+        ent[2] += 1
+        if ent[2] == 2 and ent[1].shape[1] % 64 == 0:
+            ops.attach_frag(ent[1], ent[1].shape[0])
+        return ent[1]
+
+    def _fwd_weight(self, w: torch.Tensor) -> torch.Tensor:
+        """A weight about to be multiplied in a forward product: from its second use since the last optimizer step it carries a
+        fragment-major twin (ops.gemm16 then takes the B-direct kernel)."""
+        if self.derived_operands:
+            ent = self._fwd_uses.get(w.data_ptr())
+            if ent is None or ent[0] != self._wver:
+                ent = [self._wver, 0]
+                self._fwd_uses[w.data_ptr()] = ent
+            ent[1] += 1
+            if ent[1] == 2 and w.shape[1] % 64 == 0:
+                ops.attach_frag(w, w.shape[0])
+        return w
+
+    def _weights_changed(self) -> None:
+        """After an optimizer step: every derived operand is stale."""
+        self._wver += 1
+        if self.derived_operands:
+            for _, p in self.params:
+                if p.dim() == 2:
+                    ops.detach_frag(p)
+
     def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
         """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout)."""
-        wT = ops.transposed16(w)                      # [K][Np]
+        wT = self._w_transposed(w)                    # [K][Np]
         if dy16.shape[1] < wT.shape[1]:               # pad dY columns up to the 64-multiple K of this product
             pad = torch.zeros((dy16.shape[0], wT.shape[1]), dtype=_BF, device=dy16.device)
             pad[:, : dy16.shape[1]] = dy16
@@ -140,21 +182,21 @@ class HipLlamaTrainer:
             x1 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x1)
             qkv = torch.empty((rows, 3 * H), **f32)
-            ops.gemm16(x1, None, L.wqkv, None, 3 * H, ops.EPI_F32, c=qkv)
+            ops.gemm16(x1, None, self._fwd_weight(L.wqkv), None, 3 * H, ops.EPI_F32, c=qkv)
             q = torch.empty((B, nh, S, hd), **bf)
             kc, vc = eng.k_cache[i, :B], eng.vt_cache[i, :B]
             ops.rope_split_heads(qkv, B, S, nh, hd, 0, eng.cos, eng.sin, q, kc, vc)
             att = torch.empty((rows, H), **bf)
             ops.attn_prefill(q, kc, vc, B, S, nh, hd, 0, att)
-            ops.gemm16(att, None, L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+            ops.gemm16(att, None, self._fwd_weight(L.wo), None, H, ops.EPI_RESID, c=h, resid=h)
             st.update(x1=x1, q=q, att=att, h_mid=h.clone())
             x2 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
             gu = torch.empty((rows, 2 * I), **f32)
-            ops.gemm16(x2, None, L.wgu, None, 2 * I, ops.EPI_F32, c=gu)
+            ops.gemm16(x2, None, self._fwd_weight(L.wgu), None, 2 * I, ops.EPI_F32, c=gu)
             act = torch.empty((rows, I), **bf)
             ops.swiglu_fwd(gu, act)
-            ops.gemm16(act, None, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+            ops.gemm16(act, None, self._fwd_weight(L.wdown), None, H, ops.EPI_RESID, c=h, resid=h)
             st.update(x2=x2, gu=gu, act=act)
             return st
 
@@ -354,6 +396,7 @@ class HipLlamaTrainer:
             off, n = self._slices[name]
             ops.adamw(p.view(-1), self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n],
                       self.lr, b1, b2, self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world)
+        self._weights_changed()
         self.zero_grad()
 
     # ------------------------------------------------------------------------------------------
