@@ -46,9 +46,6 @@ struct Cfg256N {
 // loop, waves 0..3 one after it, and every phase has a barrier in its middle -- so that one of them is always in the middle of its
 // MFMA stream while the other crosses a phase boundary (first fragment reads, barrier).  What this needs from the DMA protocol is
 // spelled out at kstep() below.
-#ifndef LO8N_SKEW
-#define LO8N_SKEW 1
-#endif
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
@@ -131,9 +128,7 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
     };
     // per-lane byte offsets of the rows this wave stages (clamped to the last valid row; masked on store)
     unsigned voA[4], voW[4], vo8[2], voW8[2];
-#if LO8N_SKEW
     unsigned voW8p[2];                                            // W8 rows of wave w ^ 4 (requested by the leading wave of the pair)
-#endif
     auto set_offsets = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -152,11 +147,9 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             int rw = n0 + q * 128 + w * 16 + rl8;
             rw = rw < p.N ? rw : p.N - 1;
             voW8[q] = (unsigned)rw * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
-#if LO8N_SKEW
             int rp = n0 + q * 128 + (w ^ 4) * 16 + rl8;
             rp = rp < p.N ? rp : p.N - 1;
             voW8p[q] = (unsigned)rp * (unsigned)p.ldw8 + (unsigned)(dch8 << 4);
-#endif
         }
     };
     auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
@@ -176,20 +169,21 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
         const int b8 = C::O_A8 + st * 2 * C::UNIT8 + wb;
         dma(rA8, vo8[0], k << 6, b8); dma(rA8, vo8[1], k << 6, b8 + C::UNIT8);
     };
+    auto issue_A1 = [&](auto ic, int k, int st) __attribute__((always_inline)) {  // request i of issue_A (0..3 Ahi row groups, 4..5 A8): one per MFMA gap
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < 4) dma(rAh, voA[i], k << 7, C::O_A + st * 2 * C::UNIT + wb + (i >> 1) * C::UNIT + (i & 1) * 8192);
+        else dma(rA8, vo8[i - 4], k << 6, C::O_A8 + st * 2 * C::UNIT8 + wb + (i - 4) * C::UNIT8);
+    };
     // fp8 weight plane of one half (q = 0: left -> O_8L, 1: right -> O_8R).  LO8N_SKEW: the 8 KiB units are single-buffered, so a
     // trailing wave's request would always be half a phase late for the leading waves' reads: the LEADING wave of each pair
     // (w < 4) requests both shares, the trailing wave none.  (The only wave-dependent branch in the loop; wave-dependent
     // s_waitcnt counts instead cost 40-60 spilled registers, so the request order below is chosen to make the counts equal.)
     auto issue_W8 = [&](int q, int k) __attribute__((always_inline)) {
         const int dst = q ? C::O_8R : C::O_8L;
-#if LO8N_SKEW
         if (w < 4) {
             dma(rW8, voW8[q], k << 6, dst + wb);
             dma(rW8, voW8p[q], k << 6, dst + (wb ^ 4096));
         }
-#else
-        dma(rW8, voW8[q], k << 6, dst + wb);
-#endif
     };
     // prologue of a tile: the L set of K-step 0 (W8L, WL -> slot 0, Ahi / A8 -> stage 0), then WR(0) -> slot 1
     auto prologue = [&]() __attribute__((always_inline)) {
@@ -262,46 +256,56 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
                 bf[0][0] = *(const frag*)(smem + rdW(0) + oW);
                 bf[0][1] = *(const frag*)(smem + rdW(0) + oW + 4096);
                 __builtin_amdgcn_sched_barrier(0);
+                // Round 3 (measured first on gemm256n.hip, profiles/r03_phase_cycles_*.txt): every sub-step is MFMA-FIRST and whatever
+                // else the wave has to issue -- the fragment reads of sub-step s + 1, the LDS-DMA requests (60 .. 185 cycles of issue
+                // each), the fp8 fragment reads -- sits one item per MFMA gap behind them.  With the requests and reads in a block right
+                // after the barrier the matrix pipe idled ~350 cycles per half-phase (the partner wave is waiting for its own first
+                // fragments just then): 2070 cycles per phase for 1536 of matrix work.  Request ORDER within a phase is unchanged, so
+                // the vmcnt counts of kstep()'s table still hold.  Gaps (after MFMA g + 1):
+                //   s = 0: 0 A hi (s+1), 1 W (s+1), 2 req 0, 3 req 1        s = 1: 0 A hi, 1 W, 2 req 2 + 3, 3 req 4 + 5   (L only: A(k+1))
+                //   s = 2 (after the half-phase barrier): 0 -, 1 mid requests, 2 A hi / W (s+1), 3 fp8 fragments          s = 3: -
                 static_for<4>([&](auto sc) __attribute__((always_inline)) {
                     constexpr int s = decltype(sc)::value, cur = s & 1;
-#if LO8N_SKEW
                     if constexpr (s == 2) {        // half-phase boundary: the other wave of the pair starts its next phase here
                         if (half == 0) VMCNT(6);   // WR(k) landed            (newer: Ahi / A8 (k+1) x6)
                         else VMCNT(0);             // WL / Ahi / A8 (k+1) and W8R(k) landed
                         __builtin_amdgcn_s_barrier();
-                        issue_mid();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#endif
-                    if constexpr (s < 3) {         // fragments of sub-step s + 1
-                        if (half == 0) {
-                            ah[0][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA);
-                            ah[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA + 4096);
+                    static_for<4>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value, tm = i & 1, tn = i >> 1;
+                        acc[tm][2 * half + tn] = Mfma<T>::run(ah[tm][s], bf[cur][tn], acc[tm][2 * half + tn]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        constexpr int rg = s == 2 ? 2 : 0;                                 // gap of the A / W fragment reads
+                        if constexpr (s < 3) {
+                            if constexpr (i == rg) {
+                                if (half == 0) {
+                                    ah[0][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA);
+                                    ah[1][s + 1] = *(const frag*)(smem + rdA(s + 1) + oA + 4096);
+                                }
+                                if constexpr (s == 2) {
+                                    bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1) + oW);
+                                    bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + oW + 4096);
+                                }
+                            }
+                            if constexpr (s < 2 && i == 1) {
+                                bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1) + oW);
+                                bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + oW + 4096);
+                            }
                         }
-                        bf[cur ^ 1][0] = *(const frag*)(smem + rdW(s + 1) + oW);
-                        bf[cur ^ 1][1] = *(const frag*)(smem + rdW(s + 1) + oW + 4096);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc[0][2 * half] = Mfma<T>::run(ah[0][s], bf[cur][0], acc[0][2 * half]);
-                    acc[1][2 * half] = Mfma<T>::run(ah[1][s], bf[cur][0], acc[1][2 * half]);
-                    acc[0][2 * half + 1] = Mfma<T>::run(ah[0][s], bf[cur][1], acc[0][2 * half + 1]);
-                    acc[1][2 * half + 1] = Mfma<T>::run(ah[1][s], bf[cur][1], acc[1][2 * half + 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (s == 0) {                                                // this phase's DMA requests
-                        issue();
-#if !LO8N_SKEW
-                        issue_mid();
-#endif
-                    }
-                    if constexpr (s == (LO8N_SKEW ? 2 : 1)) {                              // fp8 fragments: needed after sub-step 3
-                        if (half == 0) {
-                            a8[0] = rd_i32x8(rd8a + oA8, (opaque(rd8a) ^ 16) + oA8);
-                            a8[1] = rd_i32x8(rd8a + oA8 + 2048, (opaque(rd8a) ^ 16) + oA8 + 2048);
+                        if constexpr (s == 0 && i >= 2) issue(std::integral_constant<int, i - 2>{});
+                        if constexpr (s == 1 && i >= 2) { issue(std::integral_constant<int, 2 * i - 2>{}); issue(std::integral_constant<int, 2 * i - 1>{}); }
+                        if constexpr (s == 2 && i == 1) issue_mid();
+                        if constexpr (s == 2 && i == 3) {                                  // fp8 fragments: needed after sub-step 3
+                            if (half == 0) {
+                                a8[0] = rd_i32x8(rd8a + oA8, (opaque(rd8a) ^ 16) + oA8);
+                                a8[1] = rd_i32x8(rd8a + oA8 + 2048, (opaque(rd8a) ^ 16) + oA8 + 2048);
+                            }
+                            w8[0] = rd_i32x8(rdW8a + o8, (opaque(rdW8a) ^ 16) + o8);
+                            w8[1] = rd_i32x8(rdW8a + o8 + 2048, (opaque(rdW8a) ^ 16) + o8 + 2048);
                         }
-                        w8[0] = rd_i32x8(rdW8a + o8, (opaque(rdW8a) ^ 16) + o8);
-                        w8[1] = rd_i32x8(rdW8a + o8 + 2048, (opaque(rdW8a) ^ 16) + o8 + 2048);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 });
                 acc[0][2 * half] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[0], w8[0], acc[0][2 * half], 0, 0, 0, scale_a, 0, scale_b);
                 acc[1][2 * half] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[1], w8[0], acc[1][2 * half], 0, 0, 0, scale_a, 0, scale_b);
@@ -311,7 +315,6 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             };
             // One K-step from A stage ST; wL = ring slot of WL(k).  Both phases ALWAYS issue their requests (the last step re-requests
             // itself, clamped k) so the vmcnt counts and the instruction stream are the same for every K-step.
-#if LO8N_SKEW
             // Skewed form.  Time in half-phases ("slots"): the leading waves run La(k) Lb(k) Ra(k) Rb(k) in slots 4k .. 4k+3, the
             // trailing waves one slot later; a barrier separates consecutive slots.  Reads: La: A(k), A8(k), WL(k); Lb: WL(k), W8L(k);
             // Ra: WR(k); Rb: WR(k), W8R(k).  Requests and what they overwrite (last read by the trailing waves in slot ...):
@@ -330,49 +333,21 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
                 const int kn = k + 1 < nk ? k + 1 : nk - 1;
                 const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // slots of WR(k), WL(k+1)
                 phase(std::integral_constant<int, 0>{}, st_tag, wL,
-                      [&]() __attribute__((always_inline)) { issue_A(kn, st ^ 1); },
+                      [&](auto ic) __attribute__((always_inline)) { issue_A1(decltype(ic){}, kn, st ^ 1); },
                       [&]() __attribute__((always_inline)) { issue_WL(kn, wN); issue_W8(1, k); });
                 PROF_ADD(pacc0);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
                 phase(std::integral_constant<int, 1>{}, st_tag, wR,
-                      [&]() __attribute__((always_inline)) {},
+                      [&](auto) __attribute__((always_inline)) {},
                       [&]() __attribute__((always_inline)) { issue_WR(kn, wL); issue_W8(0, kn); });
                 PROF_ADD(pacc0);
                 __builtin_amdgcn_s_barrier();
                 PROF_ADD(pacc2);
             };
-#else
-            auto kstep = [&](auto st_tag, int k, int wL) __attribute__((always_inline)) {
-                constexpr int st = decltype(st_tag)::value;
-                const int kn = k + 1 < nk ? k + 1 : nk - 1;
-                const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // slots of WR(k), WL(k+1)
-                phase(std::integral_constant<int, 0>{}, st_tag, wL, [&]() __attribute__((always_inline)) {
-                    issue_W8(1, k);                                        // W8R(k): read by the NEXT phase
-                    issue_WL(kn, wN);
-                    issue_A(kn, st ^ 1);
-                }, [&]() __attribute__((always_inline)) {});
-                PROF_ADD(pacc0);
-                VMCNT(8);                                                  // WR(k) (requested in R(k-1)) and W8R(k) have landed
-                PROF_ADD(pacc1);
-                __builtin_amdgcn_s_barrier();
-                PROF_ADD(pacc2);
-                phase(std::integral_constant<int, 1>{}, st_tag, wR, [&]() __attribute__((always_inline)) {
-                    issue_W8(0, kn);                                       // W8L(k+1): read by the NEXT phase
-                    issue_WR(kn, wL);
-                }, [&]() __attribute__((always_inline)) {});
-                PROF_ADD(pacc0);
-                VMCNT(2);                                                  // WL / Ahi / A8 (k+1) from L(k) and W8L(k+1) have landed
-                PROF_ADD(pacc1);
-                __builtin_amdgcn_s_barrier();
-                PROF_ADD(pacc2);
-            };
-#endif
 
             PROF_T0();
-#if LO8N_SKEW
             if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
-#endif
             {
                 int k = 0, wL = 0;
                 for (; k + 1 < nk; k += 2) {
@@ -385,9 +360,7 @@ __global__ __launch_bounds__(Cfg256N::THREADS, Cfg256N::MINW) void gemm256_lo8n_
             }
             // (alternating s_setprio between the two waves of a SIMD, +4 % on the M-split form, measured -0.7 % here: with just-in-time
             //  reads both waves already finish their phases together -- profiles/r02_lo8_phase_cycles.txt)
-#if LO8N_SKEW
             if (w < 4) __builtin_amdgcn_s_barrier();                       // the trailing waves' last half-phase
-#endif
             VMCNT(0);
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
             if (ch + 1 < nchunks) {
