@@ -418,7 +418,6 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
             loadB((s + 3) & 3, kt * 4 + s + 3);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int dummy = 0;
             const int cur = SPLIT ? 0 : (s & 1);
             if (SPLIT) ldA(0, s);
             else if (s < 3) ldA(cur ^ 1, s + 1);

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                            bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                            int S, int nh, int past, int smax, float scale,
-                                                           const float* __restrict__ alibi) {
+                                                           const float* __restrict__ alibi, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 16 KiB
     char* sV = smem + 16384;         // 16 KiB
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
         const int qi = q0 + wv * 16 + g * 4 + r;
         if (qi >= S) continue;
         const float inv = l_run[r] > 0.0f ? 1.0f / l_run[r] : 0.0f;
+        if (lse && c == 0) lse[bh * S + qi] = m_run[r] + logf(l_run[r]);    // log-sum-exp of the scaled, masked scores (attn_bwd.hip)
         const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) store_split(out, SPLIT ? out_lo : nullptr, dst + dt * 16 + c, o[dt][r] * inv);
@@ -655,13 +656,28 @@ extern "C" int llark_attn_prefill_bf16_alibi(const void* q, const void* k_cache,
         (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_prefill_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(
             (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo,
-            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale, alibi_slopes);
+            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale, alibi_slopes, nullptr);
     } else {
         attn_prefill_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(
             (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr,
-            s, nh, past, smax, scale, alibi_slopes);
+            s, nh, past, smax, scale, alibi_slopes, nullptr);
     }
     return check_launch("attn_prefill");
+}
+
+// The training forward: bf16 operands, no past keys, and the per-query log-sum-exp lse [batch*nh][s] fp32 that
+// llark_attn_backward_bf16 (attn_bwd.hip) recomputes the probabilities from.
+extern "C" int llark_attn_prefill_bf16_lse(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh,
+                                           int hd, int smax, void* out, float* lse, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && vt_cache && out && lse, "attn_prefill_lse: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_prefill_lse: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && smax % 8 == 0, "attn_prefill_lse: bad shape");
+    const float scale = (float)(1.0 / sqrt((double)hd));
+    dim3 grid(cdiv(s, 64), nh, batch);
+    attn_prefill_kernel<false><<<grid, 256, 16384 + 16384 + 4 * 4096, (hipStream_t)stream>>>(
+        (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr, s, nh,
+        0, smax, scale, nullptr, lse);
+    return check_launch("attn_prefill_lse");
 }
 
 extern "C" int llark_attn_prefill_bf16(const void* q, const void* k_cache, const void* vt_cache, const void* q_lo,

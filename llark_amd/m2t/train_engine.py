@@ -187,9 +187,10 @@ class HipLlamaTrainer:
             kc, vc = eng.k_cache[i, :B], eng.vt_cache[i, :B]
             ops.rope_split_heads(qkv, B, S, nh, hd, 0, eng.cos, eng.sin, q, kc, vc)
             att = torch.empty((rows, H), **bf)
-            ops.attn_prefill(q, kc, vc, B, S, nh, hd, 0, att)
+            lse = torch.empty((B * nh, S), **f32)                         # per-query log-sum-exp: the backward recomputes P from it
+            ops.attn_prefill_lse(q, kc, vc, B, S, nh, hd, att, lse)
             ops.gemm16(att, None, self._fwd_weight(L.wo), None, H, ops.EPI_RESID, c=h, resid=h)
-            st.update(x1=x1, q=q, att=att, h_mid=h.clone())
+            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h.clone())
             x2 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
             gu = torch.empty((rows, 2 * I), **f32)
@@ -254,31 +255,21 @@ class HipLlamaTrainer:
             q = st["q"].view(BH, S, hd)
             kc = eng.k_cache[i, :B]                                      # [B][nh][smax][hd]
             vtc = eng.vt_cache[i, :B]                                    # [B][nh][hd][smax]
-            sc = torch.empty((BH, S, S), **f32)
-            ops.gemm16_batched(q, S * hd, hd, kc, smax * hd, hd, S, S, hd, BH, sc, S, S * S)
-            P = torch.empty((BH, S, Sp), **bf)
-            ops.causal_softmax_rows(sc, BH, S, scale, P)
-            v_rm = torch.empty((BH, S, hd), **bf)                        # V row-major from the transposed cache
+            # flash-style backward (csrc/attn_bwd.hip): P is recomputed per tile from the forward's log-sum-exp, no S x S matrix
+            # exists; the only layout work is three S x 128 transposes per head and V back to row-major
+            v_rm = torch.empty((BH, S, hd), **bf)
             ops.transpose16(vtc, smax, hd, S, v_rm, hd, BH, hd * smax, S * hd)
-            ops.gemm16_batched(dO, S * hd, hd, v_rm, S * hd, hd, S, S, hd, BH, sc, S, S * S)      # sc <- dP
-            dS = torch.empty((BH, S, Sp), **bf)
-            ops.attn_ds(P, sc, BH, S, scale, dS)
-            PT = torch.empty((BH, S, Sp), **bf)
-            ops.transpose16(P, Sp, S, S, PT, Sp, BH, S * Sp, S * Sp)
             dOT = torch.empty((BH, hd, Sp), **bf)
             ops.transpose16(dO, hd, S, hd, dOT, Sp, BH, S * hd, hd * Sp)
-            dv = torch.empty((BH, S, hd), **f32)
-            ops.gemm16_batched(PT, S * Sp, Sp, dOT, hd * Sp, Sp, S, hd, Sp, BH, dv, hd, S * hd)
             kT = torch.empty((BH, hd, Sp), **bf)
             ops.transpose16(kc, hd, S, hd, kT, Sp, BH, smax * hd, hd * Sp)
-            dq = torch.empty((BH, S, hd), **f32)
-            ops.gemm16_batched(dS, S * Sp, Sp, kT, hd * Sp, Sp, S, hd, Sp, BH, dq, hd, S * hd)
-            dST = PT                                                     # reuse the buffer
-            ops.transpose16(dS, Sp, S, S, dST, Sp, BH, S * Sp, S * Sp)
-            qT = kT
+            qT = torch.empty((BH, hd, Sp), **bf)
             ops.transpose16(q, hd, S, hd, qT, Sp, BH, S * hd, hd * Sp)
+            dq = torch.empty((BH, S, hd), **f32)
             dk = torch.empty((BH, S, hd), **f32)
-            ops.gemm16_batched(dST, S * Sp, Sp, qT, hd * Sp, Sp, S, hd, Sp, BH, dk, hd, S * hd)
+            dv = torch.empty((BH, S, hd), **f32)
+            dsum = torch.empty((BH, S), **f32)
+            ops.attn_backward(q, qT, kc, kT, v_rm, dO, dOT, st["att"], st["lse"], dsum, B, S, Sp, nh, hd, dq, dk, dv)
             dqkv = torch.empty((rows, 3 * H), **bf)
             ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
             self._dx(dqkv, L.wqkv, dtmp)
