@@ -9,11 +9,13 @@
 //   dV = P^T dO          dP = dO V^T          D = rowsum(dO * O)
 //   dS = P * (dP - D) * scale          dQ = dS K          dK = dS^T Q
 // Two kernels, so that no accumulator is shared between workgroups and nothing needs atomics:
-//   attn_bwd_dkv_kernel: one workgroup per 64 keys (a wave owns 16 keys: dK, dV [16][128] fp32 in registers, K and V fragments in
-//       registers), loop over the query tiles at or after it; S^T and dP^T come out of the MFMA with keys as rows, P^T and dS^T
-//       go through a wave-private LDS scratch to become A operands;
-//   attn_bwd_dq_kernel: one workgroup per 64 queries (a wave owns 16 queries: dQ [16][128], Q and dO fragments in registers), loop
-//       over the key tiles at or before it.
+//   attn_bwd_dkv_kernel: one workgroup per 128 keys (a wave owns 32: dK^T, dV^T fp32 in registers, K and V fragments in registers),
+//       loop over the 64-query tiles at or after it;
+//   attn_bwd_dq_kernel: one workgroup per 128 queries (a wave owns 32: dQ^T in registers, Q and dO fragments in registers), loop
+//       over the 64-key tiles at or before it.
+// In both, the score tile is computed in the orientation whose accumulator layout ("column c, rows 4g..4g+3" per lane) IS the
+// B-operand layout of the product that consumes P / dS, so the probabilities never leave the registers (see the forward kernel in
+// llama.hip for the same device); every LDS fragment read feeds two MFMAs (the wave's two sets).
 // Operand layouts (bf16): the row-major tensors q, k (the K cache), v_rm, dO [BH][S][128] feed the products that contract over d;
 // the products that contract over the sequence need the other operand with the sequence contiguous: qT, dOT (dkv) and kT (dq),
 // [BH][128][Sp] -- three S x 128 transposes per head instead of the two S x S ones of the materialising path.
@@ -28,9 +30,6 @@ namespace {
 
 __device__ __forceinline__ int bk_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }             // [64][128] bf16
 __device__ __forceinline__ int bv_off(int d, int chunk) { return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4); }            // [128][64] bf16
-__device__ __forceinline__ int bp_off(int r, int col) {                                                                    // [16][64] bf16
-    return r * 128 + ((((col >> 3) ^ ((r >> 1) & 7))) << 4) + ((col & 7) << 1);
-}
 
 // rows r0 .. r0+63 of a row-major [.][128] tensor -> LDS [64][128]; rows >= limit are zero
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, size_t ld, int r0, int limit, char* dst) {
@@ -84,23 +83,52 @@ __global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const bf16_t* __re
     if (lane == 0) dsum[row] = v;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qT,
+// Blocks -> (tile, batch*head): the 8 XCDs each take whole heads (one L2 sees one head's operands)
+__device__ __forceinline__ void block_to_tile(int nt, int nbh, int& tile, int& bhid) {
+    const int L = blockIdx.x;
+    if ((nbh & 7) == 0) {
+        bhid = (L & 7) + 8 * (L / (8 * nt));
+        tile = (L >> 3) % nt;
+    } else {
+        bhid = L / nt;
+        tile = L - bhid * nt;
+    }
+}
+
+// the 16 rows of MFMA sub-tile `sub` (0..3) of a 64-row LDS tile: lane group g ends up with rows 32p + 8g + 4(sub&1) + r, so that
+// the two sub-tiles of pair p = sub / 2 hand it 8 consecutive rows = the contraction slots of one b128 read of a transposed tile
+__device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5) + ((i >> 2) << 3) + ((sub & 1) << 2) + (i & 3); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+#ifndef DKV_NK
+#define DKV_NK 1
+#endif
+
+// One workgroup per 128 keys: wave wv owns keys kb0 + 32 wv .. + 31 as two sets of 16 (B operands K, V in registers; dK^T, dV^T
+// [128 d][16 keys] x 2 in accumulators).  Per 64-query tile: S = Q K^T and dP = dO V^T with the queries as MFMA rows (A from LDS),
+// so P and dS leave the MFMA as "column = key, 4 rows = queries" -- the B-operand layout of dV^T = dO^T P and dK^T = Q^T dS
+// (A = the sequence-contiguous tiles in LDS).  Nothing goes through an LDS scratch.
+template <int NK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2 : 1, NK == 1 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qT,
                                                            const bf16_t* __restrict__ kc, const bf16_t* __restrict__ v_rm,
                                                            const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            float* __restrict__ dk, float* __restrict__ dv, int S, int Sp, int smax,
-                                                           float scale) {
+                                                           int nbh, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sQ = smem;                   // [64 q][128 d]
     char* sdO = smem + 16384;          // [64 q][128 d]
     char* sQT = smem + 32768;          // [128 d][64 q]
     char* sdOT = smem + 49152;         // [128 d][64 q]
-    char* sP = smem + 65536;           // 4 waves x (P^T [16 keys][64 q] + dS^T [16][64])
+    float* sL = (float*)(smem + 65536);        // [64] log-sum-exp * log2(e)
+    float* sD = sL + 64;                       // [64] rowsum(dO * O)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const size_t bh = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
-    const int kb0 = blockIdx.x * 64;
+    int tile, bhid;
+    block_to_tile((S + 64 * NK - 1) / (64 * NK), nbh, tile, bhid);               // key tile 0 has the most query tiles: dispatched first
+    const size_t bh = (size_t)bhid;
+    const int kb0 = tile * 64 * NK;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* dob = dO + bh * S * 128;
     const bf16_t* qtb = qT + bh * (size_t)128 * Sp;
@@ -109,128 +137,151 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     const bf16_t* vb = v_rm + bh * S * 128;
     const float* lb = lse + bh * S;
     const float* db = dsum + bh * S;
+    const int wk0 = kb0 + wv * 16 * NK;                                  // the wave's first key
+    const float scale2 = scale * kLog2e;
 
-    bf16x8_t kf[4], vf[4];             // A operands: row = key c of the wave's 16, d = ks*32 + g*8 .. +8
-    {
-        int kr = kb0 + wv * 16 + c;
+    bf16x8_t kf[NK][4], vf[NK][4];       // B operands: column = key c of set u, d = ks*32 + g*8 .. +8
+#pragma unroll
+    for (int u = 0; u < NK; ++u) {
+        int kr = wk0 + u * 16 + c;
         kr = kr < S ? kr : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = *(const bf16x8_t*)(kb + (size_t)kr * 128 + ks * 32 + g * 8);
-            vf[ks] = *(const bf16x8_t*)(vb + (size_t)kr * 128 + ks * 32 + g * 8);
+            kf[u][ks] = *(const bf16x8_t*)(kb + (size_t)kr * 128 + ks * 32 + g * 8);
+            vf[u][ks] = *(const bf16x8_t*)(vb + (size_t)kr * 128 + ks * 32 + g * 8);
         }
     }
-    f32x4_t dka[8], dva[8];
+    f32x4_t dka[NK][8], dva[NK][8];      // dK^T, dV^T: d = dt*16 + 4g + r, key c of set u
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) dka[dt] = dva[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    char* myP = sP + wv * 4096;
-    char* myS = myP + 2048;
+    for (int u = 0; u < NK; ++u)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) dka[u][dt] = dva[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int nqt = (S + 63) / 64;
-    for (int qt = blockIdx.x; qt < nqt; ++qt) {
+    for (int qt = kb0 / 64; qt < nqt; ++qt) {
         const int q0 = qt * 64;
         __syncthreads();
         stage_rows(qb, 128, q0, S, sQ);
         stage_rows(dob, 128, q0, S, sdO);
         stage_cols(qtb, Sp, q0, S, sQT);
         stage_cols(dotb, Sp, q0, S, sdOT);
-        __syncthreads();
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) {
-            f32x4_t st = f32x4_t{0.f, 0.f, 0.f, 0.f}, dpt = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t qf = *(const bf16x8_t*)(sQ + bk_off(qs * 16 + c, ks * 4 + g));
-                const bf16x8_t df = *(const bf16x8_t*)(sdO + bk_off(qs * 16 + c, ks * 4 + g));
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf, st, 0, 0, 0);
-                dpt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], df, dpt, 0, 0, 0);
-            }
-            const int qi = q0 + qs * 16 + c;                        // this lane's column
-            const bool qok = qi < S;
-            const float l = qok ? lb[qi] : 0.0f;
-            const float dd = qok ? db[qi] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb0 + wv * 16 + g * 4 + r;
-                const bool ok = qok && key <= qi;
-                const bf16_t p = (bf16_t)(ok ? __expf(st[r] * scale - l) : 0.0f);
-                const float ds = (float)p * (dpt[r] - dd) * scale;
-                *(bf16_t*)(myP + bp_off(g * 4 + r, qs * 16 + c)) = p;
-                *(bf16_t*)(myS + bp_off(g * 4 + r, qs * 16 + c)) = (bf16_t)ds;
-            }
+        if (threadIdx.x < 64) {
+            const int qi = q0 + threadIdx.x;
+            sL[threadIdx.x] = qi < S ? lb[qi] * kLog2e : 0.0f;
+            sD[threadIdx.x] = qi < S ? db[qi] : 0.0f;
         }
         __syncthreads();
+        if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int poff = c * 128 + (((ks * 4 + g) ^ ((c >> 1) & 7)) << 4);
-            const bf16x8_t pf = *(const bf16x8_t*)(myP + poff);
-            const bf16x8_t sf = *(const bf16x8_t*)(myS + poff);
+        for (int p = 0; p < 2; ++p) {
+            bf16x8_t pf[NK], sf[NK];
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                const int sub = 2 * p + hb;
+                f32x4_t sa[NK], dp[NK];
+#pragma unroll
+                for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t qfr = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
+                    const bf16x8_t dfr = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
+#pragma unroll
+                    for (int u = 0; u < NK; ++u) {
+                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], sa[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+                const int ql = 32 * p + 8 * g + 4 * hb;              // this lane's 4 query rows: ql .. ql + 3
+                const float4 l4 = *(const float4*)(sL + ql);
+                const float4 d4 = *(const float4*)(sD + ql);
+                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    const int key = wk0 + u * 16 + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qa = q0 + ql + r;
+                        const bool ok = qa < S && key <= qa;
+                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 - lr[r]) : 0.0f);
+                        pf[u][hb * 4 + r] = pb;
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
+                    }
+                }
+            }
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t dof = *(const bf16x8_t*)(sdOT + bv_off(dt * 16 + c, ks * 4 + g));
-                const bf16x8_t qtf = *(const bf16x8_t*)(sQT + bv_off(dt * 16 + c, ks * 4 + g));
-                dva[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, dof, dva[dt], 0, 0, 0);
-                dka[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, qtf, dka[dt], 0, 0, 0);
+                const bf16x8_t dof = *(const bf16x8_t*)(sdOT + bv_off(dt * 16 + c, p * 4 + g));
+                const bf16x8_t qtf = *(const bf16x8_t*)(sQT + bv_off(dt * 16 + c, p * 4 + g));
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    dva[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[u], dva[u][dt], 0, 0, 0);
+                    dka[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sf[u], dka[u][dt], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int key = kb0 + wv * 16 + g * 4 + r;
+    for (int u = 0; u < NK; ++u) {
+        const int key = wk0 + u * 16 + c;
         if (key >= S) continue;
-        float* ko = dk + (bh * S + key) * 128;
-        float* vo = dv + (bh * S + key) * 128;
+        float* ko = dk + (bh * S + key) * 128 + 4 * g;
+        float* vo = dv + (bh * S + key) * 128 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-            ko[dt * 16 + c] = dka[dt][r];
-            vo[dt * 16 + c] = dva[dt][r];
+            *(f32x4_t*)(ko + dt * 16) = dka[u][dt];
+            *(f32x4_t*)(vo + dt * 16) = dva[u][dt];
         }
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+// One workgroup per 128 queries: wave wv owns queries q0 + 32 wv .. + 31 as two sets of 16 (B operands Q, dO in registers, dQ^T in
+// accumulators).  Per 64-key tile: S^T = K Q^T and dP^T = V dO^T with the keys as MFMA rows (A from LDS), dS^T leaves the MFMA in
+// the B-operand layout of dQ^T = K^T dS^T (A = the sequence-contiguous K tile in LDS).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ kT, const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           const float* __restrict__ dsum, float* __restrict__ dq, int S, int Sp,
-                                                          int smax, float scale) {
+                                                          int smax, int nbh, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                   // [64 keys][128 d]
     char* sV = smem + 16384;           // [64 keys][128 d]
     char* sKT = smem + 32768;          // [128 d][64 keys]
-    char* sP = smem + 49152;           // 4 waves x dS [16 q][64 keys]
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const size_t bh = (size_t)blockIdx.z * gridDim.y + blockIdx.y;
-    const int nqt = (S + 63) / 64;
-    const int q0 = (nqt - 1 - (int)blockIdx.x) * 64;                // the tiles with the most keys first
+    const int nt = (S + 127) / 128;
+    int tile, bhid;
+    block_to_tile(nt, nbh, tile, bhid);
+    tile = nt - 1 - tile;                                           // the query tiles with the most keys first
+    const size_t bh = (size_t)bhid;
+    const int q0 = tile * 128;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* dob = dO + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* ktb = kT + bh * (size_t)128 * Sp;
     const bf16_t* vb = v_rm + bh * S * 128;
+    const int wq0 = q0 + wv * 32;
+    const float scale2 = scale * kLog2e;
 
-    bf16x8_t qf[4], df[4];
-    {
-        int qr = q0 + wv * 16 + c;
-        qr = qr < S ? qr : S - 1;
+    bf16x8_t qf[2][4], df[2][4];       // B operands: column = query c of set u
+    float l2[2], dd[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int qi = wq0 + u * 16 + c;
+        const int qr = qi < S ? qi : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
-            df[ks] = *(const bf16x8_t*)(dob + (size_t)qr * 128 + ks * 32 + g * 8);
+            qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+            df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * 128 + ks * 32 + g * 8);
         }
+        l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
+        dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
     }
-    float l[4], dd[4];
+    f32x4_t dqa[2][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wv * 16 + g * 4 + r;
-        l[r] = qi < S ? lse[bh * S + qi] : 0.0f;
-        dd[r] = qi < S ? dsum[bh * S + qi] : 0.0f;
-    }
-    f32x4_t dqa[8];
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) dqa[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    char* myS = sP + wv * 2048;
-    int last_key = q0 + 63;
+        for (int dt = 0; dt < 8; ++dt) dqa[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int last_key = q0 + 127;
     if (last_key > S - 1) last_key = S - 1;
     const int nkt = last_key / 64 + 1;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -240,44 +291,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         stage_rows(vb, 128, key0, S, sV);
         stage_cols(ktb, Sp, key0, S, sKT);
         __syncthreads();
+        if (key0 > wq0 + 31) continue;                              // every key of the tile is beyond the wave's queries
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-            f32x4_t sa = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < 2; ++p) {
+            bf16x8_t sf[2];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kfr = *(const bf16x8_t*)(sK + bk_off(sub * 16 + c, ks * 4 + g));
-                const bf16x8_t vfr = *(const bf16x8_t*)(sV + bk_off(sub * 16 + c, ks * 4 + g));
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kfr, sa, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[ks], vfr, dp, 0, 0, 0);
+            for (int hb = 0; hb < 2; ++hb) {
+                const int sub = 2 * p + hb;
+                f32x4_t sa[2], dp[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t kfr = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
+                    const bf16x8_t vfr = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], sa[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, df[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+                const int kl = key0 + 32 * p + 8 * g + 4 * hb;       // this lane's 4 key rows: kl .. kl + 3
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qa = wq0 + u * 16 + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = qa < S && kl + r <= qa;
+                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 - l2[u]) : 0.0f);
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
+                    }
+                }
             }
-            const int key = key0 + sub * 16 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qi = q0 + wv * 16 + g * 4 + r;
-                const bool ok = qi < S && key <= qi;
-                const bf16_t p = (bf16_t)(ok ? __expf(sa[r] * scale - l[r]) : 0.0f);
-                const float ds = (float)p * (dp[r] - dd[r]) * scale;
-                *(bf16_t*)(myS + bp_off(g * 4 + r, sub * 16 + c)) = (bf16_t)ds;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t sf = *(const bf16x8_t*)(myS + c * 128 + (((ks * 4 + g) ^ ((c >> 1) & 7)) << 4));
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t ktf = *(const bf16x8_t*)(sKT + bv_off(dt * 16 + c, ks * 4 + g));
-                dqa[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, ktf, dqa[dt], 0, 0, 0);
+                const bf16x8_t ktf = *(const bf16x8_t*)(sKT + bv_off(dt * 16 + c, p * 4 + g));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) dqa[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, sf[u], dqa[u][dt], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wv * 16 + g * 4 + r;
+    for (int u = 0; u < 2; ++u) {
+        const int qi = wq0 + u * 16 + c;
         if (qi >= S) continue;
-        float* o = dq + (bh * S + qi) * 128;
+        float* o = dq + (bh * S + qi) * 128 + 4 * g;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[dt * 16 + c] = dqa[dt][r];
+        for (int dt = 0; dt < 8; ++dt) *(f32x4_t*)(o + dt * 16) = dqa[u][dt];
     }
 }
 
@@ -300,13 +360,14 @@ extern "C" int llark_attn_backward_bf16(const void* q, const void* qT, const voi
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)batch * nh * s;
     attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows);
-    dim3 grid(cdiv(s, 64), nh, batch);
-    const int lds_kv = 65536 + 4 * 4096, lds_q = 49152 + 4 * 2048;
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    const int nbh = batch * nh;
+    const int grid = cdiv(s, 128) * nbh;
+    const int lds_kv = 65536 + 512, lds_q = 49152;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attn_bwd_dkv_kernel<<<grid, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)qT, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
-                                                   (const bf16_t*)dO, (const bf16_t*)dOT, lse, dsum, dk, dv, s, sp, smax, scale);
+    attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)qT, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
+                                                   (const bf16_t*)dO, (const bf16_t*)dOT, lse, dsum, dk, dv, s, sp, smax, nbh, scale);
     attn_bwd_dq_kernel<<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)kT, (const bf16_t*)v_rm,
-                                                 (const bf16_t*)dO, lse, dsum, dq, s, sp, smax, scale);
+                                                 (const bf16_t*)dO, lse, dsum, dq, s, sp, smax, nbh, scale);
     return check_launch("attn_backward");
 }

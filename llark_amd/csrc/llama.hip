@@ -144,68 +144,100 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------
 // Causal flash attention, bf16 MFMA 16x16x32, fp32 online softmax, head_dim 128.
-// Block = 4 waves x 16 query rows = 64 queries of one (batch, head); KV tiles of 64 keys staged in
+// Block = 4 waves x NQ sets of 16 queries = 64*NQ queries of one (batch, head); KV tiles of 64 keys staged in
 // LDS (K row-major, V already transposed in HBM), both XOR-swizzled for conflict-free b128 reads.
 // key j is visible to query i  iff  j <= past + i.
+//
+// The probabilities never leave the registers: the scores are computed TRANSPOSED, S^T = K Q^T (A = K rows from LDS,
+// B = the wave's Q fragments), so a lane ends up with the scores of ONE query (its MFMA column) against 4 keys per
+// sub-tile -- and a 16x16 accumulator tile read as "column c, rows 4g..4g+3" is exactly the B-operand layout of the
+// next product O^T = V^T P^T (A = V^T rows from LDS).  The 16 rows of score sub-tile `sub` are the keys
+// sub_row(sub, i) = 32 (sub / 2) + 8 (i / 4) + 4 (sub % 2) + i % 4, so that the two sub-tiles of a pair hand lane
+// group g the 8 consecutive keys 32 p + 8 g .. + 7: the contraction slots of ONE b128 read of V^T.  Row statistics
+// (running max, running sum, the rescale factor) are per lane, reduced over the 4 lane groups with two shuffles;
+// O^T leaves the MFMA with 4 consecutive d per lane for the lane's own query.  No P scratch, no third barrier.
+// Softmax in base 2: scores are scaled by log2(e) / sqrt(d) and exponentiated with v_exp_f32.
+// Blocks are numbered so that the 8 XCDs each take whole (batch, head) pairs (one L2 sees one head's K / V) and the
+// query tiles with the most keys are dispatched first.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }        // [64][128] bf16
 __device__ __forceinline__ int v_off(int d, int chunk) { return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4); }       // [128][64] bf16
-__device__ __forceinline__ int p_off(int q, int key) {                                                              // [16][64] bf16
-    return q * 128 + ((((key >> 3) ^ ((q >> 1) & 7))) << 4) + ((key & 7) << 1);
-}
+__device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5) + ((i >> 2) << 3) + ((sub & 1) << 2) + (i & 3); }
 
-// SPLIT = fp32-class mode: q, k, v arrive as bf16 hi+lo planes (16 significant bits each);
+// SPLIT = fp32-class mode: q, k, v arrive as bf16 hi+lo planes (16 significant bits each) and p is split the same way;
 //   S = qh.kh + qh.kl + ql.kh   and   O = ph.vh + pl.vh + ph.vl   (the lo.lo terms are < 2^-16 relative).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+// P2 = p enters the second product as bf16 hi+lo planes (16 significant bits: finer than the reference's bf16 probabilities);
+// !P2 (the training forward) = p rounded to bf16 once, the reference's bf16 flow (modeling_llama.py: softmax(fp32).to(query
+// dtype)) and the same p the backward recomputes.
+template <bool SPLIT, int NQ, bool P2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
                                                            const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                            bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
-                                                           int S, int nh, int past, int smax, float scale,
+                                                           int S, int nh, int nbh, int past, int smax, float scale,
                                                            const float* __restrict__ alibi, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;                 // 16 KiB
     char* sV = smem + 16384;         // 16 KiB
-    char* sP = smem + 32768;         // 4 waves x (2 KiB hi + 2 KiB lo): probabilities as bf16 hi+lo planes
-    char* sKl = smem + 49152;        // SPLIT only: lo planes of K and V^T
-    char* sVl = smem + 65536;
+    char* sKl = smem + 32768;        // SPLIT only: lo planes of K and V^T
+    char* sVl = smem + 49152;
+    constexpr int BQ = 64 * NQ;
+    constexpr float LOG2E = 1.4426950408889634f;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64;
+    const int nt = (S + BQ - 1) / BQ;
+    int tile, bhid;
+    {
+        const int L = blockIdx.x;
+        if ((nbh & 7) == 0) {
+            bhid = (L & 7) + 8 * (L / (8 * nt));
+            tile = (L >> 3) % nt;
+        } else {
+            bhid = L / nt;
+            tile = L - bhid * nt;
+        }
+        tile = nt - 1 - tile;
+    }
+    const int b = bhid / nh, h = bhid - b * nh;
+    const int q0 = tile * BQ;
     const int total = past + S;                                     // keys available
     // ALiBi (MPT, m2t/llava/model/mpt/attention.py build_alibi_bias): additive bias slope_h * (key - (total - 1))
-    const float slope = alibi ? alibi[h] : 0.0f;
-    const size_t bh = (size_t)b * nh + h;
+    const float slope2 = alibi ? alibi[h] * LOG2E : 0.0f;
+    const float scale2 = scale * LOG2E;
+    const size_t bh = (size_t)bhid;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = vtc + bh * (size_t)128 * smax;
     const bf16_t* kbl = SPLIT ? kc_lo + bh * (size_t)smax * 128 : nullptr;
     const bf16_t* vbl = SPLIT ? vtc_lo + bh * (size_t)128 * smax : nullptr;
+    const int wq0 = q0 + wv * 16 * NQ;                              // the wave's first query
 
-    // Q fragments (A operand): row = wave's 16 rows, lane (g,c): row c, d = ks*32 + g*8 .. +8
-    bf16x8_t qf[4], ql[4];
-    {
-        int qr = q0 + wv * 16 + c;
+    // Q fragments (B operand): column = query c of set u, d = ks*32 + g*8 .. +8
+    bf16x8_t qf[NQ][4], ql[SPLIT ? NQ : 1][4];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        int qr = wq0 + u * 16 + c;
         qr = qr < S ? qr : S - 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
-            if (SPLIT) ql[ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
+            qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+            if (SPLIT) ql[u][ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
         }
     }
-    f32x4_t o[8];
+    f32x4_t o[NQ][8];                                               // O^T: d = dt*16 + 4g + r, query c
+    float m_run[NQ], l_run[NQ];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
+    for (int u = 0; u < NQ; ++u) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.0f; }
+        for (int dt = 0; dt < 8; ++dt) o[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        m_run[u] = -INFINITY;
+        l_run[u] = 0.0f;
+    }
 
-    int last_key = past + q0 + 63;                                  // last key any query of this block may see
+    int last_key = past + q0 + BQ - 1;                              // last key any query of this block may see
     if (last_key > total - 1) last_key = total - 1;
     const int ntiles = last_key / 64 + 1;
-    char* myP = sP + wv * 4096;      // hi plane; lo plane at +2048
 
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
@@ -239,95 +271,132 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const bf16_t* __restr
             }
         };
         stage_kv(kb, vb, sK, sV);
-        if (SPLIT) stage_kv(kbl, vbl, sKl, sVl);
+        if (SPLIT) {
+            __builtin_amdgcn_sched_barrier(0);
+            stage_kv(kbl, vbl, sKl, sVl);
+        }
         __syncthreads();
-        // ---- S = Q K^T : 4 key sub-tiles x 4 k-steps ----
-        f32x4_t sacc[4];
+        if (key0 > past + wq0 + 16 * NQ - 1) continue;              // every key of the tile is beyond the wave's queries
+        // ---- S^T = K Q^T : 4 key sub-tiles x 4 k-steps, for each query set ----
+        f32x4_t st[NQ][4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
-            sacc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub * 16 + c, ks * 4 + g));
-                sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sacc[sub], 0, 0, 0);
-                if (SPLIT) {
-                    const bf16x8_t kfl = *(const bf16x8_t*)(sKl + k_off(sub * 16 + c, ks * 4 + g));
-                    sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kfl, sacc[sub], 0, 0, 0);
-                    sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[ks], kf, sacc[sub], 0, 0, 0);
+                const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), ks * 4 + g));
+                bf16x8_t kfl;
+                if (SPLIT) kfl = *(const bf16x8_t*)(sKl + k_off(sub_row(sub, c), ks * 4 + g));
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][sub], 0, 0, 0);
+                    if (SPLIT) {
+                        st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[u][ks], st[u][sub], 0, 0, 0);
+                        st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[u][ks], st[u][sub], 0, 0, 0);
+                    }
                 }
             }
         }
-        // ---- mask + online softmax (rows 4g+r, cols sub*16+c) ----
-        float mx[4];
+        // ---- mask + online softmax: this lane owns query c of each set; rows are keys sub_row(sub, 4g + r) ----
+        bf16x8_t ph[NQ][2], pl[P2 ? NQ : 1][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + wv * 16 + g * 4 + r;
+        for (int u = 0; u < NQ; ++u) {
+            const int lim = past + wq0 + u * 16 + c;                 // last visible key of this lane's query
             float mloc = -INFINITY;
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const int key = key0 + sub * 16 + c;
-                float sv = sacc[sub][r] * scale;
-                if (alibi) sv += slope * (float)(key - (total - 1));
-                if (key > past + qi || key >= total) sv = -INFINITY;
-                sacc[sub][r] = sv;
-                mloc = fmaxf(mloc, sv);
-            }
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, off, 64));
-            mx[r] = mloc;
-        }
-        float alpha[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mn = fmaxf(m_run[r], mx[r]);
-            alpha[r] = (mn == -INFINITY) ? 1.0f : expf(m_run[r] - mn);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + sub_row(sub, 4 * g + r);
+                    float sv = st[u][sub][r] * scale2;
+                    if (alibi) sv += slope2 * (float)(key - (total - 1));
+                    if (key > lim || key >= total) sv = -INFINITY;
+                    st[u][sub][r] = sv;
+                    mloc = fmaxf(mloc, sv);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mn = fmaxf(m_run[u], mloc);
+            const bool dead = mn == -INFINITY;
+            const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
             float rs = 0.0f;
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const float pv = (mn == -INFINITY) ? 0.0f : expf(sacc[sub][r] - mn);
-                const bf16_t pb = (bf16_t)pv;                         // p = hi + lo: 16 significant bits enter PV
-                rs += pv;
-                *(bf16_t*)(myP + p_off(g * 4 + r, sub * 16 + c)) = pb;
-                *(bf16_t*)(myP + 2048 + p_off(g * 4 + r, sub * 16 + c)) = (bf16_t)(pv - (float)pb);
-            }
+            for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off, 64);
-            l_run[r] = l_run[r] * alpha[r] + rs;
-            m_run[r] = mn;
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(st[u][sub][r] - mn);
+                    rs += pv;
+                    const bf16_t pb = (bf16_t)pv;
+                    ph[u][sub >> 1][(sub & 1) * 4 + r] = pb;
+                    if (P2) pl[u][sub >> 1][(sub & 1) * 4 + r] = (bf16_t)(pv - (float)pb);
+                }
+            rs += __shfl_xor(rs, 16, 64);
+            rs += __shfl_xor(rs, 32, 64);
+            l_run[u] = l_run[u] * alpha + rs;
+            m_run[u] = mn;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
         }
+        // ---- O^T += V^T P^T : 2 k-steps (32 keys) x 8 d-tiles ----
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha[r];
-        __syncthreads();                                            // P visible to the whole wave (and block)
-        // ---- O += P V : 2 k-steps (32 keys) x 8 d-tiles ----
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int poff = c * 128 + (((ks * 4 + g) ^ ((c >> 1) & 7)) << 4);
-            const bf16x8_t pf = *(const bf16x8_t*)(myP + poff);
-            const bf16x8_t pl = *(const bf16x8_t*)(myP + 2048 + poff);
+        for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, ks * 4 + g));
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, o[dt], 0, 0, 0);
-                if (SPLIT) {
-                    const bf16x8_t vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, ks * 4 + g));
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vfl, o[dt], 0, 0, 0);
+                const bf16x8_t vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, p * 4 + g));
+                bf16x8_t vfl;
+                if (SPLIT) vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, p * 4 + g));
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[u][p], o[u][dt], 0, 0, 0);
+                    if (P2) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[u][p], o[u][dt], 0, 0, 0);
+                    if (SPLIT) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph[u][p], o[u][dt], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- normalise and store: out[(b*S + q)][h*128 + d] ----
+    // ---- normalise and store: out[(b*S + q)][h*128 + d], 4 consecutive d per lane ----
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wv * 16 + g * 4 + r;
+    for (int u = 0; u < NQ; ++u) {
+        const int qi = wq0 + u * 16 + c;
         if (qi >= S) continue;
-        const float inv = l_run[r] > 0.0f ? 1.0f / l_run[r] : 0.0f;
-        if (lse && c == 0) lse[bh * S + qi] = m_run[r] + logf(l_run[r]);    // log-sum-exp of the scaled, masked scores (attn_bwd.hip)
+        const float inv = l_run[u] > 0.0f ? 1.0f / l_run[u] : 0.0f;
+        // natural-log log-sum-exp of the scaled, masked scores (attn_bwd.hip recomputes P from it)
+        if (lse && g == 0) lse[bh * S + qi] = (m_run[u] + log2f(l_run[u])) * 0.6931471805599453f;
         const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) store_split(out, SPLIT ? out_lo : nullptr, dst + dt * 16 + c, o[dt][r] * inv);
+        for (int dt = 0; dt < 8; ++dt) {
+            bf16x4_t hi4, lo4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = o[u][dt][r] * inv;
+                hi4[r] = (bf16_t)v;
+                lo4[r] = (bf16_t)(v - (float)hi4[r]);
+            }
+            *(bf16x4_t*)(out + dst + dt * 16 + 4 * g) = hi4;
+            if (SPLIT) *(bf16x4_t*)(out_lo + dst + dt * 16 + 4 * g) = lo4;
+        }
+    }
+}
+
+// 128-query blocks (two query sets per wave: every K / V^T fragment read from LDS feeds two MFMAs) once the sequence is long
+// enough to still fill the chip; 64-query blocks for short prompts
+template <bool SPLIT, bool P2>
+static void launch_attn_prefill(hipStream_t st, const bf16_t* q, const bf16_t* kc, const bf16_t* vtc, const bf16_t* q_lo,
+                                const bf16_t* kc_lo, const bf16_t* vtc_lo, bf16_t* out, bf16_t* out_lo, int batch, int s, int nh,
+                                int past, int smax, float scale, const float* alibi, float* lse) {
+    const int lds = SPLIT ? 65536 : 32768;
+    const int nbh = batch * nh;
+    if ((long)cdiv(s, 128) * nbh >= 1024) {
+        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 2, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_prefill_kernel<SPLIT, 2, P2><<<cdiv(s, 128) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
+                                                                          past, smax, scale, alibi, lse);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attn_prefill_kernel<SPLIT, 1, P2><<<cdiv(s, 64) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
+                                                                         past, smax, scale, alibi, lse);
     }
 }
 
@@ -650,18 +719,14 @@ extern "C" int llark_attn_prefill_bf16_alibi(const void* q, const void* k_cache,
     const float scale = (float)(1.0 / sqrt((double)hd));
     const bool split = q_lo != nullptr;
     LLARK_REQUIRE(!split || (k_cache_lo && vt_cache_lo && out_lo), "attn_prefill: fp32-class mode needs every lo plane");
-    const int lds = 16384 + 16384 + 4 * 4096 + (split ? 32768 : 0);
-    dim3 grid(cdiv(s, 64), nh, batch);
-    if (split) {
-        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attn_prefill_kernel<true><<<grid, 256, lds, (hipStream_t)stream>>>(
-            (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo,
-            (const bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, s, nh, past, smax, scale, alibi_slopes, nullptr);
-    } else {
-        attn_prefill_kernel<false><<<grid, 256, lds, (hipStream_t)stream>>>(
-            (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr,
-            s, nh, past, smax, scale, alibi_slopes, nullptr);
-    }
+    if (split)
+        launch_attn_prefill<true, true>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
+                                  (const bf16_t*)q_lo, (const bf16_t*)k_cache_lo, (const bf16_t*)vt_cache_lo, (bf16_t*)out,
+                                  (bf16_t*)out_lo, batch, s, nh, past, smax, scale, alibi_slopes, nullptr);
+    else
+        launch_attn_prefill<false, true>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache,
+                                         nullptr, nullptr, nullptr, (bf16_t*)out, nullptr, batch, s, nh, past, smax, scale,
+                                         alibi_slopes, nullptr);
     return check_launch("attn_prefill");
 }
 
@@ -673,10 +738,8 @@ extern "C" int llark_attn_prefill_bf16_lse(const void* q, const void* k_cache, c
     LLARK_REQUIRE(hd == 128, "attn_prefill_lse: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && smax % 8 == 0, "attn_prefill_lse: bad shape");
     const float scale = (float)(1.0 / sqrt((double)hd));
-    dim3 grid(cdiv(s, 64), nh, batch);
-    attn_prefill_kernel<false><<<grid, 256, 16384 + 16384 + 4 * 4096, (hipStream_t)stream>>>(
-        (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr, nullptr, nullptr, (bf16_t*)out, nullptr, s, nh,
-        0, smax, scale, nullptr, lse);
+    launch_attn_prefill<false, false>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr,
+                                      nullptr, nullptr, (bf16_t*)out, nullptr, batch, s, nh, 0, smax, scale, nullptr, lse);
     return check_launch("attn_prefill_lse");
 }
 
