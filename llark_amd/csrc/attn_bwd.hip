@@ -65,6 +65,30 @@ __device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ base, size
     }
 }
 
+// The same two tiles streamed global -> LDS by LDS-DMA (no registers; the tile must lie completely inside the tensor): the DMA
+// image is lane-linear, so lane i of the instruction covering rows 4j..4j+3 (8j..8j+7 of a transposed tile) FETCHES the chunk that
+// belongs in its slot -- the XOR swizzle of bk_off / bv_off applied to the source address.  Each wave issues 4 of the 16 x 1 KiB.
+__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0, char* dst, int wv, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wv * 4 + i;
+        const int row = 4 * j + (lane >> 4);
+        const bf16_t* src = base + (size_t)(r0 + row) * 128 + (((lane & 15) ^ (row & 15)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void dma_cols(const bf16_t* __restrict__ base, size_t ld, int c0, char* dst, int wv, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wv * 4 + i;
+        const int d = 8 * j + (lane >> 3);
+        const bf16_t* src = base + (size_t)d * ld + c0 + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    }
+}
+
 }  // namespace
 
 // D[bh][s] = sum_d dO[bh][s][d] * O[(b*S + s)][h*128 + d]; one wave per row
@@ -101,7 +125,7 @@ __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5
 
 constexpr float kLog2e = 1.4426950408889634f;
 #ifndef DKV_NK
-#define DKV_NK 1
+#define DKV_NK 2
 #endif
 
 // One workgroup per 128 keys: wave wv owns keys kb0 + 32 wv .. + 31 as two sets of 16 (B operands K, V in registers; dK^T, dV^T
@@ -109,19 +133,16 @@ constexpr float kLog2e = 1.4426950408889634f;
 // so P and dS leave the MFMA as "column = key, 4 rows = queries" -- the B-operand layout of dV^T = dO^T P and dK^T = Q^T dS
 // (A = the sequence-contiguous tiles in LDS).  Nothing goes through an LDS scratch.
 template <int NK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2 : 1, NK == 1 ? 2 : 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qT,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qT,
                                                            const bf16_t* __restrict__ kc, const bf16_t* __restrict__ v_rm,
                                                            const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            float* __restrict__ dk, float* __restrict__ dv, int S, int Sp, int smax,
-                                                           int nbh, float scale) {
+                                                           int nbh, int nh, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;                   // [64 q][128 d]
-    char* sdO = smem + 16384;          // [64 q][128 d]
-    char* sQT = smem + 32768;          // [128 d][64 q]
-    char* sdOT = smem + 49152;         // [128 d][64 q]
-    float* sL = (float*)(smem + 65536);        // [64] log-sum-exp * log2(e)
-    float* sD = sL + 64;                       // [64] rowsum(dO * O)
+    // two LDS stages of DKV_STAGE bytes: Q [64 q][128 d] | dO [64][128] | Q^T [128 d][64 q] | dO^T [128][64] | log-sum-exp [64] |
+    // rowsum(dO * O) [64].  Tile qt+1 streams in by LDS-DMA while tile qt is computed: one barrier per tile.
+    constexpr int DKV_STAGE = 65536 + 512;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -139,6 +160,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2
     const float* db = dsum + bh * S;
     const int wk0 = kb0 + wv * 16 * NK;                                  // the wave's first key
     const float scale2 = scale * kLog2e;
+    // ALiBi (MPT): the forward added slope_h * (key - (S - 1)) to the scaled scores; it has no gradient of its own
+    const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
 
     bf16x8_t kf[NK][4], vf[NK][4];       // B operands: column = key c of set u, d = ks*32 + g*8 .. +8
 #pragma unroll
@@ -157,20 +180,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) dka[u][dt] = dva[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int nqt = (S + 63) / 64;
-    for (int qt = kb0 / 64; qt < nqt; ++qt) {
+    const int qt0 = kb0 / 64;
+    auto stage = [&](int qt) __attribute__((always_inline)) {
         const int q0 = qt * 64;
-        __syncthreads();
-        stage_rows(qb, 128, q0, S, sQ);
-        stage_rows(dob, 128, q0, S, sdO);
-        stage_cols(qtb, Sp, q0, S, sQT);
-        stage_cols(dotb, Sp, q0, S, sdOT);
-        if (threadIdx.x < 64) {
-            const int qi = q0 + threadIdx.x;
-            sL[threadIdx.x] = qi < S ? lb[qi] * kLog2e : 0.0f;
-            sD[threadIdx.x] = qi < S ? db[qi] : 0.0f;
+        char* base = smem + ((qt - qt0) & 1) * DKV_STAGE;
+        if (q0 + 64 <= S) {
+            dma_rows(qb, q0, base, wv, lane);
+            dma_rows(dob, q0, base + 16384, wv, lane);
+            dma_cols(qtb, Sp, q0, base + 32768, wv, lane);
+            dma_cols(dotb, Sp, q0, base + 49152, wv, lane);
+            if (wv == 0) {                                          // the 64 log-sum-exps and row sums: 4 B per lane
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb + q0 + lane),
+                                                 (__attribute__((address_space(3))) void*)(base + 65536), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + q0 + lane),
+                                                 (__attribute__((address_space(3))) void*)(base + 65536 + 256), 4, 0, 0);
+            }
+        } else {                                                    // the ragged last tile: through registers, zero-filled
+            stage_rows(qb, 128, q0, S, base);
+            stage_rows(dob, 128, q0, S, base + 16384);
+            stage_cols(qtb, Sp, q0, S, base + 32768);
+            stage_cols(dotb, Sp, q0, S, base + 49152);
+            if (threadIdx.x < 64) {
+                const int qi = q0 + threadIdx.x;
+                float* sl = (float*)(base + 65536);
+                sl[threadIdx.x] = qi < S ? lb[qi] : 0.0f;
+                sl[64 + threadIdx.x] = qi < S ? db[qi] : 0.0f;
+            }
         }
-        __syncthreads();
+    };
+    if (qt0 < nqt) stage(qt0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int q0 = qt * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile qt has landed
+        __syncthreads();                                            // ... everybody's has, and tile qt-1 is fully consumed
+        if (qt + 1 < nqt) stage(qt + 1);
+        const char* sQ = smem + ((qt - qt0) & 1) * DKV_STAGE;
+        const char* sdO = sQ + 16384;
+        const char* sQT = sQ + 32768;
+        const char* sdOT = sQ + 49152;
+        const float* sL = (const float*)(sQ + 65536);
+        const float* sD = sL + 64;
         if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
+        const bool need_mask = q0 < wk0 + 16 * NK || q0 + 63 >= S;  // else every (query, key) pair of the tile is visible
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf16x8_t pf[NK], sf[NK];
@@ -193,15 +244,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2
                 const int ql = 32 * p + 8 * g + 4 * hb;              // this lane's 4 query rows: ql .. ql + 3
                 const float4 l4 = *(const float4*)(sL + ql);
                 const float4 d4 = *(const float4*)(sD + ql);
-                const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int u = 0; u < NK; ++u) {
                     const int key = wk0 + u * 16 + c;
+                    const float bias2 = slope2 * (float)(key - (S - 1));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int qa = q0 + ql + r;
-                        const bool ok = qa < S && key <= qa;
-                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 - lr[r]) : 0.0f);
+                        const bool ok = !need_mask || (qa < S && key <= qa);
+                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 + bias2 - lr[r]) : 0.0f);
                         pf[u][hb * 4 + r] = pb;
                         sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
                     }
@@ -236,15 +288,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NK == 1 ? 2
 // One workgroup per 128 queries: wave wv owns queries q0 + 32 wv .. + 31 as two sets of 16 (B operands Q, dO in registers, dQ^T in
 // accumulators).  Per 64-key tile: S^T = K Q^T and dP^T = V dO^T with the keys as MFMA rows (A from LDS), dS^T leaves the MFMA in
 // the B-operand layout of dQ^T = K^T dS^T (A = the sequence-contiguous K tile in LDS).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ kT, const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           const float* __restrict__ dsum, float* __restrict__ dq, int S, int Sp,
-                                                          int smax, int nbh, float scale) {
+                                                          int smax, int nbh, int nh, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                   // [64 keys][128 d]
-    char* sV = smem + 16384;           // [64 keys][128 d]
-    char* sKT = smem + 32768;          // [128 d][64 keys]
+    // two LDS stages of 48 KiB: K [64 keys][128 d] | V [64][128] | K^T [128 d][64 keys]; tile kt+1 streams in by LDS-DMA while
+    // tile kt is computed
+    constexpr int DQ_STAGE = 49152;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -261,6 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* vb = v_rm + bh * S * 128;
     const int wq0 = q0 + wv * 32;
     const float scale2 = scale * kLog2e;
+    const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
 
     bf16x8_t qf[2][4], df[2][4];       // B operands: column = query c of set u
     float l2[2], dd[2];
@@ -284,14 +337,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int last_key = q0 + 127;
     if (last_key > S - 1) last_key = S - 1;
     const int nkt = last_key / 64 + 1;
+    auto stage = [&](int kt) __attribute__((always_inline)) {
+        const int key0 = kt * 64;
+        char* base = smem + (kt & 1) * DQ_STAGE;
+        if (key0 + 64 <= S) {
+            dma_rows(kb, key0, base, wv, lane);
+            dma_rows(vb, key0, base + 16384, wv, lane);
+            dma_cols(ktb, Sp, key0, base + 32768, wv, lane);
+        } else {
+            stage_rows(kb, 128, key0, S, base);
+            stage_rows(vb, 128, key0, S, base + 16384);
+            stage_cols(ktb, Sp, key0, S, base + 32768);
+        }
+    };
+    stage(0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int key0 = kt * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        stage_rows(kb, 128, key0, S, sK);
-        stage_rows(vb, 128, key0, S, sV);
-        stage_cols(ktb, Sp, key0, S, sKT);
-        __syncthreads();
+        if (kt + 1 < nkt) stage(kt + 1);
+        const char* sK = smem + (kt & 1) * DQ_STAGE;
+        const char* sV = sK + 16384;
+        const char* sKT = sK + 32768;
         if (key0 > wq0 + 31) continue;                              // every key of the tile is beyond the wave's queries
+        const bool need_mask = key0 + 63 > wq0 || wq0 + 31 >= S;    // else every (query, key) pair of the tile is visible
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf16x8_t sf[2];
@@ -317,8 +386,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int qa = wq0 + u * 16 + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool ok = qa < S && kl + r <= qa;
-                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 - l2[u]) : 0.0f);
+                        const bool ok = !need_mask || (qa < S && kl + r <= qa);
+                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u]) : 0.0f);
                         sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
                     }
                 }
@@ -349,10 +418,11 @@ using namespace llark;
 //   q, dO, v_rm [B*nh][s][128] bf16; k_cache [B*nh][smax][128] bf16; qT, kT, dOT [B*nh][128][sp] bf16 (sp % 8 == 0, sp >= s);
 //   o [B*s][nh*128] bf16 (the forward's output); lse [B*nh][s] fp32 from llark_attn_prefill_bf16_lse;
 //   dsum [B*nh][s] fp32 scratch; dq, dk, dv [B*nh][s][128] fp32 outputs (dk, dv before the RoPE / head merge).
+//   alibi_slopes: nullptr (Llama) or fp32 [nh] (MPT, m2t/llava/model/mpt/attention.py:build_alibi_bias), as given to the forward.
 extern "C" int llark_attn_backward_bf16(const void* q, const void* qT, const void* k_cache, const void* kT, const void* v_rm,
                                         const void* dO, const void* dOT, const void* o, const float* lse, float* dsum, int batch,
                                         int s, int sp, int nh, int hd, int smax, float* dq, float* dk, float* dv,
-                                        llark_stream_t stream) {
+                                        const float* alibi_slopes, llark_stream_t stream) {
     LLARK_REQUIRE(q && qT && k_cache && kT && v_rm && dO && dOT && o && lse && dsum && dq && dk && dv, "attn_backward: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_backward: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && sp >= s && sp % 8 == 0, "attn_backward: bad shape");
@@ -362,12 +432,13 @@ extern "C" int llark_attn_backward_bf16(const void* q, const void* qT, const voi
     attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows);
     const int nbh = batch * nh;
     const int grid = cdiv(s, 128) * nbh;
-    const int lds_kv = 65536 + 512, lds_q = 49152;
+    const int lds_kv = 2 * (65536 + 512), lds_q = 2 * 49152;
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
     attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)qT, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
-                                                   (const bf16_t*)dO, (const bf16_t*)dOT, lse, dsum, dk, dv, s, sp, smax, nbh, scale);
+                                                   (const bf16_t*)dO, (const bf16_t*)dOT, lse, dsum, dk, dv, s, sp, smax, nbh, nh, scale,
+                                                   alibi_slopes);
     attn_bwd_dq_kernel<<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)kT, (const bf16_t*)v_rm,
-                                                 (const bf16_t*)dO, lse, dsum, dq, s, sp, smax, nbh, scale);
+                                                 (const bf16_t*)dO, lse, dsum, dq, s, sp, smax, nbh, nh, scale, alibi_slopes);
     return check_launch("attn_backward");
 }

@@ -1073,6 +1073,7 @@ typedef Cfg<4, 2, 2, 2, 32, 4> Cfg1;   // 256x128x32, 8 waves, 80 KiB           
 typedef Cfg<2, 2, 2, 4, 32, 2> Cfg2;   // 128x256x32, 4 waves (64x128 per wave), 64 KiB : 2 blocks/CU
 // BK = 64: every DMA instruction moves 8 rows x 128 B (full cache lines) instead of 16 rows x 64 B
 typedef Cfg<2, 2, 2, 2, 64, 3, 1> Cfg11;  // 128x128x64, 4 waves, single stage 48 KiB                    : 3 blocks/CU
+typedef Cfg<2, 2, 4, 4, 64, 1, 2> Cfg13;  // 256x256x64, 4 waves (128x128 per wave), two stages 128 KiB (plain only) : 1 block/CU
 typedef Cfg<2, 2, 2, 4, 64, 2, 1> Cfg12;  // 128x256x64, 4 waves (64x128 per wave), single stage 64 KiB  : 2 blocks/CU
 // B-direct kernels (weights fragment-major, L2 -> VGPR): waves 1 x 4 over N
 typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBD0;  // 128x256x64, wave 128x64, A double-buffered 64 KiB (split)    : 2 blocks/CU
@@ -1086,6 +1087,15 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
         case 2: return dispatch<T, Cfg2>(p, split, epi, s);
         case 11: return dispatch<T, Cfg11>(p, split, epi, s);
         case 12: return dispatch<T, Cfg12>(p, split, epi, s);
+        case 13:
+            if (split) break;
+            switch (epi) {
+                case EPI_F32: return launch_gemm<T, false, EPI_F32, Cfg13>(p, s);
+                case EPI_RESID: return launch_gemm<T, false, EPI_RESID, Cfg13>(p, s);
+                case EPI_OUT16: return launch_gemm<T, false, EPI_OUT16, Cfg13>(p, s);
+                case EPI_SWIGLU16: return launch_gemm<T, false, EPI_SWIGLU16, Cfg13>(p, s);
+            }
+            break;
         case 31: {                                                  // 256x256x64 split tile, phases over N with resident A fragments (gemm256n.hip), else 30
             if (split && ws && ws->cus % 8 == 0) {
                 GemmParams q = p;

@@ -170,15 +170,14 @@ __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5
 // !P2 (the training forward) = p rounded to bf16 once, the reference's bf16 flow (modeling_llama.py: softmax(fp32).to(query
 // dtype)) and the same p the backward recomputes.
 template <bool SPLIT, int NQ, bool P2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 && !SPLIT) ? 3 : 2, (NQ == 1 && !SPLIT) ? 3 : 2))) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
                                                            const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                            bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                            int S, int nh, int nbh, int past, int smax, float scale,
                                                            const float* __restrict__ alibi, float* __restrict__ lse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;                 // 16 KiB
-    char* sV = smem + 16384;         // 16 KiB
+    // LDS: per stage K [64][128] 16 KiB + V^T [128][64] 16 KiB; !SPLIT two stages, SPLIT one stage + the lo planes
     char* sKl = smem + 32768;        // SPLIT only: lo planes of K and V^T
     char* sVl = smem + 49152;
     constexpr int BQ = 64 * NQ;
@@ -239,43 +238,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (last_key > total - 1) last_key = total - 1;
     const int ntiles = last_key / 64 + 1;
 
+    // ---- staging.  !SPLIT: two LDS stages; tile kt+1 streams global -> LDS (LDS-DMA, no registers) while tile kt is computed,
+    //      one barrier per tile.  The DMA image is lane-linear, so lane i of the instruction that covers rows 4j..4j+3 of K
+    //      (8j..8j+7 of V^T) FETCHES the chunk that belongs in its slot (the XOR swizzle applied to the source address).
+    //      A tile that crosses `total` (the last one of a ragged sequence) goes through registers so that it can be zero-filled.
+    //      SPLIT (64 KiB of planes per tile): one stage, registers, two barriers -- two workgroups per CU cover each other.
+    constexpr int NST = SPLIT ? 1 : 2;
+    constexpr int STAGE_BYTES = 32768;
+    auto stage_regs = [&](const bf16_t* kbase, const bf16_t* vbase, char* dK, char* dV, int key0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
+            {
+                const int key = idx >> 4, ch = idx & 15;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (key0 + key < total) val = *(const uint4*)(kbase + (size_t)(key0 + key) * 128 + ch * 8);
+                *(uint4*)(dK + k_off(key, ch)) = val;
+            }
+            {
+                const int d = idx >> 3, ch = idx & 7;
+                uint4 val = make_uint4(0, 0, 0, 0);
+                const int kk = key0 + ch * 8;
+                if (kk + 7 < total) {
+                    val = *(const uint4*)(vbase + (size_t)d * smax + kk);
+                } else if (kk < total) {
+                    const bf16_t* src = vbase + (size_t)d * smax + kk;
+                    unsigned short tmp[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) tmp[e] = (kk + e < total) ? ((const unsigned short*)src)[e] : (unsigned short)0;
+                    val = *(uint4*)tmp;
+                }
+                *(uint4*)(dV + v_off(d, ch)) = val;
+            }
+        }
+    };
+    auto stage_dma = [&](char* dK, char* dV, int key0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = wv * 4 + i;                                // this wave's 1 KiB pieces of each 16 KiB tile
+            const int krow = 4 * j + (lane >> 4);
+            const bf16_t* ks = kb + (size_t)(key0 + krow) * 128 + (((lane & 15) ^ (krow & 15)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                             (__attribute__((address_space(3))) void*)(dK + j * 1024), 16, 0, 0);
+            const int d = 8 * j + (lane >> 3);
+            const bf16_t* vs = vb + (size_t)d * smax + key0 + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                             (__attribute__((address_space(3))) void*)(dV + j * 1024), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int kt) __attribute__((always_inline)) {
+        const int key0 = kt * 64;
+        char* base = smem + (NST == 2 ? (kt & 1) * STAGE_BYTES : 0);
+        if (!SPLIT && key0 + 64 <= total) {
+            stage_dma(base, base + 16384, key0);
+        } else {
+            stage_regs(kb, vb, base, base + 16384, key0);
+            if (SPLIT) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_regs(kbl, vbl, sKl, sVl, key0);
+            }
+        }
+    };
+    if (NST == 2) stage(0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
-        __syncthreads();                                            // previous tile fully consumed
-        // ---- stage K [64][128] and V^T [128][64] (zero beyond `total`); SPLIT: also the lo planes ----
-        auto stage_kv = [&](const bf16_t* kbase, const bf16_t* vbase, char* dK, char* dV) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
-                {
-                    const int key = idx >> 4, ch = idx & 15;
-                    uint4 val = make_uint4(0, 0, 0, 0);
-                    if (key0 + key < total) val = *(const uint4*)(kbase + (size_t)(key0 + key) * 128 + ch * 8);
-                    *(uint4*)(dK + k_off(key, ch)) = val;
-                }
-                {
-                    const int d = idx >> 3, ch = idx & 7;
-                    uint4 val = make_uint4(0, 0, 0, 0);
-                    const int kk = key0 + ch * 8;
-                    if (kk + 7 < total) {
-                        val = *(const uint4*)(vbase + (size_t)d * smax + kk);
-                    } else if (kk < total) {
-                        const bf16_t* src = vbase + (size_t)d * smax + kk;
-                        unsigned short tmp[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) tmp[e] = (kk + e < total) ? ((const unsigned short*)src)[e] : (unsigned short)0;
-                        val = *(uint4*)tmp;
-                    }
-                    *(uint4*)(dV + v_off(d, ch)) = val;
-                }
-            }
-        };
-        stage_kv(kb, vb, sK, sV);
-        if (SPLIT) {
-            __builtin_amdgcn_sched_barrier(0);
-            stage_kv(kbl, vbl, sKl, sVl);
+        if (NST == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile kt has landed
+            __syncthreads();                                        // ... everybody's has, and tile kt-1 is fully consumed
+            if (kt + 1 < ntiles) stage(kt + 1);
+        } else {
+            __syncthreads();                                        // previous tile fully consumed
+            stage(kt);
+            __syncthreads();
         }
-        __syncthreads();
+        const char* sK = smem + (NST == 2 ? (kt & 1) * STAGE_BYTES : 0);
+        const char* sV = sK + 16384;
         if (key0 > past + wq0 + 16 * NQ - 1) continue;              // every key of the tile is beyond the wave's queries
         // ---- S^T = K Q^T : 4 key sub-tiles x 4 k-steps, for each query set ----
         f32x4_t st[NQ][4];
@@ -299,22 +336,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         // ---- mask + online softmax: this lane owns query c of each set; rows are keys sub_row(sub, 4g + r) ----
+        // tiles entirely below the diagonal of every query of the wave (and inside `total`) need no mask: wave-uniform test
+        const bool need_mask = key0 + 63 > past + wq0 || key0 + 63 >= total;
         bf16x8_t ph[NQ][2], pl[P2 ? NQ : 1][2];
 #pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int lim = past + wq0 + u * 16 + c;                 // last visible key of this lane's query
             float mloc = -INFINITY;
+            if (need_mask || alibi) {
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
+                for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + sub_row(sub, 4 * g + r);
-                    float sv = st[u][sub][r] * scale2;
-                    if (alibi) sv += slope2 * (float)(key - (total - 1));
-                    if (key > lim || key >= total) sv = -INFINITY;
-                    st[u][sub][r] = sv;
-                    mloc = fmaxf(mloc, sv);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + sub_row(sub, 4 * g + r);
+                        float sv = st[u][sub][r] * scale2;
+                        if (alibi) sv += slope2 * (float)(key - (total - 1));
+                        if (key > lim || key >= total) sv = -INFINITY;
+                        st[u][sub][r] = sv;
+                        mloc = fmaxf(mloc, sv);
+                    }
+            } else {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[u][sub][r] *= scale2;
+                        mloc = fmaxf(mloc, st[u][sub][r]);
+                    }
+            }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float mn = fmaxf(m_run[u], mloc);
@@ -335,10 +384,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             rs += __shfl_xor(rs, 32, 64);
             l_run[u] = l_run[u] * alpha + rs;
             m_run[u] = mn;
+            // once the running maxima have settled (after the first tiles of a row) no lane rescales: skip the 32 multiplies
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt)
+                for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T : 2 k-steps (32 keys) x 8 d-tiles ----
 #pragma unroll
@@ -387,9 +439,9 @@ template <bool SPLIT, bool P2>
 static void launch_attn_prefill(hipStream_t st, const bf16_t* q, const bf16_t* kc, const bf16_t* vtc, const bf16_t* q_lo,
                                 const bf16_t* kc_lo, const bf16_t* vtc_lo, bf16_t* out, bf16_t* out_lo, int batch, int s, int nh,
                                 int past, int smax, float scale, const float* alibi, float* lse) {
-    const int lds = SPLIT ? 65536 : 32768;
+    const int lds = 65536;                                          // SPLIT: hi + lo planes, one stage; else two stages
     const int nbh = batch * nh;
-    if ((long)cdiv(s, 128) * nbh >= 1024) {
+    if (!SPLIT && (long)cdiv(s, 128) * nbh >= 1024) {          // (hi+lo planes: two query sets per wave do not fit 256 registers)
         (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 2, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attn_prefill_kernel<SPLIT, 2, P2><<<cdiv(s, 128) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
                                                                           past, smax, scale, alibi, lse);
@@ -733,13 +785,14 @@ extern "C" int llark_attn_prefill_bf16_alibi(const void* q, const void* k_cache,
 // The training forward: bf16 operands, no past keys, and the per-query log-sum-exp lse [batch*nh][s] fp32 that
 // llark_attn_backward_bf16 (attn_bwd.hip) recomputes the probabilities from.
 extern "C" int llark_attn_prefill_bf16_lse(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh,
-                                           int hd, int smax, void* out, float* lse, llark_stream_t stream) {
+                                           int hd, int smax, void* out, float* lse, const float* alibi_slopes,
+                                           llark_stream_t stream) {
     LLARK_REQUIRE(q && k_cache && vt_cache && out && lse, "attn_prefill_lse: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_prefill_lse: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && smax % 8 == 0, "attn_prefill_lse: bad shape");
     const float scale = (float)(1.0 / sqrt((double)hd));
     launch_attn_prefill<false, false>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)vt_cache, nullptr,
-                                      nullptr, nullptr, (bf16_t*)out, nullptr, batch, s, nh, 0, smax, scale, nullptr, lse);
+                                      nullptr, nullptr, (bf16_t*)out, nullptr, batch, s, nh, 0, smax, scale, alibi_slopes, lse);
     return check_launch("attn_prefill_lse");
 }
 

@@ -3,7 +3,7 @@ checkpoint: scripts/training/train_mpt_model.sh -> HF Trainer -> ``WrappedMPTFor
 :259-330 -> loss.backward() -> AdamW).  Same design as ``HipLlamaTrainer`` (llark_amd/m2t/train_engine.py): forward with
 saved activations, full backward through the same MFMA GEMM on transposed operands, one flat fp32 gradient buffer (bucketed
 all-reduce), fused AdamW.  What differs from Llama: LayerNorm instead of RMSNorm (``llark_layernorm_bwd``), exact-GELU MLP
-(``llark_gelu_bwd``), ALiBi inside the softmax of the materialised attention backward (``llark_causal_softmax_rows_alibi``),
+(``llark_gelu_bwd``), ALiBi inside the flash-style attention backward (``llark_attn_backward_bf16`` with the slopes),
 no rotation (the RoPE kernels run with an identity table), optional biases and ``qk_ln``, tied ``wte`` / ``lm_head``.
 
 ``train_wte``: the reference recipe ends with ``wte.requires_grad = False`` (initialize_audio_tokenizer sets the INPUT
@@ -123,9 +123,10 @@ class HipMptTrainer:
             kc, vc = eng.k_cache[i], eng.vt_cache[i]
             ops.rope_split_heads(qkv, B, S, nh, 128, 0, eng.cos, eng.sin, q, kc, vc)
             att = torch.empty((rows, D), **bf)
-            ops.attn_prefill(q, kc, vc, B, S, nh, 128, 0, att, alibi_slopes=eng.slopes)
+            lse = torch.empty((B * nh, S), **f32)                         # per-query log-sum-exp: the backward recomputes P from it
+            ops.attn_prefill_lse(q, kc, vc, B, S, nh, 128, att, lse, alibi_slopes=eng.slopes)
             ops.gemm16(att, None, Bk.wo, Bk.bo, D, ops.EPI_RESID, c=h, resid=h)
-            st.update(x1=x1, q=q, att=att, h_mid=h.clone())
+            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h.clone())
             x2 = torch.empty((rows, D), **bf)
             ops.layernorm_bf16(h, Bk.n2w, Bk.n2b, d.ln_eps, x2)
             up = torch.empty((rows, E), **f32)
@@ -182,31 +183,19 @@ class HipMptTrainer:
             ops.split_heads16(dctx16, B, S, nh, 128, dO)
             q = st["q"].view(BH, S, 128)
             kc, vtc = eng.k_cache[i], eng.vt_cache[i]
-            sc = torch.empty((BH, S, S), **f32)
-            ops.gemm16_batched(q, S * 128, 128, kc, smax * 128, 128, S, S, 128, BH, sc, S, S * S)
-            P = torch.empty((BH, S, Sp), **bf)
-            ops.causal_softmax_rows_alibi(sc, BH, S, scale, eng.slopes, nh, P)
+            # flash-style backward (csrc/attn_bwd.hip), ALiBi inside: P is recomputed per tile from the forward's log-sum-exp
             v_rm = torch.empty((BH, S, 128), **bf)
             ops.transpose16(vtc, smax, 128, S, v_rm, 128, BH, 128 * smax, S * 128)
-            ops.gemm16_batched(dO, S * 128, 128, v_rm, S * 128, 128, S, S, 128, BH, sc, S, S * S)          # sc <- dP
-            dS = torch.empty((BH, S, Sp), **bf)
-            ops.attn_ds(P, sc, BH, S, scale, dS)
-            PT = torch.empty((BH, S, Sp), **bf)
-            ops.transpose16(P, Sp, S, S, PT, Sp, BH, S * Sp, S * Sp)
             dOT = torch.empty((BH, 128, Sp), **bf)
             ops.transpose16(dO, 128, S, 128, dOT, Sp, BH, S * 128, 128 * Sp)
-            dv = torch.empty((BH, S, 128), **f32)
-            ops.gemm16_batched(PT, S * Sp, Sp, dOT, 128 * Sp, Sp, S, 128, Sp, BH, dv, 128, S * 128)
             kT = torch.empty((BH, 128, Sp), **bf)
             ops.transpose16(kc, 128, S, 128, kT, Sp, BH, smax * 128, 128 * Sp)
-            dq = torch.empty((BH, S, 128), **f32)
-            ops.gemm16_batched(dS, S * Sp, Sp, kT, 128 * Sp, Sp, S, 128, Sp, BH, dq, 128, S * 128)
-            dST = PT
-            ops.transpose16(dS, Sp, S, S, dST, Sp, BH, S * Sp, S * Sp)
-            qT = kT
+            qT = torch.empty((BH, 128, Sp), **bf)
             ops.transpose16(q, 128, S, 128, qT, Sp, BH, S * 128, 128 * Sp)
-            dk = torch.empty((BH, S, 128), **f32)
-            ops.gemm16_batched(dST, S * Sp, Sp, qT, 128 * Sp, Sp, S, 128, Sp, BH, dk, 128, S * 128)
+            dq, dk, dv = (torch.empty((BH, S, 128), **f32) for _ in range(3))
+            dsum = torch.empty((BH, S), **f32)
+            ops.attn_backward(q, qT, kc, kT, v_rm, dO, dOT, st["att"], st["lse"], dsum, B, S, Sp, nh, 128, dq, dk, dv,
+                              alibi_slopes=eng.slopes)
             dqkv = torch.empty((rows, 3 * D), **bf)
             ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, 128, 0, dqkv)      # identity rotation: heads -> [rows][3D]
             if d.qk_ln:                                    # through the LayerNorms over q and k (fp32), then back to bf16

@@ -636,25 +636,26 @@ def attn_prefill(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, pas
                                                    _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_prefill")
 
 
-def attn_prefill_lse(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, out: torch.Tensor, lse: torch.Tensor) -> None:
+def attn_prefill_lse(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int, out: torch.Tensor, lse: torch.Tensor,
+                     alibi_slopes=None) -> None:
     """Training forward: causal attention without past keys that also leaves each query's log-sum-exp (fp32 [batch*nh][s])."""
     smax = k_cache.shape[-2]
     bf = torch.bfloat16
     check(_lib.lib().llark_attn_prefill_bf16_lse(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
                                                  batch, s, nh, hd, smax, _dev(out, "out", bf), _dev(lse, "lse", torch.float32),
-                                                 _stream()), "attn_prefill_lse")
+                                                 _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_prefill_lse")
 
 
 def attn_backward(q, qT, k_cache, kT, v_rm, dO, dOT, o, lse, dsum, batch: int, s: int, sp: int, nh: int, hd: int,
-                  dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor) -> None:
+                  dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, alibi_slopes=None) -> None:
     """Flash-style backward of causal attention (csrc/attn_bwd.hip); layouts in include/llark_hip.h."""
     smax = k_cache.shape[-2]
     bf, f32 = torch.bfloat16, torch.float32
     check(_lib.lib().llark_attn_backward_bf16(_dev(q, "q", bf), _dev(qT, "qT", bf), _dev(k_cache, "k_cache", bf), _dev(kT, "kT", bf),
                                               _dev(v_rm, "v_rm", bf), _dev(dO, "dO", bf), _dev(dOT, "dOT", bf), _dev(o, "o", bf),
                                               _dev(lse, "lse", f32), _dev(dsum, "dsum", f32), batch, s, sp, nh, hd, smax,
-                                              _dev(dq, "dq", f32), _dev(dk, "dk", f32), _dev(dv, "dv", f32), _stream()),
-          "attn_backward")
+                                              _dev(dq, "dq", f32), _dev(dk, "dk", f32), _dev(dv, "dv", f32),
+                                              _opt(alibi_slopes, "alibi_slopes", f32), _stream()), "attn_backward")
 
 
 def attn_decode(q, k_cache, vt_cache, batch: int, nh: int, hd: int, total: int, out: torch.Tensor,

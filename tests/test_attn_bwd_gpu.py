@@ -24,10 +24,12 @@ def _case(B, nh, S, smax, seed):
     return q, k, v, dO
 
 
-def _reference(q, k, v, dO):
+def _reference(q, k, v, dO, slopes=None):
     q, k, v = (t.float().cuda().requires_grad_(True) for t in (q, k, v))
     S = q.shape[2]
     s = (q @ k.transpose(-1, -2)) / math.sqrt(HD)
+    if slopes is not None:                   # ALiBi (m2t/llava/model/mpt/attention.py build_alibi_bias): slope_h * (key - (S - 1))
+        s = s + slopes.cuda().view(1, -1, 1, 1) * (torch.arange(S, device="cuda").float() - (S - 1)).view(1, 1, 1, S)
     mask = torch.ones(S, S, dtype=torch.bool, device="cuda").tril()
     s = s.masked_fill(~mask, float("-inf"))
     lse = torch.logsumexp(s, dim=-1)
@@ -36,7 +38,7 @@ def _reference(q, k, v, dO):
     return o.detach(), lse.detach(), q.grad, k.grad, v.grad
 
 
-def _run(q, k, v, dO, smax):
+def _run(q, k, v, dO, smax, slopes=None):
     from llark_amd import ops
     B, nh, S, _ = q.shape
     BH = B * nh
@@ -49,7 +51,8 @@ def _run(q, k, v, dO, smax):
     qd = q.cuda().contiguous()
     att = torch.empty((B * S, nh * HD), **bf)
     lse = torch.empty((BH, S), **f32)
-    ops.attn_prefill_lse(qd, kc, vtc, B, S, nh, HD, att, lse)
+    sl = slopes.cuda().float().contiguous() if slopes is not None else None
+    ops.attn_prefill_lse(qd, kc, vtc, B, S, nh, HD, att, lse, alibi_slopes=sl)
     Sp = ops.round_up(S, 64)
     # the sequence-contiguous copies carry NaN in their padding: the kernels must not read it
     qT = torch.full((BH, HD, Sp), float("nan"), **bf)
@@ -62,17 +65,20 @@ def _run(q, k, v, dO, smax):
     v_rm = v.cuda().contiguous().view(BH, S, HD)
     dq, dk, dv = (torch.empty((BH, S, HD), **f32) for _ in range(3))
     dsum = torch.empty((BH, S), **f32)
-    ops.attn_backward(qd.view(BH, S, HD), qT, kc, kT, v_rm, dOd, dOT, att, lse, dsum, B, S, Sp, nh, HD, dq, dk, dv)
+    ops.attn_backward(qd.view(BH, S, HD), qT, kc, kT, v_rm, dOd, dOT, att, lse, dsum, B, S, Sp, nh, HD, dq, dk, dv, alibi_slopes=sl)
     torch.cuda.synchronize()
     o = att.view(B, S, nh, HD).permute(0, 2, 1, 3).float()
     return o, lse.view(B, nh, S), dq.view(B, nh, S, HD), dk.view(B, nh, S, HD), dv.view(B, nh, S, HD)
 
 
-@pytest.mark.parametrize("B,nh,S,smax", [(1, 2, 64, 64), (2, 3, 100, 128), (1, 2, 130, 256), (1, 4, 1024, 1024), (2, 2, 333, 512), (1, 1, 7, 64)])
-def test_attention_backward_vs_torch_fp32(B, nh, S, smax):
+@pytest.mark.parametrize("B,nh,S,smax,alibi", [(1, 2, 64, 64, False), (2, 3, 100, 128, False), (1, 2, 130, 256, False), (1, 4, 1024, 1024, False),
+                                               (2, 2, 333, 512, False), (1, 1, 7, 64, False), (2, 8, 300, 320, False), (2, 4, 200, 256, True),
+                                               (1, 16, 515, 576, True)])
+def test_attention_backward_vs_torch_fp32(B, nh, S, smax, alibi):
     q, k, v, dO = _case(B, nh, S, smax, seed=S)
-    ro, rlse, rdq, rdk, rdv = _reference(q, k, v, dO)
-    o, lse, dq, dk, dv = _run(q, k, v, dO, smax)
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / nh) for i in range(nh)]) if alibi else None
+    ro, rlse, rdq, rdk, rdv = _reference(q, k, v, dO, slopes)
+    o, lse, dq, dk, dv = _run(q, k, v, dO, smax, slopes)
     assert (lse - rlse).abs().max().item() <= 2e-3
     assert (o - ro).abs().max().item() <= 2e-2 * ro.abs().max().item()
     for name, got, ref in (("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv)):
@@ -89,7 +95,7 @@ def test_attention_backward_vs_torch_fp32(B, nh, S, smax):
 
 
 def test_attention_backward_matches_materialised_path():
-    """Same gradients as the S x S path the MPT trainer still uses (scores -> softmax rows -> dS -> three batched products)."""
+    """Same gradients as the materialising kernels (scores -> llark_causal_softmax_rows -> llark_attn_ds -> three batched products)."""
     from llark_amd import ops
     B, nh, S, smax = 1, 2, 200, 256
     q, k, v, dO = _case(B, nh, S, smax, seed=3)

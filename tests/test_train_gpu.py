@@ -429,3 +429,27 @@ def test_grads_at_7b_width_vs_autograd_fixture():
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
     print(f"\n[train7b] loss {loss:.5f} (oracle {ref_loss:.5f}); worst gradient errors at 7B width, S = {ids.shape[1]}: "
           + ", ".join(f"{k.replace('model.', '')} {v:.2e}" for k, v in top))
+
+
+@pytest.mark.parametrize("rows,width,accumulate", [(1000, 4096, False), (1000, 4096, True), (37, 256, False), (5000, 1024, True), (9, 8192, False)])
+def test_rmsnorm_bwd_vs_autograd(rows, width, accumulate):
+    """llark_rmsnorm_bwd (rows walked by a fixed grid, dw accumulated in registers) vs torch autograd of LlamaRMSNorm in fp32
+    (transformers==4.29.2 modeling_llama.py:LlamaRMSNorm).  fp32 on both sides: 1e-5 relative to the largest entry; dw, a sum
+    over `rows` terms accumulated in a different order (atomics), 1e-4."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(rows + width)
+    x = torch.randn(rows, width, generator=g)
+    w = 1.0 + 0.1 * torch.randn(width, generator=g)
+    dy = torch.randn(rows, width, generator=g)
+    dx0 = torch.randn(rows, width, generator=g)
+    dw0 = torch.randn(width, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    y.backward(dy)
+    dx = dx0.clone().cuda()
+    dw = dw0.clone().cuda()
+    ops.rmsnorm_bwd(x.cuda(), w.cuda(), dy.cuda(), 1e-5, dx, accumulate, dw)
+    ref_dx = xr.grad + (dx0 if accumulate else 0.0)
+    ref_dw = wr.grad + dw0
+    assert (dx.cpu() - ref_dx).abs().max().item() <= 1e-5 * ref_dx.abs().max().item()
+    assert (dw.cpu() - ref_dw).abs().max().item() <= 1e-4 * ref_dw.abs().max().item()
