@@ -274,6 +274,16 @@ int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, const void*
                                  const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
                                  void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream);
 
+/* Backward products of nn.Linear without transposed copies of their operands (csrc/gemm_tn.hip; torch autograd of the Linear
+ * layers under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
+ *   c[m][n] (= | +=) sum_k A(m, k) W(n, k), 16-bit operands, fp32 accumulate / output.
+ * trans_a == 0: a is [m][lda], k contiguous; trans_a != 0: a is [kp][lda], row = k and column = m (e.g. dY for dW = dY^T X).
+ * trans_b == 0: wt is [n][ldw], k contiguous; trans_b != 0: wt is [kp][ldw], row = k and column = n (e.g. W itself for dX = dY W).
+ * kp % 64 == 0 and every one of the kp contraction rows / columns is read (pad with zeros); lda, ldw % 8 == 0; a transposed
+ * operand's free size % 8 == 0.  epilogue: LLARK_EPI_F32 or LLARK_EPI_RESID (resid may alias c). */
+int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m, int n,
+                   int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream);
+
 /* Training pair (csrc/llama.hip, csrc/attn_bwd.hip): what torch autograd does for LlamaAttention's eager path
  * (transformers==4.29.2 modeling_llama.py) under WrappedLlamav2ForCausalLM.forward + loss.backward()
  * (m2t/models/llamav2.py:259-337, m2t/train.py:53-277), without ever writing an S x S matrix.

@@ -1,0 +1,177 @@
+// Plain 16-bit GEMM whose operands may be stored with the CONTRACTION index as the row ("transposed" operands), for the backward
+// products of the training step -- so that no operand has to be transposed in HBM first:
+//     dX[m][k] = sum_n dY[m][n] W[n][k]        W as stored by the forward ([N][K], n = its row)          -> trans_b
+//     dW[n][k] (+)= sum_m dY[m][n] X[m][k]     dY [M][N] and X [M][K] as the forward / backward left them -> trans_a, trans_b
+// (torch autograd of nn.Linear inside WrappedLlamav2ForCausalLM.forward, m2t/models/llamav2.py:259-337, under m2t/train.py:53-277.)
+//
+// A transposed operand's tile is staged in LDS exactly as it lies in memory -- [64 contraction rows][128 free columns], rows of
+// 256 B, by LDS-DMA -- and its MFMA fragments are fetched with gfx950's transposing LDS read: `ds_read_b64_tr_b16` hands lane i of a
+// 16-lane group column i of a [4 rows][16 columns] block whose row r / 4-column group a is addressed by source lane 4r + a
+// (scripts/probes/tr_b16_probe.hip prints the map).  Two such reads (rows c..c+3 and c+4..c+7) are one 32x32x16 operand fragment
+// (row = the lane's free index, 8 consecutive contraction indices).  Bank conflicts: the four rows of a block are 256 B apart, i.e. on
+// the same banks, so the 16-byte chunks of row r are stored at chunk ^ 4 (r & 3) (swizzle applied to the SOURCE address of the DMA):
+// the 32 lanes that are serviced together then touch 32 distinct 8-byte slots of one 256-byte bank row.
+// An operand with the contraction index contiguous uses the usual image (gemm_core.h: dma_rows, Cfg::off) and b128 reads.
+// Tile 128 x 128 x 64, 4 waves (64 x 64 each), one LDS stage of 32 KiB, 3 workgroups per CU covering each other's staging (the
+// structure of the generic kernel's Cfg11, gemm.hip); epilogues EPI_F32 / EPI_RESID.
+#include "gemm_core.h"
+
+namespace llark {
+
+namespace {
+
+typedef Cfg<2, 2, 2, 2, 64, 3, 1> CfgT;            // 128x128x64, 4 waves
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+
+// 1 KiB of a transposed-operand tile: 4 contraction rows x 128 free columns.  Lane i lands on (row i / 16, slot i % 16) and
+// fetches chunk slot ^ 4 (row & 3).  The free index is clamped to the last 8 valid columns (masked on store).
+template <typename T>
+__device__ __forceinline__ void dma_rows_t(const T* __restrict__ g, int ld, int krow0, int f0, int fvalid, char* lds_dst, int lane) {
+    const int rl = lane >> 4, slot = lane & 15;
+    const int row = krow0 + rl;                                     // krow0 % 4 == 0: row & 3 == rl
+    int col = f0 + ((slot ^ (rl << 2)) << 3);
+    col = col + 8 <= fvalid ? col : fvalid - 8;
+    const T* src = g + (size_t)row * ld + col;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::frag read_frag_t(const char* tile, int off) {
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + off));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + off + 1024));
+    const v8s_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename Mfma<T>::frag, v);
+}
+
+}  // namespace
+
+template <typename T, bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const GemmParams p) {
+    typedef CfgT C;
+    typedef typename Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                     // 16 KiB: [128 rows][64 k] (swizzled) or, transposed, [64 k][128 rows]
+    char* sW = smem + C::A_BYTES;        // 16 KiB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+
+    int base, count;
+    xcd_band(p.tiles_m * p.tiles_n, blockIdx.x & 7, base, count);
+    const int bid = base + (blockIdx.x >> 3);
+    constexpr int GM = 8;                // M-grouped tile order (as gemm.hip: neighbouring tiles share panels)
+    const int gsz = GM * p.tiles_n;
+    const int gi = bid / gsz;
+    const int first_m = gi * GM;
+    const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+    const int m0 = (first_m + (bid % gsz) % gm) * C::BM, n0 = ((bid % gsz) / gm) * C::BN;
+
+    const T* A = (const T*)p.Ahi;
+    const T* W = (const T*)p.Wt;
+    auto stage = [&](int kt) {
+        const int k0 = kt * C::BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = w + i * C::NW;                                // 16 DMA instructions per 16 KiB tile
+            if (TA) dma_rows_t<T>(A, p.lda, k0 + 4 * j, m0, p.M, sA + j * 1024, lane);
+            else dma_rows<T, C>(A, p.lda, m0 + j * C::RPI, p.M, k0, j * C::RPI, sA + j * 1024, lane);
+            if (TB) dma_rows_t<T>(W, p.ldw, k0 + 4 * j, n0, p.N, sW + j * 1024, lane);
+            else dma_rows<T, C>(W, p.ldw, n0 + j * C::RPI, p.N, k0, j * C::RPI, sW + j * 1024, lane);
+        }
+    };
+    // transposed fragments: lane (q = lane / 16, i = lane % 16) is SOURCE lane for row 8 (q / 2) + i / 4 of the k16 step and the
+    // 4 columns 16 (q % 2) + 4 (i % 4) .. of the 32-column MFMA tile; it RECEIVES column 16 (q % 2) + i
+    const int q = lane >> 4, i16 = lane & 15;
+    const int trow = 8 * (q >> 1) + (i16 >> 2);
+    const int tcol = 16 * (q & 1) + 4 * (i16 & 3);
+    auto toff = [&](int f0, int s) __attribute__((always_inline)) {    // f0 % 32 == 0
+        const int col = f0 + tcol;
+        return (s * 16 + trow) * 256 + ((((col >> 3) ^ ((i16 >> 2) << 2)) << 4) | ((col & 7) << 1));
+    };
+
+    f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = p.Kp / C::BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt) __syncthreads();
+        stage(kt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < C::BK / 16; ++s) {
+            const int c = s * 2 + (lane >> 5);
+            frag bf[C::TN], af[C::TM];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bf[tn] = TB ? read_frag_t<T>(sW, toff((wn * C::TN + tn) * 32, s))
+                            : *(const frag*)(sW + C::off((wn * C::TN + tn) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                af[tm] = TA ? read_frag_t<T>(sA, toff((wm * C::TM + tm) * 32, s))
+                            : *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(af[tm], bf[tn], acc[tm][tn]);
+        }
+    }
+    gemm_epilogue<T, false, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+}
+
+template <typename T, bool TA, bool TB, int EPI>
+static int launch_t(GemmParams p, hipStream_t s) {
+    constexpr int LDS = CfgT::A_BYTES + CfgT::B_BYTES;
+    p.tiles_m = cdiv(p.M, CfgT::BM);
+    p.tiles_n = cdiv(p.N, CfgT::BN);
+    gemm_t_kernel<T, TA, TB, EPI><<<p.tiles_m * p.tiles_n, CfgT::THREADS, LDS, s>>>(p);
+    return check_launch("gemm16_t");
+}
+
+template <typename T, int EPI>
+static int dispatch_t(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
+    if (ta && tb) return launch_t<T, true, true, EPI>(p, s);
+    if (tb) return launch_t<T, false, true, EPI>(p, s);
+    if (ta) return launch_t<T, true, false, EPI>(p, s);
+    set_error("gemm16_t: neither operand is transposed -- use llark_gemm16");
+    return LLARK_ERR_INVALID;
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+// C[m][n] (= | +=) sum_k A(m, k) W(n, k), 16-bit operands, fp32 accumulate and output.
+//   trans_a == 0: a is [m][lda] (k contiguous);  trans_a != 0: a is [kp][lda] (row = k, column = m).
+//   trans_b == 0: wt is [n][ldw] (k contiguous); trans_b != 0: wt is [kp][ldw] (row = k, column = n).
+//   kp % 64 == 0 (all kp contraction rows / columns are read: pad with zeros);  a transposed operand's free size (m or n) % 8 == 0.
+//   epilogue: LLARK_EPI_F32 (c = product) or LLARK_EPI_RESID (c = resid + product; resid may alias c).
+extern "C" int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
+                              int n, int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream) {
+    LLARK_REQUIRE(a && wt && c, "gemm16_t: null pointer");
+    LLARK_REQUIRE(dtype == LLARK_F16 || dtype == LLARK_BF16, "gemm16_t: dtype must be LLARK_F16 or LLARK_BF16");
+    LLARK_REQUIRE(m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_t: bad shape m=%d n=%d kp=%d (kp %% 64 == 0)", m, n, kp);
+    LLARK_REQUIRE(!trans_a || (m % 8 == 0 && lda >= m), "gemm16_t: transposed a needs m %% 8 == 0 and lda >= m (m=%d lda=%d)", m, lda);
+    LLARK_REQUIRE(!trans_b || (n % 8 == 0 && ldw >= n), "gemm16_t: transposed wt needs n %% 8 == 0 and ldw >= n (n=%d ldw=%d)", n, ldw);
+    LLARK_REQUIRE(trans_a || lda >= kp, "gemm16_t: lda %d < kp %d", lda, kp);
+    LLARK_REQUIRE(trans_b || ldw >= kp, "gemm16_t: ldw %d < kp %d", ldw, kp);
+    LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, "gemm16_t: lda and ldw must be multiples of 8 (16-byte rows)");
+    LLARK_REQUIRE(epilogue == EPI_F32 || (epilogue == EPI_RESID && resid), "gemm16_t: epilogue must be F32 or RESID (with resid)");
+    GemmParams p = {};
+    p.Ahi = a; p.lda = lda; p.Wt = wt; p.ldw = ldw;
+    p.M = m; p.N = n; p.Kp = kp;
+    p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    hipStream_t s = (hipStream_t)stream;
+    const bool ta = trans_a != 0, tb = trans_b != 0;
+    if (dtype == LLARK_BF16)
+        return epilogue == EPI_F32 ? dispatch_t<bf16_t, EPI_F32>(p, ta, tb, s) : dispatch_t<bf16_t, EPI_RESID>(p, ta, tb, s);
+    return epilogue == EPI_F32 ? dispatch_t<half_t, EPI_F32>(p, ta, tb, s) : dispatch_t<half_t, EPI_RESID>(p, ta, tb, s);
+}

@@ -70,13 +70,22 @@ class HipMptTrainer:
     # ---- product helpers (same formulation as HipLlamaTrainer) -----------------------------------
     @staticmethod
     def _dw(dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor) -> None:
-        """grad[N][K] += dY^T . X"""
+        """grad[N][K] += dY^T . X  (both operands contraction-major as they stand: llark_gemm16_t, no transposed copies, when the
+        token count is a multiple of 64)"""
+        n, k = dy16.shape[1], x16.shape[1]
+        if dy16.shape[0] % 64 == 0 and n % 8 == 0 and k % 8 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
+            ops.gemm16_t(dy16, x16, n, k, dy16.shape[0], True, True, grad, accumulate=True)
+            return
         dyT, xT = ops.transposed16(dy16), ops.transposed16(x16)
         ops.gemm16(dyT, None, xT, None, x16.shape[1], ops.EPI_RESID, c=grad, resid=grad, m=dy16.shape[1])
 
     @staticmethod
     def _dx(dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
-        """out[rows][K] = dY . W   (w [N][K])"""
+        """out[rows][K] = dY . W   (w [N][K]: its row is the contraction index -> llark_gemm16_t on W as stored)"""
+        n, k = w.shape
+        if n % 64 == 0 and k % 8 == 0 and dy16.shape[1] >= n and dy16.stride(0) % 8 == 0:
+            ops.gemm16_t(dy16, w, dy16.shape[0], k, n, False, True, out)
+            return
         wT = ops.transposed16(w)
         if dy16.shape[1] < wT.shape[1]:
             pad = torch.zeros((dy16.shape[0], wT.shape[1]), dtype=_BF, device=dy16.device)

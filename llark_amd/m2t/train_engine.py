@@ -74,15 +74,16 @@ class HipLlamaTrainer:
         self.micro_batches = 0
         self._matrix_grads = {n for n, p in self.params if p.dim() == 2 and n != "embed"}
         self._fresh = set()                            # flat_grad starts zeroed: accumulate until the first zero_grad()
-        # Operands DERIVED from the weights, valid until the next optimizer step (self._wver): the K-contiguous transpose W^T that
-        # dX = dY . W multiplies by (was re-made by every micro-batch: 4 x 13.5 GB read + written per step at accumulation 4), and --
-        # from the second micro-batch of a step on, when the packing has something to amortise over -- fragment-major twins of W
-        # and W^T, so that the forward and dX products take the B-direct kernel like the inference engine (+8 .. 13 %).  Only when
-        # this object owns the optimizer: on the autograd-bridge path the weights are rebuilt outside (sync_engine).
+        # Operands DERIVED from the weights, valid until the next optimizer step (self._wver).  The first micro-batch of a step
+        # needs none: dX = dY . W runs on W as stored (llark_gemm16_t).  From the second micro-batch on, when there is something to
+        # amortise over, fragment-major twins of W and of a K-contiguous W^T are built once, so that the forward and dX products
+        # take the B-direct kernel like the inference engine (+8 .. 13 %).  Only when this object owns the optimizer: on the
+        # autograd-bridge path the weights are rebuilt outside (sync_engine).
         self.derived_operands = bool(optimizer_state)
         self._wver = 0
         self._derived: Dict[int, list] = {}
         self._fwd_uses: Dict[int, list] = {}
+        self._dx_uses: Dict[int, list] = {}
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -95,26 +96,34 @@ class HipLlamaTrainer:
         self.micro_batches = 0
 
     def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor, name: str) -> None:
-        """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch."""
+        """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch.
+        Both operands are contraction-major as they stand (the token index is their row): ``llark_gemm16_t`` reads them through
+        the transposing LDS load, no dY^T / X^T copies; token counts that are not a multiple of 64 take the transposing path."""
+        n, k = dy16.shape[1], x16.shape[1]
+        fresh = name in self._fresh
+        self._fresh.discard(name)
+        if dy16.shape[0] % 64 == 0 and n % 8 == 0 and k % 8 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
+            ops.gemm16_t(dy16, x16, n, k, dy16.shape[0], True, True, grad, accumulate=not fresh)
+            return
         dyT = ops.transposed16(dy16)
         xT = ops.transposed16(x16)
-        n, k = dy16.shape[1], x16.shape[1]
-        if name in self._fresh:
-            self._fresh.discard(name)
+        if fresh:
             ops.gemm16(dyT, None, xT, None, k, ops.EPI_F32, c=grad, m=n)
         else:
             ops.gemm16(dyT, None, xT, None, k, ops.EPI_RESID, c=grad, resid=grad, m=n)
 
     def _w_transposed(self, w: torch.Tensor) -> torch.Tensor:
+        """The K-contiguous W^T of a dX product that does not go through llark_gemm16_t (shapes it does not take, or -- with
+        ``derived_operands`` -- the second and later micro-batches of an optimizer step, which share one W^T with a fragment-major
+        twin for the B-direct kernel)."""
         if not self.derived_operands:
             return ops.transposed16(w)
         ent = self._derived.get(w.data_ptr())
         if ent is None or ent[0] != self._wver:
-            ent = [self._wver, ops.transposed16(w), 0]
+            ent = [self._wver, ops.transposed16(w)]
             self._derived[w.data_ptr()] = ent
-        ent[2] += 1
-        if ent[2] == 2 and ent[1].shape[1] % 64 == 0:
-            ops.attach_frag(ent[1], ent[1].shape[0])
+            if ent[1].shape[1] % 64 == 0:
+                ops.attach_frag(ent[1], ent[1].shape[0])
         return ent[1]
 
     def _fwd_weight(self, w: torch.Tensor) -> torch.Tensor:
@@ -139,7 +148,23 @@ class HipLlamaTrainer:
                     ops.detach_frag(p)
 
     def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
-        """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout)."""
+        """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout: its row IS the contraction index).
+        First use of a weight since the last optimizer step: ``llark_gemm16_t`` on W as it stands (no W^T).  From the second use
+        (gradient accumulation) the K-contiguous transpose + fragment-major twin are built once and the B-direct kernel, 10 %
+        faster per product, amortises them over the remaining micro-batches."""
+        n, k = w.shape
+        if self.derived_operands:
+            ent = self._dx_uses.get(w.data_ptr())
+            if ent is None or ent[0] != self._wver:
+                ent = [self._wver, 0]
+                self._dx_uses[w.data_ptr()] = ent
+            ent[1] += 1
+            first = ent[1] == 1
+        else:
+            first = True
+        if first and n % 64 == 0 and k % 8 == 0 and dy16.shape[1] >= n and dy16.stride(0) % 8 == 0:
+            ops.gemm16_t(dy16, w, dy16.shape[0], k, n, False, True, out)
+            return
         wT = self._w_transposed(w)                    # [K][Np]
         if dy16.shape[1] < wT.shape[1]:               # pad dY columns up to the 64-multiple K of this product
             pad = torch.zeros((dy16.shape[0], wT.shape[1]), dtype=_BF, device=dy16.device)

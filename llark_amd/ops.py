@@ -440,6 +440,19 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         out_hi.stride(0) if out_hi is not None else 0, workspace(), _stream()), "gemm16")
 
 
+def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a: bool, trans_b: bool, c: torch.Tensor,
+             accumulate: bool = False) -> None:
+    """c[m][n] (= | +=) sum_k A(m, k) W(n, k) with operands that may be stored contraction-major (csrc/gemm_tn.hip;
+    include/llark_hip.h: llark_gemm16_t): ``trans_a`` -> a is [kp][>= m], ``trans_b`` -> wt is [kp][>= n]."""
+    dtype = a.dtype
+    assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype and a.stride(-1) == 1 and wt.stride(-1) == 1
+    with _timed("gemm_f16" if dtype == torch.float16 else "gemm_bf16", 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_t(_DT[dtype], EPI_RESID if accumulate else EPI_F32, int(trans_a), int(trans_b),
+                                        _dev(a, "a", contiguous=False), a.stride(0), _dev(wt, "wt", contiguous=False), wt.stride(0), m, n, kp,
+                                        _dev(c, "c", torch.float32, contiguous=False), c.stride(0),
+                                        _dev(c, "c", torch.float32, contiguous=False) if accumulate else None, c.stride(0), _stream()), "gemm16_t")
+
+
 def lo8_weight_exponent(w: torch.Tensor) -> int:
     """sw with max|W| * 2^sw <= 448 (the E4M3 maximum): the per-matrix scale of the in-kernel fp8 weight plane."""
     amax = float(w.detach().abs().max().float())

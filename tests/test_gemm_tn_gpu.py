@@ -1,0 +1,74 @@
+"""GPU parity: llark_gemm16_t (csrc/gemm_tn.hip) -- the backward products of nn.Linear on operands stored contraction-major, read
+through ds_read_b64_tr_b16 -- vs a plain torch fp32 product of the same 16-bit operands (what autograd computes for
+dX = dY W and dW = dY^T X under m2t/models/llamav2.py:259-337).
+
+Tolerance: identical 16-bit operand values, fp32 accumulation on both sides in different orders: |err| <= 2e-6 * sum_k |a||w|
+(a few fp32 ulps of the absolute-value product), which a swapped row / column / k-slot misses by orders of magnitude (random,
+non-symmetric operands)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(c, a_mk, w_nk, init=None):
+    ref = a_mk.double() @ w_nk.double().t()
+    bound = a_mk.double().abs() @ w_nk.double().abs().t()
+    if init is not None:
+        ref = ref + init.double()
+        bound = bound + init.double().abs()
+    err = (c.double() - ref).abs()
+    assert (err <= 2e-6 * bound + 1e-30).all(), (err / (bound + 1e-30)).max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,kp", [(128, 128, 64), (200, 136, 128), (4096, 4096, 2048), (1000, 72, 448), (8, 8, 64), (352, 12288, 192)])
+def test_dx_form_w_contraction_major(dtype, m, n, kp):
+    """dX[m][n] = sum_k dY[m][k] W[k][n]: W stored [kp][n] (trans_b)."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n)
+    a = torch.randn(m, kp, generator=g, device="cuda").to(dtype)
+    w = (torch.randn(kp, n, generator=g, device="cuda") * 0.1).to(dtype)
+    c = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_t(a, w, m, n, kp, False, True, c)
+    _check(c, a.float(), w.float().t())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,kp,accumulate", [(128, 128, 64, False), (136, 200, 128, True), (4096, 11008, 1024, True), (72, 1000, 448, False),
+                                               (12288, 4096, 512, False)])
+def test_dw_form_both_contraction_major(dtype, m, n, kp, accumulate):
+    """dW[m][n] (+)= sum_k dY[k][m] X[k][n]: both operands stored with the contraction index as the row."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m * 5 + n)
+    a = torch.randn(kp, m, generator=g, device="cuda").to(dtype)
+    w = (torch.randn(kp, n, generator=g, device="cuda") * 0.1).to(dtype)
+    init = torch.randn(m, n, generator=g, device="cuda") if accumulate else None
+    c = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_t(a, w, m, n, kp, True, True, c, accumulate=accumulate)
+    _check(c, a.float().t(), w.float().t(), init)
+
+
+def test_a_contraction_major_only_and_strided_views():
+    """trans_a alone, and operands that are column slices of wider buffers (lda / ldw > free size)."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    kp, m, n = 256, 264, 136
+    abuf = torch.randn(kp, m + 40, generator=g, device="cuda").bfloat16()
+    wbuf = (torch.randn(n, kp + 64, generator=g, device="cuda") * 0.1).bfloat16()
+    a, w = abuf[:, :m], wbuf[:, :kp]
+    c = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_t(a, w, m, n, kp, True, False, c)
+    _check(c, a.float().t(), w.float())
+
+
+def test_rejects_what_it_cannot_do():
+    from llark_amd import ops
+    from llark_amd._lib import LlarkHipError
+    a = torch.zeros(64, 100, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")
+    c = torch.zeros(100, 128, device="cuda")
+    with pytest.raises(LlarkHipError):
+        ops.gemm16_t(a, w, 100, 128, 64, True, True, c)            # m % 8 != 0 for a transposed operand
+    with pytest.raises(LlarkHipError):
+        ops.gemm16_t(w, w, 128, 128, 32, True, True, c)            # kp % 64 != 0
