@@ -309,6 +309,9 @@ int llark_layernorm_bf16(const float* x, int ldx, int rows, int width, const flo
 int llark_layernorm_f32(const float* x, int ldx, int rows, int width, const float* gamma, const float* beta, float eps,
                         float* y, int ldy, llark_stream_t stream);
 int llark_clamp_f32(float* x, long long n, float limit, llark_stream_t stream);
+/* backward of that clamp in the MPT training step: dy (bf16 [n], in place) keeps its value where |x| <= limit (x = the qkv
+ * BEFORE the clamp) and becomes 0 elsewhere -- torch.clamp's gradient under loss.backward() (m2t/train.py:53-277). */
+int llark_clamp_bwd_bf16(const float* x, long long n, float limit, void* dy, llark_stream_t stream);
 int llark_scale_f32(float* x, long long n, float a, llark_stream_t stream);   /* logits *= logit_scale */
 int llark_gelu_split_bf16(const float* x, int ldx, int rows, int width, void* out_hi, void* out_lo, int ldo,
                           llark_stream_t stream);

@@ -89,6 +89,12 @@ __global__ void clamp_f32_kernel(float* __restrict__ x, long long n, float lim) 
     if (i < n) x[i] = fminf(fmaxf(x[i], -lim), lim);
 }
 
+// backward of the clamp: torch.clamp passes the gradient where -lim <= x <= lim (x = the value BEFORE the clamp), else 0
+__global__ void clamp_bwd_bf16_kernel(const float* __restrict__ x, long long n, float lim, bf16_t* __restrict__ dy) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !(x[i] >= -lim && x[i] <= lim)) dy[i] = (bf16_t)0.0f;
+}
+
 // exact GELU (nn.GELU(approximate="none"), m2t/llava/model/mpt/blocks.py:15): 0.5 x (1 + erf(x / sqrt 2)) -> bf16 planes
 __global__ void gelu_split_kernel(const float* __restrict__ x, int ldx, int rows, int width, bf16_t* __restrict__ hi,
                                   bf16_t* __restrict__ lo, int ldo) {
@@ -262,6 +268,14 @@ extern "C" int llark_clamp_f32(float* x, long long n, float limit, llark_stream_
     LLARK_REQUIRE(x && n > 0 && limit > 0.0f, "clamp_f32: bad arguments");
     clamp_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, n, limit);
     return check_launch("clamp_f32");
+}
+
+// training: dy (bf16, n contiguous elements, in place) <- dy where |x| <= limit, 0 elsewhere; x = the fused qkv BEFORE llark_clamp_f32
+// (attn_config.clip_qkv, m2t/llava/model/mpt/attention.py: qkv.clamp_(min=-clip_qkv, max=clip_qkv) under loss.backward())
+extern "C" int llark_clamp_bwd_bf16(const float* x, long long n, float limit, void* dy, llark_stream_t stream) {
+    LLARK_REQUIRE(x && dy && n > 0 && limit > 0.0f, "clamp_bwd_bf16: bad arguments");
+    clamp_bwd_bf16_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, n, limit, (bf16_t*)dy);
+    return check_launch("clamp_bwd_bf16");
 }
 
 extern "C" int llark_scale_f32(float* x, long long n, float a, llark_stream_t stream) {     // logits *= logit_scale (modeling_mpt.py:410-416)

@@ -9,7 +9,8 @@ no rotation (the RoPE kernels run with an identity table), optional biases and `
 ``train_wte``: the reference recipe ends with ``wte.requires_grad = False`` (initialize_audio_tokenizer sets the INPUT
 embeddings trainable and then freezes the OUTPUT embeddings, which is the same tied tensor, m2t/models/mpt.py:405-411), so
 the default keeps ``wte`` frozen; ``train_wte=True`` accumulates both of its uses (gather rows and the logits product).
-Not built: ``clip_qkv`` (clamp mask) and ``logit_scale`` in training.
+``clip_qkv`` (clamp in the forward, gradient mask ``llark_clamp_bwd_bf16`` in the backward) and ``logit_scale`` (logits scaled in
+place before the loss, the factor folded into the scale of d(logits)) follow ``attn_config`` / ``config.logit_scale``.
 """
 from __future__ import annotations
 
@@ -31,8 +32,6 @@ class HipMptTrainer:
         self.grad_comm = grad_comm
         if engine.split:
             raise ValueError("the training step runs in the reference's bf16 flow: build the engine with precision='bf16'")
-        if d.clip_qkv or d.logit_scale is not None:
-            raise NotImplementedError("clip_qkv / logit_scale are not built for the MPT training step")
         self.eng, self.lr, self.betas, self.eps, self.wd = engine, lr, betas, eps, weight_decay
         self.train_wte, self.step_count = train_wte, 0
         for B in engine.blocks:                                  # weights change in place from now on
@@ -124,6 +123,9 @@ class HipMptTrainer:
             ops.layernorm_bf16(h, Bk.n1w, Bk.n1b, d.ln_eps, x1)
             qkv = torch.empty((rows, 3 * D), **f32)
             ops.gemm16(x1, None, Bk.wqkv, Bk.bqkv, 3 * D, ops.EPI_F32, c=qkv)
+            if d.clip_qkv:
+                st["qkv_raw"] = qkv.clone()              # the clamp's gradient mask needs the values before it
+                ops.clamp_f32_(qkv, d.clip_qkv)
             if d.qk_ln:
                 st["qkv_pre"] = qkv.clone()
                 ops.layernorm_f32_(qkv[:, :D], Bk.qlw, Bk.qlb, d.ln_eps)
@@ -150,7 +152,11 @@ class HipMptTrainer:
         logits = torch.empty((rows, V), **f32)
         ops.gemm16(xf, None, eng.wte, None, V, ops.EPI_F32, c=logits)
         dlogits = torch.empty((rows, ops.round_up(V, 64)), **bf)
-        loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale)
+        lscale = 1.0
+        if d.logit_scale is not None:                    # modeling_mpt.py:410-416: logits *= logit_scale; d(raw logits) = scale * d(logits)
+            lscale = float(d.logit_scale)
+            ops.scale_f32_(logits, lscale)
+        loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale * lscale)
         del logits
         # ---------------- backward ----------------
         g = self.grads
@@ -215,6 +221,8 @@ class HipMptTrainer:
                 d32[:, : 2 * D] = dpre
                 dqkv = self._to16(d32, 3 * D)
                 del d32, dpre
+            if d.clip_qkv:
+                ops.clamp_bwd_bf16_(st["qkv_raw"], d.clip_qkv, dqkv)
             self._dx(dqkv, Bk.wqkv, dtmp)
             self._dw(dqkv, st["x1"], g[pre + "wqkv"])
             if Bk.bqkv is not None:

@@ -726,6 +726,13 @@ def clamp_f32_(x: torch.Tensor, limit: float) -> None:
     check(_lib.lib().llark_clamp_f32(_dev(x, "x", torch.float32), x.numel(), float(limit), _stream()), "clamp_f32")
 
 
+def clamp_bwd_bf16_(x_pre: torch.Tensor, limit: float, dy: torch.Tensor) -> None:
+    """dy (bf16, in place) <- dy where |x_pre| <= limit else 0: the gradient of clamp_f32_ (x_pre = the values before it)."""
+    assert x_pre.numel() == dy.numel()
+    check(_lib.lib().llark_clamp_bwd_bf16(_dev(x_pre, "x_pre", torch.float32), x_pre.numel(), float(limit),
+                                          _dev(dy, "dy", torch.bfloat16), _stream()), "clamp_bwd_bf16")
+
+
 def layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, dy: torch.Tensor, eps: float, dx: torch.Tensor, dgamma: torch.Tensor,
                   dbeta: Optional[torch.Tensor], accumulate: bool) -> None:
     """x, dy, dx: fp32 [rows][width] views with unit column stride (column slices of wider buffers are fine)."""

@@ -167,14 +167,20 @@ def test_wrapped_mpt_surface_forward_generate_errors():
     assert (a2.audio_patch_token, a2.audio_start_token, a2.audio_end_token) == tuple(tok.convert_tokens_to_ids(["<audio_patch>", "<audio_start>", "<audio_end>"]))
 
 
-@pytest.mark.parametrize("case", ["alibi", "alibi+qk_ln+bias"])
+@pytest.mark.parametrize("case", ["alibi", "alibi+qk_ln+bias", "alibi+qk_ln+clip+bias+logit_scale", "alibi+clip"])
 def test_mpt_training_step_gradients_match_autograd(case):
     """HipMptTrainer (forward with saved activations, full backward, AdamW) vs torch autograd of the fp32 oracle on bf16-valued
     weights: per-tensor relative Frobenius error <= 5e-2 and cosine >= 0.995 (bf16 operands in both passes), loss within 1 %;
     then a few optimizer steps reduce the loss."""
     from llark_amd.m2t.mpt_train_engine import HipMptTrainer
     from oracle import mpt_ref as MR
-    extra = {} if case == "alibi" else dict(qk_ln=True, no_bias=False, alibi_bias_max=4)
+    extra = {"alibi": {}, "alibi+qk_ln+bias": dict(qk_ln=True, no_bias=False, alibi_bias_max=4),
+             "alibi+qk_ln+clip+bias+logit_scale": dict(qk_ln=True, clip_qkv=3.0, no_bias=False, alibi_bias_max=4, logit_scale=0.5),
+             "alibi+clip": dict(clip_qkv=3.2)}[case]
+    # clip at ~2.5 sigma of these weights' qkv (sigma ~ 0.08 sqrt(256) = 1.28): about 1 % of the entries are cut -- a missing mask
+    # would be a ~10 % gradient error, an inverted one ~100 % -- while few entries sit within the bf16 rounding of the threshold
+    # (the GPU's qkv comes from bf16 activations, the oracle's from fp32: at a clip of 0.4 sigma the entries that land on different
+    # sides of it are a 5.5 % gradient difference by themselves, measured)
     spec = MR.MptSpec(**BASE, audio_start_token=93, audio_end_token=94, audio_patch_token=95, **extra)
     w = MR.make_weights(spec, seed=31, std=0.08)
     g = torch.Generator().manual_seed(8)
