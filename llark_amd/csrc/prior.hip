@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_split8_kernel(const float* __re
 // Factored attention (block / transpose-block / previous-block), fp32, one workgroup per
 // (64-query group, head, clip).  Q K^T and P V run on the fp32-input matrix cores
 // (v_mfma_f32_16x16x4_f32: exact fp32 fma chains at the fp32 vector rate, no precision trade), the
-// softmax is fp32 in LDS.  K / V^T tiles of 64 keys and the score tile live in LDS (65-82 KiB).
+// softmax is fp32 in registers.  K / V tiles of 64 keys live in LDS (47 KiB).
 // Output is written as fp16 hi/lo for the c_proj GEMM.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
@@ -212,9 +212,9 @@ struct AttnParams {
     int nk_max;         // LDS rows reserved for K/V
 };
 
-// LDS geometry (floats): one [64][ATT_KP] tile that holds Q, then each K tile, then each V tile
-// (all row-major, staged with coalesced 8-byte row loads); scores [64][SP].  ATT_KP = 188 and
-// SP = 68 / 132 keep the ds_read_b128 operand reads at <= 2-way bank conflicts.
+// LDS geometry (floats): one [64][ATT_KP] tile that holds each K tile, then each V tile, then the output
+// (all row-major, staged with coalesced 8-byte row loads); the scores / probabilities live in registers.
+// ATT_KP = 188 keeps the ds_read_b128 operand reads at <= 2-way bank conflicts.
 enum { ATT_KP = 188 };
 
 // 16 token rows (this wave's quarter of a 64-row tile) of `hd` floats, HBM -> registers -> LDS.
@@ -265,7 +265,12 @@ __device__ __forceinline__ void store_rows16(const RowRegs& R, float* __restrict
 #define ATTN_ABLATE 0      // profiling builds only (scripts/build_attn_ablations.sh): 1 no softmax, 2 no PV MFMAs, 3 no QK MFMAs, 4 no output stores
 #endif
 template <int NKS>      // NKS = compile-time number of 16-wide head-dim steps (>= ceil(hd/16)); pad columns are zero
-__global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) {
+// 2 waves per SIMD: with the K/V prefetch registers, Q, the scores and the output accumulators live at once the kernel needs ~220
+// registers at head_dim 150; at 3 (170 registers, which the 47 KiB of LDS would allow) it spills and is 25 % slower (measured)
+#ifndef ATTN_WPE
+#define ATTN_WPE 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WPE, ATTN_WPE))) void prior_attn_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
@@ -274,9 +279,7 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
     const int hd = p.hd;
     constexpr int nks = NKS;
     constexpr int wcols = 16 * NKS;
-    const int sp = p.nk_max + 4;                  // score pitch (68 or 132)
     float* sT = sm;                               // [64][ATT_KP]: K tiles, then V tiles
-    float* sS = sm + 64 * ATT_KP;                 // [64][sp]: rows of wave w are written and read by wave w only
 
     int nq, q0, qs, nkeys, k0, ks, coff;
     bool causal = true, zero_out = false;
@@ -335,9 +338,17 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
         }
     }
 
-    // ---- scores: S = scale2 * Q K^T, one 64-key tile at a time; the next tile (K, then V) is
-    //      already being fetched while the MFMAs of the current one run ----
-    for (int kt = 0; kt < ntile; ++kt) {
+    // ---- scores, TRANSPOSED: S^T = scale2 * K Q^T (A = K rows from LDS, B = the wave's Q fragments), one 64-key tile at a time;
+    //      the next tile (K, then V) is already being fetched while the MFMAs of the current one run.  A lane ends up with the scores
+    //      of ONE query (its MFMA column c) against keys 16 sub + 4g + r -- which is exactly the B operand P^T[key][query] of the
+    //      j = r-th MFMA of step sub in O^T = V^T P^T below: the probabilities never leave the registers (round 2 wrote them to a
+    //      [64][nk+4] LDS tile, softmaxed there and read them back: 17-34 KiB of LDS and two more barriers; the time is the
+    //      same within 5 % -- 427 / 740 / 412 us for the three patterns at 8 clips -- the kernel is bound by its strided 600-byte
+    //      row reads, profiles/r03_prior_attn_regs.txt) ----
+    f32x4_t sc[2][4];                                 // [key tile][sub]; nk_max <= 128
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (kt >= ntile) break;
         if (kt) __syncthreads();                  // previous K tile fully consumed
         store_rows16(R, sT, wv * 16, nkeys - kt * 64, hd, wcols, lane);
         __syncthreads();
@@ -348,89 +359,86 @@ __global__ __launch_bounds__(256, 2) void prior_attn_kernel(const AttnParams p) 
         for (int sub = 0; sub < 4; ++sub) acc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            {
-                f32x4_t kf[4];
+            f32x4_t kf[4];
 #pragma unroll
-                for (int sub = 0; sub < 4; ++sub) kf[sub] = *(const f32x4_t*)(sT + (sub * 16 + c) * ATT_KP + 16 * s + 4 * g);
+            for (int sub = 0; sub < 4; ++sub) kf[sub] = *(const f32x4_t*)(sT + (sub * 16 + c) * ATT_KP + 16 * s + 4 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int sub = 0; sub < 4; ++sub)      // 4 independent accumulators between dependent MFMAs
+                for (int sub = 0; sub < 4; ++sub)      // 4 independent accumulators between dependent MFMAs
 #if ATTN_ABLATE == 3
-                        acc[sub][0] += qf[s][j] * kf[sub][j];
+                    acc[sub][0] += qf[s][j] * kf[sub][j];
 #else
-                        acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s][j], kf[sub][j], acc[sub], 0, 0, 0);
+                    acc[sub] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[sub][j], qf[s][j], acc[sub], 0, 0, 0);
 #endif
-            }
         }
-        // C layout: col = c (key), rows = 4g + r (query within the wave's 16)
+        // C layout: col = c (query within the wave's 16), rows = 4g + r (key within the sub-tile)
+        const int i = wv * 16 + c;
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = wv * 16 + 4 * g + r;
-                const int j = kt * 64 + sub * 16 + c;
+                const int j = kt * 64 + sub * 16 + 4 * g + r;
                 const bool ok = (j < nkeys) && (!causal || (j <= i + coff));
-                sS[i * sp + j] = ok ? acc[sub][r] * p.scale2 : -INFINITY;
+                sc[kt][sub][r] = ok ? acc[sub][r] * p.scale2 : -INFINITY;
             }
     }
 
-    // ---- fp32 softmax over the wave's own 16 rows (no block barrier needed).  Four lanes per row, each owning a contiguous
-    //      quarter (16 or 32 scores): the row maximum and sum need two cross-lane steps instead of a 64-lane butterfly per row, and
-    //      all 16 rows of the wave are processed at once (the row-at-a-time form was 23 % of the kernel:
-    //      profiles/r02_attn_ablation.txt).  Masked scores are -inf: exp gives 0; a fully masked row cannot occur (key 0 is
-    //      always visible), and a zero sum would still give zeros, not NaN. ----
-    const int ncol = ntile * 64;
+    // ---- fp32 softmax in registers: a lane holds 16 (or 32) scores of its query; the other 48 (96) sit in the three lanes with the
+    //      same c in the other lane groups: two cross-lane steps per reduction.  Masked scores are -inf: exp gives 0; a fully masked
+    //      row cannot occur (key 0 is always visible), and a zero sum would still give zeros, not NaN. ----
 #if ATTN_ABLATE != 1
     {
-        float* srow = sS + (wv * 16 + (lane >> 2)) * sp + (lane & 3) * (ncol >> 2);
-        auto softmax_quarter = [&](auto nv_tag) __attribute__((always_inline)) {
-            constexpr int NV = decltype(nv_tag)::value;                 // float4 per lane: 4 (64 keys) or 8 (128 keys)
-            f32x4_t v[NV];
+        float mx = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = *(const f32x4_t*)(srow + 4 * i);
-            float mx = -INFINITY;
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])), mx);
-            mx = fmaxf(mx, __shfl_xor(mx, 1));
-            mx = fmaxf(mx, __shfl_xor(mx, 2));
-            float sum = 0.0f;
+            for (int sub = 0; sub < 4; ++sub)
+                mx = fmaxf(fmaxf(fmaxf(sc[kt][sub][0], sc[kt][sub][1]), fmaxf(sc[kt][sub][2], sc[kt][sub][3])), mx);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float ex = mx > -INFINITY ? expf(v[i][e] - mx) : 0.0f;
-                    v[i][e] = ex;
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ex = mx > -INFINITY ? expf(sc[kt][sub][r] - mx) : 0.0f;
+                    sc[kt][sub][r] = ex;
                     sum += ex;
                 }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v[i] *= inv;
-                *(f32x4_t*)(srow + 4 * i) = v[i];
-            }
-        };
-        if (ntile == 1) softmax_quarter(std::integral_constant<int, 4>{});
-        else softmax_quarter(std::integral_constant<int, 8>{});
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) sc[kt][sub] *= inv;
+        }
     }
 #endif
 
     // ---- O^T = V^T P^T per 64-key tile: A operand = V^T[d][key] read column-wise from the row-major V
-    //      tile, B operand = P^T[key][q] = one float4 of the score row; O^T acc: col = q, rows = d ----
+    //      tile, B operand = P^T[key][q] = the score registers; O^T acc: col = q, rows = d ----
     f32x4_t o[NKS];
 #pragma unroll
     for (int dt = 0; dt < NKS; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < ntile; ++kt) {
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (kt >= ntile) break;
         __syncthreads();                          // K (or previous V) tile fully consumed by every wave
         store_rows16(R, sT, wv * 16, nkeys - kt * 64, hd, wcols, lane);
         __syncthreads();
         if (kt + 1 < ntile) load_rows16(R, wv * 16, vbase, rowbase + k0 + (size_t)(kt + 1) * 64 * ks, ks, p.ldq, nkeys - (kt + 1) * 64, hd, lane);
-        const float* prow = sS + (wv * 16 + c) * sp + kt * 64 + 4 * g;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const f32x4_t pf = *(const f32x4_t*)(prow + 16 * s);
+            const f32x4_t pf = sc[kt][s];
             const float* vcol = sT + (16 * s + 4 * g) * ATT_KP + c;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -627,7 +635,8 @@ static int prior_attn_impl(const float* qkv, int ldq, int n, int t, int n_state,
     p.hdp = 0;
     p.nk_max = (pattern == 2 && blocks > 64) ? 128 : 64;      // score columns: one or two 64-key tiles
     int gx = (pattern == 2) ? bc * (blocks / p.qc) : blocks;
-    size_t lds = ((size_t)64 * ATT_KP + (size_t)64 * (p.nk_max + 4)) * sizeof(float);
+    size_t lds = (size_t)64 * ATT_KP * sizeof(float);               // one [64][ATT_KP] tile: 47 KiB
+    LLARK_REQUIRE(p.nk_max <= 128, "prior_attn: at most 128 keys per query group (got %d)", p.nk_max);
     LLARK_REQUIRE(hd % 2 == 0 && n_state % 2 == 0 && ldq % 2 == 0 && ldo % 2 == 0,
                   "prior_attn: head_dim, n_state, ldq and ldo must be even (8-byte row loads, 4-byte stores)");
     LLARK_REQUIRE(lds <= 160 * 1024, "prior_attn: LDS %zu B exceeds 160 KiB", lds);
