@@ -450,8 +450,8 @@ def main():
                     "generate": "configs[2]: %d clip(s) -> Jukebox embed -> projector -> Llama-2-7B prefill (S=371) + %d greedy decode steps (KV cache, stopping criterion off)" % (args.batch, args.new_tokens),
                     "mpt": "configs[4]: 10 s 48 kHz clips -> log-mel -> CLAP HTSAT-base -> (1,512) embedding -> projector -> MPT-1B prefill (S=132) + %d greedy decode steps" % args.new_tokens,
                     "clap": "configs[4] audio half: %d x 10 s 48 kHz clips -> int16 round trip + log-mel (1001x64) -> CLAP HTSAT-base -> (B,512) unit embeddings" % args.batch,
-                    "mpt-train": "MPT-1B instruction-tuning step on CLAP-style (1,512) embeddings: per GPU %d clips x %d tokens, fwd+bwd+all-reduce+AdamW (train_mpt_model.sh analogue of configs[3])" % (args.batch, args.train_seq),
-                    "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+AdamW"
+                    "mpt-train": "MPT-1B instruction-tuning step on CLAP-style (1,512) embeddings: per GPU %d clips x %d tokens, fwd+bwd+all-reduce+grad-norm clip 1.0+AdamW (train_mpt_model.sh analogue of configs[3])" % (args.batch, args.train_seq),
+                    "train": "configs[3]: instruction-tuning step, random-init Llama-2-7B + projector on frozen Jukebox features; per GPU %d clips = %d x %d accumulation micro-steps, S=%d; fwd+bwd+grad all-reduce+grad-norm clip 1.0 (HF Trainer default)+AdamW"
                              % (args.batch, args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq)}[args.stages]
         line = {
             "metric": {"train": "clips/sec instruction-tuning step (fwd+bwd+all-reduce+AdamW)",

@@ -403,6 +403,11 @@ int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows,
 /* SwiGLU on the interleaved [32 gate | 32 up] layout: gu fp32 [rows][2*inter] */
 int llark_swiglu_fwd(const float* gu, int rows, int inter, void* act, llark_stream_t stream);
 int llark_swiglu_bwd(const float* gu, const float* dact, int rows, int inter, void* dgu, llark_stream_t stream);
+/* out (one double in device memory) (= | +=) sum_i x[i]^2 over n contiguous fp32 values: the squared global gradient norm behind HF
+ * Trainer's clip_grad_norm_ (transformers TrainingArguments.max_grad_norm = 1.0, not overridden by scripts/training/train_llark.sh;
+ * reached from m2t/train.py:53-277 -> trainer.train()).  accumulate == 0 zeroes `out` on the stream first; != 0 adds to it, so the
+ * norm can be collected slice by slice while the backward is still running. */
+int llark_sumsq_f32(const float* x, long long n, double* out, int accumulate, llark_stream_t stream);
 /* d(mean shifted CE)/dlogits * loss_scale as bf16 [batch*s][ldd]; row_loss / loss_cnt come from llark_cross_entropy_shifted */
 int llark_cross_entropy_bwd(const float* logits, int ldl, int batch, int s, int vocab, const int64_t* labels,
                             const float* row_loss, const float* loss_cnt, float loss_scale, void* dlogits, int ldd,
@@ -415,6 +420,12 @@ int llark_scatter_add_rows_f32(const float* src, int ld_src, const int64_t* idx,
 /* torch.optim.AdamW step on bf16 (param_dtype 1) or fp32 (2) parameters with fp32 gradients (scaled by grad_scale) and moments */
 int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int step, float grad_scale, llark_stream_t stream);
+/* the same step with HF Trainer's clip_grad_norm_ (TrainingArguments.max_grad_norm) applied on the device: grad_sumsq = the squared norm
+ * of the whole unscaled gradient (llark_sumsq_f32, device memory); gradients are multiplied by
+ * grad_scale * min(1, max_grad_norm / (sqrt(*grad_sumsq) * grad_scale + 1e-6)) -- no host read between backward and update. */
+int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm,
+                     llark_stream_t stream);
 
 #ifdef __cplusplus
 }

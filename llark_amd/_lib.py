@@ -94,6 +94,7 @@ _SIGS = {
     "llark_layernorm_f32": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, c_int, _P],
     "llark_clamp_f32": [_P, c_int64, c_float, _P],
     "llark_clamp_bwd_bf16": [_P, c_int64, c_float, _P, _P],
+    "llark_sumsq_f32": [_P, c_int64, _P, c_int, _P],
     "llark_scale_f32": [_P, c_int64, c_float, _P],
     "llark_gelu_split_bf16": [_P, c_int, c_int, c_int, _P, _P, c_int, _P],
     "llark_layernorm_bwd": [_P, c_int, _P, _P, c_int, c_int, c_int, c_float, _P, c_int, _P, _P, c_int, _P],
@@ -128,6 +129,7 @@ _SIGS = {
     "llark_gather_rows_f32": [_P, c_int, _P, c_int, c_int, _P, c_int, _P],
     "llark_scatter_add_rows_f32": [_P, c_int, _P, c_int, c_int, _P, c_int, _P],
     "llark_adamw": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P],
+    "llark_adamw_clip": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P],
 }
 
 

@@ -255,6 +255,31 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
 }
 
+// out[0] += sum_i x[i]^2 in double: the squared global gradient norm of HF Trainer's clip_grad_norm_ (transformers
+// TrainingArguments.max_grad_norm = 1.0, which scripts/training/train_llark.sh does not override).  float4 grid-stride loads over the
+// 16-byte-aligned body (`head` leading and up to 3 trailing scalars go to block 0), per-thread double partials, one wave reduction
+// and one atomic per wave.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, int head, double* __restrict__ out) {
+    const float* body = x + head;
+    const long long nb = n - head, n4 = nb >> 2;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = ((const float4*)body)[i];
+        acc += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+    }
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < head) acc += (double)(x[threadIdx.x] * x[threadIdx.x]);
+        const int tail = (int)(nb & 3);
+        if ((int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < tail) {
+            const float v = body[(n4 << 2) + threadIdx.x - 64];
+            acc += (double)(v * v);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(out, acc);
+}
+
 // out[c] (+)= sum_r x[r][c]
 __global__ void colsum_kernel(const float* __restrict__ x, int ld, int rows, int cols, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,9 +305,18 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int ld_sr
 // AdamW (torch.optim.AdamW semantics, decoupled weight decay, bias correction) on bf16 parameters with fp32
 // gradients and fp32 moments:  p <- p (1 - lr wd) - lr * mhat / (sqrt(vhat) + eps)
 // ------------------------------------------------------------------------------------------
+// gradient clipping without a host round trip: sumsq (nullable) = the squared norm of the UNSCALED gradient sum in device memory
+// (llark_sumsq_f32); the gradient scale becomes gscale * min(1, max_norm / (sqrt(*sumsq) * gscale + 1e-6)) = clip_grad_norm_
+__device__ __forceinline__ float clipped_scale(float gscale, const double* __restrict__ sumsq, float max_norm) {
+    if (sumsq == nullptr) return gscale;
+    const float norm = (float)sqrt(*sumsq) * gscale;
+    const float coef = max_norm / (norm + 1e-6f);
+    return coef < 1.0f ? gscale * coef : gscale;
+}
 __global__ void adamw_bf16_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                  float bc1, float bc2, float gscale) {
+                                  float bc1, float bc2, float gscale, const double* __restrict__ sumsq, float max_norm) {
+    gscale = clipped_scale(gscale, sumsq, max_norm);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -296,7 +330,8 @@ __global__ void adamw_bf16_kernel(bf16_t* __restrict__ p, const float* __restric
 }
 __global__ void adamw_f32_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                                 float bc1, float bc2, float gscale) {
+                                 float bc1, float bc2, float gscale, const double* __restrict__ sumsq, float max_norm) {
+    gscale = clipped_scale(gscale, sumsq, max_norm);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -399,6 +434,24 @@ extern "C" int llark_cross_entropy_bwd(const float* logits, int ldl, int batch, 
     return check_launch("cross_entropy_bwd");
 }
 
+// out (a double in device memory) (= | +=) sum of x[i]^2 over n contiguous fp32 values: the squared gradient norm for gradient
+// clipping.  accumulate == 0: the call zeroes `out` on the stream first; != 0: adds to it (per-slice partial norms).
+extern "C" int llark_sumsq_f32(const float* x, long long n, double* out, int accumulate, llark_stream_t stream) {
+    LLARK_REQUIRE(x && out && n > 0 && ((uintptr_t)x & 3) == 0, "sumsq_f32: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(double), s) != hipSuccess) {
+        set_error("sumsq_f32: hipMemsetAsync failed");
+        return LLARK_ERR_LAUNCH;
+    }
+    int head = (int)(((16 - ((uintptr_t)x & 15)) & 15) >> 2);
+    if (head > n) head = (int)n;
+    long long blocks = ((n - head) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    sumsq_kernel<<<(int)blocks, 256, 0, s>>>(x, n, head, out);
+    return check_launch("sumsq_f32");
+}
+
 extern "C" int llark_colsum_f32(const float* x, int ld, int rows, int cols, float* out, llark_stream_t stream) {
     LLARK_REQUIRE(x && out && rows > 0 && cols > 0, "colsum: bad arguments");
     colsum_kernel<<<cdiv(cols, 256), 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols, out);
@@ -419,18 +472,36 @@ extern "C" int llark_scatter_add_rows_f32(const float* src, int ld_src, const in
     return check_launch("scatter_add_rows");
 }
 
-extern "C" int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, int step, float grad_scale, llark_stream_t stream) {
+static int adamw_impl(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float grad_scale, const double* sumsq, float max_norm,
+                      llark_stream_t stream) {
     LLARK_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipStream_t s = (hipStream_t)stream;
     if (param_dtype == LLARK_BF16)
-        adamw_bf16_kernel<<<grid_for((size_t)n), 256, 0, s>>>((bf16_t*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+        adamw_bf16_kernel<<<grid_for((size_t)n), 256, 0, s>>>((bf16_t*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                                                              grad_scale, sumsq, max_norm);
     else if (param_dtype == 2)
-        adamw_f32_kernel<<<grid_for((size_t)n), 256, 0, s>>>((float*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+        adamw_f32_kernel<<<grid_for((size_t)n), 256, 0, s>>>((float*)p, g, m, v, (size_t)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                                                             grad_scale, sumsq, max_norm);
     else {
         set_error("adamw: parameter dtype must be bf16 (1) or fp32 (2), got %d", param_dtype);
         return LLARK_ERR_INVALID;
     }
     return check_launch("adamw");
+}
+
+extern "C" int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int step, float grad_scale, llark_stream_t stream) {
+    return adamw_impl(param_dtype, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, 0.0f, stream);
+}
+
+// The same step with HF Trainer's clip_grad_norm_ applied on the device: grad_sumsq = the squared norm of the whole (unscaled)
+// gradient in device memory (llark_sumsq_f32); every gradient is multiplied by
+// grad_scale * min(1, max_grad_norm / (sqrt(*grad_sumsq) * grad_scale + 1e-6)) -- no host read between the backward and the update.
+extern "C" int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq,
+                                float max_grad_norm, llark_stream_t stream) {
+    LLARK_REQUIRE(grad_sumsq && max_grad_norm > 0.0f, "adamw_clip: grad_sumsq and a positive max_grad_norm are required");
+    return adamw_impl(param_dtype, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, grad_sumsq, max_grad_norm, stream);
 }

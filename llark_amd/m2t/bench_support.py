@@ -144,9 +144,10 @@ class TrainWorkload:
         for k, (ids, labels, emb) in enumerate(self.batches):
             segs = [(b, 1, emb[b]) for b in range(self.micro)]
             loss = tr.forward_backward(ids, segs, labels, 1.0 / self.accum,
-                                       overlap_allreduce_world=self.world if k == len(self.batches) - 1 else 1)
+                                       overlap_allreduce_world=self.world if k == len(self.batches) - 1 else 1,
+                                       last_micro_batch=k == len(self.batches) - 1)
         tr.allreduce_grads(self.world)
-        tr.step(self.world)
+        tr.step(self.world, max_grad_norm=1.0)       # HF Trainer's default clip_grad_norm_: one reduction over the 27 GB of gradients
         return loss
 
     def flops_per_step(self) -> float:
@@ -274,5 +275,5 @@ class MptTrainWorkload(MptWorkload):
         segs = [(b, 1, self.emb[b]) for b in range(self.batch)]
         loss = self.trainer.forward_backward(self.full, segs, self.labels)
         self.trainer.allreduce_grads(self.world)
-        self.trainer.step(self.world)
+        self.trainer.step(self.world, max_grad_norm=1.0)
         return loss

@@ -256,13 +256,18 @@ class HipMptTrainer:
         for wk in [D.all_reduce_sum_async(self.flat_grad[o: min(o + bucket_elems, n)], comm) for o in range(0, n, bucket_elems)]:
             wk.wait()
 
-    def step(self, world: int = 1) -> None:
+    def step(self, world: int = 1, max_grad_norm=None) -> None:
+        """AdamW; ``max_grad_norm`` = HF Trainer's clip_grad_norm_, coefficient formed on the device (see HipLlamaTrainer.step)."""
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        sumsq = ops.sumsq_f32(self.flat_grad) if clip else None
+        self.last_grad_sumsq = sumsq
         self.step_count += 1
         b1, b2 = self.betas
         for name, p in self.params:
             off, n = self._slices[name]
             ops.adamw(p.view(-1), self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n], self.lr, b1, b2,
-                      self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world)
+                      self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world,
+                      grad_sumsq=sumsq, max_grad_norm=float(max_grad_norm) if clip else 0.0)
         self.zero_grad()
 
     def export_grads_ref(self) -> Dict[str, torch.Tensor]:

@@ -32,6 +32,7 @@ class TrainConfig:
     adam_epsilon: float = 1e-8
     lr_scheduler_type: str = "cosine"           # :35
     gradient_checkpointing: bool = False        # train_llark.sh:25 (per-layer recompute in the backward; same gradients, less HBM)
+    max_grad_norm: float = 1.0                  # transformers TrainingArguments default (clip_grad_norm_ in Trainer's step); not set by train_llark.sh
     grad_comm: str = "bf16"                     # the reference's DDP buckets are bf16 (m2t/train.py:94-103 casts the model): 13.5 GB/step; "fp32" = 27 GB
 
 
@@ -77,13 +78,13 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
         segs = plan_audio_splice(ids, feats, audio_cfg, False)
         last = (micro + 1) % cfg.gradient_accumulation_steps == 0          # DDP no_sync boundary: exchange only on the last micro-step
         loss = tr.forward_backward(ids, segs, batch["labels"].to(engine.device), 1.0 / cfg.gradient_accumulation_steps,
-                                   overlap_allreduce_world=world if last else 1)
+                                   overlap_allreduce_world=world if last else 1, last_micro_batch=last and cfg.max_grad_norm > 0)
         acc += float(loss.item()) / cfg.gradient_accumulation_steps
         micro += 1
         if micro % cfg.gradient_accumulation_steps == 0:
             tr.allreduce_grads(world)                       # the one exchange step of the path
             tr.lr = lr_at(tr.step_count, cfg)
-            tr.step(world)
+            tr.step(world, max_grad_norm=cfg.max_grad_norm)
             mean_loss = D.max_over_ranks(acc, 1)            # local value; rank 0 logs
             losses.append(mean_loss)
             if log:
@@ -159,6 +160,7 @@ def main(argv=None):
     ap.add_argument("--freeze_backbone", type=boolean, default=False)
     ap.add_argument("--lr_scheduler_type", default="cosine")
     ap.add_argument("--bf16", type=boolean, default=True)
+    ap.add_argument("--max_grad_norm", type=float, default=1.0, help="HF TrainingArguments.max_grad_norm (gradient clipping; 0 = off)")
     for ignored in ("--tf32", "--report_to", "--logging_steps", "--evaluation_strategy", "--save_strategy",
                     "--ddp_find_unused_parameters", "--dataloader_num_workers", "--num_train_epochs"):
         ap.add_argument(ignored, default=None, help="accepted for script compatibility (no effect on the arithmetic of the native loop)")
@@ -194,7 +196,7 @@ def main(argv=None):
     mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
                       max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm,
-                      gradient_checkpointing=args.gradient_checkpointing)
+                      gradient_checkpointing=args.gradient_checkpointing, max_grad_norm=args.max_grad_norm)
     def batches(skip_micro_batches: int):
         return micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
                              seed=args.seed, allow_pickle=args.allow_pickle, skip_micro_batches=skip_micro_batches)

@@ -174,9 +174,13 @@ class HipLlamaTrainer:
 
     # ------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids: torch.Tensor, audio_segments, labels: torch.Tensor, loss_scale: float = 1.0,
-                         overlap_allreduce_world: int = 1) -> torch.Tensor:
+                         overlap_allreduce_world: int = 1, last_micro_batch: bool = False) -> torch.Tensor:
         """One micro-batch: returns the (unscaled) loss as a device scalar and ACCUMULATES gradients.
         ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer.
+        ``last_micro_batch``: this call completes the gradients of an optimizer step: as soon as a decoder layer's slice is final
+        its contribution to the global gradient norm is summed on a side stream, under the backward of the layers below --
+        ``step(max_grad_norm=...)`` then only reduces what is left (embedding rows, projector, final norm) instead of re-reading all
+        27 GB of gradients.  (Single rank only: with an all-reduce pending the norm is taken after it, in one pass.)
         ``overlap_allreduce_world`` > 1 (pass it on the LAST micro-batch of an optimizer step, the reference's DDP
         ``no_sync`` boundary): as soon as the backward of decoder layer i is complete its ~0.8 GB gradient slice is
         all-reduced asynchronously (RCCL stream) while layers i-1 ... 0 are still being differentiated; call
@@ -303,6 +307,8 @@ class HipLlamaTrainer:
             saved[i] = None
             if overlap_allreduce_world > 1:
                 self._start_layer_allreduce(i)
+            if last_micro_batch and self.flat_m is not None and overlap_allreduce_world <= 1:
+                self._layer_norm_async(i)      # (with an exchange in flight the norm is taken after allreduce_grads, in one pass)
         # ---- bottom: projector and the trainable embedding rows ----
         if seg_rows:
             ridx = torch.cat(seg_rows)
@@ -401,17 +407,79 @@ class HipLlamaTrainer:
         torch.cuda.synchronize()
         return float(sum(a.elapsed_time(b) for a, b in evs))
 
-    def step(self, world: int = 1) -> None:
-        """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients."""
+    def _layer_norm_async(self, i: int) -> None:
+        """Side stream: add sum(g^2) of layer i's (final) gradient slice to the step's running scalar."""
+        o0, o1 = self._layer_span(i)
+        if getattr(self, "_aux_stream", None) is None:
+            self._aux_stream = torch.cuda.Stream(device=self.flat_grad.device)
+            self._norm_acc = torch.zeros((1,), dtype=torch.float64, device=self.flat_grad.device)
+            self._norm_spans = []
+        ev = torch.cuda.Event()
+        ev.record()                                        # layer i's gradients are complete on the compute stream
+        with torch.cuda.stream(self._aux_stream):
+            self._aux_stream.wait_event(ev)
+            ops.sumsq_f32(self.flat_grad[o0:o1], out=self._norm_acc, accumulate=bool(self._norm_spans))
+        self._norm_spans.append((o0, o1))
+
+    def _grad_sumsq(self) -> torch.Tensor:
+        """Device double: sum of g^2 over the whole flat gradient (the slices the backward has already summed on the side stream,
+        ``last_micro_batch``, are not read again).  Call after ``allreduce_grads``."""
+        self._finalize_grads()
+        spans = sorted(getattr(self, "_norm_spans", []))
+        if spans:
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+            acc, first = self._norm_acc, False
+        else:
+            acc, first = torch.empty((1,), dtype=torch.float64, device=self.flat_grad.device), True
+        pos, n = 0, self.flat_grad.numel()
+        for a, b in spans + [(n, n)]:                       # the gaps between the spans summed so far
+            if a > pos:
+                ops.sumsq_f32(self.flat_grad[pos:a], out=acc, accumulate=not first)
+                first = False
+            pos = max(pos, b)
+        self._norm_spans = []
+        return acc
+
+    def grad_norm(self, world: int = 1) -> float:
+        """L2 norm of the (rank-averaged) gradient over every trainable tensor -- what torch.nn.utils.clip_grad_norm_ returns in HF
+        Trainer's step (a host read of the device scalar)."""
+        return math.sqrt(float(self._grad_sumsq().item())) / world
+
+    @property
+    def last_grad_norm(self) -> Optional[float]:
+        """Gradient norm of the last ``step(max_grad_norm=...)`` (read from the device on first access), else None."""
+        ss = getattr(self, "_last_sumsq", None)
+        if ss is None:
+            return None
+        if isinstance(ss, tuple):
+            self._last_sumsq = math.sqrt(float(ss[0].item())) / ss[1]
+        return self._last_sumsq
+
+    def step(self, world: int = 1, max_grad_norm: Optional[float] = None) -> None:
+        """AdamW over every trainable tensor (bias-corrected, decoupled weight decay), then zero the gradients.
+        ``max_grad_norm``: HF Trainer's gradient clipping (``TrainingArguments.max_grad_norm``, default 1.0, which the reference's
+        train_llark.sh leaves alone): gradients are scaled by min(1, max_grad_norm / (norm + 1e-6)).  The squared norm stays in
+        device memory and the coefficient is formed inside the AdamW kernels (``llark_adamw_clip``): no host read between the
+        backward and the update, no extra pass over the gradients; ``last_grad_norm`` reads it back on demand."""
         if self.flat_m is None:
             raise RuntimeError("this HipLlamaTrainer was built with optimizer_state=False (autograd bridge): use a torch optimizer")
         self._finalize_grads()
+        clip = max_grad_norm is not None and max_grad_norm > 0
+        sumsq = None
+        self._last_sumsq = None
+        if clip:
+            sumsq = self._grad_sumsq()
+            self._last_sumsq = (sumsq.clone(), world)
+        elif getattr(self, "_norm_spans", None):             # partial sums nobody asked for: drop them, but order the streams
+            torch.cuda.current_stream().wait_stream(self._aux_stream)
+            self._norm_spans = []
         self.step_count += 1
         b1, b2 = self.betas
         for name, p in self.params:
             off, n = self._slices[name]
             ops.adamw(p.view(-1), self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n],
-                      self.lr, b1, b2, self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world)
+                      self.lr, b1, b2, self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world,
+                      grad_sumsq=sumsq, max_grad_norm=float(max_grad_norm) if clip else 0.0)
         self._weights_changed()
         self.zero_grad()
 

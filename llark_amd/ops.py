@@ -862,6 +862,17 @@ def cross_entropy_fwd_bwd(logits: torch.Tensor, labels: torch.Tensor, dlogits: t
     return out[0]
 
 
+def sumsq_f32(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """sum of squares of a contiguous fp32 tensor as a device double scalar (the squared gradient norm of clip_grad_norm_);
+    ``out`` + ``accumulate``: add to an existing scalar (per-slice partial norms)."""
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float64, device=x.device)
+        accumulate = False
+    check(_lib.lib().llark_sumsq_f32(_dev(x, "x", torch.float32), x.numel(), _dev(out, "out", torch.float64), int(accumulate), _stream()),
+          "sumsq_f32")
+    return out
+
+
 def colsum_add(x: torch.Tensor, out: torch.Tensor) -> None:
     rows, cols = x.shape
     check(_lib.lib().llark_colsum_f32(_dev(x, "x", torch.float32), x.stride(0), rows, cols, _dev(out, "out", torch.float32),
@@ -881,11 +892,17 @@ def scatter_add_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) ->
 
 
 def adamw(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
-          weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+          weight_decay: float, step: int, grad_scale: float = 1.0, grad_sumsq: Optional[torch.Tensor] = None,
+          max_grad_norm: float = 0.0) -> None:
+    """torch.optim.AdamW step; with ``grad_sumsq`` (device double from sumsq_f32 over the WHOLE gradient) and ``max_grad_norm`` the
+    clip_grad_norm_ coefficient is computed and applied on the device (include/llark_hip.h: llark_adamw_clip)."""
     assert p.numel() == g.numel() == m.numel() == v.numel()
-    check(_lib.lib().llark_adamw(_DT[p.dtype], _dev(p, "p"), _dev(g, "g", torch.float32), _dev(m, "m", torch.float32),
-                                 _dev(v, "v", torch.float32), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-                                 float(weight_decay), int(step), float(grad_scale), _stream()), "adamw")
+    args = (_DT[p.dtype], _dev(p, "p"), _dev(g, "g", torch.float32), _dev(m, "m", torch.float32), _dev(v, "v", torch.float32), p.numel(),
+            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale))
+    if grad_sumsq is None:
+        check(_lib.lib().llark_adamw(*args, _stream()), "adamw")
+    else:
+        check(_lib.lib().llark_adamw_clip(*args, _dev(grad_sumsq, "grad_sumsq", torch.float64), float(max_grad_norm), _stream()), "adamw_clip")
 
 
 def device_info(device: int = 0) -> Tuple[int, str]:

@@ -453,3 +453,59 @@ def test_rmsnorm_bwd_vs_autograd(rows, width, accumulate):
     ref_dw = wr.grad + dw0
     assert (dx.cpu() - ref_dx).abs().max().item() <= 1e-5 * ref_dx.abs().max().item()
     assert (dw.cpu() - ref_dw).abs().max().item() <= 1e-4 * ref_dw.abs().max().item()
+
+
+def test_grad_norm_clipping_matches_torch():
+    """HF Trainer's step clips with torch.nn.utils.clip_grad_norm_(parameters, max_grad_norm) before optimizer.step():
+    llark_sumsq_f32 over the flat gradient + the clip coefficient folded into AdamW's gradient scale must give the same norm and
+    the same update as torch (fp32 reference on the trainer's own gradients; parameters are bf16: one ulp of slack)."""
+    from llark_amd import ops
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    tr = HipLlamaTrainer(eng, lr=1e-2, weight_decay=0.0, embed_grad_tokens=(spec.audio_start_token, spec.audio_end_token))
+    tr.forward_backward(ids.cuda(), segs, labels.cuda())
+    tr._finalize_grads()
+    ref_norm = tr.flat_grad.double().norm().item()
+    assert abs(tr.grad_norm() - ref_norm) <= 1e-6 * ref_norm
+    x = torch.randn(1000003, device="cuda")                                  # ragged length: the scalar tail of the kernel
+    assert abs(ops.sumsq_f32(x).item() - x.double().pow(2).sum().item()) <= 1e-9 * x.numel()
+    # Adam's first update is lr * g / (|g| + eps): blind to a scale of g.  So: one unclipped step, then a clipped one -- the second
+    # update mixes the two gradient scales in m and v and moves by a different amount if the coefficient is wrong or missing.
+    name = "layers.1.wdown"
+    ref_p = torch.nn.Parameter(dict(tr.params)[name].float().clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    ref_p.grad = tr.grads[name].clone()
+    opt.step()
+    tr.step()
+    with torch.no_grad():
+        ref_p.copy_(dict(tr.params)[name].float())                           # follow the bf16 rounding of the stored weights
+    tr.forward_backward(ids.cuda(), segs, labels.cuda())
+    tr._finalize_grads()
+    norm2 = tr.flat_grad.double().norm().item()
+    max_norm = 0.05 * norm2                                                  # clip coefficient ~0.05
+    p_before = dict(tr.params)[name].float().clone()
+    ref_p.grad = tr.grads[name].clone() * (max_norm / (norm2 + 1e-6))
+    unclipped = torch.nn.Parameter(p_before.clone())                         # what a missing clip would produce
+    opt_u = torch.optim.AdamW([unclipped], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    opt_u.load_state_dict(opt.state_dict())
+    unclipped.grad = tr.grads[name].clone()
+    tr.step(max_grad_norm=max_norm)
+    opt.step()
+    opt_u.step()
+    assert abs(tr.last_grad_norm - norm2) <= 1e-6 * norm2
+    p_after = dict(tr.params)[name].float()
+    err = (p_after - ref_p.detach().bfloat16().float()).abs().max().item()
+    err_if_unclipped = (p_after - unclipped.detach().bfloat16().float()).abs().max().item()
+    assert err <= 2 ** -7 * p_before.abs().max().item() + 1e-3, err
+    assert err_if_unclipped > 4 * err + 1e-3, (err, err_if_unclipped)         # the test can tell the two apart
+    # a norm below the threshold leaves the gradients alone; with last_micro_batch the per-layer partial sums collected on the side
+    # stream during the backward plus the remaining slices must give the same norm as one pass over the whole buffer
+    tr.forward_backward(ids.cuda(), segs, labels.cuda(), last_micro_batch=True)
+    assert len(tr._norm_spans) == len(eng.layers)
+    tr._finalize_grads()
+    full = tr.flat_grad.double().norm().item()
+    tr.step(max_grad_norm=1e9)
+    assert abs(tr.last_grad_norm - full) <= 1e-9 * full and tr._norm_spans == []
+    tr.forward_backward(ids.cuda(), segs, labels.cuda(), last_micro_batch=True)      # partial sums nobody asks for are dropped
+    tr.step()
+    assert tr._norm_spans == [] and tr.last_grad_norm is None
