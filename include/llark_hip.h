@@ -274,6 +274,16 @@ int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, const void*
                                  const void* k_cache_lo, const void* vt_cache_lo, int batch, int nh, int hd, int total, int smax,
                                  void* out, void* out_lo, const float* alibi_slopes, llark_stream_t stream);
 
+/* Decode-step Linear: c[m][n] = sum_k a[m][k] wt[n][k] (+ bias[n]) for m <= 4 activation rows, bf16 operands (a = hi plane + optional
+ * lo plane for the fp32-class mode), fp32 accumulate -- the weight-streaming form of llark_gemm16 (csrc/gemv_dma.hip: weights global ->
+ * LDS by LDS-DMA, 96 KiB in flight per CU, no barrier in the K loop).  Replaces nn.Linear under LlamaModel.forward with one new token
+ * (m2t/infer.py:146 -> model.generate; transformers==4.29.2 modeling_llama.py).  epilogue: LLARK_EPI_F32, LLARK_EPI_RESID (resid may
+ * alias c), LLARK_EPI_SWIGLU16 / LLARK_EPI_SWIGLU_SPLIT (wt rows interleaved [gate 32 | up 32], out [m][n / 2]).  kp % 8 == 0,
+ * kp <= 12288, lda / ldw % 8 == 0; other shapes return LLARK_ERR_UNSUPPORTED (use llark_gemm16). */
+int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias,
+                     int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                     llark_stream_t stream);
+
 /* Backward products of nn.Linear without transposed copies of their operands (csrc/gemm_tn.hip; torch autograd of the Linear
  * layers under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
  *   c[m][n] (= | +=) sum_k A(m, k) W(n, k), 16-bit operands, fp32 accumulate / output.

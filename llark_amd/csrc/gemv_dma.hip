@@ -1,0 +1,310 @@
+// Decode-step Linear (M = 1 .. 4 activation rows against an [N][K] bf16 weight): a weight-STREAMING kernel built on LDS-DMA.
+//
+// Replaces nn.Linear inside LlamaDecoderLayer / MPTBlock during `model.generate` (m2t/infer.py:146 -> 64 x LlamaModel.forward with
+// one new token; transformers==4.29.2 modeling_llama.py: q/k/v/o_proj, gate/up/down_proj, lm_head), where every weight byte is
+// read once per token and nothing else matters.
+//
+// The MFMA skinny kernel (gemm.hip: gemm_skinny_kernel) streams its weights L2 -> VGPR and settles at 4.3 TB/s whatever the
+// number of loads in flight, their width or their temporal hint (profiles/r02_decode_experiments.txt).  Here the weights go
+// global -> LDS with `global_load_lds` (no registers, 16 B per lane, 1 KiB per instruction): one workgroup per CU, 8 waves, and
+// every wave streams WHOLE weight rows of its own through a private ring of 16 x 1 KiB in LDS -- it requests a piece, waits for it
+// with a counted `s_waitcnt vmcnt`, and consumes exactly the bytes it requested: no barrier in the main loop, 15 KiB per wave
+// (120 KiB per CU) in flight at any time, one wave reduction per weight row and no reduction across waves.  The activation values a
+// lane needs (its 8 k positions of each of the row's 1 KiB pieces) sit in registers for the whole kernel when K <= 4096 and M <= 2,
+// otherwise in LDS in the order the lanes read them.  Products: `v_dot2c_f32_bf16` chains (hi and lo activation planes against the
+// same weight pair in the fp32-class mode).  Epilogues: fp32 (+bias), fp32 + residual, SwiGLU -> bf16 hi (+ lo) on the
+// [gate 32 | up 32] row interleave of the packed gate/up weight.
+// (A first version cut every row over all 8 waves -- 16 B per lane and unit, a wave reduction and integer divisions per 1 KiB --
+// and was instruction-bound at 3.1 TB/s; profiles/r03_decode_gemv_dma.txt.)
+#include "gemm_core.h"
+
+namespace llark {
+
+namespace {
+
+constexpr int GV_WAVES = 8;
+constexpr int GV_CHUNK = 4096;                   // k elements per chunk of a weight row = 8 pieces of 1 KiB (64 lanes x 16 B)
+constexpr int GV_MAXCH = 3;                      // k-chunks per weight row: Kp <= 12288
+constexpr int GV_XLDS_MAX = 48 * 1024;           // activation planes kept in LDS when they do not fit registers
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+
+struct GemvParams {
+    const bf16_t* ahi;
+    const bf16_t* alo;
+    int lda;
+    const bf16_t* wt;
+    int ldw;
+    const float* bias;
+    int M, N, Kp;
+    float* C;
+    int ldc;
+    const float* R;
+    int ldr;
+    bf16_t* ohi;
+    bf16_t* olo;
+    int ldo;
+    int ncols;           // output columns: N, or N / 2 for SwiGLU
+    int cols_per_block;
+    int xbytes;          // LDS bytes of the activation planes (0 in the register form)
+};
+
+__device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf2_t a = {w[2 * e], w[2 * e + 1]}, b = {x[2 * e], x[2 * e + 1]};
+        acc = __builtin_amdgcn_fdot2_f32_bf16(a, b, acc, false);
+    }
+    return acc;
+}
+
+}  // namespace
+
+// XREG: K <= 4096 and MM <= 2 -- the lane's activation fragments (8 pieces x hi / lo x MM) live in registers.
+template <bool SPLIT, int EPI, int MM, bool XREG>
+__global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;                      // weight rows per output column
+    constexpr int NP = SPLIT ? 2 : 1;                                // activation planes
+    constexpr int GV_NSLOT = XREG ? 16 : 12;                         // 1 KiB pieces per wave ring (the LDS form keeps 48 KiB for x)
+    constexpr int GV_RING = GV_NSLOT * 1024;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* ring = smem + w * GV_RING;                                 // this wave's 16 (12) x 1 KiB
+    char* xs = smem + GV_WAVES * GV_RING;                            // !XREG: [MM][NP][nch * 8 pieces][64 lanes] x 16 B
+    float* part = (float*)(xs + p.xbytes);                           // [rows of the block][MM]
+    const int nch = (p.Kp + GV_CHUNK - 1) / GV_CHUNK;
+    const int npc = nch * 8;                                         // 1 KiB pieces per weight row
+    const int col0 = blockIdx.x * p.cols_per_block;
+    int ncb = p.ncols - col0;
+    ncb = ncb < 0 ? 0 : (ncb > p.cols_per_block ? p.cols_per_block : ncb);
+    const int nrows = ncb * RPC;                                     // weight rows of this workgroup; wave w takes rows w, w + 8, ...
+    const int myrows = nrows > w ? (nrows - w + GV_WAVES - 1) / GV_WAVES : 0;
+
+    // ---- the wave's stream: piece t = (row i of the wave, piece j of the row); issue cursor and consume cursor advance alike ----
+    const int total = myrows * npc;
+    int ii = 0, ij = 0, islot = 0;                                   // issue cursor: row index, piece, ring slot
+    auto issue = [&]() __attribute__((always_inline)) {
+        const int rr = w + ii * GV_WAVES;                            // row of the block
+        const int cl = rr / RPC, which = rr - cl * RPC;              // RPC is 1 or 2 (compile time)
+        const int col = col0 + cl;
+        const int row = IS_SWIGLU(EPI) ? 64 * (col >> 5) + (col & 31) + 32 * which : col;
+        int k = ij * 512 + lane * 8;
+        k = k < p.Kp ? k : 0;                                        // beyond Kp: a valid address, its activation entries are zero
+        const bf16_t* src = p.wt + (size_t)row * p.ldw + k;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(ring + islot * 1024), 16, 0, 0);
+        islot = islot + 1 == GV_NSLOT ? 0 : islot + 1;
+        if (++ij == npc) { ij = 0; ++ii; }
+    };
+    const int pro = total < GV_NSLOT - 1 ? total : GV_NSLOT - 1;
+    for (int t = 0; t < pro; ++t) issue();             // the weight stream starts before anything else: it does not depend on x
+
+
+    // ---- activations ----
+    bf16x8_t xr[XREG ? MM : 1][NP][8];
+    if (XREG) {
+#pragma unroll
+        for (int m = 0; m < MM; ++m)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = j * 512 + lane * 8;
+                const bool ok = m < p.M && k < p.Kp;
+                bf16x8_t zero;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zero[e] = (bf16_t)0.0f;
+                xr[m][0][j] = ok ? *(const bf16x8_t*)(p.ahi + (size_t)m * p.lda + k) : zero;
+                if (SPLIT) xr[m][NP - 1][j] = ok ? *(const bf16x8_t*)(p.alo + (size_t)m * p.lda + k) : zero;
+            }
+    } else {
+        const int per_m = NP * npc * 64;                             // 16-byte entries per activation row
+        for (int idx = threadIdx.x; idx < MM * per_m; idx += GV_WAVES * 64) {
+            const int m = idx / per_m, r = idx - m * per_m;
+            const int pl = r / (npc * 64), q = r - pl * (npc * 64);  // q = piece * 64 + lane
+            const int k = q * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (m < p.M && k < p.Kp) v = *(const uint4*)((pl ? p.alo : p.ahi) + (size_t)m * p.lda + k);
+            *(uint4*)(xs + (size_t)idx * 16) = v;
+        }
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // x in registers / LDS (and, in order, the first pieces landed);
+                                                                     // from here on the only vector-memory traffic is the DMA stream
+
+    float acc[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) acc[m] = 0.0f;
+    int ci = 0, cslot = 0, t = 0;                                    // consume cursor: row index of the wave, ring slot, piece count
+    // one piece: keep the ring full, wait for piece t, read it
+    auto next_piece = [&]() __attribute__((always_inline)) {
+        if (t + GV_NSLOT - 1 < total) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot being refilled was read one step ago: its data has arrived
+            issue();
+            if (XREG) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // GV_NSLOT - 1 newer requests may be outstanding: piece t has landed
+            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const bf16x8_t wv = *(const bf16x8_t*)(ring + cslot * 1024 + lane * 16);
+        cslot = cslot + 1 == GV_NSLOT ? 0 : cslot + 1;
+        ++t;
+        return wv;
+    };
+    auto row_done = [&]() __attribute__((always_inline)) {           // one wave reduction per activation row
+        const int rr = w + ci * GV_WAVES;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            const float r = wave_sum(acc[m]);
+            if (lane == 0) part[rr * MM + m] = r;
+            acc[m] = 0.0f;
+        }
+        ++ci;
+    };
+    if (XREG) {                                                      // 8 pieces per row, the piece index is a compile-time constant
+        for (int r = 0; r < myrows; ++r) {
+            static_for<8>([&](auto jt) {
+                constexpr int j = decltype(jt)::value;
+                const bf16x8_t wv = next_piece();
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    acc[m] = dot8(wv, xr[m][0][j], acc[m]);
+                    if (SPLIT) acc[m] = dot8(wv, xr[m][NP - 1][j], acc[m]);
+                }
+            });
+            row_done();
+        }
+    } else {
+        for (int r = 0; r < myrows; ++r) {
+            for (int cj = 0; cj < npc; ++cj) {
+                const bf16x8_t wv = next_piece();
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const char* xb = xs + ((size_t)(m * NP) * npc * 64 + (size_t)cj * 64 + lane) * 16;
+                    acc[m] = dot8(wv, *(const bf16x8_t*)xb, acc[m]);
+                    if (SPLIT) acc[m] = dot8(wv, *(const bf16x8_t*)(xb + (size_t)npc * 64 * 16), acc[m]);
+                }
+            }
+            row_done();
+        }
+    }
+    __syncthreads();
+    // ---- epilogue: thread t -> (column t / MM, activation row t % MM) ----
+    for (int t = threadIdx.x; t < ncb * MM; t += GV_WAVES * 64) {
+        const int cl = t / MM, m = t - cl * MM;
+        if (m >= p.M) continue;
+        float v[RPC];
+#pragma unroll
+        for (int q = 0; q < RPC; ++q) v[q] = part[(cl * RPC + q) * MM + m];
+        const int n = col0 + cl;
+        if (EPI == EPI_F32) {
+            p.C[(size_t)m * p.ldc + n] = v[0] + (p.bias ? p.bias[n] : 0.0f);
+        } else if (EPI == EPI_RESID) {
+            p.C[(size_t)m * p.ldc + n] = p.R[(size_t)m * p.ldr + n] + (v[0] + (p.bias ? p.bias[n] : 0.0f));
+        } else if (IS_SWIGLU(EPI)) {
+            const float a = silu(v[0]) * v[RPC - 1];
+            const bf16_t hi = (bf16_t)a;
+            p.ohi[(size_t)m * p.ldo + n] = hi;
+            if (EPI == EPI_SWIGLU_SPLIT) p.olo[(size_t)m * p.ldo + n] = (bf16_t)(a - (float)hi);
+        }
+    }
+}
+
+
+// true when the kernel takes the shape: activation fragments in registers (K <= 4096, M <= 2) or within GV_XLDS_MAX bytes of LDS
+static bool gemv_shape_ok(int split, int m, int kp) {
+    if (m < 1 || m > 4 || kp % 8 != 0 || kp > GV_MAXCH * GV_CHUNK) return false;
+    if (kp <= GV_CHUNK && m <= 2) return true;
+    const int mm = m <= 2 ? m : 4;
+    const long xbytes = (long)mm * (split ? 2 : 1) * ((kp + GV_CHUNK - 1) / GV_CHUNK) * GV_CHUNK * 2;
+    return xbytes <= GV_XLDS_MAX;
+}
+
+template <bool SPLIT, int EPI, int MM, bool XREG>
+static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
+    constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;
+    p.ncols = IS_SWIGLU(EPI) ? p.N / 2 : p.N;
+    p.cols_per_block = cdiv(p.ncols, cus);
+    const int blocks = cdiv(p.ncols, p.cols_per_block);
+    p.xbytes = XREG ? 0 : MM * (SPLIT ? 2 : 1) * ((p.Kp + GV_CHUNK - 1) / GV_CHUNK) * GV_CHUNK * 2;
+    const int lds = GV_WAVES * (XREG ? 16 : 12) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
+    if (lds > 160 * 1024) return -1000;
+    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    kern<<<blocks, GV_WAVES * 64, lds, s>>>(p);
+    return check_launch("gemv16_dma");
+}
+
+template <bool SPLIT, int EPI>
+static int dispatch_gemv_m(const GemvParams& p, hipStream_t s, int cus) {
+    const bool xreg = p.Kp <= GV_CHUNK && p.M <= 2;
+    if (p.M == 1) return xreg ? launch_gemv<SPLIT, EPI, 1, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 1, false>(p, s, cus);
+    if (p.M == 2) return xreg ? launch_gemv<SPLIT, EPI, 2, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 2, false>(p, s, cus);
+    return launch_gemv<SPLIT, EPI, 4, false>(p, s, cus);
+}
+
+}  // namespace llark
+
+using namespace llark;
+
+static int gemv_device_cus() {
+    static int cus = 0;                                  // a property of the device, not state: queried once
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+// c[m][n] = sum_k a[m][k] wt[n][k] (+ bias[n]) for m <= 4 rows, bf16 operands (a as hi + optional lo plane), fp32 accumulate:
+// the weight-streaming form of llark_gemm16 for the decode step.  epilogue: LLARK_EPI_F32, LLARK_EPI_RESID (c = resid + ...; resid may
+// alias c), LLARK_EPI_SWIGLU16 / LLARK_EPI_SWIGLU_SPLIT (wt rows interleaved [gate 32 | up 32], out_hi / out_lo [m][n / 2]).
+// kp % 8 == 0, kp <= 12288, and the activation planes must fit (kp <= 4096 with m <= 2, or m' * planes * ceil(kp / 4096) * 8 KiB
+// <= 48 KiB with m' = m rounded up to 1, 2, 4); a rows, wt rows 16-byte aligned.  LLARK_ERR_UNSUPPORTED for other shapes.
+extern "C" int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw,
+                                const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi,
+                                void* out_lo, int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && wt && m > 0 && n > 0 && kp > 0, "gemv16_dma: bad arguments");
+    LLARK_REQUIRE(!split || a_lo, "gemv16_dma: the fp32-class mode needs the lo plane");
+    if (!gemv_shape_ok(split, m, kp) || lda % 8 != 0 || ldw % 8 != 0 || ((uintptr_t)a_hi & 15) || ((uintptr_t)wt & 15) ||
+        (split && ((uintptr_t)a_lo & 15))) {
+        set_error("gemv16_dma: shape / alignment not handled (m=%d kp=%d lda=%d ldw=%d)", m, kp, lda, ldw);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    GemvParams p = {};
+    p.ahi = (const bf16_t*)a_hi; p.alo = (const bf16_t*)a_lo; p.lda = lda; p.wt = (const bf16_t*)wt; p.ldw = ldw; p.bias = bias;
+    p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.ohi = (bf16_t*)out_hi; p.olo = (bf16_t*)out_lo; p.ldo = ldo;
+    hipStream_t s = (hipStream_t)stream;
+    const int cus = gemv_device_cus();
+    int rc = -1000;
+#define GV(E)                                                                                          \
+    case E:                                                                                            \
+        rc = split ? dispatch_gemv_m<true, E>(p, s, cus) : dispatch_gemv_m<false, E>(p, s, cus);       \
+        break;
+    switch (epilogue) {
+        case EPI_F32:
+            LLARK_REQUIRE(c && ldc >= n, "gemv16_dma: fp32 output missing");
+            rc = split ? dispatch_gemv_m<true, EPI_F32>(p, s, cus) : dispatch_gemv_m<false, EPI_F32>(p, s, cus);
+            break;
+        case EPI_RESID:
+            LLARK_REQUIRE(c && resid && ldc >= n && ldr >= n, "gemv16_dma: residual epilogue needs c and resid");
+            rc = split ? dispatch_gemv_m<true, EPI_RESID>(p, s, cus) : dispatch_gemv_m<false, EPI_RESID>(p, s, cus);
+            break;
+        case EPI_SWIGLU16:
+            LLARK_REQUIRE(out_hi && n % 64 == 0 && ldo >= n / 2, "gemv16_dma: SwiGLU output missing");
+            rc = split ? dispatch_gemv_m<true, EPI_SWIGLU16>(p, s, cus) : dispatch_gemv_m<false, EPI_SWIGLU16>(p, s, cus);
+            break;
+        case EPI_SWIGLU_SPLIT:
+            LLARK_REQUIRE(out_hi && out_lo && n % 64 == 0 && ldo >= n / 2, "gemv16_dma: SwiGLU outputs missing");
+            rc = split ? dispatch_gemv_m<true, EPI_SWIGLU_SPLIT>(p, s, cus) : dispatch_gemv_m<false, EPI_SWIGLU_SPLIT>(p, s, cus);
+            break;
+        default:
+            set_error("gemv16_dma: epilogue %d not handled", epilogue);
+            return LLARK_ERR_UNSUPPORTED;
+    }
+#undef GV
+    if (rc == -1000) {
+        set_error("gemv16_dma: n = %d needs more LDS than a CU has", n);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    return rc;
+}

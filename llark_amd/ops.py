@@ -396,6 +396,10 @@ def split16(x: torch.Tensor, dtype: torch.dtype, want_lo: bool = True, kmult: in
 # From 129 rows (more than one 128-row tile) the B-direct kernels win: with the uniform K split a single clip's prefill (M = 371)
 # runs its four products in 0.47 ms per layer against 0.92 ms through the LDS-staged tiles (bench.py --stages llama --batch 1:
 # 32.9 -> 19.1 ms split, 18.6 -> 13.2 ms bf16; profiles/r02_streamk.txt).
+GEMV_DMA = os.environ.get("LLARK_GEMV_DMA", "1") == "1"      # decode-step Linear (m <= 4, bf16) through the LDS-DMA weight-streaming kernel
+# ... for weights of at least this many bytes: the streaming kernel runs at 5.0 TB/s + 3.7 us per launch, the MFMA skinny kernel at
+# 4.3 TB/s + 0.4 us (Llama-2-7B o_proj, 33.5 MB: 10.0 vs 8.1 us; qkv, 100 MB: 21.1 vs 22.9; gate_up, 180 MB: 35.1 vs 41.9)
+GEMV_DMA_MIN_BYTES = 64 * 1000 * 1000
 FRAG_MIN_ROWS = int(os.environ.get("LLARK_FRAG_MIN_ROWS", "129"))
 
 
@@ -412,6 +416,16 @@ def detach_frag(wt: torch.Tensor) -> None:
         del wt._llark_frag
 
 
+def _gemv_dma_takes(split: bool, m: int, kp: int) -> bool:
+    """The shapes csrc/gemv_dma.hip takes (gemv_shape_ok there): activation fragments in registers or within 48 KiB of LDS."""
+    if m < 1 or m > 4 or kp % 8 or kp > 12288:
+        return False
+    if kp <= 4096 and m <= 2:
+        return True
+    mm = m if m <= 2 else 4
+    return mm * (2 if split else 1) * ((kp + 4095) // 4096) * 8192 <= 48 * 1024
+
+
 def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, bias: Optional[torch.Tensor], n: int,
            epilogue: int, c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
            out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
@@ -425,6 +439,18 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
     name = ("gemm_split_" if a_lo is not None else "gemm_") + ("f16" if dtype == torch.float16 else "bf16") + ("_skinny" if m <= 16 else "")
     if epilogue == EPI_SWIGLU_SPLIT and out_lo is None:
         raise ValueError("gemm16: EPI_SWIGLU_SPLIT needs out_lo")
+    if (variant < 0 and GEMV_DMA and dtype == torch.bfloat16 and n * kp * 2 >= GEMV_DMA_MIN_BYTES and _gemv_dma_takes(a_lo is not None, m, kp)
+            and epilogue in (EPI_F32, EPI_RESID, EPI_SWIGLU16, EPI_SWIGLU_SPLIT) and a_hi.stride(0) % 8 == 0 and wt.stride(0) % 8 == 0):
+        # decode step: the weight-streaming LDS-DMA kernel (csrc/gemv_dma.hip)
+        with _timed(name, 2.0 * m * n * kp):
+            check(_lib.lib().llark_gemv16_dma(
+                int(a_lo is not None), epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype) if a_lo is not None else None, a_hi.stride(0),
+                _dev(wt, "wt"), wt.stride(0), _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp,
+                _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
+                _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+                _dev(out_hi, "out_hi", dtype) if out_hi is not None else None, _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
+                out_hi.stride(0) if out_hi is not None else 0, _stream()), "gemv16_dma")
+        return
     if variant < 0 and m >= FRAG_MIN_ROWS:
         fr = getattr(wt, "_llark_frag", None)
         if fr is not None and fr[1] == n and fr[2] == kp:
