@@ -283,6 +283,12 @@ int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, const void*
 int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias,
                      int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
                      llark_stream_t stream);
+/* ... with LlamaRMSNorm fused in front (decode: input_layernorm -> q/k/v_proj, post_attention_layernorm -> gate/up_proj, norm ->
+ * lm_head; modeling_llama.py LlamaRMSNorm): a = bf16 hi (+ lo when split) of norm_w * (x * rstd), x fp32 [m][ldx].  Bit-identical to
+ * llark_rmsnorm_bf16 followed by llark_gemv16_dma.  m == 1, kp <= 4096; epilogue LLARK_EPI_F32 or SwiGLU. */
+int llark_gemv16_dma_rmsnorm(int split, int epilogue, const float* x, int ldx, const float* norm_w, float eps, const void* wt, int ldw,
+                             const float* bias, int m, int n, int kp, float* c, int ldc, void* out_hi, void* out_lo, int ldo,
+                             llark_stream_t stream);
 
 /* Backward products of nn.Linear without transposed copies of their operands (csrc/gemm_tn.hip; torch autograd of the Linear
  * layers under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):

@@ -46,6 +46,11 @@ struct GemvParams {
     int ncols;           // output columns: N, or N / 2 for SwiGLU
     int cols_per_block;
     int xbytes;          // LDS bytes of the activation planes (0 in the register form)
+    // fused RMSNorm of the activation rows (register form only): a = bf16 hi / lo of g * (x * rstd), x fp32 [M][ldxn]
+    const float* xn;
+    const float* xg;
+    int ldxn;
+    float xeps;
 };
 
 __device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float acc) {
@@ -60,7 +65,7 @@ __device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float 
 }  // namespace
 
 // XREG: K <= 4096 and MM <= 2 -- the lane's activation fragments (8 pieces x hi / lo x MM) live in registers.
-template <bool SPLIT, int EPI, int MM, bool XREG>
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;                      // weight rows per output column
@@ -102,7 +107,48 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
 
     // ---- activations ----
     bf16x8_t xr[XREG ? MM : 1][NP][8];
-    if (XREG) {
+    if (XREG && NORM) {
+        // RMSNorm fused in (decode: saves the rmsnorm launch in front of this Linear).  Every wave holds the whole row, so it derives
+        // rstd by itself, under the weight stream that is already flowing -- with the lane / summation order of rmsnorm_kernel
+        // (llama.hip: lane owns float4 columns lane + 64 k, k ascending; same wave reduction), so that rstd and the hi / lo planes
+        // are bit-identical to the separate launch; then it normalises its own 8 x 8 k positions.
+        const int w4 = p.Kp >> 2;
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            const int mr = m < p.M ? m : p.M - 1;
+            const float4* xr4 = (const float4*)(p.xn + (size_t)mr * p.ldxn);
+            float4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int c = lane + 64 * k;
+                v[k] = c < w4 ? xr4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float sq = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (lane + 64 * k < w4) sq += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+            const float var = wave_sum(sq) / (float)p.Kp;
+            const float rstd = 1.0f / sqrtf(var + p.xeps);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = j * 512 + lane * 8;
+                const bool ok = m < p.M && k < p.Kp;
+                const int ke = ok ? k : 0;
+                const float* xp = p.xn + (size_t)mr * p.ldxn + ke;
+                const float4 x0 = *(const float4*)xp, x1 = *(const float4*)(xp + 4);
+                const float4 g0 = *(const float4*)(p.xg + ke), g1 = *(const float4*)(p.xg + ke + 4);
+                const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = gv[e] * (xv[e] * rstd);
+                    const bf16_t h = (bf16_t)y;
+                    xr[m][0][j][e] = ok ? h : (bf16_t)0.0f;
+                    if (SPLIT) xr[m][NP - 1][j][e] = ok ? (bf16_t)(y - (float)h) : (bf16_t)0.0f;
+                }
+            }
+        }
+    } else if (XREG) {
 #pragma unroll
         for (int m = 0; m < MM; ++m)
 #pragma unroll
@@ -218,7 +264,7 @@ static bool gemv_shape_ok(int split, int m, int kp) {
     return xbytes <= GV_XLDS_MAX;
 }
 
-template <bool SPLIT, int EPI, int MM, bool XREG>
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM = false>
 static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;
     p.ncols = IS_SWIGLU(EPI) ? p.N / 2 : p.N;
@@ -227,7 +273,7 @@ static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     p.xbytes = XREG ? 0 : MM * (SPLIT ? 2 : 1) * ((p.Kp + GV_CHUNK - 1) / GV_CHUNK) * GV_CHUNK * 2;
     const int lds = GV_WAVES * (XREG ? 16 : 12) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
     if (lds > 160 * 1024) return -1000;
-    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG>;
+    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     kern<<<blocks, GV_WAVES * 64, lds, s>>>(p);
     return check_launch("gemv16_dma");
@@ -236,6 +282,7 @@ static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
 template <bool SPLIT, int EPI>
 static int dispatch_gemv_m(const GemvParams& p, hipStream_t s, int cus) {
     const bool xreg = p.Kp <= GV_CHUNK && p.M <= 2;
+    if (p.xn != nullptr) return launch_gemv<SPLIT, EPI, 1, true, true>(p, s, cus);       // fused RMSNorm: m == 1, kp <= 4096 (checked by the caller)
     if (p.M == 1) return xreg ? launch_gemv<SPLIT, EPI, 1, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 1, false>(p, s, cus);
     if (p.M == 2) return xreg ? launch_gemv<SPLIT, EPI, 2, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 2, false>(p, s, cus);
     return launch_gemv<SPLIT, EPI, 4, false>(p, s, cus);
@@ -260,6 +307,8 @@ static int gemv_device_cus() {
 // alias c), LLARK_EPI_SWIGLU16 / LLARK_EPI_SWIGLU_SPLIT (wt rows interleaved [gate 32 | up 32], out_hi / out_lo [m][n / 2]).
 // kp % 8 == 0, kp <= 12288, and the activation planes must fit (kp <= 4096 with m <= 2, or m' * planes * ceil(kp / 4096) * 8 KiB
 // <= 48 KiB with m' = m rounded up to 1, 2, 4); a rows, wt rows 16-byte aligned.  LLARK_ERR_UNSUPPORTED for other shapes.
+static int gemv_run(GemvParams& p, int split, int epilogue, llark_stream_t stream);
+
 extern "C" int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw,
                                 const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi,
                                 void* out_lo, int ldo, llark_stream_t stream) {
@@ -273,6 +322,15 @@ extern "C" int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const
     GemvParams p = {};
     p.ahi = (const bf16_t*)a_hi; p.alo = (const bf16_t*)a_lo; p.lda = lda; p.wt = (const bf16_t*)wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.ohi = (bf16_t*)out_hi; p.olo = (bf16_t*)out_lo; p.ldo = ldo;
+    return gemv_run(p, split, epilogue, stream);
+}
+
+static int gemv_run(GemvParams& p, int split, int epilogue, llark_stream_t stream) {
+    const int n = p.N, ldc = p.ldc, ldr = p.ldr, ldo = p.ldo;
+    float* c = p.C;
+    const float* resid = p.R;
+    void* out_hi = p.ohi;
+    void* out_lo = p.olo;
     hipStream_t s = (hipStream_t)stream;
     const int cus = gemv_device_cus();
     int rc = -1000;
@@ -307,4 +365,24 @@ extern "C" int llark_gemv16_dma(int split, int epilogue, const void* a_hi, const
         return LLARK_ERR_UNSUPPORTED;
     }
     return rc;
+}
+
+// The same Linear with LlamaRMSNorm fused in front (decode: input_layernorm -> q/k/v, post_attention_layernorm -> gate/up, norm ->
+// lm_head): a = bf16 hi (+ lo when split) of norm_w * (x * rstd), x fp32 [m][ldx]; bit-identical to llark_rmsnorm_bf16 followed by
+// llark_gemv16_dma.  m == 1, kp <= 4096 (the row lives in every wave's registers); LLARK_ERR_UNSUPPORTED otherwise.
+extern "C" int llark_gemv16_dma_rmsnorm(int split, int epilogue, const float* x, int ldx, const float* norm_w, float eps, const void* wt,
+                                        int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, void* out_hi, void* out_lo,
+                                        int ldo, llark_stream_t stream) {
+    LLARK_REQUIRE(x && norm_w && wt && m > 0 && n > 0 && kp > 0, "gemv16_dma_rmsnorm: bad arguments");
+    if (m != 1 || kp > GV_CHUNK || kp % 8 != 0 || ldx % 4 != 0 || ldx < kp || ldw % 8 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)norm_w & 15) ||
+        ((uintptr_t)wt & 15)) {
+        set_error("gemv16_dma_rmsnorm: shape / alignment not handled (m=%d kp=%d ldx=%d ldw=%d)", m, kp, ldx, ldw);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    LLARK_REQUIRE(epilogue != EPI_RESID, "gemv16_dma_rmsnorm: epilogue must be F32 or SwiGLU");
+    GemvParams p = {};
+    p.wt = (const bf16_t*)wt; p.ldw = ldw; p.bias = bias; p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc;
+    p.ohi = (bf16_t*)out_hi; p.olo = (bf16_t*)out_lo; p.ldo = ldo;
+    p.xn = x; p.xg = norm_w; p.ldxn = ldx; p.xeps = eps;
+    return gemv_run(p, split, epilogue, stream);
 }

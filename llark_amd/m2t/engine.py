@@ -101,7 +101,11 @@ class HipLlamaEngine:
         # instructions per k-step and wave), so the fused kernel turns VALU-bound (+15 us per launch, more than the
         # rmsnorm launch it removes); hoisting the weight loads above the scale derivation and batching the raw loads
         # before the conversions (tried, round 1) changed nothing.  Opt-in (LLARK_DECODE_FUSE_NORM_A=1).
-        self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "0") == "1"
+        # Round 3: the LDS-DMA streaming Linear (csrc/gemv_dma.hip) holds the whole activation row in every wave's registers, so
+        # it derives rstd and the hi / lo planes itself under the weight stream that is already flowing: that form (B = 1, weights
+        # >= 64 MB: q/k/v, gate/up, lm_head) is the default ("auto"); "1" forces the fusion for every decode shape (the MFMA skinny
+        # kernel's per-k-step form for the others), "0" switches it off.
+        self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "auto")
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         # decode step as a recorded host launch list over static buffers (ops.LaunchList): removes the per-launch Python cost
         self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
@@ -243,7 +247,8 @@ class HipLlamaEngine:
         sp = self.split
         # decode (one token per sequence): o_proj / down_proj carry the FOLLOWING RMSNorm in their launch
         fused = s == 1 and batch <= 16 and n_layers > 0 and self.fuse_decode_norm and H <= 8192
-        norm_a = s == 1 and batch <= 16 and self.fuse_decode_norm_a and not fused and H % 32 == 0
+        norm_a = (s == 1 and batch <= 16 and not fused and H % 32 == 0 and
+                  (self.fuse_decode_norm_a == "1" or (self.fuse_decode_norm_a == "auto" and ops.gemv_dma_rmsnorm_takes(batch, 3 * H, H))))
         if fused:
             ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         for i in range(n_layers):
@@ -389,7 +394,7 @@ class HipLlamaEngine:
             ops.gemm16(x16, x16_lo, self.lm_head, None, d.vocab_size, ops.EPI_F32, c=logits)
             return logits.view(B, 1, d.vocab_size)
         logits = torch.empty((B * S, d.vocab_size), dtype=torch.float32, device=self.device)
-        if S == 1 and B <= 16 and self.fuse_decode_norm_a and not normed:
+        if S == 1 and B <= 16 and not normed and (self.fuse_decode_norm_a == "1" or (self.fuse_decode_norm_a == "auto" and ops.gemv_dma_rmsnorm_takes(B, d.vocab_size, d.hidden_size))):
             ops.gemm16_rmsnorm_a(h, self.norm, d.rms_norm_eps, self.lm_head, d.vocab_size, ops.EPI_F32, self.split, c=logits)
             return logits.view(B, S, d.vocab_size)
         if not normed:

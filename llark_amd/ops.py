@@ -553,12 +553,25 @@ def gemm16_resid_rmsnorm(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: t
             _dev(x_hi, "x_hi", bf), _opt(x_lo, "x_lo", bf), x_hi.stride(0), _stream()), "gemm16_resid_rmsnorm")
 
 
+def gemv_dma_rmsnorm_takes(m: int, n: int, kp: int) -> bool:
+    """RMSNorm + decode Linear in one launch of the streaming kernel (csrc/gemv_dma.hip): the row must live in registers."""
+    return GEMV_DMA and m == 1 and kp <= 4096 and kp % 8 == 0 and n * kp * 2 >= GEMV_DMA_MIN_BYTES
+
+
 def gemm16_rmsnorm_a(x: torch.Tensor, norm_w: torch.Tensor, eps: float, wt: torch.Tensor, n: int, epilogue: int, split: bool,
                      c: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None) -> None:
     """Decode step: RMSNorm(x) . wt^T in one launch (x fp32 [m <= 16][k]); epilogue EPI_F32 or SwiGLU."""
     m, kp = x.shape[0], wt.shape[1]
     bf = torch.bfloat16
     name = ("gemm_split_" if split else "gemm_") + "bf16_skinny"
+    if gemv_dma_rmsnorm_takes(m, n, kp):
+        with _timed(name, 2.0 * m * n * kp):
+            check(_lib.lib().llark_gemv16_dma_rmsnorm(
+                int(split), epilogue, _dev(x, "x", torch.float32), x.stride(0), _dev(norm_w, "norm_w", torch.float32), float(eps),
+                _dev(wt, "wt", bf), wt.stride(0), None, m, n, kp, _opt(c, "c", torch.float32), c.stride(0) if c is not None else 0,
+                _opt(out_hi, "out_hi", bf), _opt(out_lo, "out_lo", bf), out_hi.stride(0) if out_hi is not None else 0, _stream()),
+                "gemv16_dma_rmsnorm")
+        return
     with _timed(name, 2.0 * m * n * kp):
         check(_lib.lib().llark_gemm16_rmsnorm_a(
             _DT[bf], int(split), epilogue, _dev(x, "x", torch.float32), x.stride(0), _dev(norm_w, "norm_w", torch.float32), float(eps),

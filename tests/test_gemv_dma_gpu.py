@@ -83,3 +83,30 @@ def test_same_result_as_the_mfma_skinny_kernel_within_rounding():
     ops.gemm16(hi, lo, w, None, 12288, ops.EPI_F32, c=c1)
     ops.gemm16(hi, lo, w, None, 12288, ops.EPI_F32, c=c2, variant=0)
     assert (c1 - c2).abs().max().item() <= 2e-5 * c2.abs().max().item()
+
+
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("n,k,swiglu", [(12288, 4096, False), (22016, 4096, True), (640, 512, False)])
+def test_fused_rmsnorm_is_bit_identical_to_the_separate_launch(split, n, k, swiglu):
+    """llark_gemv16_dma_rmsnorm == llark_rmsnorm_bf16 followed by llark_gemv16_dma, bit for bit (same rstd, same hi / lo planes,
+    same stream): the decode step may fuse LlamaRMSNorm into q/k/v_proj, gate/up_proj and lm_head without changing a token."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(n + k)
+    x = torch.randn(1, k, generator=g, device="cuda") * 3.0
+    gam = 1.0 + 0.2 * torch.randn(k, generator=g, device="cuda")
+    w = (torch.randn(n, k, generator=g, device="cuda") * 0.05).bfloat16()
+    hi = torch.empty(1, k, dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty_like(hi) if split else None
+    ops.rmsnorm_bf16(x, gam, 1e-5, hi, lo)
+    if swiglu:
+        epi = ops.EPI_SWIGLU_SPLIT if split else ops.EPI_SWIGLU16
+        o1, l1, o2, l2 = (torch.full((1, n // 2), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(4))
+        ops.gemm16(hi, lo, w, None, n, epi, out_hi=o1, out_lo=l1 if split else None)
+        ops.gemm16_rmsnorm_a(x, gam, 1e-5, w, n, epi, split, out_hi=o2, out_lo=l2 if split else None)
+        assert torch.equal(o1, o2) and (not split or torch.equal(l1, l2))
+    else:
+        c1 = torch.full((1, n), float("nan"), device="cuda")
+        c2 = torch.full((1, n), float("nan"), device="cuda")
+        ops.gemm16(hi, lo, w, None, n, ops.EPI_F32, c=c1)
+        ops.gemm16_rmsnorm_a(x, gam, 1e-5, w, n, ops.EPI_F32, split, c=c2)
+        assert torch.equal(c1, c2)
