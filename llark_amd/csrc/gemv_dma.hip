@@ -65,7 +65,7 @@ __device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float 
 }  // namespace
 
 // XREG: K <= 4096 and MM <= 2 -- the lane's activation fragments (8 pieces x hi / lo x MM) live in registers.
-template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM>
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM, int NPCM = 8>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;                      // weight rows per output column
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
     char* xs = smem + GV_WAVES * GV_RING;                            // !XREG: [MM][NP][nch * 8 pieces][64 lanes] x 16 B
     float* part = (float*)(xs + p.xbytes);                           // [rows of the block][MM]
     const int nch = (p.Kp + GV_CHUNK - 1) / GV_CHUNK;
-    const int npc = nch * 8;                                         // 1 KiB pieces per weight row
+    const int npc = (XREG && NPCM > 8) ? (p.Kp + 511) / 512 : nch * 8;  // 1 KiB pieces per weight row (the LDS form pads to whole chunks)
     const int col0 = blockIdx.x * p.cols_per_block;
     int ncb = p.ncols - col0;
     ncb = ncb < 0 ? 0 : (ncb > p.cols_per_block ? p.cols_per_block : ncb);
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
 
 
     // ---- activations ----
-    bf16x8_t xr[XREG ? MM : 1][NP][8];
-    if (XREG && NORM) {
+    bf16x8_t xr[XREG ? MM : 1][NP][XREG ? NPCM : 1];                 // NPCM = 8 (K <= 4096) or 24 (K <= 12288, one activation row)
+    if constexpr (XREG && NORM) {
         // RMSNorm fused in (decode: saves the rmsnorm launch in front of this Linear).  Every wave holds the whole row, so it derives
         // rstd by itself, under the weight stream that is already flowing -- with the lane / summation order of rmsnorm_kernel
         // (llama.hip: lane owns float4 columns lane + 64 k, k ascending; same wave reduction), so that rstd and the hi / lo planes
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
                 }
             }
         }
-    } else if (XREG) {
+    } else if constexpr (XREG) {
 #pragma unroll
         for (int m = 0; m < MM; ++m)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NPCM; ++j) {
                 const int k = j * 512 + lane * 8;
                 const bool ok = m < p.M && k < p.Kp;
                 bf16x8_t zero;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
             if (XREG) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // GV_NSLOT - 1 newer requests may be outstanding: piece t has landed
             else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail (a counted wait per remaining piece measured nothing)
         }
         const bf16x8_t wv = *(const bf16x8_t*)(ring + cslot * 1024 + lane * 16);
         cslot = cslot + 1 == GV_NSLOT ? 0 : cslot + 1;
@@ -205,10 +205,11 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
         }
         ++ci;
     };
-    if (XREG) {                                                      // 8 pieces per row, the piece index is a compile-time constant
+    if constexpr (XREG) {                                            // the piece index is a compile-time constant (register array index)
         for (int r = 0; r < myrows; ++r) {
-            static_for<8>([&](auto jt) {
+            static_for<NPCM>([&](auto jt) {
                 constexpr int j = decltype(jt)::value;
+                if (NPCM > 8 && j >= npc) return;
                 const bf16x8_t wv = next_piece();
 #pragma unroll
                 for (int m = 0; m < MM; ++m) {
@@ -264,7 +265,7 @@ static bool gemv_shape_ok(int split, int m, int kp) {
     return xbytes <= GV_XLDS_MAX;
 }
 
-template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM = false>
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM = false, int NPCM = 8>
 static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;
     p.ncols = IS_SWIGLU(EPI) ? p.N / 2 : p.N;
@@ -273,7 +274,7 @@ static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     p.xbytes = XREG ? 0 : MM * (SPLIT ? 2 : 1) * ((p.Kp + GV_CHUNK - 1) / GV_CHUNK) * GV_CHUNK * 2;
     const int lds = GV_WAVES * (XREG ? 16 : 12) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
     if (lds > 160 * 1024) return -1000;
-    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM>;
+    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM, NPCM>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     kern<<<blocks, GV_WAVES * 64, lds, s>>>(p);
     return check_launch("gemv16_dma");
@@ -283,6 +284,7 @@ template <bool SPLIT, int EPI>
 static int dispatch_gemv_m(const GemvParams& p, hipStream_t s, int cus) {
     const bool xreg = p.Kp <= GV_CHUNK && p.M <= 2;
     if (p.xn != nullptr) return launch_gemv<SPLIT, EPI, 1, true, true>(p, s, cus);       // fused RMSNorm: m == 1, kp <= 4096 (checked by the caller)
+    if (p.M == 1 && p.Kp > GV_CHUNK) return launch_gemv<SPLIT, EPI, 1, true, false, 24>(p, s, cus);     // one row of up to 12288: 24 pieces in registers
     if (p.M == 1) return xreg ? launch_gemv<SPLIT, EPI, 1, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 1, false>(p, s, cus);
     if (p.M == 2) return xreg ? launch_gemv<SPLIT, EPI, 2, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 2, false>(p, s, cus);
     return launch_gemv<SPLIT, EPI, 4, false>(p, s, cus);
