@@ -306,13 +306,13 @@ int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void
  * Forward: bf16 operands, no past keys; also writes lse fp32 [batch*nh][s], the log-sum-exp of each query's scaled masked scores. */
 int llark_attn_prefill_bf16_lse(const void* q, const void* k_cache, const void* vt_cache, int batch, int s, int nh, int hd,
                                 int smax, void* out, float* lse, const float* alibi_slopes, llark_stream_t stream);
-/* Backward: q, dO, v_rm bf16 [batch*nh][s][128]; k_cache bf16 [batch*nh][smax][128]; qT, kT, dOT bf16 [batch*nh][128][sp]
- * (sequence contiguous, sp % 8 == 0, columns >= s ignored); o bf16 [batch*s][nh*128] = the forward's out; lse from the forward;
- * dsum fp32 [batch*nh][s] scratch.  Outputs dq, dk, dv fp32 [batch*nh][s][128] (before the RoPE backward / head merge).
+/* Backward: q, dO, v_rm bf16 [batch*nh][s][128] (row-major); k_cache bf16 [batch*nh][smax][128]; o bf16 [batch*s][nh*128] = the
+ * forward's out; lse from the forward; dsum fp32 [batch*nh][s] scratch.  Outputs dq, dk, dv fp32 [batch*nh][s][128] (before the RoPE
+ * backward / head merge).  No transposed copies of any operand are needed (transposing LDS reads inside).
  * alibi_slopes (both calls): nullptr (Llama) or fp32 [nh] (MPT-1B trainer), the bias of llark_attn_prefill_bf16_alibi. */
-int llark_attn_backward_bf16(const void* q, const void* qT, const void* k_cache, const void* kT, const void* v_rm, const void* dO,
-                             const void* dOT, const void* o, const float* lse, float* dsum, int batch, int s, int sp, int nh,
-                             int hd, int smax, float* dq, float* dk, float* dv, const float* alibi_slopes, llark_stream_t stream);
+int llark_attn_backward_bf16(const void* q, const void* k_cache, const void* v_rm, const void* dO, const void* o, const float* lse,
+                             float* dsum, int batch, int s, int nh, int hd, int smax, float* dq, float* dk, float* dv,
+                             const float* alibi_slopes, llark_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * MPT backbone (m2t/models/mpt.py over m2t/llava/model/mpt/{blocks,attention,norm}.py): the row-wise / element-wise

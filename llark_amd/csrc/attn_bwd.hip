@@ -16,9 +16,9 @@
 // In both, the score tile is computed in the orientation whose accumulator layout ("column c, rows 4g..4g+3" per lane) IS the
 // B-operand layout of the product that consumes P / dS, so the probabilities never leave the registers (see the forward kernel in
 // llama.hip for the same device); every LDS fragment read feeds two MFMAs (the wave's two sets).
-// Operand layouts (bf16): the row-major tensors q, k (the K cache), v_rm, dO [BH][S][128] feed the products that contract over d;
-// the products that contract over the sequence need the other operand with the sequence contiguous: qT, dOT (dkv) and kT (dq),
-// [BH][128][Sp] -- three S x 128 transposes per head instead of the two S x S ones of the materialising path.
+// Operand layouts (bf16): q, k (the K cache), v_rm, dO, all row-major [BH][S][128].  The products that contract over d read them as
+// they are (b128 fragments); the products that contract over the SEQUENCE (dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T) read the
+// same LDS tiles through the transposing LDS read (tr_frag below) -- no transposed copies in HBM or LDS.
 // MFMA 16x16x32 bf16 throughout; LDS tiles use the XOR layouts of the forward kernel.
 #include <stdlib.h>
 
@@ -29,7 +29,6 @@ namespace llark {
 namespace {
 
 __device__ __forceinline__ int bk_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }             // [64][128] bf16
-__device__ __forceinline__ int bv_off(int d, int chunk) { return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4); }            // [128][64] bf16
 
 // rows r0 .. r0+63 of a row-major [.][128] tensor -> LDS [64][128]; rows >= limit are zero
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, size_t ld, int r0, int limit, char* dst) {
@@ -43,31 +42,9 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, size
     }
 }
 
-// columns c0 .. c0+63 of a [128][ld] tensor (sequence contiguous) -> LDS [128][64]; columns >= limit are zero (the padding of
-// the source up to ld is not initialised)
-__device__ __forceinline__ void stage_cols(const bf16_t* __restrict__ base, size_t ld, int c0, int limit, char* dst) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = threadIdx.x + i * 256;
-        const int d = idx >> 3, ch = idx & 7;
-        const int cc = c0 + ch * 8;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (cc + 7 < limit) {
-            val = *(const uint4*)(base + (size_t)d * ld + cc);
-        } else if (cc < limit) {
-            const unsigned short* src = (const unsigned short*)(base + (size_t)d * ld + cc);
-            unsigned short tmp[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tmp[e] = (cc + e < limit) ? src[e] : (unsigned short)0;
-            val = *(uint4*)tmp;
-        }
-        *(uint4*)(dst + bv_off(d, ch)) = val;
-    }
-}
-
-// The same two tiles streamed global -> LDS by LDS-DMA (no registers; the tile must lie completely inside the tensor): the DMA
-// image is lane-linear, so lane i of the instruction covering rows 4j..4j+3 (8j..8j+7 of a transposed tile) FETCHES the chunk that
-// belongs in its slot -- the XOR swizzle of bk_off / bv_off applied to the source address.  Each wave issues 4 of the 16 x 1 KiB.
+// The same tile streamed global -> LDS by LDS-DMA (no registers; the tile must lie completely inside the tensor): the DMA image is
+// lane-linear, so lane i of the instruction covering rows 4j..4j+3 FETCHES the chunk that belongs in its slot -- the XOR swizzle of
+// bk_off applied to the source address.  Each wave issues 4 of the 16 x 1 KiB.
 __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0, char* dst, int wv, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -78,15 +55,23 @@ __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0
                                          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
     }
 }
-__device__ __forceinline__ void dma_cols(const bf16_t* __restrict__ base, size_t ld, int c0, char* dst, int wv, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = wv * 4 + i;
-        const int d = 8 * j + (lane >> 3);
-        const bf16_t* src = base + (size_t)d * ld + c0 + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
-    }
+
+// A-operand fragment of a 16x16x32 MFMA whose row index is a COLUMN of a row-major [64 rows][128 columns] LDS tile and whose 8
+// contraction slots are 8 consecutive ROWS of it (the sequence index): two transposing LDS reads.  `ds_read_b64_tr_b16` hands lane
+// i of a 16-lane group column i of the [4 rows][16 columns] block whose (row r, 4-column group a) is addressed by source lane
+// 4r + a (scripts/probes/tr_b16_probe.hip); lane group g takes rows row0 + 8g .. + 7, columns col0 .. col0 + 15 of the tile (in
+// the bk_off swizzle: consecutive rows land on different 16-byte chunks, at most 2-way bank conflicts).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int col0, int g, int c) {
+    const int col = col0 + 4 * (c & 3);
+    const int ra = row0 + 8 * g + (c >> 2), rb = ra + 4;
+    const int oa = ra * 256 + ((((col >> 3) ^ (ra & 15)) << 4) | ((col & 7) << 1));
+    const int ob = rb * 256 + ((((col >> 3) ^ (rb & 15)) << 4) | ((col & 7) << 1));
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + oa));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + ob));
+    const v8s_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
 }
 
 }  // namespace
@@ -125,7 +110,7 @@ __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5
 
 constexpr float kLog2e = 1.4426950408889634f;
 #ifndef DKV_NK
-#define DKV_NK 2
+#define DKV_NK 1
 #endif
 
 // One workgroup per 128 keys: wave wv owns keys kb0 + 32 wv .. + 31 as two sets of 16 (B operands K, V in registers; dK^T, dV^T
@@ -133,16 +118,18 @@ constexpr float kLog2e = 1.4426950408889634f;
 // so P and dS leave the MFMA as "column = key, 4 rows = queries" -- the B-operand layout of dV^T = dO^T P and dK^T = Q^T dS
 // (A = the sequence-contiguous tiles in LDS).  Nothing goes through an LDS scratch.
 template <int NK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qT,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ kc, const bf16_t* __restrict__ v_rm,
-                                                           const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOT,
+                                                           const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                           float* __restrict__ dk, float* __restrict__ dv, int S, int Sp, int smax,
+                                                           float* __restrict__ dk, float* __restrict__ dv, int S, int smax,
                                                            int nbh, int nh, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // two LDS stages of DKV_STAGE bytes: Q [64 q][128 d] | dO [64][128] | Q^T [128 d][64 q] | dO^T [128][64] | log-sum-exp [64] |
-    // rowsum(dO * O) [64].  Tile qt+1 streams in by LDS-DMA while tile qt is computed: one barrier per tile.
-    constexpr int DKV_STAGE = 65536 + 512;
+    // two LDS stages of DKV_STAGE bytes: Q [64 q][128 d] | dO [64][128] | log-sum-exp [64] | rowsum(dO * O) [64].  Tile qt+1 streams in
+    // by LDS-DMA while tile qt is computed: one barrier per tile.  The products that contract over the queries (dV^T = dO^T P,
+    // dK^T = Q^T dS) read their A operands from the SAME row-major tiles through the transposing LDS read (tr_frag): no Q^T / dO^T
+    // copies in HBM or LDS, 64.5 KiB per workgroup, two workgroups per CU.
+    constexpr int DKV_STAGE = 32768 + 512;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -152,8 +139,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int kb0 = tile * 64 * NK;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* dob = dO + bh * S * 128;
-    const bf16_t* qtb = qT + bh * (size_t)128 * Sp;
-    const bf16_t* dotb = dOT + bh * (size_t)128 * Sp;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
     const float* lb = lse + bh * S;
@@ -187,22 +172,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (q0 + 64 <= S) {
             dma_rows(qb, q0, base, wv, lane);
             dma_rows(dob, q0, base + 16384, wv, lane);
-            dma_cols(qtb, Sp, q0, base + 32768, wv, lane);
-            dma_cols(dotb, Sp, q0, base + 49152, wv, lane);
             if (wv == 0) {                                          // the 64 log-sum-exps and row sums: 4 B per lane
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb + q0 + lane),
-                                                 (__attribute__((address_space(3))) void*)(base + 65536), 4, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + 32768), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + q0 + lane),
-                                                 (__attribute__((address_space(3))) void*)(base + 65536 + 256), 4, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(base + 32768 + 256), 4, 0, 0);
             }
         } else {                                                    // the ragged last tile: through registers, zero-filled
             stage_rows(qb, 128, q0, S, base);
             stage_rows(dob, 128, q0, S, base + 16384);
-            stage_cols(qtb, Sp, q0, S, base + 32768);
-            stage_cols(dotb, Sp, q0, S, base + 49152);
             if (threadIdx.x < 64) {
                 const int qi = q0 + threadIdx.x;
-                float* sl = (float*)(base + 65536);
+                float* sl = (float*)(base + 32768);
                 sl[threadIdx.x] = qi < S ? lb[qi] : 0.0f;
                 sl[64 + threadIdx.x] = qi < S ? db[qi] : 0.0f;
             }
@@ -216,9 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (qt + 1 < nqt) stage(qt + 1);
         const char* sQ = smem + ((qt - qt0) & 1) * DKV_STAGE;
         const char* sdO = sQ + 16384;
-        const char* sQT = sQ + 32768;
-        const char* sdOT = sQ + 49152;
-        const float* sL = (const float*)(sQ + 65536);
+        const float* sL = (const float*)(sQ + 32768);
         const float* sD = sL + 64;
         if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
         const bool need_mask = q0 < wk0 + 16 * NK || q0 + 63 >= S;  // else every (query, key) pair of the tile is visible
@@ -261,8 +240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t dof = *(const bf16x8_t*)(sdOT + bv_off(dt * 16 + c, p * 4 + g));
-                const bf16x8_t qtf = *(const bf16x8_t*)(sQT + bv_off(dt * 16 + c, p * 4 + g));
+                const bf16x8_t dof = tr_frag(sdO, 32 * p, dt * 16, g, c);      // dO^T rows d = dt*16 + c, queries 32p + 8g ..
+                const bf16x8_t qtf = tr_frag(sQ, 32 * p, dt * 16, g, c);       // Q^T
 #pragma unroll
                 for (int u = 0; u < NK; ++u) {
                     dva[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[u], dva[u][dt], 0, 0, 0);
@@ -288,15 +267,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // One workgroup per 128 queries: wave wv owns queries q0 + 32 wv .. + 31 as two sets of 16 (B operands Q, dO in registers, dQ^T in
 // accumulators).  Per 64-key tile: S^T = K Q^T and dP^T = V dO^T with the keys as MFMA rows (A from LDS), dS^T leaves the MFMA in
 // the B-operand layout of dQ^T = K^T dS^T (A = the sequence-contiguous K tile in LDS).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
-                                                          const bf16_t* __restrict__ kT, const bf16_t* __restrict__ v_rm,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
-                                                          const float* __restrict__ dsum, float* __restrict__ dq, int S, int Sp,
+                                                          const float* __restrict__ dsum, float* __restrict__ dq, int S,
                                                           int smax, int nbh, int nh, float scale, const float* __restrict__ alibi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // two LDS stages of 48 KiB: K [64 keys][128 d] | V [64][128] | K^T [128 d][64 keys]; tile kt+1 streams in by LDS-DMA while
-    // tile kt is computed
-    constexpr int DQ_STAGE = 49152;
+    // two LDS stages of 32 KiB: K [64 keys][128 d] | V [64][128]; tile kt+1 streams in by LDS-DMA while tile kt is computed.
+    // dQ^T = K^T dS^T reads its A operand (row = d, contraction over the keys) from the row-major K tile through tr_frag.
+    constexpr int DQ_STAGE = 32768;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
@@ -309,7 +288,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* dob = dO + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
-    const bf16_t* ktb = kT + bh * (size_t)128 * Sp;
     const bf16_t* vb = v_rm + bh * S * 128;
     const int wq0 = q0 + wv * 32;
     const float scale2 = scale * kLog2e;
@@ -343,11 +321,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (key0 + 64 <= S) {
             dma_rows(kb, key0, base, wv, lane);
             dma_rows(vb, key0, base + 16384, wv, lane);
-            dma_cols(ktb, Sp, key0, base + 32768, wv, lane);
         } else {
             stage_rows(kb, 128, key0, S, base);
             stage_rows(vb, 128, key0, S, base + 16384);
-            stage_cols(ktb, Sp, key0, S, base + 32768);
         }
     };
     stage(0);
@@ -358,7 +334,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (kt + 1 < nkt) stage(kt + 1);
         const char* sK = smem + (kt & 1) * DQ_STAGE;
         const char* sV = sK + 16384;
-        const char* sKT = sK + 32768;
         if (key0 > wq0 + 31) continue;                              // every key of the tile is beyond the wave's queries
         const bool need_mask = key0 + 63 > wq0 || wq0 + 31 >= S;    // else every (query, key) pair of the tile is visible
 #pragma unroll
@@ -394,7 +369,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t ktf = *(const bf16x8_t*)(sKT + bv_off(dt * 16 + c, p * 4 + g));
+                const bf16x8_t ktf = tr_frag(sK, 32 * p, dt * 16, g, c);       // K^T rows d = dt*16 + c, keys 32p + 8g ..
 #pragma unroll
                 for (int u = 0; u < 2; ++u) dqa[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, sf[u], dqa[u][dt], 0, 0, 0);
             }
@@ -415,30 +390,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 using namespace llark;
 
 // Backward of causal attention (no past keys), see the header of this file.  All tensors device memory.
-//   q, dO, v_rm [B*nh][s][128] bf16; k_cache [B*nh][smax][128] bf16; qT, kT, dOT [B*nh][128][sp] bf16 (sp % 8 == 0, sp >= s);
+//   q, dO, v_rm [B*nh][s][128] bf16; k_cache [B*nh][smax][128] bf16;
 //   o [B*s][nh*128] bf16 (the forward's output); lse [B*nh][s] fp32 from llark_attn_prefill_bf16_lse;
 //   dsum [B*nh][s] fp32 scratch; dq, dk, dv [B*nh][s][128] fp32 outputs (dk, dv before the RoPE / head merge).
 //   alibi_slopes: nullptr (Llama) or fp32 [nh] (MPT, m2t/llava/model/mpt/attention.py:build_alibi_bias), as given to the forward.
-extern "C" int llark_attn_backward_bf16(const void* q, const void* qT, const void* k_cache, const void* kT, const void* v_rm,
-                                        const void* dO, const void* dOT, const void* o, const float* lse, float* dsum, int batch,
-                                        int s, int sp, int nh, int hd, int smax, float* dq, float* dk, float* dv,
-                                        const float* alibi_slopes, llark_stream_t stream) {
-    LLARK_REQUIRE(q && qT && k_cache && kT && v_rm && dO && dOT && o && lse && dsum && dq && dk && dv, "attn_backward: null pointer");
+extern "C" int llark_attn_backward_bf16(const void* q, const void* k_cache, const void* v_rm, const void* dO, const void* o,
+                                        const float* lse, float* dsum, int batch, int s, int nh, int hd, int smax, float* dq, float* dk,
+                                        float* dv, const float* alibi_slopes, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && v_rm && dO && o && lse && dsum && dq && dk && dv, "attn_backward: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_backward: head_dim must be 128 (Llama-2), got %d", hd);
-    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && sp >= s && sp % 8 == 0, "attn_backward: bad shape");
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax, "attn_backward: bad shape");
     const float scale = (float)(1.0 / sqrt((double)hd));
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)batch * nh * s;
     attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows);
     const int nbh = batch * nh;
     const int grid = cdiv(s, 128) * nbh;
-    const int lds_kv = 2 * (65536 + 512), lds_q = 2 * 49152;
+    const int lds_kv = 2 * (32768 + 512), lds_q = 2 * 32768;
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)qT, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
-                                                   (const bf16_t*)dO, (const bf16_t*)dOT, lse, dsum, dk, dv, s, sp, smax, nbh, nh, scale,
-                                                   alibi_slopes);
-    attn_bwd_dq_kernel<<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)kT, (const bf16_t*)v_rm,
-                                                 (const bf16_t*)dO, lse, dsum, dq, s, sp, smax, nbh, nh, scale, alibi_slopes);
+    attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
+                                                                               (const bf16_t*)dO, lse, dsum, dk, dv, s, smax, nbh, nh, scale,
+                                                                               alibi_slopes);
+    attn_bwd_dq_kernel<<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
+                                                 dq, s, smax, nbh, nh, scale, alibi_slopes);
     return check_launch("attn_backward");
 }

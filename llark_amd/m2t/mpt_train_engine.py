@@ -201,15 +201,9 @@ class HipMptTrainer:
             # flash-style backward (csrc/attn_bwd.hip), ALiBi inside: P is recomputed per tile from the forward's log-sum-exp
             v_rm = torch.empty((BH, S, 128), **bf)
             ops.transpose16(vtc, smax, 128, S, v_rm, 128, BH, 128 * smax, S * 128)
-            dOT = torch.empty((BH, 128, Sp), **bf)
-            ops.transpose16(dO, 128, S, 128, dOT, Sp, BH, S * 128, 128 * Sp)
-            kT = torch.empty((BH, 128, Sp), **bf)
-            ops.transpose16(kc, 128, S, 128, kT, Sp, BH, smax * 128, 128 * Sp)
-            qT = torch.empty((BH, 128, Sp), **bf)
-            ops.transpose16(q, 128, S, 128, qT, Sp, BH, S * 128, 128 * Sp)
             dq, dk, dv = (torch.empty((BH, S, 128), **f32) for _ in range(3))
             dsum = torch.empty((BH, S), **f32)
-            ops.attn_backward(q, qT, kc, kT, v_rm, dO, dOT, st["att"], st["lse"], dsum, B, S, Sp, nh, 128, dq, dk, dv,
+            ops.attn_backward(q, kc, v_rm, dO, st["att"], st["lse"], dsum, B, S, nh, 128, dq, dk, dv,
                               alibi_slopes=eng.slopes)
             dqkv = torch.empty((rows, 3 * D), **bf)
             ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, 128, 0, dqkv)      # identity rotation: heads -> [rows][3D]

@@ -285,20 +285,14 @@ class HipLlamaTrainer:
             kc = eng.k_cache[i, :B]                                      # [B][nh][smax][hd]
             vtc = eng.vt_cache[i, :B]                                    # [B][nh][hd][smax]
             # flash-style backward (csrc/attn_bwd.hip): P is recomputed per tile from the forward's log-sum-exp, no S x S matrix
-            # exists; the only layout work is three S x 128 transposes per head and V back to row-major
+            # exists and no operand is transposed; the only layout work is V back to row-major from the transposed cache
             v_rm = torch.empty((BH, S, hd), **bf)
             ops.transpose16(vtc, smax, hd, S, v_rm, hd, BH, hd * smax, S * hd)
-            dOT = torch.empty((BH, hd, Sp), **bf)
-            ops.transpose16(dO, hd, S, hd, dOT, Sp, BH, S * hd, hd * Sp)
-            kT = torch.empty((BH, hd, Sp), **bf)
-            ops.transpose16(kc, hd, S, hd, kT, Sp, BH, smax * hd, hd * Sp)
-            qT = torch.empty((BH, hd, Sp), **bf)
-            ops.transpose16(q, hd, S, hd, qT, Sp, BH, S * hd, hd * Sp)
             dq = torch.empty((BH, S, hd), **f32)
             dk = torch.empty((BH, S, hd), **f32)
             dv = torch.empty((BH, S, hd), **f32)
             dsum = torch.empty((BH, S), **f32)
-            ops.attn_backward(q, qT, kc, kT, v_rm, dO, dOT, st["att"], st["lse"], dsum, B, S, Sp, nh, hd, dq, dk, dv)
+            ops.attn_backward(q, kc, v_rm, dO, st["att"], st["lse"], dsum, B, S, nh, hd, dq, dk, dv)
             dqkv = torch.empty((rows, 3 * H), **bf)
             ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
             self._dx(dqkv, L.wqkv, dtmp)

@@ -698,14 +698,13 @@ def attn_prefill_lse(q, k_cache, vt_cache, batch: int, s: int, nh: int, hd: int,
                                                  _opt(alibi_slopes, "alibi_slopes", torch.float32), _stream()), "attn_prefill_lse")
 
 
-def attn_backward(q, qT, k_cache, kT, v_rm, dO, dOT, o, lse, dsum, batch: int, s: int, sp: int, nh: int, hd: int,
+def attn_backward(q, k_cache, v_rm, dO, o, lse, dsum, batch: int, s: int, nh: int, hd: int,
                   dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, alibi_slopes=None) -> None:
     """Flash-style backward of causal attention (csrc/attn_bwd.hip); layouts in include/llark_hip.h."""
     smax = k_cache.shape[-2]
     bf, f32 = torch.bfloat16, torch.float32
-    check(_lib.lib().llark_attn_backward_bf16(_dev(q, "q", bf), _dev(qT, "qT", bf), _dev(k_cache, "k_cache", bf), _dev(kT, "kT", bf),
-                                              _dev(v_rm, "v_rm", bf), _dev(dO, "dO", bf), _dev(dOT, "dOT", bf), _dev(o, "o", bf),
-                                              _dev(lse, "lse", f32), _dev(dsum, "dsum", f32), batch, s, sp, nh, hd, smax,
+    check(_lib.lib().llark_attn_backward_bf16(_dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(v_rm, "v_rm", bf), _dev(dO, "dO", bf),
+                                              _dev(o, "o", bf), _dev(lse, "lse", f32), _dev(dsum, "dsum", f32), batch, s, nh, hd, smax,
                                               _dev(dq, "dq", f32), _dev(dk, "dk", f32), _dev(dv, "dv", f32),
                                               _opt(alibi_slopes, "alibi_slopes", f32), _stream()), "attn_backward")
 

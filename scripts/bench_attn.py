@@ -52,16 +52,10 @@ def main():
         print(f"forward + lse  B={B} nh={nh} S={S}: {ms:.3f} ms  {pairs * 4 * HD / ms / 1e9:.1f} TFLOP/s")
         dO = (torch.randn((BH, S, HD), generator=g, **f32) * 0.1).to(torch.bfloat16)
         qv = q.view(BH, S, HD)
-        qT = torch.zeros((BH, HD, Sp), **bf)
-        kT = torch.zeros((BH, HD, Sp), **bf)
-        dOT = torch.zeros((BH, HD, Sp), **bf)
-        qT[:, :, :S] = qv.transpose(1, 2)
-        kT[:, :, :S] = kc.view(BH, smax, HD)[:, :S].transpose(1, 2)
-        dOT[:, :, :S] = dO.transpose(1, 2)
         v_rm = vtc.view(BH, HD, smax)[:, :, :S].transpose(1, 2).contiguous()
         dq, dk, dv = (torch.empty((BH, S, HD), **f32) for _ in range(3))
         dsum = torch.empty((BH, S), **f32)
-        ms = timed(lambda: ops.attn_backward(qv, qT, kc, kT, v_rm, dO, dOT, att, lse, dsum, B, S, Sp, nh, HD, dq, dk, dv))
+        ms = timed(lambda: ops.attn_backward(qv, kc, v_rm, dO, att, lse, dsum, B, S, nh, HD, dq, dk, dv))
         print(f"backward       B={B} nh={nh} S={S}: {ms:.3f} ms  {pairs * 14 * HD / ms / 1e9:.1f} TFLOP/s (7 products: S and dP twice)")
 
 

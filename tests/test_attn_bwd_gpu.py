@@ -53,19 +53,11 @@ def _run(q, k, v, dO, smax, slopes=None):
     lse = torch.empty((BH, S), **f32)
     sl = slopes.cuda().float().contiguous() if slopes is not None else None
     ops.attn_prefill_lse(qd, kc, vtc, B, S, nh, HD, att, lse, alibi_slopes=sl)
-    Sp = ops.round_up(S, 64)
-    # the sequence-contiguous copies carry NaN in their padding: the kernels must not read it
-    qT = torch.full((BH, HD, Sp), float("nan"), **bf)
-    kT = torch.full((BH, HD, Sp), float("nan"), **bf)
-    dOT = torch.full((BH, HD, Sp), float("nan"), **bf)
     dOd = dO.cuda().contiguous().view(BH, S, HD)
-    qT[:, :, :S] = qd.view(BH, S, HD).transpose(1, 2)
-    kT[:, :, :S] = k.cuda().view(BH, S, HD).transpose(1, 2)
-    dOT[:, :, :S] = dOd.transpose(1, 2)
     v_rm = v.cuda().contiguous().view(BH, S, HD)
     dq, dk, dv = (torch.empty((BH, S, HD), **f32) for _ in range(3))
     dsum = torch.empty((BH, S), **f32)
-    ops.attn_backward(qd.view(BH, S, HD), qT, kc, kT, v_rm, dOd, dOT, att, lse, dsum, B, S, Sp, nh, HD, dq, dk, dv, alibi_slopes=sl)
+    ops.attn_backward(qd.view(BH, S, HD), kc, v_rm, dOd, att, lse, dsum, B, S, nh, HD, dq, dk, dv, alibi_slopes=sl)
     torch.cuda.synchronize()
     o = att.view(B, S, nh, HD).permute(0, 2, 1, 3).float()
     return o, lse.view(B, nh, S), dq.view(B, nh, S, HD), dk.view(B, nh, S, HD), dv.view(B, nh, S, HD)
