@@ -44,6 +44,29 @@ __global__ void split16_kernel(const float* __restrict__ x, int ldx, int rows, i
     }
 }
 
+// the same, four columns per thread (16-B loads, 8-B stores), one row per blockIdx.y step: no division per element.
+// width, ldx, ldo % 4 == 0 and 16- / 8-byte aligned bases (the launcher checks).
+template <typename D>
+__global__ void split16_v4_kernel(const float* __restrict__ x, int ldx, int rows, int width, D* __restrict__ hi,
+                                  D* __restrict__ lo, int ldo) {
+    typedef D d4_t __attribute__((ext_vector_type(4)));
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (c >= ldo) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < width) v = *(const float4*)(x + (size_t)r * ldx + c);          // width % 4 == 0: the float4 is inside or outside
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        d4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (D)xv[e];
+            l[e] = (D)(xv[e] - (float)h[e]);
+        }
+        *(d4_t*)(hi + (size_t)r * ldo + c) = h;
+        if (lo) *(d4_t*)(lo + (size_t)r * ldo + c) = l;
+    }
+}
+
 // fp16 weight rows -> E4M3 plane fp8(W * 2^sw) in MFMA slot order (lo8_pos): the B operand of the low-plane product
 __global__ void pack_weight_lo8_kernel(const half_t* __restrict__ wt, int ldw, int n, int kp, float mul, unsigned char* __restrict__ out, int ldo) {
     const size_t total = (size_t)n * (kp >> 2);
@@ -125,6 +148,15 @@ extern "C" int llark_split16(int dtype, const float* x, int ldx, int rows, int w
     int grid = (int)((total + 255) / 256);
     if (grid > 8192) grid = 8192;
     hipStream_t s = (hipStream_t)stream;
+    if ((dtype == LLARK_F16 || dtype == LLARK_BF16) && width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+        ((uintptr_t)out_hi & 7) == 0 && ((uintptr_t)out_lo & 7) == 0) {
+        const int bx = (ldo / 4 + 255) / 256;
+        int by = rows < 4096 ? rows : 4096;
+        dim3 g4(bx, by);
+        if (dtype == LLARK_F16) split16_v4_kernel<half_t><<<g4, 256, 0, s>>>(x, ldx, rows, width, (half_t*)out_hi, (half_t*)out_lo, ldo);
+        else split16_v4_kernel<bf16_t><<<g4, 256, 0, s>>>(x, ldx, rows, width, (bf16_t*)out_hi, (bf16_t*)out_lo, ldo);
+        return check_launch("split16");
+    }
     if (dtype == LLARK_F16)
         split16_kernel<half_t><<<grid, 256, 0, s>>>(x, ldx, rows, width, (half_t*)out_hi, (half_t*)out_lo, ldo);
     else if (dtype == LLARK_BF16)

@@ -72,3 +72,20 @@ def test_rejects_what_it_cannot_do():
         ops.gemm16_t(a, w, 100, 128, 64, True, True, c)            # m % 8 != 0 for a transposed operand
     with pytest.raises(LlarkHipError):
         ops.gemm16_t(w, w, 128, 128, 32, True, True, c)            # kp % 64 != 0
+
+
+@pytest.mark.parametrize("rows,width,dtype,kmult", [(2048, 4096, torch.bfloat16, 64), (333, 200, torch.float16, 64), (7, 4800, torch.float16, 32),
+                                                    (65, 1216, torch.bfloat16, 64), (5, 130, torch.bfloat16, 64), (4100, 36, torch.float16, 32)])
+def test_split16_vector_and_scalar_forms(rows, width, dtype, kmult):
+    """llark_split16 (fp32 -> 16-bit hi + lo planes, zero-padded to the K multiple): the four-columns-per-thread form (width % 4 == 0)
+    and the scalar form (width = 130) give exactly torch's rounding; more than 4096 rows exercise the row loop."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(rows + width)
+    x = torch.randn(rows, width, generator=g, device="cuda") * 3
+    hi, lo = ops.split16(x, dtype, want_lo=True, kmult=kmult)
+    ref_hi = x.to(dtype)
+    ref_lo = (x - ref_hi.float()).to(dtype)
+    assert hi.shape[1] % kmult == 0
+    assert torch.equal(hi[:, :width], ref_hi) and torch.equal(lo[:, :width], ref_lo)
+    if hi.shape[1] > width:
+        assert hi[:, width:].abs().max().item() == 0 and lo[:, width:].abs().max().item() == 0
