@@ -299,6 +299,10 @@ int llark_gemv16_dma_rmsnorm(int split, int epilogue, const float* x, int ldx, c
  * operand's free size % 8 == 0.  epilogue: LLARK_EPI_F32 or LLARK_EPI_RESID (resid may alias c). */
 int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m, int n,
                    int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream);
+/* ... and *sumsq (a double in device memory) += the sum of squares of every value written to c: the dW product of the last
+ * micro-batch leaves its share of the squared gradient norm behind (HF Trainer's clip_grad_norm_; llark_adamw_clip consumes it). */
+int llark_gemm16_t_sumsq(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m, int n,
+                         int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream);
 
 /* Training pair (csrc/llama.hip, csrc/attn_bwd.hip): what torch autograd does for LlamaAttention's eager path
  * (transformers==4.29.2 modeling_llama.py) under WrappedLlamav2ForCausalLM.forward + loss.backward()

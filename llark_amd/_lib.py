@@ -90,6 +90,7 @@ _SIGS = {
     "llark_gemv16_dma": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P],
     "llark_gemv16_dma_rmsnorm": [c_int, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P],
     "llark_gemm16_t": [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "llark_gemm16_t_sumsq": [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_attn_prefill_bf16_lse": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "llark_attn_backward_bf16": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
     "llark_layernorm_bf16": [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, c_int, _P],

@@ -107,6 +107,7 @@ struct GemmParams {
     float* sk_part;    // [resident workgroups][BM * BN] fp32 slabs (caller's scratch)
     unsigned* sk_flag; // [resident workgroups] hand-off flags, zero between launches
     long long* prof;   // profiling builds only (-DLLARK_LO8_PROF): per-wave cycle counters, nullptr otherwise
+    double* sumsq;     // gemm_tn.hip, EPI_F32 / EPI_RESID: += sum of squares of every value the epilogue stores (nullptr = off)
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
@@ -161,7 +162,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
 
 // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Shared by every main-loop variant.
-template <typename T, bool SPLIT, int EPI, typename C>
+template <typename T, bool SPLIT, int EPI, typename C, bool SUMSQ = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
                                               const int wm, const int wn, const int lane, const long long bz) {
     // Outputs go through buffer descriptors based at this wave's sub-tile origin: every store is
@@ -202,6 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     if (EPI == EPI_SPLIT16)
         rH2 = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)(dup_hi ? p.Ohi2 : p.Ohi) + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
     const bool act_erf = (EPI == EPI_SPLIT16 || EPI == EPI_OUT16) && p.act == 2;
+    float ssq = 0.0f;                                            // SUMSQ: this lane's sum of squares of the stored values
 
     auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -239,8 +241,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                     if (!FULL && mrow0 + ml + lr >= p.M) continue;
                     float v = acc[tm][tn][r] + bv;
                     if (EPI == EPI_F32) {
+                        if (SUMSQ) ssq += v * v;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
                     } else if (EPI == EPI_RESID) {
+                        if (SUMSQ) ssq += (res[tn][r] + v) * (res[tn][r] + v);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[tn][r] + v), rC, vC, (ml * p.ldc + ocl) * 4, 0);
                     } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
                         if (EPI == EPI_QGELU_SPLIT) v = quick_gelu(v);
@@ -282,6 +286,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     };
     if (full) epilogue(std::true_type{});      // interior tile: no per-element bounds checks
     else epilogue(std::false_type{});
+    if (SUMSQ && p.sumsq != nullptr) {          // one double atomic per wave (the squared gradient norm for clip_grad_norm_)
+        const float tot = wave_sum(ssq);
+        if (lane == 0 && tot != 0.0f) atomicAdd(p.sumsq, (double)tot);
+    }
 }
 
 // XCD-aware remap of the hardware block index: workgroups are dealt round-robin to the 8 XCDs, so XCD x gets the

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const
                 for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(af[tm], bf[tn], acc[tm][tn]);
         }
     }
-    gemm_epilogue<T, false, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+    gemm_epilogue<T, false, EPI, C, true>(p, acc, m0, n0, wm, wn, lane, 0);
 }
 
 template <typename T, bool TA, bool TB, int EPI>
@@ -154,8 +154,8 @@ using namespace llark;
 //   trans_b == 0: wt is [n][ldw] (k contiguous); trans_b != 0: wt is [kp][ldw] (row = k, column = n).
 //   kp % 64 == 0 (all kp contraction rows / columns are read: pad with zeros);  a transposed operand's free size (m or n) % 8 == 0.
 //   epilogue: LLARK_EPI_F32 (c = product) or LLARK_EPI_RESID (c = resid + product; resid may alias c).
-extern "C" int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
-                              int n, int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream) {
+static int gemm16_t_impl(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
+                         int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream) {
     LLARK_REQUIRE(a && wt && c, "gemm16_t: null pointer");
     LLARK_REQUIRE(dtype == LLARK_F16 || dtype == LLARK_BF16, "gemm16_t: dtype must be LLARK_F16 or LLARK_BF16");
     LLARK_REQUIRE(m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_t: bad shape m=%d n=%d kp=%d (kp %% 64 == 0)", m, n, kp);
@@ -169,9 +169,25 @@ extern "C" int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b,
     p.Ahi = a; p.lda = lda; p.Wt = wt; p.ldw = ldw;
     p.M = m; p.N = n; p.Kp = kp;
     p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    p.sumsq = sumsq;
     hipStream_t s = (hipStream_t)stream;
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (dtype == LLARK_BF16)
         return epilogue == EPI_F32 ? dispatch_t<bf16_t, EPI_F32>(p, ta, tb, s) : dispatch_t<bf16_t, EPI_RESID>(p, ta, tb, s);
     return epilogue == EPI_F32 ? dispatch_t<half_t, EPI_F32>(p, ta, tb, s) : dispatch_t<half_t, EPI_RESID>(p, ta, tb, s);
+}
+
+extern "C" int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
+                              int n, int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream) {
+    return gemm16_t_impl(dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, nullptr, stream);
+}
+
+// The same product; additionally *sumsq (a double in device memory) += the sum of squares of every value written to c: the dW product
+// of the LAST micro-batch leaves its share of the squared gradient norm behind (HF Trainer's clip_grad_norm_), so that the
+// optimizer step does not have to read the gradients once more for it.
+extern "C" int llark_gemm16_t_sumsq(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw,
+                                    int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq,
+                                    llark_stream_t stream) {
+    LLARK_REQUIRE(sumsq, "gemm16_t_sumsq: null sumsq");
+    return gemm16_t_impl(dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, sumsq, stream);
 }

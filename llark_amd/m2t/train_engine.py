@@ -96,6 +96,7 @@ class HipLlamaTrainer:
         self.micro_batches = 0
 
     def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor, name: str) -> None:
+        sumsq = self._norm_acc if getattr(self, "_norm_collect", False) else None
         """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch.
         Both operands are contraction-major as they stand (the token index is their row): ``llark_gemm16_t`` reads them through
         the transposing LDS load, no dY^T / X^T copies; token counts that are not a multiple of 64 take the transposing path."""
@@ -103,7 +104,10 @@ class HipLlamaTrainer:
         fresh = name in self._fresh
         self._fresh.discard(name)
         if dy16.shape[0] % 64 == 0 and n % 8 == 0 and k % 8 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
-            ops.gemm16_t(dy16, x16, n, k, dy16.shape[0], True, True, grad, accumulate=not fresh)
+            ops.gemm16_t(dy16, x16, n, k, dy16.shape[0], True, True, grad, accumulate=not fresh, sumsq=sumsq)
+            if sumsq is not None:                          # this gradient's share of the squared norm is in the accumulator already
+                off, cnt = self._slices[name]
+                self._norm_spans.append((off, off + cnt))
             return
         dyT = ops.transposed16(dy16)
         xT = ops.transposed16(x16)
@@ -177,10 +181,10 @@ class HipLlamaTrainer:
                          overlap_allreduce_world: int = 1, last_micro_batch: bool = False) -> torch.Tensor:
         """One micro-batch: returns the (unscaled) loss as a device scalar and ACCUMULATES gradients.
         ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer.
-        ``last_micro_batch``: this call completes the gradients of an optimizer step: as soon as a decoder layer's slice is final
-        its contribution to the global gradient norm is summed on a side stream, under the backward of the layers below --
-        ``step(max_grad_norm=...)`` then only reduces what is left (embedding rows, projector, final norm) instead of re-reading all
-        27 GB of gradients.  (Single rank only: with an all-reduce pending the norm is taken after it, in one pass.)
+        ``last_micro_batch``: this call completes the gradients of an optimizer step: every dW product then also adds the sum of
+        squares of the gradient it writes to a device scalar (epilogue of ``llark_gemm16_t_sumsq``) -- ``step(max_grad_norm=...)``
+        only reduces what is left (norm gains, embedding rows) instead of re-reading all 27 GB of gradients.  (Single rank only: with
+        an all-reduce pending the norm is taken after it, in one pass.)
         ``overlap_allreduce_world`` > 1 (pass it on the LAST micro-batch of an optimizer step, the reference's DDP
         ``no_sync`` boundary): as soon as the backward of decoder layer i is complete its ~0.8 GB gradient slice is
         all-reduced asynchronously (RCCL stream) while layers i-1 ... 0 are still being differentiated; call
@@ -188,6 +192,14 @@ class HipLlamaTrainer:
         eng, d = self.eng, self.eng.dims
         dev = eng.device
         B, S = input_ids.shape
+        # last micro-batch on one rank: every dW product also leaves the sum of squares of the gradient it completes (epilogue of
+        # llark_gemm16_t_sumsq), so step(max_grad_norm=...) only has to reduce the small rest instead of re-reading 27 GB
+        self._norm_collect = bool(last_micro_batch and self.flat_m is not None and overlap_allreduce_world <= 1)
+        if self._norm_collect:
+            if getattr(self, "_norm_acc", None) is None:
+                self._norm_acc = torch.zeros((1,), dtype=torch.float64, device=self.flat_grad.device)
+            self._norm_acc.zero_()
+            self._norm_spans = []
         rows = B * S
         H, I, nh, hd, V = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim, d.vocab_size
         f32 = dict(dtype=torch.float32, device=dev)
@@ -301,8 +313,6 @@ class HipLlamaTrainer:
             saved[i] = None
             if overlap_allreduce_world > 1:
                 self._start_layer_allreduce(i)
-            if last_micro_batch and self.flat_m is not None and overlap_allreduce_world <= 1:
-                self._layer_norm_async(i)      # (with an exchange in flight the norm is taken after allreduce_grads, in one pass)
         # ---- bottom: projector and the trainable embedding rows ----
         if seg_rows:
             ridx = torch.cat(seg_rows)
@@ -325,6 +335,7 @@ class HipLlamaTrainer:
                 tmp = torch.empty((ridx.numel(), H), **f32)
                 ops.gather_rows(dh, ridx, tmp)
                 ops.scatter_add_rows(tmp, ids_flat[ridx].contiguous(), g["embed"])
+        self._norm_collect = False
         self.micro_batches += 1
         return loss
 
@@ -401,27 +412,12 @@ class HipLlamaTrainer:
         torch.cuda.synchronize()
         return float(sum(a.elapsed_time(b) for a, b in evs))
 
-    def _layer_norm_async(self, i: int) -> None:
-        """Side stream: add sum(g^2) of layer i's (final) gradient slice to the step's running scalar."""
-        o0, o1 = self._layer_span(i)
-        if getattr(self, "_aux_stream", None) is None:
-            self._aux_stream = torch.cuda.Stream(device=self.flat_grad.device)
-            self._norm_acc = torch.zeros((1,), dtype=torch.float64, device=self.flat_grad.device)
-            self._norm_spans = []
-        ev = torch.cuda.Event()
-        ev.record()                                        # layer i's gradients are complete on the compute stream
-        with torch.cuda.stream(self._aux_stream):
-            self._aux_stream.wait_event(ev)
-            ops.sumsq_f32(self.flat_grad[o0:o1], out=self._norm_acc, accumulate=bool(self._norm_spans))
-        self._norm_spans.append((o0, o1))
-
     def _grad_sumsq(self) -> torch.Tensor:
-        """Device double: sum of g^2 over the whole flat gradient (the slices the backward has already summed on the side stream,
+        """Device double: sum of g^2 over the whole flat gradient (the slices whose dW product already added its share,
         ``last_micro_batch``, are not read again).  Call after ``allreduce_grads``."""
         self._finalize_grads()
         spans = sorted(getattr(self, "_norm_spans", []))
         if spans:
-            torch.cuda.current_stream().wait_stream(self._aux_stream)
             acc, first = self._norm_acc, False
         else:
             acc, first = torch.empty((1,), dtype=torch.float64, device=self.flat_grad.device), True
@@ -464,9 +460,8 @@ class HipLlamaTrainer:
         if clip:
             sumsq = self._grad_sumsq()
             self._last_sumsq = (sumsq.clone(), world)
-        elif getattr(self, "_norm_spans", None):             # partial sums nobody asked for: drop them, but order the streams
-            torch.cuda.current_stream().wait_stream(self._aux_stream)
-            self._norm_spans = []
+        else:
+            self._norm_spans = []                           # partial sums nobody asked for
         self.step_count += 1
         b1, b2 = self.betas
         for name, p in self.params:

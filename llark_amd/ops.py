@@ -467,16 +467,20 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
 
 
 def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a: bool, trans_b: bool, c: torch.Tensor,
-             accumulate: bool = False) -> None:
+             accumulate: bool = False, sumsq: Optional[torch.Tensor] = None) -> None:
     """c[m][n] (= | +=) sum_k A(m, k) W(n, k) with operands that may be stored contraction-major (csrc/gemm_tn.hip;
-    include/llark_hip.h: llark_gemm16_t): ``trans_a`` -> a is [kp][>= m], ``trans_b`` -> wt is [kp][>= n]."""
+    include/llark_hip.h: llark_gemm16_t): ``trans_a`` -> a is [kp][>= m], ``trans_b`` -> wt is [kp][>= n].
+    ``sumsq`` (device double): += the sum of squares of every value written to c (llark_gemm16_t_sumsq)."""
     dtype = a.dtype
     assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype and a.stride(-1) == 1 and wt.stride(-1) == 1
+    args = (_DT[dtype], EPI_RESID if accumulate else EPI_F32, int(trans_a), int(trans_b), _dev(a, "a", contiguous=False), a.stride(0),
+            _dev(wt, "wt", contiguous=False), wt.stride(0), m, n, kp, _dev(c, "c", torch.float32, contiguous=False), c.stride(0),
+            _dev(c, "c", torch.float32, contiguous=False) if accumulate else None, c.stride(0))
     with _timed("gemm_f16" if dtype == torch.float16 else "gemm_bf16", 2.0 * m * n * kp):
-        check(_lib.lib().llark_gemm16_t(_DT[dtype], EPI_RESID if accumulate else EPI_F32, int(trans_a), int(trans_b),
-                                        _dev(a, "a", contiguous=False), a.stride(0), _dev(wt, "wt", contiguous=False), wt.stride(0), m, n, kp,
-                                        _dev(c, "c", torch.float32, contiguous=False), c.stride(0),
-                                        _dev(c, "c", torch.float32, contiguous=False) if accumulate else None, c.stride(0), _stream()), "gemm16_t")
+        if sumsq is None:
+            check(_lib.lib().llark_gemm16_t(*args, _stream()), "gemm16_t")
+        else:
+            check(_lib.lib().llark_gemm16_t_sumsq(*args, _dev(sumsq, "sumsq", torch.float64), _stream()), "gemm16_t_sumsq")
 
 
 def lo8_weight_exponent(w: torch.Tensor) -> int:

@@ -393,7 +393,12 @@ def test_grads_at_7b_width_vs_autograd_fixture():
     del w
     tr = HipLlamaTrainer(eng, embed_grad_tokens=(spec.audio_start_token, spec.audio_end_token))
     segs = [(0, int((ids[0] == spec.audio_start_token).nonzero()[0, 0]), aud[0].cuda())]
-    loss = tr.forward_backward(ids.cuda(), segs, labels.cuda()).item()
+    loss = tr.forward_backward(ids.cuda(), segs, labels.cuda(), last_micro_batch=True).item()
+    # S = 1024 rows: the dW products run llark_gemm16_t_sumsq and leave their share of the squared gradient norm behind
+    assert len(tr._norm_spans) >= 4 * spec.num_hidden_layers
+    tr._finalize_grads()
+    full_norm = tr.flat_grad.double().norm().item()
+    assert abs(tr.grad_norm() - full_norm) <= 1e-6 * full_norm
     ref_loss = float(z["loss"])
     assert abs(loss - ref_loss) <= 5e-3 * max(1.0, abs(ref_loss)), (loss, ref_loss)
     got = tr.export_grads_hf()
@@ -498,10 +503,11 @@ def test_grad_norm_clipping_matches_torch():
     err_if_unclipped = (p_after - unclipped.detach().bfloat16().float()).abs().max().item()
     assert err <= 2 ** -7 * p_before.abs().max().item() + 1e-3, err
     assert err_if_unclipped > 4 * err + 1e-3, (err, err_if_unclipped)         # the test can tell the two apart
-    # a norm below the threshold leaves the gradients alone; with last_micro_batch the per-layer partial sums collected on the side
-    # stream during the backward plus the remaining slices must give the same norm as one pass over the whole buffer
+    # a norm below the threshold leaves the gradients alone; with last_micro_batch the sums of squares the dW epilogues collected
+    # during the backward plus the remaining slices must give the same norm as one pass over the whole buffer (this tiny model's
+    # token count, 34, is not a multiple of 64: its dW products take the transposing path and collect nothing -- the 7B-width test
+    # below covers the collecting path)
     tr.forward_backward(ids.cuda(), segs, labels.cuda(), last_micro_batch=True)
-    assert len(tr._norm_spans) == len(eng.layers)
     tr._finalize_grads()
     full = tr.flat_grad.double().norm().item()
     tr.step(max_grad_norm=1e9)
