@@ -9,7 +9,7 @@
 //   dV = P^T dO          dP = dO V^T          D = rowsum(dO * O)
 //   dS = P * (dP - D) * scale          dQ = dS K          dK = dS^T Q
 // Two kernels, so that no accumulator is shared between workgroups and nothing needs atomics:
-//   attn_bwd_dkv_kernel: one workgroup per 128 keys (a wave owns 32: dK^T, dV^T fp32 in registers, K and V fragments in registers),
+//   attn_bwd_dkv_kernel: one workgroup per 64 keys (a wave owns 16: dK^T, dV^T fp32 in registers, K and V fragments in registers),
 //       loop over the 64-query tiles at or after it;
 //   attn_bwd_dq_kernel: one workgroup per 128 queries (a wave owns 32: dQ^T in registers, Q and dO fragments in registers), loop
 //       over the 64-key tiles at or before it.
@@ -109,12 +109,12 @@ __device__ __forceinline__ void block_to_tile(int nt, int nbh, int& tile, int& b
 __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5) + ((i >> 2) << 3) + ((sub & 1) << 2) + (i & 3); }
 
 constexpr float kLog2e = 1.4426950408889634f;
-#ifndef DKV_NK
+// key sets of 16 per wave in the dK / dV kernel: 1 (64-key workgroups, two per CU; with 2 the accumulators and the K / V fragments of
+// 32 keys need ~270 registers: spills at two waves per SIMD, and one workgroup per CU measured 12 % slower)
 #define DKV_NK 1
-#endif
 
-// One workgroup per 128 keys: wave wv owns keys kb0 + 32 wv .. + 31 as two sets of 16 (B operands K, V in registers; dK^T, dV^T
-// [128 d][16 keys] x 2 in accumulators).  Per 64-query tile: S = Q K^T and dP = dO V^T with the queries as MFMA rows (A from LDS),
+// One workgroup per 64 NK keys: wave wv owns keys kb0 + 16 NK wv .. as NK sets of 16 (B operands K, V in registers; dK^T, dV^T
+// [128 d][16 keys] x NK in accumulators).  Per 64-query tile: S = Q K^T and dP = dO V^T with the queries as MFMA rows (A from LDS),
 // so P and dS leave the MFMA as "column = key, 4 rows = queries" -- the B-operand layout of dV^T = dO^T P and dK^T = Q^T dS
 // (A = the sequence-contiguous tiles in LDS).  Nothing goes through an LDS scratch.
 template <int NK>
