@@ -12,49 +12,53 @@
 // the same banks, so the 16-byte chunks of row r are stored at chunk ^ 4 (r & 3) (swizzle applied to the SOURCE address of the DMA):
 // the 32 lanes that are serviced together then touch 32 distinct 8-byte slots of one 256-byte bank row.
 // An operand with the contraction index contiguous uses the usual image (gemm_core.h: dma_rows, Cfg::off) and b128 reads.
-// Tile 128 x 128 x 64, 4 waves (64 x 64 each), one LDS stage of 32 KiB, 3 workgroups per CU covering each other's staging (the
-// structure of the generic kernel's Cfg11, gemm.hip); epilogues EPI_F32 / EPI_RESID.
+// Tile 128 x 128 x 64 (4 waves of 64 x 64, one LDS stage of 32 KiB, 3 workgroups per CU covering each other's staging: the
+// structure of the generic kernel's Cfg11, gemm.hip) or 128 x 256 x 64 for deep products with many tiles; epilogues EPI_F32 /
+// EPI_RESID.
 #include "gemm_core.h"
 
 namespace llark {
 
 namespace {
 
-typedef Cfg<2, 2, 2, 2, 64, 3, 1> CfgT;            // 128x128x64, 4 waves
+typedef Cfg<2, 2, 2, 2, 64, 3, 1> CfgT;            // 128x128x64, 4 waves (64x64 each), 32 KiB: 3 workgroups per CU
+typedef Cfg<2, 2, 2, 4, 64, 2, 1> CfgTW;           // 128x256x64, 4 waves (64x128 each), 48 KiB: 2 per CU -- 0.75 fragment reads per MFMA
+                                                   // instead of 1: +8 % on the deep, many-tile products (K >= 4096, >= 512 tiles)
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef short v8s_t __attribute__((ext_vector_type(8)));
 
-// 1 KiB of a transposed-operand tile: 4 contraction rows x 128 free columns.  Lane i lands on (row i / 16, slot i % 16) and
-// fetches chunk slot ^ 4 (row & 3).  The free index is clamped to the last 8 valid columns (masked on store).
-template <typename T>
+// 1 KiB of a transposed-operand tile of FW free columns (128: 4 contraction rows per instruction, 256: 2).  Lane i lands on
+// (row i / (FW / 8), slot i % (FW / 8)) and fetches chunk slot ^ 4 (row & 3).  The free index is clamped to the last 8 valid
+// columns (masked on store).
+template <typename T, int FW>
 __device__ __forceinline__ void dma_rows_t(const T* __restrict__ g, int ld, int krow0, int f0, int fvalid, char* lds_dst, int lane) {
-    const int rl = lane >> 4, slot = lane & 15;
-    const int row = krow0 + rl;                                     // krow0 % 4 == 0: row & 3 == rl
-    int col = f0 + ((slot ^ (rl << 2)) << 3);
+    constexpr int SPR = FW / 8;                                     // 16-byte slots per tile row
+    const int rl = lane / SPR, slot = lane % SPR;
+    const int row = krow0 + rl;
+    int col = f0 + ((slot ^ ((row & 3) << 2)) << 3);
     col = col + 8 <= fvalid ? col : fvalid - 8;
     const T* src = g + (size_t)row * ld + col;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T>
+template <typename T, int FW>
 __device__ __forceinline__ typename Mfma<T>::frag read_frag_t(const char* tile, int off) {
     const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + off));
-    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + off + 1024));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + off + 4 * FW * 2));
     const v8s_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(typename Mfma<T>::frag, v);
 }
 
 }  // namespace
 
-template <typename T, bool TA, bool TB, int EPI>
-__global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const GemmParams p) {
-    typedef CfgT C;
+template <typename T, bool TA, bool TB, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_t_kernel(const GemmParams p) {
     typedef typename Mfma<T>::frag frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                     // 16 KiB: [128 rows][64 k] (swizzled) or, transposed, [64 k][128 rows]
-    char* sW = smem + C::A_BYTES;        // 16 KiB
+    char* sA = smem;                     // [BM rows][64 k] (swizzled) or, transposed, [64 k][BM rows]
+    char* sW = smem + C::A_BYTES;        // [BN][64 k] or [64 k][BN]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w / C::WN, wn = w % C::WN;
@@ -73,12 +77,17 @@ __global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const
     const T* W = (const T*)p.Wt;
     auto stage = [&](int kt) {
         const int k0 = kt * C::BK;
+        // 1 KiB DMA instructions per tile: BM / 8 (BN / 8), dealt round-robin to the 4 waves
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = w + i * C::NW;                                // 16 DMA instructions per 16 KiB tile
-            if (TA) dma_rows_t<T>(A, p.lda, k0 + 4 * j, m0, p.M, sA + j * 1024, lane);
+        for (int i = 0; i < C::BM / 8 / C::NW; ++i) {
+            const int j = w + i * C::NW;
+            if (TA) dma_rows_t<T, C::BM>(A, p.lda, k0 + j * (512 / C::BM), m0, p.M, sA + j * 1024, lane);
             else dma_rows<T, C>(A, p.lda, m0 + j * C::RPI, p.M, k0, j * C::RPI, sA + j * 1024, lane);
-            if (TB) dma_rows_t<T>(W, p.ldw, k0 + 4 * j, n0, p.N, sW + j * 1024, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < C::BN / 8 / C::NW; ++i) {
+            const int j = w + i * C::NW;
+            if (TB) dma_rows_t<T, C::BN>(W, p.ldw, k0 + j * (512 / C::BN), n0, p.N, sW + j * 1024, lane);
             else dma_rows<T, C>(W, p.ldw, n0 + j * C::RPI, p.N, k0, j * C::RPI, sW + j * 1024, lane);
         }
     };
@@ -87,9 +96,9 @@ __global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const
     const int q = lane >> 4, i16 = lane & 15;
     const int trow = 8 * (q >> 1) + (i16 >> 2);
     const int tcol = 16 * (q & 1) + 4 * (i16 & 3);
-    auto toff = [&](int f0, int s) __attribute__((always_inline)) {    // f0 % 32 == 0
+    auto toff = [&](int f0, int s, int fw) __attribute__((always_inline)) {    // f0 % 32 == 0; fw = free width of the tile
         const int col = f0 + tcol;
-        return (s * 16 + trow) * 256 + ((((col >> 3) ^ ((i16 >> 2) << 2)) << 4) | ((col & 7) << 1));
+        return (s * 16 + trow) * (fw * 2) + ((((col >> 3) ^ ((i16 >> 2) << 2)) << 4) | ((col & 7) << 1));
     };
 
     f32x16_t acc[C::TM][C::TN];
@@ -112,11 +121,11 @@ __global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const
             frag bf[C::TN], af[C::TM];
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn)
-                bf[tn] = TB ? read_frag_t<T>(sW, toff((wn * C::TN + tn) * 32, s))
+                bf[tn] = TB ? read_frag_t<T, C::BN>(sW, toff((wn * C::TN + tn) * 32, s, C::BN))
                             : *(const frag*)(sW + C::off((wn * C::TN + tn) * 32 + (lane & 31), c));
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
-                af[tm] = TA ? read_frag_t<T>(sA, toff((wm * C::TM + tm) * 32, s))
+                af[tm] = TA ? read_frag_t<T, C::BM>(sA, toff((wm * C::TM + tm) * 32, s, C::BM))
                             : *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
@@ -127,13 +136,21 @@ __global__ __launch_bounds__(CfgT::THREADS, CfgT::MINW) void gemm_t_kernel(const
     gemm_epilogue<T, false, EPI, C, true>(p, acc, m0, n0, wm, wn, lane, 0);
 }
 
-template <typename T, bool TA, bool TB, int EPI>
-static int launch_t(GemmParams p, hipStream_t s) {
-    constexpr int LDS = CfgT::A_BYTES + CfgT::B_BYTES;
-    p.tiles_m = cdiv(p.M, CfgT::BM);
-    p.tiles_n = cdiv(p.N, CfgT::BN);
-    gemm_t_kernel<T, TA, TB, EPI><<<p.tiles_m * p.tiles_n, CfgT::THREADS, LDS, s>>>(p);
+template <typename T, bool TA, bool TB, int EPI, typename C>
+static int launch_tc(GemmParams p, hipStream_t s) {
+    constexpr int LDS = C::A_BYTES + C::B_BYTES;
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    gemm_t_kernel<T, TA, TB, EPI, C><<<p.tiles_m * p.tiles_n, C::THREADS, LDS, s>>>(p);
     return check_launch("gemm16_t");
+}
+
+// 128x256 tiles for the deep products with many tiles (the dX / dW products of a 4096-token micro-batch), 128x128 otherwise
+// (profiles/r03_gemm_train_variants_m{2048,4096}.txt: the same rule for the plain kernel's variants 11 / 12)
+template <typename T, bool TA, bool TB, int EPI>
+static int launch_t(const GemmParams& p, hipStream_t s) {
+    if (p.Kp >= 4096 && (long)cdiv(p.M, CfgTW::BM) * cdiv(p.N, CfgTW::BN) >= 512) return launch_tc<T, TA, TB, EPI, CfgTW>(p, s);
+    return launch_tc<T, TA, TB, EPI, CfgT>(p, s);
 }
 
 template <typename T, int EPI>

@@ -22,7 +22,8 @@ def _check(c, a_mk, w_nk, init=None):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,n,kp", [(128, 128, 64), (200, 136, 128), (4096, 4096, 2048), (1000, 72, 448), (8, 8, 64), (352, 12288, 192)])
+@pytest.mark.parametrize("m,n,kp", [(128, 128, 64), (200, 136, 128), (4096, 4096, 2048), (1000, 72, 448), (8, 8, 64), (352, 12288, 192),
+                                    (4096, 4096, 4096), (4100, 4360, 4096)])      # the last two: the 128 x 256 tile (K >= 4096, >= 512 tiles)
 def test_dx_form_w_contraction_major(dtype, m, n, kp):
     """dX[m][n] = sum_k dY[m][k] W[k][n]: W stored [kp][n] (trans_b)."""
     from llark_amd import ops
@@ -36,7 +37,7 @@ def test_dx_form_w_contraction_major(dtype, m, n, kp):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,kp,accumulate", [(128, 128, 64, False), (136, 200, 128, True), (4096, 11008, 1024, True), (72, 1000, 448, False),
-                                               (12288, 4096, 512, False)])
+                                               (12288, 4096, 512, False), (12288, 4096, 4096, True), (4104, 4360, 4096, False)])   # 128 x 256 tile
 def test_dw_form_both_contraction_major(dtype, m, n, kp, accumulate):
     """dW[m][n] (+)= sum_k dY[k][m] X[k][n]: both operands stored with the contraction index as the row."""
     from llark_amd import ops
