@@ -11,7 +11,7 @@
 // Two kernels, so that no accumulator is shared between workgroups and nothing needs atomics:
 //   attn_bwd_dkv_kernel: one workgroup per 64 keys (a wave owns 16: dK^T, dV^T fp32 in registers, K and V fragments in registers),
 //       loop over the 64-query tiles at or after it;
-//   attn_bwd_dq_kernel: one workgroup per 128 queries (a wave owns 32: dQ^T in registers, Q and dO fragments in registers), loop
+//   attn_bwd_dq_kernel: one workgroup per 64 queries (a wave owns 16: dQ^T in registers, Q and dO fragments in registers), loop
 //       over the 64-key tiles at or before it.
 // In both, the score tile is computed in the orientation whose accumulator layout ("column c, rows 4g..4g+3" per lane) IS the
 // B-operand layout of the product that consumes P / dS, so the probabilities never leave the registers (see the forward kernel in
@@ -112,6 +112,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 // key sets of 16 per wave in the dK / dV kernel: 1 (64-key workgroups, two per CU; with 2 the accumulators and the K / V fragments of
 // 32 keys need ~270 registers: spills at two waves per SIMD, and one workgroup per CU measured 12 % slower)
 #define DKV_NK 1
+// query sets of 16 per wave in the dQ kernel: 1 (two sets: 256 registers with 16 spills at two waves per SIMD, 592 vs 546 us at
+// 2 x 32 x 2048)
+#define DQ_NQ 1
 
 // One workgroup per 64 NK keys: wave wv owns keys kb0 + 16 NK wv .. as NK sets of 16 (B operands K, V in registers; dK^T, dV^T
 // [128 d][16 keys] x NK in accumulators).  Per 64-query tile: S = Q K^T and dP = dO V^T with the queries as MFMA rows (A from LDS),
@@ -264,9 +267,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-// One workgroup per 128 queries: wave wv owns queries q0 + 32 wv .. + 31 as two sets of 16 (B operands Q, dO in registers, dQ^T in
+// One workgroup per 64 NQ queries: wave wv owns queries q0 + 16 NQ wv .. as NQ sets of 16 (B operands Q, dO in registers, dQ^T in
 // accumulators).  Per 64-key tile: S^T = K Q^T and dP^T = V dO^T with the keys as MFMA rows (A from LDS), dS^T leaves the MFMA in
 // the B-operand layout of dQ^T = K^T dS^T (A = the sequence-contiguous K tile in LDS).
+template <int NQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
@@ -279,24 +283,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    const int nt = (S + 127) / 128;
+    const int nt = (S + 64 * NQ - 1) / (64 * NQ);
     int tile, bhid;
     block_to_tile(nt, nbh, tile, bhid);
     tile = nt - 1 - tile;                                           // the query tiles with the most keys first
     const size_t bh = (size_t)bhid;
-    const int q0 = tile * 128;
+    const int q0 = tile * 64 * NQ;
     const bf16_t* qb = q + bh * S * 128;
     const bf16_t* dob = dO + bh * S * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
-    const int wq0 = q0 + wv * 32;
+    const int wq0 = q0 + wv * 16 * NQ;
     const float scale2 = scale * kLog2e;
     const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
 
-    bf16x8_t qf[2][4], df[2][4];       // B operands: column = query c of set u
-    float l2[2], dd[2];
+    bf16x8_t qf[NQ][4], df[NQ][4];       // B operands: column = query c of set u
+    float l2[NQ], dd[NQ];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NQ; ++u) {
         const int qi = wq0 + u * 16 + c;
         const int qr = qi < S ? qi : S - 1;
 #pragma unroll
@@ -307,12 +311,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
         dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
     }
-    f32x4_t dqa[2][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
+    f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NQ; ++u)
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) dqa[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    int last_key = q0 + 127;
+    int last_key = q0 + 64 * NQ - 1;
     if (last_key > S - 1) last_key = S - 1;
     const int nkt = last_key / 64 + 1;
     auto stage = [&](int kt) __attribute__((always_inline)) {
@@ -334,30 +338,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (kt + 1 < nkt) stage(kt + 1);
         const char* sK = smem + (kt & 1) * DQ_STAGE;
         const char* sV = sK + 16384;
-        if (key0 > wq0 + 31) continue;                              // every key of the tile is beyond the wave's queries
-        const bool need_mask = key0 + 63 > wq0 || wq0 + 31 >= S;    // else every (query, key) pair of the tile is visible
+        if (key0 > wq0 + 16 * NQ - 1) continue;                              // every key of the tile is beyond the wave's queries
+        const bool need_mask = key0 + 63 > wq0 || wq0 + 16 * NQ - 1 >= S;    // else every (query, key) pair of the tile is visible
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            bf16x8_t sf[2];
+            bf16x8_t sf[NQ];
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
                 const int sub = 2 * p + hb;
-                f32x4_t sa[2], dp[2];
+                f32x4_t sa[NQ], dp[NQ];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t kfr = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
                     const bf16x8_t vfr = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
+                    for (int u = 0; u < NQ; ++u) {
                         sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], sa[u], 0, 0, 0);
                         dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, df[u][ks], dp[u], 0, 0, 0);
                     }
                 }
                 const int kl = key0 + 32 * p + 8 * g + 4 * hb;       // this lane's 4 key rows: kl .. kl + 3
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NQ; ++u) {
                     const int qa = wq0 + u * 16 + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -371,12 +375,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int dt = 0; dt < 8; ++dt) {
                 const bf16x8_t ktf = tr_frag(sK, 32 * p, dt * 16, g, c);       // K^T rows d = dt*16 + c, keys 32p + 8g ..
 #pragma unroll
-                for (int u = 0; u < 2; ++u) dqa[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, sf[u], dqa[u][dt], 0, 0, 0);
+                for (int u = 0; u < NQ; ++u) dqa[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, sf[u], dqa[u][dt], 0, 0, 0);
             }
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NQ; ++u) {
         const int qi = wq0 + u * 16 + c;
         if (qi >= S) continue;
         float* o = dq + (bh * S + qi) * 128 + 4 * g;
@@ -405,14 +409,14 @@ extern "C" int llark_attn_backward_bf16(const void* q, const void* k_cache, cons
     const long rows = (long)batch * nh * s;
     attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows);
     const int nbh = batch * nh;
-    const int grid = cdiv(s, 128) * nbh;
+    const int grid = cdiv(s, 64 * DQ_NQ) * nbh;
     const int lds_kv = 2 * (32768 + 512), lds_q = 2 * 32768;
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
     attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
                                                                                (const bf16_t*)dO, lse, dsum, dk, dv, s, smax, nbh, nh, scale,
                                                                                alibi_slopes);
-    attn_bwd_dq_kernel<<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
+    attn_bwd_dq_kernel<DQ_NQ><<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
                                                  dq, s, smax, nbh, nh, scale, alibi_slopes);
     return check_launch("attn_backward");
 }
