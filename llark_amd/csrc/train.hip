@@ -188,6 +188,90 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         if (sdw[c] != 0.0f) atomicAdd(&dw[c], sdw[c]);
 }
 
+// The same for wide rows (2048 < width <= 4096: Llama-2-7B): TWO waves per row, each owning half of its columns -- a quarter of the
+// registers of the one-wave form (which sits at one wave per SIMD with the whole row, dy, the gain and the dw partials in 400
+// registers), so four waves per SIMD hide the row loads; the two row reductions (sum x^2, sum g xhat) meet through LDS.
+__global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ dy, int rows, int width, float eps,
+                                                           float* __restrict__ dx, float* __restrict__ dw, int accumulate) {
+    constexpr int NV = 8;                                // float4 per lane: 64 lanes x 8 x 4 = 2048 columns per wave
+    extern __shared__ float sdw[];                      // [width] per-block partial dw
+    __shared__ float sred[2][2][2];                      // [reduction][row slot][half]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int slot = wv >> 1, half = wv & 1;             // two rows per workgroup and iteration
+    const int w4 = width >> 2, h4 = (w4 + 1) >> 1;       // float4 columns per half
+    for (int c = threadIdx.x; c < width; c += 256) sdw[c] = 0.0f;
+    float4 wv4[NV], dwv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = half * h4 + lane + 64 * k;
+        const bool ok = lane + 64 * k < h4 && c < w4;
+        wv4[k] = ok ? ((const float4*)w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dwv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int iters = (rows + 2 * gridDim.x - 1) / (2 * gridDim.x);
+    for (int it = 0; it < iters; ++it) {
+        const int row = (it * gridDim.x + blockIdx.x) * 2 + slot;
+        const bool live = row < rows;
+        const float4* xr = (const float4*)(x + (size_t)(live ? row : 0) * width);
+        const float4* dr = (const float4*)(dy + (size_t)(live ? row : 0) * width);
+        float4 xv[NV], gv[NV];
+        float ss = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = half * h4 + lane + 64 * k;
+            const bool ok = live && lane + 64 * k < h4 && c < w4;
+            xv[k] = ok ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[k] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ss += (xv[k].x * xv[k].x + xv[k].y * xv[k].y) + (xv[k].z * xv[k].z + xv[k].w * xv[k].w);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) sred[0][slot][half] = ss;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf((sred[0][slot][0] + sred[0][slot][1]) / (float)width + eps);
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float4 d = gv[k];
+            const float4 xh = make_float4(xv[k].x * rstd, xv[k].y * rstd, xv[k].z * rstd, xv[k].w * rstd);
+            dwv[k].x += d.x * xh.x; dwv[k].y += d.y * xh.y; dwv[k].z += d.z * xh.z; dwv[k].w += d.w * xh.w;
+            gv[k] = make_float4(d.x * wv4[k].x, d.y * wv4[k].y, d.z * wv4[k].z, d.w * wv4[k].w);
+            dot += (gv[k].x * xh.x + gv[k].y * xh.y) + (gv[k].z * xh.z + gv[k].w * xh.w);
+            xv[k] = xh;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) sred[1][slot][half] = dot;
+        __syncthreads();
+        const float mdot = (sred[1][slot][0] + sred[1][slot][1]) / (float)width;
+        float4* dxr = (float4*)(dx + (size_t)(live ? row : 0) * width);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = half * h4 + lane + 64 * k;
+            if (live && lane + 64 * k < h4 && c < w4) {
+                float4 v = make_float4(rstd * (gv[k].x - xv[k].x * mdot), rstd * (gv[k].y - xv[k].y * mdot),
+                                       rstd * (gv[k].z - xv[k].z * mdot), rstd * (gv[k].w - xv[k].w * mdot));
+                if (accumulate) {
+                    const float4 o = dxr[c];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                dxr[c] = v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = half * h4 + lane + 64 * k;
+        if (lane + 64 * k < h4 && c < w4) {
+            atomicAdd(&sdw[4 * c], dwv[k].x); atomicAdd(&sdw[4 * c + 1], dwv[k].y);
+            atomicAdd(&sdw[4 * c + 2], dwv[k].z); atomicAdd(&sdw[4 * c + 3], dwv[k].w);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256)
+        if (sdw[c] != 0.0f) atomicAdd(&dw[c], sdw[c]);
+}
+
 // ------------------------------------------------------------------------------------------
 // SwiGLU on the interleaved gate/up layout ([32 gate | 32 up] per 64 columns of gu):
 //   fwd: act[m][32q+j] = silu(g) * u ;  bwd: dg = dact * u * sig * (1 + g (1 - sig)), du = dact * g * sig
@@ -402,7 +486,10 @@ extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy
 #define RB(NV) rmsnorm_bwd_kernel<NV><<<grid, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate)
     if (width <= 256) RB(1);
     else if (width <= 1024) RB(4);
-    else if (width <= 4096) RB(16);
+    else if (width > 2048 && width <= 4096) {
+        const int nb2 = cdiv(rows, 2) < 1024 ? cdiv(rows, 2) : 1024;         // two rows per workgroup and iteration
+        rmsnorm_bwd2_kernel<<<nb2, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate);
+    } else if (width <= 4096) RB(16);
     else if (width <= 8192) RB(32);                                 // (wider than Llama-2-7B: works, spills part of the row)
     else {
         set_error("rmsnorm_bwd: width %d too large", width);

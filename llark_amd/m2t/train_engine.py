@@ -20,6 +20,7 @@ data-parallel exchange is a handful of large all-reduces.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -75,15 +76,20 @@ class HipLlamaTrainer:
         self._matrix_grads = {n for n, p in self.params if p.dim() == 2 and n != "embed"}
         self._fresh = set()                            # flat_grad starts zeroed: accumulate until the first zero_grad()
         # Operands DERIVED from the weights, valid until the next optimizer step (self._wver).  The first micro-batch of a step
-        # needs none: dX = dY . W runs on W as stored (llark_gemm16_t).  From the second micro-batch on, when there is something to
-        # amortise over, fragment-major twins of W and of a K-contiguous W^T are built once, so that the forward and dX products
-        # take the B-direct kernel like the inference engine (+8 .. 13 %).  Only when this object owns the optimizer: on the
-        # autograd-bridge path the weights are rebuilt outside (sync_engine).
+        # needs none.  From the second micro-batch on, when there is something to amortise over, a fragment-major twin of W is
+        # built once so that the forward products take the B-direct kernel like the inference engine (+8 .. 13 %); dX = dY . W
+        # runs on W as stored (llark_gemm16_t) unless dx_direct_uses says otherwise.  Only when this object owns the optimizer:
+        # on the autograd-bridge path the weights are rebuilt outside (sync_engine).
         self.derived_operands = bool(optimizer_state)
         self._wver = 0
         self._derived: Dict[int, list] = {}
         self._fwd_uses: Dict[int, list] = {}
         self._dx_uses: Dict[int, list] = {}
+        # how many dX products per weight and optimizer step read W as it stands (llark_gemm16_t) before a K-contiguous W^T and
+        # its fragment-major twin are built for the rest.  Default: all of them -- with the 128 x 256 tile llark_gemm16_t is within
+        # 3 % of the B-direct kernel on these shapes, and the twins cost a transpose + a pack of all 13.5 GB of weights per step
+        # (25 ms and 24 GB of HBM at 7B: 896 -> 868 ms for 4 micro-batches of 2 x 2048); they would pay from ~16 micro-batches.
+        self.dx_direct_uses = int(os.environ.get("LLARK_TRAIN_DX_DIRECT_USES", str(1 << 30)))
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -153,9 +159,9 @@ class HipLlamaTrainer:
 
     def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
         """out[rows][K] = dY . W   (w [N][K] bf16 kernel layout: its row IS the contraction index).
-        First use of a weight since the last optimizer step: ``llark_gemm16_t`` on W as it stands (no W^T).  From the second use
-        (gradient accumulation) the K-contiguous transpose + fragment-major twin are built once and the B-direct kernel, 10 %
-        faster per product, amortises them over the remaining micro-batches."""
+        ``llark_gemm16_t`` on W as it stands (no W^T) for the first ``dx_direct_uses`` products of a weight since the last optimizer
+        step -- by default all of them; past that the K-contiguous transpose + fragment-major twin are built once and the B-direct
+        kernel (~3 % faster per product) amortises them over the remaining micro-batches."""
         n, k = w.shape
         if self.derived_operands:
             ent = self._dx_uses.get(w.data_ptr())
@@ -163,7 +169,7 @@ class HipLlamaTrainer:
                 ent = [self._wver, 0]
                 self._dx_uses[w.data_ptr()] = ent
             ent[1] += 1
-            first = ent[1] == 1
+            first = ent[1] <= self.dx_direct_uses
         else:
             first = True
         if first and n % 64 == 0 and k % 8 == 0 and dy16.shape[1] >= n and dy16.stride(0) % 8 == 0:

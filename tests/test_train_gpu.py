@@ -74,11 +74,15 @@ def test_forward_backward_grads_match_autograd():
     assert "lm_head.weight" not in got                                   # frozen like the reference
 
 
-def test_accumulation_and_adamw_step():
-    """Two micro-batches with loss_scale 1/2 == one batch of both; then one AdamW step == torch.optim.AdamW."""
+@pytest.mark.parametrize("dx_direct_uses", [None, 1])
+def test_accumulation_and_adamw_step(dx_direct_uses):
+    """Two micro-batches with loss_scale 1/2 == one batch of both; then one AdamW step == torch.optim.AdamW.
+    dx_direct_uses=1: the second micro-batch takes its dX products through the W^T / fragment-major twins (default: W as stored)."""
     from llark_amd.m2t.train_engine import HipLlamaTrainer
     spec, w, ids, aud, labels, eng, segs = _setup(B=2)
     tr = HipLlamaTrainer(eng, lr=1e-2, weight_decay=0.0, embed_grad_tokens=(spec.audio_start_token, spec.audio_end_token))
+    if dx_direct_uses is not None:
+        tr.dx_direct_uses = dx_direct_uses
     tr.forward_backward(ids.cuda(), segs, labels.cuda())
     g_full = tr.flat_grad.clone()
     tr.zero_grad()
@@ -436,7 +440,7 @@ def test_grads_at_7b_width_vs_autograd_fixture():
           + ", ".join(f"{k.replace('model.', '')} {v:.2e}" for k, v in top))
 
 
-@pytest.mark.parametrize("rows,width,accumulate", [(1000, 4096, False), (1000, 4096, True), (37, 256, False), (5000, 1024, True), (9, 8192, False)])
+@pytest.mark.parametrize("rows,width,accumulate", [(1000, 4096, False), (1000, 4096, True), (37, 256, False), (5000, 1024, True), (9, 8192, False), (1001, 4096, True), (3, 3000, False)])
 def test_rmsnorm_bwd_vs_autograd(rows, width, accumulate):
     """llark_rmsnorm_bwd (rows walked by a fixed grid, dw accumulated in registers) vs torch autograd of LlamaRMSNorm in fp32
     (transformers==4.29.2 modeling_llama.py:LlamaRMSNorm).  fp32 on both sides: 1e-5 relative to the largest entry; dw, a sum
