@@ -28,7 +28,18 @@ namespace llark {
 
 namespace {
 
-__device__ __forceinline__ int bk_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }             // [64][128] bf16
+// LDS tile [64 rows][128 bf16] with 256-byte rows (= one pass over the 64 banks): the 16-byte chunk `chunk` of row `row` sits in
+// slot chunk ^ swz(row).  swz is chosen for the two read patterns of these kernels (lane groups as the LDS services them,
+// MI355X_MICROARCH.md "LDS"):
+//   * ds_read_b128 fragments, lane (g, c) -> row base + 8 (c / 4) + c % 4, chunk 4 ks + g: a serviced group of 16 lanes is
+//     {g = 0, c / 4 in {0, 3}} + {g = 1, c / 4 in {1, 2}} (or the complement): 16 distinct slots need the row's bits 0, 1 in slot
+//     bits 1, 2 and row bit 3 in slot bit 3;
+//   * ds_read_b64_tr_b16, 32 lanes = rows r .. r + 3 and r + 8 .. r + 11, chunks 2 dt and 2 dt + 1: the same three row bits must
+//     land in slot bits 1 .. 3 (bit 0 tells the two chunks apart).
+// (The plain chunk ^ (row & 15) of the first version put rows r and r + 17 of a b128 group, and rows r and r + 1 of a transposing
+// read, on the same banks: SQ_LDS_BANK_CONFLICT = 47 .. 50 % of the LDS cycles of both kernels, profiles/r03_pmc_attn_final.txt.)
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | (row & 8); }
+__device__ __forceinline__ int bk_off(int row, int chunk) { return row * 256 + ((chunk ^ swz(row)) << 4); }             // [64][128] bf16
 
 // rows r0 .. r0+63 of a row-major [.][128] tensor -> LDS [64][128]; rows >= limit are zero
 __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, size_t ld, int r0, int limit, char* dst) {
@@ -50,7 +61,7 @@ __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0
     for (int i = 0; i < 4; ++i) {
         const int j = wv * 4 + i;
         const int row = 4 * j + (lane >> 4);
-        const bf16_t* src = base + (size_t)(r0 + row) * 128 + (((lane & 15) ^ (row & 15)) << 3);
+        const bf16_t* src = base + (size_t)(r0 + row) * 128 + (((lane & 15) ^ swz(row)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
     }
@@ -60,14 +71,14 @@ __device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0
 // contraction slots are 8 consecutive ROWS of it (the sequence index): two transposing LDS reads.  `ds_read_b64_tr_b16` hands lane
 // i of a 16-lane group column i of the [4 rows][16 columns] block whose (row r, 4-column group a) is addressed by source lane
 // 4r + a (scripts/probes/tr_b16_probe.hip); lane group g takes rows row0 + 8g .. + 7, columns col0 .. col0 + 15 of the tile (in
-// the bk_off swizzle: consecutive rows land on different 16-byte chunks, at most 2-way bank conflicts).
+// the bk_off swizzle the 32 lanes serviced together touch 16 distinct 16-byte slots).
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef short v8s_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int col0, int g, int c) {
     const int col = col0 + 4 * (c & 3);
     const int ra = row0 + 8 * g + (c >> 2), rb = ra + 4;
-    const int oa = ra * 256 + ((((col >> 3) ^ (ra & 15)) << 4) | ((col & 7) << 1));
-    const int ob = rb * 256 + ((((col >> 3) ^ (rb & 15)) << 4) | ((col & 7) << 1));
+    const int oa = ra * 256 + ((((col >> 3) ^ swz(ra)) << 4) | ((col & 7) << 1));
+    const int ob = rb * 256 + ((((col >> 3) ^ swz(rb)) << 4) | ((col & 7) << 1));
     const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + oa));
     const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + ob));
     const v8s_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};

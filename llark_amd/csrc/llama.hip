@@ -160,7 +160,12 @@ __global__ __launch_bounds__(256) void rope_split_kernel(const float* __restrict
 // Blocks are numbered so that the 8 XCDs each take whole (batch, head) pairs (one L2 sees one head's K / V) and the
 // query tiles with the most keys are dispatched first.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ (key & 15)) << 4); }        // [64][128] bf16
+// K tile [64 keys][128 d], 256-byte rows: chunk ^ k_swz(key).  The fragment reads below take rows base + 8 (c / 4) + c % 4 at chunk
+// 4 ks + g, and the LDS services a ds_read_b128 in the lane groups {g = 0, c / 4 in {0, 3}} + {g = 1, c / 4 in {1, 2}} (and the
+// complement): key bits 0, 1 -> slot bits 1, 2 and key bit 3 -> slot bit 3 give every group 16 distinct slots (the plain key & 15
+// put keys r and r + 17 on the same banks, 2-way on every K read: tests/test_attn_lds_layout_cpu.py, profiles/r03_pmc_attn_final.txt)
+__device__ __forceinline__ int k_swz(int key) { return ((key & 3) << 1) | (key & 8); }
+__device__ __forceinline__ int k_off(int key, int chunk) { return key * 256 + ((chunk ^ k_swz(key)) << 4); }        // [64][128] bf16
 __device__ __forceinline__ int v_off(int d, int chunk) { return d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4); }       // [128][64] bf16
 __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5) + ((i >> 2) << 3) + ((sub & 1) << 2) + (i & 3); }
 
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
         for (int i = 0; i < 4; ++i) {
             const int j = wv * 4 + i;                                // this wave's 1 KiB pieces of each 16 KiB tile
             const int krow = 4 * j + (lane >> 4);
-            const bf16_t* ks = kb + (size_t)(key0 + krow) * 128 + (((lane & 15) ^ (krow & 15)) << 3);
+            const bf16_t* ks = kb + (size_t)(key0 + krow) * 128 + (((lane & 15) ^ k_swz(krow)) << 3);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
                                              (__attribute__((address_space(3))) void*)(dK + j * 1024), 16, 0, 0);
             const int d = 8 * j + (lane >> 3);
