@@ -215,52 +215,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* sD = sL + 64;
         if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
         const bool need_mask = q0 < wk0 + 16 * NK || q0 + 63 >= S;  // else every (query, key) pair of the tile is visible
+        // Software pipeline, pinned with scheduling barriers: the LDS fragment reads of a GROUP of MFMAs (8 b128 reads for the S and
+        // dP of one sub-tile, 8 transposing reads for 2 d tiles of dV^T and dK^T) are issued one group ahead, behind the MFMAs or
+        // the softmax arithmetic of the group before, so that an MFMA never waits for a read issued just in front of it.  (Left to
+        // itself the scheduler put every read directly before its MFMA to save registers: read, wait a full LDS round trip,
+        // multiply -- the matrix pipe was busy 25 % of the time, profiles/r03_pmc_attn_swz.txt.)  A masked score becomes -inf
+        // BEFORE the exponential: one select on the argument, no branch around v_exp_f32, one basic block per tile.
+        auto load_s = [&](int sub, bf16x8_t* qfr, bf16x8_t* dfr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qfr[ks] = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
+                dfr[ks] = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
+            }
+        };
+        auto mma_s = [&](const bf16x8_t* qfr, const bf16x8_t* dfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[ks], kf[u][ks], sa[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[ks], vf[u][ks], dp[u], 0, 0, 0);
+                }
+            }
+        };
+        auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* pf, bf16x8_t* sf) __attribute__((always_inline)) {
+            const int ql = 32 * p + 8 * g + 4 * hb;                  // this lane's 4 query rows: ql .. ql + 3
+            const float4 l4 = *(const float4*)(sL + ql);
+            const float4 d4 = *(const float4*)(sD + ql);
+            const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int u = 0; u < NK; ++u) {
+                const int key = wk0 + u * 16 + c;
+                const float bias2 = slope2 * (float)(key - (S - 1));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qa = q0 + ql + r;
+                    const bool ok = !need_mask || (qa < S && key <= qa);
+                    const float x = sa[u][r] * scale2 + bias2 - lr[r];
+                    const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
+                    pf[u][hb * 4 + r] = pb;
+                    sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
+                }
+            }
+        };
+        auto load_t = [&](int p, int h, bf16x8_t* dof, bf16x8_t* qtf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                dof[j] = tr_frag(sdO, 32 * p, (2 * h + j) * 16, g, c);     // dO^T rows d = dt*16 + c, queries 32p + 8g ..
+                qtf[j] = tr_frag(sQ, 32 * p, (2 * h + j) * 16, g, c);      // Q^T
+            }
+        };
+        auto mma_t = [&](int h, const bf16x8_t* dof, const bf16x8_t* qtf, const bf16x8_t* pf, const bf16x8_t* sf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    dva[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[j], pf[u], dva[u][2 * h + j], 0, 0, 0);
+                    dka[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[j], sf[u], dka[u][2 * h + j], 0, 0, 0);
+                }
+            }
+        };
+        bf16x8_t qA[4], dA[4], qB[4], dB[4];
+        load_s(0, qA, dA);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf16x8_t pf[NK], sf[NK];
+            f32x4_t sa0[NK], dp0[NK], sa1[NK], dp1[NK];
+            bf16x8_t tdo[2][2], tq[2][2];
+            mma_s(qA, dA, sa0, dp0);
+            load_s(2 * p + 1, qB, dB);
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(p, 0, sa0, dp0, pf, sf);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_s(qB, dB, sa1, dp1);
+            load_t(p, 0, tdo[0], tq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(p, 1, sa1, dp1, pf, sf);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const int sub = 2 * p + hb;
-                f32x4_t sa[NK], dp[NK];
-#pragma unroll
-                for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t qfr = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
-                    const bf16x8_t dfr = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
-#pragma unroll
-                    for (int u = 0; u < NK; ++u) {
-                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[u][ks], sa[u], 0, 0, 0);
-                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr, vf[u][ks], dp[u], 0, 0, 0);
-                    }
-                }
-                const int ql = 32 * p + 8 * g + 4 * hb;              // this lane's 4 query rows: ql .. ql + 3
-                const float4 l4 = *(const float4*)(sL + ql);
-                const float4 d4 = *(const float4*)(sD + ql);
-                const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int u = 0; u < NK; ++u) {
-                    const int key = wk0 + u * 16 + c;
-                    const float bias2 = slope2 * (float)(key - (S - 1));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int qa = q0 + ql + r;
-                        const bool ok = !need_mask || (qa < S && key <= qa);
-                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 + bias2 - lr[r]) : 0.0f);
-                        pf[u][hb * 4 + r] = pb;
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
-                    }
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t dof = tr_frag(sdO, 32 * p, dt * 16, g, c);      // dO^T rows d = dt*16 + c, queries 32p + 8g ..
-                const bf16x8_t qtf = tr_frag(sQ, 32 * p, dt * 16, g, c);       // Q^T
-#pragma unroll
-                for (int u = 0; u < NK; ++u) {
-                    dva[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf[u], dva[u][dt], 0, 0, 0);
-                    dka[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, sf[u], dka[u][dt], 0, 0, 0);
-                }
+            for (int h = 0; h < 4; ++h) {
+                if (h < 3) load_t(p, h + 1, tdo[(h + 1) & 1], tq[(h + 1) & 1]);
+                else if (p == 0) load_s(2, qA, dA);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_t(h, tdo[h & 1], tq[h & 1], pf, sf);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -351,43 +392,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const char* sV = sK + 16384;
         if (key0 > wq0 + 16 * NQ - 1) continue;                              // every key of the tile is beyond the wave's queries
         const bool need_mask = key0 + 63 > wq0 || wq0 + 16 * NQ - 1 >= S;    // else every (query, key) pair of the tile is visible
+        // the same software pipeline as the dK / dV kernel: fragment reads one group of MFMAs ahead, pinned with scheduling barriers
+        auto load_s = [&](int sub, bf16x8_t* kfr, bf16x8_t* vfr) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kfr[ks] = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
+                vfr[ks] = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
+            }
+        };
+        auto mma_s = [&](const bf16x8_t* kfr, const bf16x8_t* vfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) {
+                    sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks], qf[u][ks], sa[u], 0, 0, 0);
+                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks], df[u][ks], dp[u], 0, 0, 0);
+                }
+            }
+        };
+        auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* sf) __attribute__((always_inline)) {
+            const int kl = key0 + 32 * p + 8 * g + 4 * hb;               // this lane's 4 key rows: kl .. kl + 3
+#pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int qa = wq0 + u * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = !need_mask || (qa < S && kl + r <= qa);
+                    const float x = sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u];
+                    const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
+                    sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
+                }
+            }
+        };
+        auto load_t = [&](int p, int h, bf16x8_t* ktf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
+        };
+        auto mma_t = [&](int h, const bf16x8_t* ktf, const bf16x8_t* sf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int u = 0; u < NQ; ++u) dqa[u][4 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[j], sf[u], dqa[u][4 * h + j], 0, 0, 0);
+            }
+        };
+        bf16x8_t kA[4], vA[4], kB[4], vB[4];
+        load_s(0, kA, vA);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             bf16x8_t sf[NQ];
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                const int sub = 2 * p + hb;
-                f32x4_t sa[NQ], dp[NQ];
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kfr = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
-                    const bf16x8_t vfr = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
-#pragma unroll
-                    for (int u = 0; u < NQ; ++u) {
-                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][ks], sa[u], 0, 0, 0);
-                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, df[u][ks], dp[u], 0, 0, 0);
-                    }
-                }
-                const int kl = key0 + 32 * p + 8 * g + 4 * hb;       // this lane's 4 key rows: kl .. kl + 3
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    const int qa = wq0 + u * 16 + c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool ok = !need_mask || (qa < S && kl + r <= qa);
-                        const bf16_t pb = (bf16_t)(ok ? __builtin_amdgcn_exp2f(sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u]) : 0.0f);
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
-                    }
-                }
-            }
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t ktf = tr_frag(sK, 32 * p, dt * 16, g, c);       // K^T rows d = dt*16 + c, keys 32p + 8g ..
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) dqa[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, sf[u], dqa[u][dt], 0, 0, 0);
-            }
+            f32x4_t sa0[NQ], dp0[NQ], sa1[NQ], dp1[NQ];
+            bf16x8_t t0[4], t1[4];
+            mma_s(kA, vA, sa0, dp0);
+            load_s(2 * p + 1, kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(p, 0, sa0, dp0, sf);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_s(kB, vB, sa1, dp1);
+            load_t(p, 0, t0);
+            __builtin_amdgcn_sched_barrier(0);
+            softmax(p, 1, sa1, dp1, sf);
+            load_t(p, 1, t1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_t(0, t0, sf);
+            if (p == 0) load_s(2, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_t(1, t1, sf);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
