@@ -188,19 +188,24 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
         if (sdw[c] != 0.0f) atomicAdd(&dw[c], sdw[c]);
 }
 
-// The same for wide rows (2048 < width <= 4096: Llama-2-7B): TWO waves per row, each owning half of its columns -- a quarter of the
-// registers of the one-wave form (which sits at one wave per SIMD with the whole row, dy, the gain and the dw partials in 400
-// registers), so four waves per SIMD hide the row loads; the two row reductions (sum x^2, sum g xhat) meet through LDS.
-__global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// The same for wide rows (2048 < width <= 4096: Llama-2-7B): WPR waves per row, each owning 1 / WPR of its columns, in workgroups of
+// NWV waves (NWV / WPR rows per iteration).  With one wave per row the whole row, dy, the gain and the dw partials take 400
+// registers (one wave per SIMD); WPR = 4 needs 110 (four waves per SIMD hide the row loads); the two row reductions (sum x^2,
+// sum g xhat) meet through LDS.  The fixed cost is the final atomicAdd of every workgroup's [width] partial dw: 8-wave workgroups
+// halve their number.  Measured cold at 4096 x 4096 (profiles/r03_rmsnorm_bwd_wpr.txt): (WPR, NWV) = (2, 4) 112 us, (4, 4) 87,
+// (4, 8) 73 [shipped], (4, 16) 75.
+template <int WPR, int NWV>
+__global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ dy, int rows, int width, float eps,
                                                            float* __restrict__ dx, float* __restrict__ dw, int accumulate) {
-    constexpr int NV = 8;                                // float4 per lane: 64 lanes x 8 x 4 = 2048 columns per wave
+    constexpr int NV = 16 / WPR;                         // float4 per lane: 64 lanes x NV x 4 columns per wave
+    constexpr int RPB = NWV / WPR;                       // rows per workgroup and iteration
     extern __shared__ float sdw[];                      // [width] per-block partial dw
-    __shared__ float sred[2][2][2];                      // [reduction][row slot][half]
+    __shared__ float sred[2][RPB][WPR];                  // [reduction][row slot][part of the row]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot = wv >> 1, half = wv & 1;             // two rows per workgroup and iteration
-    const int w4 = width >> 2, h4 = (w4 + 1) >> 1;       // float4 columns per half
-    for (int c = threadIdx.x; c < width; c += 256) sdw[c] = 0.0f;
+    const int slot = wv / WPR, half = wv % WPR;          // this wave's row slot and its part of the row
+    const int w4 = width >> 2, h4 = (w4 + WPR - 1) / WPR; // float4 columns per part
+    for (int c = threadIdx.x; c < width; c += NWV * 64) sdw[c] = 0.0f;
     float4 wv4[NV], dwv[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -209,9 +214,9 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restri
         wv4[k] = ok ? ((const float4*)w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
         dwv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int iters = (rows + 2 * gridDim.x - 1) / (2 * gridDim.x);
+    const int iters = (rows + RPB * gridDim.x - 1) / (RPB * gridDim.x);
     for (int it = 0; it < iters; ++it) {
-        const int row = (it * gridDim.x + blockIdx.x) * 2 + slot;
+        const int row = (it * gridDim.x + blockIdx.x) * RPB + slot;
         const bool live = row < rows;
         const float4* xr = (const float4*)(x + (size_t)(live ? row : 0) * width);
         const float4* dr = (const float4*)(dy + (size_t)(live ? row : 0) * width);
@@ -228,7 +233,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restri
         ss = wave_sum(ss);
         if (lane == 0) sred[0][slot][half] = ss;
         __syncthreads();
-        const float rstd = 1.0f / sqrtf((sred[0][slot][0] + sred[0][slot][1]) / (float)width + eps);
+        float ssum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < WPR; ++j) ssum += sred[0][slot][j];
+        const float rstd = 1.0f / sqrtf(ssum / (float)width + eps);
         float dot = 0.0f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -242,7 +250,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restri
         dot = wave_sum(dot);
         if (lane == 0) sred[1][slot][half] = dot;
         __syncthreads();
-        const float mdot = (sred[1][slot][0] + sred[1][slot][1]) / (float)width;
+        float dsum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < WPR; ++j) dsum += sred[1][slot][j];
+        const float mdot = dsum / (float)width;
         float4* dxr = (float4*)(dx + (size_t)(live ? row : 0) * width);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd2_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < width; c += 256)
+    for (int c = threadIdx.x; c < width; c += NWV * 64)
         if (sdw[c] != 0.0f) atomicAdd(&dw[c], sdw[c]);
 }
 
@@ -487,8 +498,16 @@ extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy
     if (width <= 256) RB(1);
     else if (width <= 1024) RB(4);
     else if (width > 2048 && width <= 4096) {
-        const int nb2 = cdiv(rows, 2) < 1024 ? cdiv(rows, 2) : 1024;         // two rows per workgroup and iteration
-        rmsnorm_bwd2_kernel<<<nb2, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate);
+#ifndef RMSNORM_BWD_WPR
+#define RMSNORM_BWD_WPR 4
+#endif
+#ifndef RMSNORM_BWD_NWV
+#define RMSNORM_BWD_NWV 8
+#endif
+        constexpr int WPR = RMSNORM_BWD_WPR, NWV = RMSNORM_BWD_NWV, RPB = NWV / WPR;
+        const int cap = 4096 / NWV;                                              // workgroups: 16 waves per CU
+        const int nb2 = cdiv(rows, RPB) < cap ? cdiv(rows, RPB) : cap;
+        rmsnorm_bwd2_kernel<WPR, NWV><<<nb2, NWV * 64, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate);
     } else if (width <= 4096) RB(16);
     else if (width <= 8192) RB(32);                                 // (wider than Llama-2-7B: works, spills part of the row)
     else {
