@@ -90,6 +90,13 @@ class HipLlamaTrainer:
         # 3 % of the B-direct kernel on these shapes, and the twins cost a transpose + a pack of all 13.5 GB of weights per step
         # (25 ms and 24 GB of HBM at 7B: 896 -> 868 ms for 4 micro-batches of 2 x 2048); they would pay from ~16 micro-batches.
         self.dx_direct_uses = int(os.environ.get("LLARK_TRAIN_DX_DIRECT_USES", str(1 << 30)))
+        # gradient-norm bookkeeping (HF Trainer max_grad_norm): sum of squares collected by the dW epilogues of a step's last
+        # micro-batch, the flat-gradient spans it already covers, and the total of the last clipped step
+        self._norm_collect = False
+        self._norm_acc: Optional[torch.Tensor] = None
+        self._norm_spans: List[Tuple[int, int]] = []
+        self._last_sumsq: Optional[torch.Tensor] = None
+        self._exchange_events: list = []
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -102,10 +109,12 @@ class HipLlamaTrainer:
         self.micro_batches = 0
 
     def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor, name: str) -> None:
-        sumsq = self._norm_acc if getattr(self, "_norm_collect", False) else None
         """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch.
         Both operands are contraction-major as they stand (the token index is their row): ``llark_gemm16_t`` reads them through
-        the transposing LDS load, no dY^T / X^T copies; token counts that are not a multiple of 64 take the transposing path."""
+        the transposing LDS load, no dY^T / X^T copies; token counts that are not a multiple of 64 take the transposing path.
+        On the last micro-batch of a step (``_norm_collect``) the product's epilogue also adds the sum of squares of the gradient
+        it completes to ``_norm_acc`` (gradient-norm clipping without re-reading the gradients)."""
+        sumsq = self._norm_acc if self._norm_collect else None
         n, k = dy16.shape[1], x16.shape[1]
         fresh = name in self._fresh
         self._fresh.discard(name)
@@ -202,7 +211,7 @@ class HipLlamaTrainer:
         # llark_gemm16_t_sumsq), so step(max_grad_norm=...) only has to reduce the small rest instead of re-reading 27 GB
         self._norm_collect = bool(last_micro_batch and self.flat_m is not None and overlap_allreduce_world <= 1)
         if self._norm_collect:
-            if getattr(self, "_norm_acc", None) is None:
+            if self._norm_acc is None:
                 self._norm_acc = torch.zeros((1,), dtype=torch.float64, device=self.flat_grad.device)
             self._norm_acc.zero_()
             self._norm_spans = []
@@ -412,7 +421,7 @@ class HipLlamaTrainer:
     def exposed_exchange_ms(self) -> float:
         """Sum over the steps since the last call of the compute-stream time spent in allreduce_grads() -- the part of the
         gradient exchange the backward did not overlap (0 on one GPU).  Needs ``time_exchange = True``."""
-        evs, self._exchange_events = getattr(self, "_exchange_events", []), []
+        evs, self._exchange_events = self._exchange_events, []
         if not evs:
             return 0.0
         torch.cuda.synchronize()
@@ -422,7 +431,7 @@ class HipLlamaTrainer:
         """Device double: sum of g^2 over the whole flat gradient (the slices whose dW product already added its share,
         ``last_micro_batch``, are not read again).  Call after ``allreduce_grads``."""
         self._finalize_grads()
-        spans = sorted(getattr(self, "_norm_spans", []))
+        spans = sorted(self._norm_spans)
         if spans:
             acc, first = self._norm_acc, False
         else:
@@ -444,7 +453,7 @@ class HipLlamaTrainer:
     @property
     def last_grad_norm(self) -> Optional[float]:
         """Gradient norm of the last ``step(max_grad_norm=...)`` (read from the device on first access), else None."""
-        ss = getattr(self, "_last_sumsq", None)
+        ss = self._last_sumsq
         if ss is None:
             return None
         if isinstance(ss, tuple):

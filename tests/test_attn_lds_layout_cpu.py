@@ -76,3 +76,31 @@ def test_every_chunk_of_a_row_keeps_its_own_slot():
 def test_first_layout_of_the_round_conflicts_two_way():
     assert worst_way(b128_addrs(swz_old, 0, 0), B128_GROUPS, 16) == 2
     assert worst_way(tr_addrs(swz_old, 0, 0, False), B64_GROUPS, 8) == 2
+
+
+# ---- the other tiles read with the same instructions ----------------------------------------------------------------------------
+def test_forward_vt_tile_reads_are_conflict_free():
+    """llama.hip v_off: V^T tile [128 d][64 keys] bf16, 128-byte rows, chunk ^ ((d >> 1) & 7); fragment reads take rows dt*16 + c at
+    chunk 4 p + g."""
+    for dt, p in itertools.product(range(8), range(2)):
+        addrs = {}
+        for lane in range(64):
+            g, c = lane >> 4, lane & 15
+            d, chunk = dt * 16 + c, p * 4 + g
+            addrs[lane] = d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4)
+        assert worst_way(addrs, B128_GROUPS, 16) == 1, (dt, p)
+
+
+@pytest.mark.parametrize("fw", [128, 256])
+def test_gemm_tn_transposed_tile_reads_are_conflict_free(fw):
+    """gemm_tn.hip: a transposed operand's tile [64 k rows][fw free columns] bf16, chunk ^ 4 (row & 3); lane (q, i) of a transposing
+    read addresses row s*16 + 8 (q / 2) + i / 4 (+ 4 for the second read), columns f0 + 16 (q % 2) + 4 (i % 4) .."""
+    for s, f0, second in itertools.product(range(4), range(0, fw, 32), (False, True)):
+        addrs = {}
+        for lane in range(64):
+            q, i = lane >> 4, lane & 15
+            trow = 8 * (q >> 1) + (i >> 2)
+            col = f0 + 16 * (q & 1) + 4 * (i & 3)
+            off = (s * 16 + trow) * (fw * 2) + ((((col >> 3) ^ ((i >> 2) << 2)) << 4) | ((col & 7) << 1))
+            addrs[lane] = off + (4 * fw * 2 if second else 0)
+        assert worst_way(addrs, B64_GROUPS, 8) == 1, (s, f0, second)
