@@ -220,14 +220,16 @@ __global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __r
         const bool live = row < rows;
         const float4* xr = (const float4*)(x + (size_t)(live ? row : 0) * width);
         const float4* dr = (const float4*)(dy + (size_t)(live ? row : 0) * width);
-        float4 xv[NV], gv[NV];
-        float ss = 0.0f;
+        float4* dxr = (float4*)(dx + (size_t)(live ? row : 0) * width);
+        float4 xv[NV], gv[NV], ov[NV];                     // ov: the dx already there (accumulate), read with the row -- not in a
+        float ss = 0.0f;                                   // second dependent round trip in front of the store
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = half * h4 + lane + 64 * k;
             const bool ok = live && lane + 64 * k < h4 && c < w4;
             xv[k] = ok ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             gv[k] = ok ? dr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ov[k] = (ok && accumulate) ? dxr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             ss += (xv[k].x * xv[k].x + xv[k].y * xv[k].y) + (xv[k].z * xv[k].z + xv[k].w * xv[k].w);
         }
         ss = wave_sum(ss);
@@ -254,7 +256,6 @@ __global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < WPR; ++j) dsum += sred[1][slot][j];
         const float mdot = dsum / (float)width;
-        float4* dxr = (float4*)(dx + (size_t)(live ? row : 0) * width);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = half * h4 + lane + 64 * k;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __r
                 float4 v = make_float4(rstd * (gv[k].x - xv[k].x * mdot), rstd * (gv[k].y - xv[k].y * mdot),
                                        rstd * (gv[k].z - xv[k].z * mdot), rstd * (gv[k].w - xv[k].w * mdot));
                 if (accumulate) {
-                    const float4 o = dxr[c];
+                    const float4 o = ov[k];
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 dxr[c] = v;
