@@ -118,6 +118,23 @@ int llark_vqvae_stage_f16x2(const float* audio, const void* in_hi, const void* i
  * ~19 bits instead of 22). */
 int llark_vqvae_pack_frag16(const float* w, int cout, int cin, int k, int perm1x1, int exp2, void* hi, void* lo, llark_stream_t stream);
 
+/* Near-tie certificate for the fused encoder (round 4; same call site: jukebox/main.py:61 -> VQVAE.encode -> bottleneck.encode).
+ * llark_codebook_argmin plus: every token whose best / second-best distance gap is below  |x| (tie_a sqrt(d_best) + tie_b |x|)  is
+ * appended to flag_list (ids n_index * t + token, at most `cap`; *flag_count -- zeroed by this call -- keeps counting past cap so the
+ * caller can detect an overflow).  An encoder-output error e moves the gap by <= 2 |e| |k_a - k_b| <= 4 |e| sqrt(d): tie_a = 4 |e| / |x|;
+ * the fp32 rounding of the distance chains moves it by a few ulp of |x|^2: tie_b = c * 2^-23. */
+int llark_codebook_argmin_tie(const float* x, int n, int emb, int t, const float* k, const float* kk, int bins, int64_t* codes,
+                              float tie_a, float tie_b, int* flag_count, int* flag_list, int cap, llark_stream_t stream);
+/* Exact fix-up of the flagged tokens: for flag_list[0 .. count) (count read back by the caller) gathers a window of `win_tokens`
+ * tokens of audio around each token (start clamp(tok - halo_tokens, 0, t_tok - win_tokens): a window edge on a clip edge is the
+ * clip edge), runs the plan's exact per-layer kernels on the `count` windows and overwrites codes[] of the flagged tokens with the
+ * argmin of the exact value -- bit-equal to llark_vqvae_encode on the whole clip when halo_tokens covers the receptive field.
+ * win [count][win_tokens * raw_to_tokens] fp32, col [count] int, buf0 / buf1 (>= count * 32 * win_tokens * raw_to_tokens / 2 floats
+ * each): caller-owned scratch.  count <= 0 is a no-op. */
+int llark_vqvae_fix_near_ties(void* plan, const float* audio, int n, int t_samples, int raw_to_tokens, const int* flag_list, int count,
+                              int halo_tokens, int win_tokens, float* win, int* col, float* buf0, float* buf1, long long buf_elems,
+                              const float* codebook, const float* kk, int bins, int64_t* codes, llark_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Jukebox top prior, only_encode: replaces `top_prior.prior.forward(...)` at jukebox/main.py:108
  * and the pooling at jukebox/main.py:113-167.

@@ -56,6 +56,8 @@ _SIGS = {
     "llark_vqvae_plan_add_conv": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int],
     "llark_vqvae_plan_add_resblock": [_P, _P, _P, _P, _P, c_int, c_int],
     "llark_vqvae_encode": [_P, _P, c_int, c_int, _P, _P, c_int64, _P, _P, c_int, _P, _P, _P],
+    "llark_codebook_argmin_tie": [_P, c_int, c_int, c_int, _P, _P, c_int, _P, c_float, c_float, _P, _P, c_int, _P],
+    "llark_vqvae_fix_near_ties": [_P, _P, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, _P, _P, c_int, _P, _P],
     "llark_vqvae_stage_f16x2": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "llark_vqvae_pack_frag16": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "llark_gemm16": [c_int, c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,

@@ -289,12 +289,46 @@ __global__ void codebook_norms_kernel(const float* __restrict__ k, float* __rest
     kk[j] = s;
 }
 
+// One wave's scan of codes [j0, j0 + per) for the 64 tokens its lanes hold (xv = the token's 64 channels, xx its squared norm):
+// the oracle's arithmetic -- dot_j = c-ascending fmaf chain from 0, d_j = (xx - 2*dot_j) + kk_j, first minimal j wins -- shared by
+// every argmin kernel below so that they cannot drift apart.  SECOND additionally tracks the second-smallest distance.
+template <int EMB, int JB, bool SECOND>
+__device__ __forceinline__ void codebook_scan(const float (&xv)[EMB], float xx, const float* __restrict__ k, const float* __restrict__ kk,
+                                              int j0, int per, float& best, int& bj, float& second) {
+    best = INFINITY;
+    second = INFINITY;
+    bj = j0;
+    for (int j = j0; j < j0 + per; j += JB) {
+        float dot[JB];
+#pragma unroll
+        for (int u = 0; u < JB; ++u) dot[u] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < EMB; ++c) {
+#pragma unroll
+            for (int u = 0; u < JB; ++u) dot[u] = fmaf(xv[c], k[(size_t)(j + u) * EMB + c], dot[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < JB; ++u) {
+            float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.0f, dot[u])), kk[j + u]);
+            if (SECOND) second = fminf(second, fmaxf(d, best));       // d if it does not win, the dethroned best if it does
+            if (d < best) {
+                best = d;
+                bj = j + u;
+            }
+        }
+    }
+}
+
 // block = 256 threads = 4 waves; 64 tokens per block; wave q scans codes [q*bins/4, (q+1)*bins/4).
-template <int EMB, int JB>
+// TIE (round 4): also finds the second-smallest distance; a token whose gap (second - best) is below
+// |x| (tie_a sqrt(best) + tie_b |x|) is appended to flag_list (n*t + token; at most `cap` entries, *flag_count keeps counting).
+template <int EMB, int JB, bool TIE>
 __global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* __restrict__ x, const float* __restrict__ k,
                                                               const float* __restrict__ kk, long long* __restrict__ codes,
-                                                              float* __restrict__ mind, int t, int bins) {
+                                                              float* __restrict__ mind, int t, int bins, float tie_a, float tie_b,
+                                                              int* __restrict__ flag_count, int* __restrict__ flag_list, int cap) {
     __shared__ float s_best[4][64];
+    __shared__ float s_second[4][64];
     __shared__ int s_idx[4][64];
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -309,36 +343,21 @@ __global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < EMB; ++c) xx = fmaf(xv[c], xv[c], xx);
     const int per = bins / 4;
-    const int j0 = q * per;
-    float best = INFINITY;
-    int bj = j0;
-    for (int j = j0; j < j0 + per; j += JB) {
-        float dot[JB];
-#pragma unroll
-        for (int u = 0; u < JB; ++u) dot[u] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < EMB; ++c) {
-#pragma unroll
-            for (int u = 0; u < JB; ++u) dot[u] = fmaf(xv[c], k[(size_t)(j + u) * EMB + c], dot[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < JB; ++u) {
-            float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.0f, dot[u])), kk[j + u]);
-            if (d < best) {
-                best = d;
-                bj = j + u;
-            }
-        }
-    }
+    float best, second;
+    int bj;
+    codebook_scan<EMB, JB, TIE>(xv, xx, k, kk, q * per, per, best, bj, second);
     s_best[q][lane] = best;
     s_idx[q][lane] = bj;
+    if (TIE) s_second[q][lane] = second;
     __syncthreads();
     if (q == 0 && tok < t) {
         float b = s_best[0][lane];
         int bi = s_idx[0][lane];
+        float sec = TIE ? s_second[0][lane] : INFINITY;
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
             float v = s_best[r][lane];
+            if (TIE) sec = fminf(sec, fminf(s_second[r][lane], fmaxf(v, b)));
             if (v < b) {
                 b = v;
                 bi = s_idx[r][lane];
@@ -346,7 +365,79 @@ __global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* __res
         }
         codes[(size_t)n * t + tok] = bi;
         if (mind) mind[(size_t)n * t + tok] = b;
+        if (TIE) {
+            // thr = |x| (tie_a sqrt(d_best) + tie_b |x|): both terms scale with the square of the data's magnitude, like the gap.
+            // NaN-safe: a NaN distance fails `>=` and is flagged
+            const float xn2 = sqrtf(xx);
+            const float thr = xn2 * fmaf(tie_a, sqrtf(fmaxf(b, 0.0f)), tie_b * xn2);
+            if (!(sec - b >= thr)) {
+                const int slot = atomicAdd(flag_count, 1);
+                if (slot < cap) flag_list[slot] = n * t + tok;
+            }
+        }
     }
+}
+
+// Near-tie fix-up, step 1: the audio window of every flagged token.  Window i = `wtok` tokens of clip n_i starting at token
+// s_i = clamp(tok_i - halo, 0, t_tok - wtok): wherever it touches a clip edge the window edge IS the clip edge, so the exact
+// encoder's zero padding there is the real one; inside the clip `halo` tokens either side cover the token's receptive field.
+__global__ void gather_windows_kernel(const float* __restrict__ audio, int t_samples, int t_tok, int r2t, const int* __restrict__ flag_list,
+                                      int count, int halo, int wtok, float* __restrict__ win, int* __restrict__ col) {
+    const int i = blockIdx.y;
+    if (i >= count) return;
+    const int id = flag_list[i];
+    const int n = id / t_tok, tok = id - n * t_tok;
+    int s = tok - halo;
+    s = s < 0 ? 0 : s;
+    s = s > t_tok - wtok ? t_tok - wtok : s;
+    const int wlen = wtok * r2t;
+    const float* src = audio + (size_t)n * t_samples + (size_t)s * r2t;
+    float* dst = win + (size_t)i * wlen;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < wlen; j += gridDim.x * blockDim.x) dst[j] = src[j];
+    if (blockIdx.x == 0 && threadIdx.x == 0) col[i] = tok - s;
+}
+
+// Near-tie fix-up, step 3: the flagged tokens' codes from the exactly re-evaluated windows.  One wave per token (its 64 lanes
+// all hold the same token; lane l scans codes [l*bins/64, ...) -- the same per-code arithmetic, merged by (distance, index)).
+template <int EMB>
+__global__ __launch_bounds__(64) void codebook_argmin_fix_kernel(const float* __restrict__ xw, int wtok, const int* __restrict__ col,
+                                                                 const int* __restrict__ flag_list, int count, const float* __restrict__ k,
+                                                                 const float* __restrict__ kk, int bins, long long* __restrict__ codes) {
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const int lane = threadIdx.x;
+    const float* xn = xw + (size_t)i * EMB * wtok + col[i];
+    float xv[EMB];
+#pragma unroll
+    for (int c = 0; c < EMB; ++c) xv[c] = xn[(size_t)c * wtok];
+    float xx = 0.0f;
+#pragma unroll
+    for (int c = 0; c < EMB; ++c) xx = fmaf(xv[c], xv[c], xx);
+    const int per = (bins + 63) / 64;
+    const int jend = (lane + 1) * per < bins ? (lane + 1) * per : bins;
+    float best = INFINITY;
+    int bj = lane * per;
+    for (int j = lane * per; j < jend; ++j) {
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < EMB; ++c) dot = fmaf(xv[c], k[(size_t)j * EMB + c], dot);
+        const float d = __fadd_rn(__fsub_rn(xx, __fmul_rn(2.0f, dot)), kk[j]);
+        if (d < best) {
+            best = d;
+            bj = j;
+        }
+    }
+    // first minimal j: smaller distance wins, equal distances go to the smaller index
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oj = __shfl_xor(bj, o);
+        if (ob < best || (ob == best && oj < bj)) {
+            best = ob;
+            bj = oj;
+        }
+    }
+    if (lane == 0) codes[flag_list[i]] = bj;
 }
 
 }  // namespace llark
@@ -439,7 +530,8 @@ extern "C" int llark_codebook_argmin(const float* x, int n, int emb, int t, cons
     LLARK_REQUIRE(emb == 64, "codebook_argmin: emb_width must be 64, got %d", emb);
     LLARK_REQUIRE(bins % 32 == 0 && bins >= 32, "codebook_argmin: bins must be a multiple of 32, got %d", bins);
     dim3 grid(cdiv(t, 64), n);
-    codebook_argmin_kernel<64, 8><<<grid, 256, 0, (hipStream_t)stream>>>(x, k, kk, (long long*)codes, min_dist, t, bins);
+    codebook_argmin_kernel<64, 8, false><<<grid, 256, 0, (hipStream_t)stream>>>(x, k, kk, (long long*)codes, min_dist, t, bins, 0.f, 0.f,
+                                                                               nullptr, nullptr, 0);
     return check_launch("codebook_argmin");
 }
 
@@ -478,14 +570,10 @@ extern "C" int llark_vqvae_plan_add_resblock(void* plan, const float* w1p, const
     return LLARK_OK;
 }
 
-// audio [n][t] fp32 -> codes [n][t_out] int64.  buf0 / buf1: ping-pong activation buffers of `buf_elems` floats each (>= the
-// widest activation n * C * T of the plan).  emb_out (optional): receives a pointer to the final [n][emb][t_out] activation.
-extern "C" int llark_vqvae_encode(void* plan, const float* audio, int n, int t, float* buf0, float* buf1, long long buf_elems,
-                                  const float* codebook, const float* kk, int bins, int64_t* codes, int* t_out, llark_stream_t stream) {
-    LLARK_REQUIRE(plan && audio && buf0 && buf1 && codebook && kk && codes && n > 0 && t > 0, "vqvae_encode: bad arguments");
-    const VqPlan* P = (const VqPlan*)plan;
+// The layer list of a plan over x [n][1][t]; *x_out points into buf0 / buf1 at the final [n][*c_out][*t_out] activation.
+static int run_plan(const VqPlan* P, const float* x, int n, int t, float* buf0, float* buf1, long long buf_elems, const float** x_out,
+                    int* c_out, int* t_out, llark_stream_t stream) {
     LLARK_REQUIRE(!P->layers.empty() && P->layers[0].kind == 0 && P->layers[0].cin == 1, "vqvae_encode: the plan must start with a 1-channel conv");
-    const float* x = audio;
     int c = 1, tt = t, slot = 0;
     for (const VqLayer& L : P->layers) {
         float* y = slot ? buf1 : buf0;
@@ -505,6 +593,75 @@ extern "C" int llark_vqvae_encode(void* plan, const float* audio, int n, int t, 
         x = y;
         slot ^= 1;
     }
+    *x_out = x;
+    *c_out = c;
+    *t_out = tt;
+    return LLARK_OK;
+}
+
+// audio [n][t] fp32 -> codes [n][t_out] int64.  buf0 / buf1: ping-pong activation buffers of `buf_elems` floats each (>= the
+// widest activation n * C * T of the plan).
+extern "C" int llark_vqvae_encode(void* plan, const float* audio, int n, int t, float* buf0, float* buf1, long long buf_elems,
+                                  const float* codebook, const float* kk, int bins, int64_t* codes, int* t_out, llark_stream_t stream) {
+    LLARK_REQUIRE(plan && audio && buf0 && buf1 && codebook && kk && codes && n > 0 && t > 0, "vqvae_encode: bad arguments");
+    const float* x = nullptr;
+    int c = 0, tt = 0;
+    const int rc = run_plan((const VqPlan*)plan, audio, n, t, buf0, buf1, buf_elems, &x, &c, &tt, stream);
+    if (rc != LLARK_OK) return rc;
     if (t_out) *t_out = tt;
     return llark_codebook_argmin(x, n, c, tt, codebook, kk, bins, codes, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Near-tie certificate + exact fix-up for the fused encoder (round 4).  The fused stage kernels (vqvae_fused.hip) reproduce the
+// encoder output to fp32 accumulation-order noise; a code can differ from the defined-order oracle's only where two codebook
+// entries are nearly equidistant from the token.  llark_codebook_argmin_tie flags every token whose best / second-best gap
+// is below  |x| (tie_a sqrt(d_best) + tie_b |x|):  an output error e moves the gap by 2 e.(k_b - k_a) <= 2 |e| |k_a - k_b|
+// <= 4 |e| sqrt(d), so tie_a = 4 |e| / |x|; the fp32 rounding of the distance chain itself (in the oracle's evaluation and in
+// this one) moves it by a few ulp of |x|^2, so tie_b = c 2^-23.  llark_vqvae_fix_near_ties re-evaluates exactly those tokens with the per-layer
+// exact kernels on a window that covers the token's receptive field -- position-independent fmaf chains, so the window's
+// value at the token is BIT-equal to the full exact path's -- and overwrites their codes.
+// ------------------------------------------------------------------------------------------
+extern "C" int llark_codebook_argmin_tie(const float* x, int n, int emb, int t, const float* k, const float* kk, int bins, int64_t* codes,
+                                         float tie_a, float tie_b, int* flag_count, int* flag_list, int cap, llark_stream_t stream) {
+    LLARK_REQUIRE(x && k && kk && codes && flag_count && flag_list && n > 0 && t > 0 && cap > 0, "codebook_argmin_tie: null pointer or empty input");
+    LLARK_REQUIRE(emb == 64, "codebook_argmin_tie: emb_width must be 64, got %d", emb);
+    LLARK_REQUIRE(bins % 32 == 0 && bins >= 32, "codebook_argmin_tie: bins must be a multiple of 32, got %d", bins);
+    LLARK_REQUIRE(tie_a >= 0.f && tie_b >= 0.f, "codebook_argmin_tie: negative threshold coefficients");
+    LLARK_REQUIRE((long long)n * t < (1ll << 31), "codebook_argmin_tie: n * t does not fit the 32-bit token ids of the flag list");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(flag_count, 0, sizeof(int), s) != hipSuccess) {
+        set_error("codebook_argmin_tie: hipMemsetAsync failed");
+        return LLARK_ERR_LAUNCH;
+    }
+    dim3 grid(cdiv(t, 64), n);
+    codebook_argmin_kernel<64, 8, true><<<grid, 256, 0, s>>>(x, k, kk, (long long*)codes, nullptr, t, bins, tie_a, tie_b, flag_count, flag_list, cap);
+    return check_launch("codebook_argmin_tie");
+}
+
+// flag_list [count] (device; from llark_codebook_argmin_tie, count read back by the caller and <= its cap): token ids n * t_tok + tok.
+// win [count][win_tokens * raw_to_tokens] fp32 and col [count] int: caller-owned scratch.  buf0 / buf1 as for llark_vqvae_encode,
+// sized for count windows.  codes [n][t_tok] is patched in place.
+extern "C" int llark_vqvae_fix_near_ties(void* plan, const float* audio, int n, int t_samples, int raw_to_tokens, const int* flag_list, int count,
+                                         int halo_tokens, int win_tokens, float* win, int* col, float* buf0, float* buf1, long long buf_elems,
+                                         const float* codebook, const float* kk, int bins, int64_t* codes, llark_stream_t stream) {
+    LLARK_REQUIRE(plan && audio && flag_list && win && col && buf0 && buf1 && codebook && kk && codes, "vqvae_fix_near_ties: null pointer");
+    LLARK_REQUIRE(n > 0 && t_samples > 0 && raw_to_tokens > 0 && t_samples % raw_to_tokens == 0, "vqvae_fix_near_ties: bad clip geometry");
+    const int t_tok = t_samples / raw_to_tokens;
+    LLARK_REQUIRE(win_tokens > 0 && win_tokens <= t_tok && halo_tokens >= 0, "vqvae_fix_near_ties: window of %d tokens does not fit a clip of %d", win_tokens, t_tok);
+    LLARK_REQUIRE(win_tokens == t_tok || win_tokens >= 2 * halo_tokens + 1, "vqvae_fix_near_ties: window %d shorter than 2 * halo %d + 1", win_tokens, halo_tokens);
+    if (count <= 0) return LLARK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int wlen = win_tokens * raw_to_tokens;
+    dim3 g(cdiv(wlen, 256 * 8), count);
+    gather_windows_kernel<<<g, 256, 0, s>>>(audio, t_samples, t_tok, raw_to_tokens, flag_list, count, halo_tokens, win_tokens, win, col);
+    int rc = check_launch("gather_windows");
+    if (rc != LLARK_OK) return rc;
+    const float* x = nullptr;
+    int c = 0, tt = 0;
+    rc = run_plan((const VqPlan*)plan, win, count, wlen, buf0, buf1, buf_elems, &x, &c, &tt, stream);
+    if (rc != LLARK_OK) return rc;
+    LLARK_REQUIRE(c == 64 && tt == win_tokens, "vqvae_fix_near_ties: the plan maps %d samples to %d x %d, expected 64 x %d", wlen, c, tt, win_tokens);
+    codebook_argmin_fix_kernel<64><<<count, 64, 0, s>>>(x, win_tokens, col, flag_list, count, codebook, kk, bins, (long long*)codes);
+    return check_launch("codebook_argmin_fix");
 }

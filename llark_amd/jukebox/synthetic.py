@@ -112,6 +112,27 @@ def synthetic_clip(clip_idx: int, seconds: float = 25.0, sr: int = 44100) -> np.
     return x.numpy().astype(np.float32)
 
 
+def synthetic_clip_rich(clip_idx: int, seconds: float = 25.0, sr: int = 44100) -> np.ndarray:
+    """A second synthetic spectrum (round 4, wide parity fixture): six partials between 55 Hz and 4 kHz with slow
+    amplitude modulation, a linear chirp 200 -> 6000 Hz, and noise gated on / off in half-second bursts; seed
+    4321 + clip_idx.  Un-normalised like :func:`synthetic_clip`."""
+    g = torch.Generator().manual_seed(4321 + clip_idx)
+    n = int(round(seconds * sr))
+    t = torch.arange(n, dtype=torch.float64) / sr
+    x = torch.zeros(n, dtype=torch.float64)
+    for _ in range(6):
+        f = 55.0 * (4000.0 / 55.0) ** torch.rand(1, generator=g).item()
+        amp = 0.05 + 0.25 * torch.rand(1, generator=g).item()
+        fm = 0.2 + 3.0 * torch.rand(1, generator=g).item()
+        ph = 2 * math.pi * torch.rand(1, generator=g).item()
+        x += amp * (0.6 + 0.4 * torch.sin(2 * math.pi * fm * t + ph)) * torch.sin(2 * math.pi * f * t + ph)
+    f0, f1 = 200.0, 6000.0
+    x += 0.15 * torch.sin(2 * math.pi * (f0 * t + 0.5 * (f1 - f0) / max(seconds, 1e-9) * t * t))
+    gate = (torch.rand(int(seconds * 2) + 1, generator=g) < 0.4).double().repeat_interleave(sr // 2)[:n]
+    x += 0.2 * gate * torch.randn(n, generator=g, dtype=torch.float64)
+    return x.float().numpy().astype(np.float32)
+
+
 def init_codebook_from_encodings(enc: torch.Tensor, l_bins: int, seed: int = 7, noise: float = 0.25) -> torch.Tensor:
     """Data-dependent codebook like upstream ``BottleneckBlock.init_k`` (sample encoder outputs).
 

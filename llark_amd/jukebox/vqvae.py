@@ -15,20 +15,56 @@ import torch
 from .. import ops
 from .hparams import JukeboxHParams
 
+# Near-tie certificate of the fused encoder (csrc/vqvae.hip: llark_codebook_argmin_tie).  A token is re-evaluated exactly when its
+# best / second-best codebook gap is below  |x| (4 TIE_E_REL sqrt(d_best) + TIE_ULPS 2^-23 |x|):
+#   TIE_E_REL  bound on |x_fused - x_exact|_2 / |x|_2 per token (the fused stages reproduce the encoder output to fp32
+#              accumulation-order noise; measured in profiles/r04_vq_near_tie_stats.txt),
+#   TIE_ULPS   slack, in ulps of |x|^2, for the fp32 rounding of the distance chains (the oracle's own evaluation and this one).
+TIE_E_REL = 2.0e-6
+TIE_ULPS = 16.0
+TIE_LIST_CAP = 4096          # flagged tokens per encode_top call the device list can hold; beyond it the whole batch goes exact
+TIE_CHUNK = 256              # windows re-evaluated per pass (bounds the scratch: 256 windows x 32 channels x 11264 positions fp32)
+
+
+def receptive_halo_tokens(hps: JukeboxHParams) -> int:
+    """Tokens either side of a level-2 token whose audio its encoder output depends on: walks upstream's EncoderConvBlock stack
+    (vqvae/encdec.py: per level block `down_t` x [Conv1d(k = 2 s, stride s, pad s / 2); Resnet1D(depth, dilations growth^r)] and a
+    Conv1d(k = 3, pad 1)) backwards from one output position.  5b: 10455 samples = 82 tokens either side."""
+    left = right = 0
+    res = sum(hps.dilation_growth_rate ** r for r in range(hps.depth))
+    for lb in reversed(range(len(hps.downs_t))):
+        left, right = left + 1, right + 1
+        s = hps.strides_t[lb]
+        for _ in range(hps.downs_t[lb]):
+            left, right = left + res, right + res
+            left, right = s * left + s // 2, s * right + (2 * s - 1 - s // 2)
+    r2t = hps.raw_to_tokens
+    return max(-(-left // r2t), -(-max(0, right - (r2t - 1)) // r2t))
+
 
 class VQVAE:
     """Level-2 encoder + codebook of the Jukebox VQ-VAE, weights resident in HBM in kernel layout."""
 
-    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", exact: bool = False):
+    def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", exact: bool = False,
+                 tie_e_rel: Optional[float] = TIE_E_REL, tie_ulps: float = TIE_ULPS):
         """exact=False (default): the fused stage kernels on the 16-bit matrix cores (csrc/vqvae_fused.hip: one launch per
-        down-sampling step, activations resident in LDS, split-fp16 products -- fp32-class activations, VQ codes equal to the
-        oracle's).  exact=True: the per-layer fp32 kernels of csrc/vqvae.hip whose activations are BIT-equal to the defined-order C
+        down-sampling step, activations resident in LDS, split-fp16 products -- fp32-class activations) followed by the near-tie
+        certificate: every token whose two nearest codebook entries are closer than the fused path's error can resolve is
+        re-evaluated by the exact kernels on a window covering its receptive field, so the CODES equal the exact path's (round 4).
+        tie_e_rel=None switches the certificate off (round 3's behaviour: codes may differ on near-ties).
+        exact=True: the per-layer fp32 kernels of csrc/vqvae.hip whose activations are BIT-equal to the defined-order C
         oracle (oracle/jukebox_ref.c); ``encoder_forward(..., taps=)`` and ``encode_top(want_dist=True)`` always use them."""
         hps.check()
         self.hps = hps
         self.device = torch.device(device)
         self.sample_length = hps.sample_length
         self.exact = bool(exact)
+        self.tie_e_rel = None if tie_e_rel is None else float(tie_e_rel)
+        self.tie_ulps = float(tie_ulps)
+        self.halo_tokens = receptive_halo_tokens(hps) + 2
+        self.win_tokens = min(hps.n_ctx, -(-(2 * self.halo_tokens + 1) // 8) * 8)
+        self.last_near_ties = 0                # tokens the last encode_top call re-evaluated exactly
+        self.near_ties_total = 0
         self.layers: List[tuple] = []          # ("conv", wp, b, stride, pad) | ("res", w1p, b1, w2p, b2, dil)
         self.stages: List[dict] = []           # fused path: one entry per down-sampling step (see _make_stage)
         dev = self.device
@@ -199,10 +235,43 @@ class VQVAE:
             # one HIP-event pair around the whole stack when bench.py times kernels: work = ALGORITHMIC bytes of the stack
             with ops._timed("vqvae_encode", float(self.algorithmic_bytes(n))):
                 xe = self.encoder_forward_fused(audio)
-                codes = ops.codebook_argmin(xe, self.k, self.kk)
+                if self.tie_e_rel is None:
+                    codes = ops.codebook_argmin(xe, self.k, self.kk)
+                else:
+                    codes = self._argmin_certified(audio, xe)
+            if codes is None:                                   # more near-ties than the list holds: the whole batch goes exact
+                return self._encode_top_exact(audio)
             if codes.shape[1] != self.hps.n_ctx:
                 raise ops._lib.LlarkHipError(f"vqvae_encode produced {codes.shape[1]} tokens per clip, hparams say {self.hps.n_ctx}")
             return codes
+        return self._encode_top_exact(audio)
+
+    def _argmin_certified(self, audio: torch.Tensor, xe: torch.Tensor):
+        """Codebook search on the fused encoder output + exact re-evaluation of the near-ties (the one host read of the encoder:
+        a 4-byte count).  Returns None when the flag list overflowed."""
+        if not hasattr(self, "_flag_count"):
+            self._flag_count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            self._flag_list = torch.empty((TIE_LIST_CAP,), dtype=torch.int32, device=self.device)
+        codes = ops.codebook_argmin_tie(xe, self.k, self.kk, 4.0 * self.tie_e_rel, self.tie_ulps * 2.0 ** -23, self._flag_count, self._flag_list)
+        count = int(self._flag_count.item())
+        self.last_near_ties = count
+        self.near_ties_total += count
+        if count > TIE_LIST_CAP:
+            return None
+        r2t = self.hps.raw_to_tokens
+        wlen = self.win_tokens * r2t
+        for i0 in range(0, count, TIE_CHUNK):
+            c = min(TIE_CHUNK, count - i0)
+            width = max(layer[1].shape[2] for layer in self.layers)
+            b0, b1 = self._buf(0, (c * width * (wlen // 2 + 1),)), self._buf(1, (c * width * (wlen // 2 + 1),))
+            win = self._buf("win", (c * wlen,))
+            col = self._bufs.setdefault("col", torch.empty((TIE_CHUNK,), dtype=torch.int32, device=self.device))
+            ops.vqvae_fix_near_ties(self._plan(), audio, r2t, self._flag_list[i0:i0 + c], c, self.halo_tokens, self.win_tokens, win, col,
+                                    b0, b1, self.k, self.kk, codes)
+        return codes
+
+    def _encode_top_exact(self, audio: torch.Tensor):
+        n = audio.shape[0]
         widest = n * max(layer[1].shape[2] for layer in self.layers) * (self.sample_length // 2 + 1)
         b0, b1 = self._buf(0, (widest,)), self._buf(1, (widest,))
         codes = torch.empty((n, self.hps.n_ctx), dtype=torch.int64, device=self.device)

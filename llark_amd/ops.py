@@ -280,6 +280,34 @@ def codebook_argmin(x: torch.Tensor, k: torch.Tensor, kk: torch.Tensor, want_dis
     return (codes, dist) if want_dist else codes
 
 
+def codebook_argmin_tie(x: torch.Tensor, k: torch.Tensor, kk: torch.Tensor, tie_a: float, tie_b: float, flag_count: torch.Tensor,
+                        flag_list: torch.Tensor, codes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """codebook_argmin + the near-tie certificate: token ids (n_index * t + token) whose best / second-best gap is below
+    |x| (tie_a sqrt(d_best) + tie_b |x|) are appended to flag_list (int32, device); flag_count (int32[1], device) is zeroed
+    by the call and counts every flagged token, also past the list's capacity."""
+    n, emb, t = x.shape
+    if codes is None:
+        codes = torch.empty((n, t), dtype=torch.int64, device=x.device)
+    check(_lib.lib().llark_codebook_argmin_tie(_dev(x, "x", torch.float32), n, emb, t, _dev(k, "k", torch.float32), _dev(kk, "kk", torch.float32),
+                                               k.shape[0], _dev(codes, "codes", torch.int64), float(tie_a), float(tie_b),
+                                               _dev(flag_count, "flag_count", torch.int32), _dev(flag_list, "flag_list", torch.int32),
+                                               flag_list.numel(), _stream()), "codebook_argmin_tie")
+    return codes
+
+
+def vqvae_fix_near_ties(plan, audio: torch.Tensor, raw_to_tokens: int, flag_list: torch.Tensor, count: int, halo_tokens: int, win_tokens: int,
+                        win: torch.Tensor, col: torch.Tensor, buf0: torch.Tensor, buf1: torch.Tensor, k: torch.Tensor, kk: torch.Tensor,
+                        codes: torch.Tensor) -> None:
+    """Exact re-evaluation of flag_list[:count] on receptive-field windows; patches `codes` (n, t_tok) in place."""
+    n, t = audio.shape
+    assert win.numel() >= count * win_tokens * raw_to_tokens and col.numel() >= count and buf0.numel() == buf1.numel()
+    check(_lib.lib().llark_vqvae_fix_near_ties(plan, _dev(audio, "audio", torch.float32), n, t, raw_to_tokens, _dev(flag_list, "flag_list", torch.int32),
+                                               int(count), int(halo_tokens), int(win_tokens), _dev(win, "win", torch.float32),
+                                               _dev(col, "col", torch.int32), _dev(buf0, "buf0", torch.float32), _dev(buf1, "buf1", torch.float32),
+                                               buf0.numel(), _dev(k, "k", torch.float32), _dev(kk, "kk", torch.float32), k.shape[0],
+                                               _dev(codes, "codes", torch.int64), _stream()), "vqvae_fix_near_ties")
+
+
 # ------------------------------------------------------------------------------------------------
 # prior
 # ------------------------------------------------------------------------------------------------

@@ -216,13 +216,14 @@ def get_cond(w: Dict[str, torch.Tensor], spec: Spec):
 # ---------------------------------------------------------------------------------------------
 # Top prior (jukebox/prior/autoregressive.py, jukebox/transformer/*)
 # ---------------------------------------------------------------------------------------------
-def _conv1d_linear(x, wm, b):
-    """transformer/ops.py Conv1D: addmm(b, x.view(-1,n_in), w) with fp16-valued w used as fp32."""
+def _conv1d_linear(x, wm, b, dtype=torch.float32):
+    """transformer/ops.py Conv1D: addmm(b, x.view(-1,n_in), w) with fp16-valued w used as fp32.
+    (dtype=float64 is the generator's noise-floor mode, tests/golden/make_jukebox_wide_golden.py: same graph, wider type.)"""
     size_out = (*x.size()[:-1], wm.shape[1])
-    return torch.addmm(b.float(), x.reshape(-1, x.size(-1)), wm.float()).view(*size_out)
+    return torch.addmm(b.to(dtype), x.reshape(-1, x.size(-1)), wm.to(dtype)).view(*size_out)
 
 
-def _dense_attn(q, k, v, heads: int, causal: bool):
+def _dense_attn(q, k, v, heads: int, causal: bool, dtype=torch.float32):
     bs, ql, d = q.shape
     kl = k.shape[1]
     hd = d // heads
@@ -232,35 +233,35 @@ def _dense_attn(q, k, v, heads: int, causal: bool):
     scale = 1.0 / math.sqrt(math.sqrt(hd))
     wt = torch.matmul(qh, kh)
     wt.mul_(scale * scale)
-    wt = wt.float()
+    wt = wt.to(dtype)
     if causal:
-        mask = torch.ones(ql, kl).tril(max(0, kl - ql)).view(1, 1, ql, kl)
+        mask = torch.ones(ql, kl, dtype=dtype).tril(max(0, kl - ql)).view(1, 1, ql, kl)
         wt = wt * mask + -1e9 * (1 - mask)
     wt = F.softmax(wt, dim=-1)
     a = torch.matmul(wt, vh)
     return a.permute(0, 2, 1, 3).contiguous().view(bs, ql, d)
 
 
-def factored_attention(q, k, v, attn_func: int, heads: int, block_ctx: int):
+def factored_attention(q, k, v, attn_func: int, heads: int, block_ctx: int, dtype=torch.float32):
     """factored_attention.py block_attn (1) / transpose_block_attn (2) / prev_block_attn (3)."""
     bs, l, d = v.shape
     if attn_func == 1:
         qq = q.view(bs * l // block_ctx, block_ctx, d)
         kk = k.view(bs * l // block_ctx, block_ctx, d)
         vv = v.view(bs * l // block_ctx, block_ctx, d)
-        return _dense_attn(qq, kk, vv, heads, True).view(bs, l, d)
+        return _dense_attn(qq, kk, vv, heads, True, dtype).view(bs, l, d)
     if attn_func == 2:
         def tr(x):
             return x.view(bs, l // block_ctx, block_ctx, d).transpose(1, 2).contiguous().view(
                 bs * block_ctx, l // block_ctx, d)
-        a = _dense_attn(tr(q), tr(k), tr(v), heads, True)
+        a = _dense_attn(tr(q), tr(k), tr(v), heads, True, dtype)
         return a.view(bs, block_ctx, l // block_ctx, d).transpose(1, 2).contiguous().view(bs, l, d)
     if attn_func == 3:
         qq = q.view(bs * l // block_ctx, block_ctx, d)
         def prev(x):
             return F.pad(x.view(bs, l // block_ctx, block_ctx, d)[:, :-1, :, :], (0, 0, 0, 0, 1, 0)).view(
                 bs * l // block_ctx, block_ctx, d)
-        return _dense_attn(qq, prev(k), prev(v), heads, False).view(bs, l, d)
+        return _dense_attn(qq, prev(k), prev(v), heads, False, dtype).view(bs, l, d)
     raise ValueError(attn_func)
 
 
@@ -274,20 +275,22 @@ def prior_embed(w, z, x_cond, y_cond, spec: Spec):
     return x
 
 
-def prior_layer(w, x, d: int, spec: Spec, taps: Optional[dict] = None):
-    """ResAttnBlock: a = attn(ln_0(x)); m = mlp(ln_1(x + a)); h = x + a + m (res_scale == 1)."""
+def prior_layer(w, x, d: int, spec: Spec, taps: Optional[dict] = None, dtype=torch.float32):
+    """ResAttnBlock: a = attn(ln_0(x)); m = mlp(ln_1(x + a)); h = x + a + m (res_scale == 1).
+    dtype=float64 evaluates the same graph in double (noise-floor reference of the wide fixture; x must be double too)."""
     p = f"prior.transformer._attn_mods.{d}"
     W = spec.prior_width
-    ln0 = F.layer_norm(x.float(), (W,), w[f"{p}.ln_0.weight"], w[f"{p}.ln_0.bias"], 1e-5)
-    qkv = _conv1d_linear(ln0, w[f"{p}.attn.c_attn.w"], w[f"{p}.attn.c_attn.b"])
+    f = lambda t: t.to(dtype)  # noqa: E731
+    ln0 = F.layer_norm(f(x), (W,), f(w[f"{p}.ln_0.weight"]), f(w[f"{p}.ln_0.bias"]), 1e-5)
+    qkv = _conv1d_linear(ln0, w[f"{p}.attn.c_attn.w"], w[f"{p}.attn.c_attn.b"], dtype)
     q, k, v = qkv.chunk(3, dim=2)
-    att = factored_attention(q.contiguous(), k.contiguous(), v.contiguous(), [1, 2, 3][d % 3], spec.heads, spec.block_ctx)
-    a = _conv1d_linear(att, w[f"{p}.attn.c_proj.w"], w[f"{p}.attn.c_proj.b"])
+    att = factored_attention(q.contiguous(), k.contiguous(), v.contiguous(), [1, 2, 3][d % 3], spec.heads, spec.block_ctx, dtype)
+    a = _conv1d_linear(att, w[f"{p}.attn.c_proj.w"], w[f"{p}.attn.c_proj.b"], dtype)
     xa = x + a
-    ln1 = F.layer_norm(xa.float(), (W,), w[f"{p}.ln_1.weight"], w[f"{p}.ln_1.bias"], 1e-5)
-    fc = _conv1d_linear(ln1, w[f"{p}.mlp.c_fc.w"], w[f"{p}.mlp.c_fc.b"])
+    ln1 = F.layer_norm(f(xa), (W,), f(w[f"{p}.ln_1.weight"]), f(w[f"{p}.ln_1.bias"]), 1e-5)
+    fc = _conv1d_linear(ln1, w[f"{p}.mlp.c_fc.w"], w[f"{p}.mlp.c_fc.b"], dtype)
     g = fc * torch.sigmoid(1.702 * fc)
-    m = _conv1d_linear(g, w[f"{p}.mlp.c_proj.w"], w[f"{p}.mlp.c_proj.b"])
+    m = _conv1d_linear(g, w[f"{p}.mlp.c_proj.w"], w[f"{p}.mlp.c_proj.b"], dtype)
     if taps is not None:
         taps.update(ln0=ln0, qkv=qkv, att=att, xa=xa, ln1=ln1, g=g)
     return xa + m

@@ -9,6 +9,8 @@
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 // ---- 1. layout: wave (sa, sb): A has 1.0 in element slot sa of every lane-half (ha), B has 1.0 in slot sb (hb) ----
@@ -83,6 +85,8 @@ __global__ void product_kernel(const unsigned char* A, const unsigned char* B, f
 // ---- 4. issue cost (one wave per SIMD, s_memtime) and 5. sustained chip rate of MFMA mixes ----
 // MIX: 0 = 8 x f16 32x32x16 per iteration (two passes of a K=64 step for one tile: what the split kernel issues today)
 //      1 = 4 x f16 + 1 x scaled fp8 32x32x64   2 = 4 x f16 + 1 x scaled fp6 32x32x64   3 = 4 x f16 only   4 = fp8 only   5 = fp6 only
+//      6 = 16 x f16 16x16x32 (round 4: the same flops as MIX 0 through the other f16 shape, 4 independent accumulators per tile)
+//      7 = 8 x bf16 32x32x16 (round 4: the Llama / training kernels' instruction)
 template <int MIX>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, int iters, unsigned seed) {
     const int lane = threadIdx.x & 63;
@@ -95,10 +99,27 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, i
     for (int i = 0; i < 8; ++i) { a8[i] = (int)(rnd() & 0x77777777u) ; b8[i] = (int)(rnd() & 0x77777777u); }   // finite e4m3 / e2m3 codes
     f32x16 acc[4];
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 acc4[4][4];
+    for (int t = 0; t < 4; ++t) for (int q = 0; q < 4; ++q) for (int r = 0; r < 4; ++r) acc4[t][q][r] = 0.f;
+    bf16x8 ab[4], bb[4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) { ab[i][j] = (__bf16)(float)ah[i][j]; bb[i][j] = (__bf16)(float)bh[i][j]; }
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            if (MIX == 6) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc4[t][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bh[(k + q) & 3], acc4[t][q], 0, 0, 0);
+            }
+            if (MIX == 7) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab[k], bb[(k + t) & 3], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb[k], ab[(k + t) & 3], acc[t], 0, 0, 0);
+            }
             if (MIX == 0 || MIX == 1 || MIX == 2 || MIX == 3) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k], bh[(k + t) & 3], acc[t], 0, 0, 0);
@@ -114,6 +135,7 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, i
     long long t1 = __builtin_readcyclecounter();
     float sum = 0.f;
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) sum += acc[t][r];
+    for (int t = 0; t < 4; ++t) for (int q = 0; q < 4; ++q) for (int r = 0; r < 4; ++r) sum += acc4[t][q][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
@@ -152,13 +174,14 @@ static void rate(const char* name, float* dout, long long* dcyc, double flop_per
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool rates_only = argc > 1 && !strcmp(argv[1], "rates");
     float* dout;
     long long* dcyc;
     CK(hipMalloc(&dout, 1 << 22));
     CK(hipMalloc(&dcyc, 8));
     std::vector<float> h(4096);
-    for (int fmt = 0; fmt <= 2; fmt += 2) {
+    for (int fmt = 0; fmt <= 2 && !rates_only; fmt += 2) {
         if (fmt == 0) layout_kernel<0><<<4096, 64>>>(dout); else layout_kernel<2><<<4096, 64>>>(dout);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(h.data(), dout, 4096 * 4, hipMemcpyDeviceToHost));
@@ -173,7 +196,7 @@ int main() {
         }
         printf("layout fmt=%d: %s\n", fmt, ident ? "IDENTITY (A slot k pairs with the same B slot; value 1024)" : "NOT identity");
     }
-    for (int mode = 0; mode <= 6; ++mode) {
+    for (int mode = 0; mode <= 6 && !rates_only; ++mode) {
         scale_kernel<<<1, 64>>>(dout, mode);
         CK(hipDeviceSynchronize());
         std::vector<float> c(1024);
@@ -182,7 +205,7 @@ int main() {
         for (int i = 0; i < 16; ++i) printf(" %g", c[i]);
         printf(" | lane1 r0 %g lane2 r0 %g lane3 r0 %g lane32 r0..3 %g %g %g %g\n", c[16], c[32], c[48], c[32 * 16], c[32 * 16 + 1], c[32 * 16 + 2], c[32 * 16 + 3]);
     }
-    {   // full product
+    if (!rates_only) {   // full product
         std::vector<unsigned char> A(32 * 64), B(32 * 64);
         srand(1);
         for (auto& v : A) { do v = rand() & 0xff; while ((v & 0x7f) == 0x7f); }
@@ -213,5 +236,7 @@ int main() {
     rate<3>("4xf16", dout, dcyc, 4 * 4 * f16);
     rate<4>("1xfp8(K64)", dout, dcyc, 4 * 4 * f16);
     rate<5>("1xfp6(K64)", dout, dcyc, 4 * 4 * f16);
+    rate<6>("16xf16 16x16x32", dout, dcyc, 4 * 8 * f16);
+    rate<7>("8xbf16 32x32x16", dout, dcyc, 4 * 8 * f16);
     return 0;
 }

@@ -22,6 +22,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 JUKEBOX_NPZ = os.path.join(GOLDEN, "jukebox_full36.npz")
 LLAMA_NPZ = os.path.join(GOLDEN, "llama7b_full32.npz")
+WIDE_NPZ = os.path.join(GOLDEN, "jukebox_full36_wide.npz")     # round 4: more clips, a short clip, outlier weights, code table
 
 CAL_CLIP = 100000            # bench.py's calibration clip for the data-dependent codebook
 GOLD_CLIP = 0                # the clip whose codes / embedding are pinned
@@ -50,6 +51,45 @@ def jukebox_clip(i: int, hps) -> np.ndarray:
     a = R.normalize_audio(synthetic_clip(i, seconds=25.0))
     a = np.pad(a, (0, max(0, hps.sample_length - len(a))))[: hps.sample_length]
     return a.astype(np.float32)
+
+
+# --- round 4: the wide fixture (VERDICT r03 items 1 + 2) -------------------------------------------------------
+CODE_CLIPS = tuple(range(10))       # bench.py's 8 clips (rank 0: clip_indices(0, 8) = 0..7) + 2 more: C-oracle code table
+WIDE_CASES = {                      # name -> (clip kind, clip index, seconds, outlier weights?)
+    "rich": ("rich", 0, 25.0, False),        # a second spectrum (synthetic_clip_rich), full length
+    "short12": ("plain", 3, 12.0, False),    # 12 s: latent_audio_len = 4134 < 8192 (jukebox/main.py:136,154), 121 frames
+    "outlier": ("plain", 0, 25.0, True),     # clip 0 through weights with x30 outlier channels in every prior layer
+}
+HEAD_TOKENS = 1024                  # the float64 noise-floor reference covers the first 1024 tokens (16 blocks; every attention
+                                    # pattern of the prior is causal, so a prefix is self-contained)
+OUTLIER_CHANNELS, OUTLIER_FACTOR = 4, 30.0
+
+
+def jukebox_case_audio(kind: str, idx: int, seconds: float):
+    """Peak-normalised waveform of a wide-fixture case BEFORE padding (len < sample_length for the short case)."""
+    from llark_amd.jukebox.synthetic import synthetic_clip, synthetic_clip_rich
+    from oracle import jukebox_ref as R
+
+    gen = synthetic_clip_rich if kind == "rich" else synthetic_clip
+    return R.normalize_audio(gen(idx, seconds=seconds)).astype(np.float32)
+
+
+def add_outlier_channels(w, hps, n_ch: int = OUTLIER_CHANNELS, factor: float = OUTLIER_FACTOR, seed: int = 11):
+    """In place: the SAME `n_ch` hidden channels become outliers in every prior layer, the way trained transformers carry a few
+    persistent massive dimensions: the residual-writing columns of attn.c_proj / mlp.c_proj x factor on those channels (the
+    residual stream then holds |h| ~ 100 there next to O(1) elsewhere).  Values stay fp16-representable (Conv1D.w is fp16-valued
+    upstream).  (A first version also multiplied the LayerNorm gains: max|h| ~ 6000 and the fp32 oracle itself 7e2 away from
+    float64 -- a chaotic system, useless as a parity case.)"""
+    g = torch.Generator().manual_seed(seed)
+    ch = torch.randperm(hps.prior_width, generator=g)[:n_ch]
+    d = 0
+    while f"prior.transformer._attn_mods.{d}.ln_0.weight" in w:
+        p = f"prior.transformer._attn_mods.{d}"
+        for name in ("attn.c_proj.w", "mlp.c_proj.w"):
+            t = w[f"{p}.{name}"]
+            t[:, ch] = (t[:, ch].float() * factor).to(t.dtype)
+        d += 1
+    return [int(c) for c in ch]
 
 
 def jukebox_weights_cpu(hps, depth=None):

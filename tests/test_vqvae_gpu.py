@@ -196,3 +196,80 @@ def test_fused_encoder_full_size_clip_codes():
     assert err <= 2e-5 * scale
     exact_codes = VQVAE(hps, w, "cuda", exact=True).encode_top(a)
     assert np.array_equal(exact_codes.cpu().numpy(), codes)
+
+
+# ---------------------------------------------------------------------------------------------
+# round 4: near-tie certificate + exact window fix-up
+# ---------------------------------------------------------------------------------------------
+def test_near_tie_fixup_reproduces_exact_codes_when_everything_is_flagged(tiny_model):
+    """With a threshold that flags EVERY token, all codes come from the exact kernels run on receptive-field windows
+    (4 passes of 256 windows; windows on both clip edges and in the interior): they must equal the exact path's / the C
+    oracle's codes -- the property the fix-up rests on (position-independent fmaf chains => window value == clip value)."""
+    from llark_amd.jukebox.vqvae import VQVAE
+    from oracle import jukebox_c as C
+    hps, w, _ = tiny_model
+    audio = np.stack([_clip(hps, i, 1.6) for i in range(2)])
+    audio[1, 3000:] = 0.0                                  # silence to the end of the clip: exact ties in the tail
+    a = torch.from_numpy(audio).cuda()
+    vq = VQVAE(hps, w, "cuda", tie_e_rel=1e3)
+    assert vq.win_tokens < hps.n_ctx and vq.win_tokens >= 2 * vq.halo_tokens + 1
+    codes = vq.encode_top(a)
+    assert vq.last_near_ties == 2 * hps.n_ctx
+    ref = C.encode_codes(w, audio, hps)
+    assert np.array_equal(codes.cpu().numpy(), ref), f"{(codes.cpu().numpy() != ref).sum()} window codes differ from the C oracle"
+    # certificate off: the plain fused argmin (round 3's behaviour) still runs
+    vq0 = VQVAE(hps, w, "cuda", tie_e_rel=None)
+    c0 = vq0.encode_top(a)
+    assert c0.shape == codes.shape and vq0.last_near_ties == 0
+    # default thresholds: few tokens flagged, codes equal
+    vqd = VQVAE(hps, w, "cuda")
+    cd = vqd.encode_top(a)
+    assert np.array_equal(cd.cpu().numpy(), ref)
+    print(f"\n[near-tie] tiny: default thresholds flag {vqd.last_near_ties} of {2 * hps.n_ctx} tokens")
+
+
+def test_near_tie_list_overflow_goes_exact():
+    """More flagged tokens than the device list holds (8192 > 4096 at 5b size): the batch is re-encoded by the exact path."""
+    from llark_amd.jukebox import vqvae as V
+    from oracle import jukebox_c as C
+    hps = hparams_5b()
+    w = make_vqvae_weights(hps, 0)
+    calib = C.encoder_forward(w, _clip(hps, 100, 25.0)[None], hps)
+    w["bottleneck.level_blocks.2.k"] = init_codebook_from_encodings(torch.from_numpy(calib), hps.l_bins)
+    a = torch.from_numpy(_clip(hps, 1, 25.0)[None]).cuda()
+    vq = V.VQVAE(hps, w, "cuda", tie_e_rel=1e3)
+    codes = vq.encode_top(a)
+    assert vq.last_near_ties == hps.n_ctx > V.TIE_LIST_CAP
+    assert torch.equal(codes, V.VQVAE(hps, w, "cuda", exact=True).encode_top(a))
+
+
+def test_default_encoder_codes_equal_c_oracle_on_bench_clips():
+    """THE parity bar of the benchmarked encoder (integer work -> exact): the default path (fused stages + near-tie
+    certificate) on bench.py's own 8 clips (rank 0: clips 0..7, one batch of 8 like the bench) + 2 more gives the C oracle's
+    codes (tests/golden/jukebox_full36_wide.npz, made by tests/golden/make_jukebox_wide_golden.py) with 0 mismatches.  The
+    fused argmin alone (certificate off) is counted next to it."""
+    import fulldepth as FD
+    from llark_amd.jukebox.vqvae import VQVAE
+    z = np.load(FD.WIDE_NPZ)
+    hps = FD.jukebox_hps()
+    w = make_vqvae_weights(hps, 0)
+    vq = VQVAE(hps, w, "cuda")
+    cal = torch.from_numpy(FD.jukebox_clip(FD.CAL_CLIP, hps)).cuda()[None, None, :]
+    k = FD.codebook_from_encoding(vq.encoder_forward(cal)[0].cpu(), hps)
+    assert FD.sha(k.numpy()) == str(z["codebook_sha"])
+    vq.set_codebook(k)
+    raw = VQVAE(hps, {**w, "bottleneck.level_blocks.2.k": k}, "cuda", tie_e_rel=None)
+    clips = [int(c) for c in z["codes10_clips"]]
+    gold = z["codes10"].astype(np.int64)
+    total_flag = total_raw_mismatch = 0
+    for lo, hi in ((0, 8), (8, 10)):
+        a = torch.from_numpy(np.stack([FD.jukebox_clip(i, hps) for i in clips[lo:hi]])).cuda()
+        got = vq.encode_top(a).cpu().numpy()
+        bad = int((got != gold[lo:hi]).sum())
+        r = int((raw.encode_top(a).cpu().numpy() != gold[lo:hi]).sum())
+        print(f"\n[near-tie] clips {clips[lo:hi]}: {vq.last_near_ties} of {got.size} tokens re-evaluated exactly; mismatches vs the C oracle: "
+              f"{bad} (fused argmin without the certificate: {r})")
+        total_flag += vq.last_near_ties
+        total_raw_mismatch += r
+        assert bad == 0, f"{bad} codes differ from the C oracle on clips {clips[lo:hi]}"
+    assert total_flag < 0.01 * gold.size, "the certificate flags more than 1 % of the tokens: thresholds far too wide"
