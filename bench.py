@@ -144,9 +144,25 @@ def build_workload(args, device):
     return hps, weights, enc, audio, llm
 
 
+def _median_time(fn, warm: int, reps: int):
+    """BASELINE.md section 2 protocol, bounded: `warm` untimed + `reps` timed calls -> (median, min) seconds."""
+    import statistics
+
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+    return statistics.median(ts), min(ts)
+
+
 def cpu_baseline(hps, weights, args):
-    """The CPU oracle on the host cores, bounded sample: 1 clip through the VQ-VAE (bit-exact C
-    restatement, OpenMP) + `cpu_layers` prior layers (torch fp32), extrapolated to 36 layers."""
+    """The CPU oracle on the host cores, bounded sample, per stage `cpu_warm` warm-up + `cpu_reps` timed runs, MEDIAN
+    (BASELINE.md section 2): 1 clip through the VQ-VAE (bit-exact C restatement, OpenMP) + `cpu_layers` prior layers (torch
+    fp32) extrapolated to 36 (+ the Llama legs of cpu_baseline_llm).  Returns the baseline dict; its "parts" (seconds per
+    clip and stage) also feed the generate leg."""
     from llark_amd.jukebox.synthetic import synthetic_clip
     from oracle import jukebox_c as C
     from oracle import jukebox_ref as R
@@ -158,29 +174,40 @@ def cpu_baseline(hps, weights, args):
     a = np.pad(a, (0, max(0, hps.sample_length - len(a))))[: hps.sample_length].astype(np.float32)
     wc = {k: v.detach().float().cpu() if not k.endswith(".w") else v.detach().cpu() for k, v in weights.items()
           if not k.startswith("prior.transformer") or int(k.split(".")[3]) < args.cpu_layers}
-    t0 = time.time()
-    z = torch.from_numpy(C.encode_codes(wc, a[None], hps))
-    t_enc = time.time() - t0
+    box = {}
+
+    def enc():
+        box["z"] = torch.from_numpy(C.encode_codes(wc, a[None], hps))
+
+    t_enc, t_enc_min = _median_time(enc, 0, args.cpu_reps)
     x_cond, y_cond = R.get_cond(wc, hps)
-    h = R.prior_embed(wc, z, x_cond, y_cond, hps)
-    t0 = time.time()
-    for d in range(args.cpu_layers):
-        h = R.prior_layer(wc, h, d, hps)
-    t_layers = time.time() - t0
+    h0 = R.prior_embed(wc, box["z"], x_cond, y_cond, hps)
+
+    def layers():
+        h = h0
+        for d in range(args.cpu_layers):
+            h = R.prior_layer(wc, h, d, hps)
+
+    t_layers, t_layers_min = _median_time(layers, args.cpu_warm, args.cpu_reps)
     t_prior = t_layers / args.cpu_layers * hps.prior_depth
     total = t_enc + t_prior
-    sample = (f"1 clip: VQ-VAE encode (C oracle, {t_enc:.2f}s) + {args.cpu_layers} of {hps.prior_depth} prior layers "
-              f"(torch fp32, {t_layers:.2f}s) extrapolated to {hps.prior_depth}")
+    proto = f"{args.cpu_warm} warm-up + {args.cpu_reps} timed runs per stage, median (min)"
+    sample = (f"1 clip, {proto}: VQ-VAE encode (C oracle) {t_enc:.2f}s ({t_enc_min:.2f}) + {args.cpu_layers} of {hps.prior_depth} prior layers "
+              f"(torch fp32) {t_layers:.2f}s ({t_layers_min:.2f}) extrapolated to {hps.prior_depth}")
+    parts = {"vqvae_s": t_enc, "prior_s": t_prior}
     if args.stages in ("e2e", "llama", "generate"):
-        t_llm, s_llm = cpu_baseline_llm(args)
+        t_llm, s_llm, llm_parts = cpu_baseline_llm(args)
         total += t_llm
         sample += "; " + s_llm
-    return {"value": 1.0 / total, "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample}
+        parts.update(llm_parts)
+    return {"value": 1.0 / total, "unit": "clips/s", "cores": cores, "kind": "port", "sample": sample,
+            "parts_s": {k: round(v, 3) for k, v in parts.items()}}
 
 
 def cpu_baseline_llm(args):
-    """Oracle Llama forward on the host: B=1, S=371, `cpu_layers` of 32 layers at full width + lm_head,
-    extrapolated to 32 layers."""
+    """Oracle Llama forward on the host: B=1, S=371, `cpu_layers` of 32 layers at full width + lm_head, extrapolated to 32
+    layers; then greedy decode steps against the oracle's KV cache (one token, same layer sample) for the generate leg.
+    Same warm-up / repeat / median protocol."""
     from llark_amd.m2t import bench_support as BS
     from oracle import llama_ref as LR
 
@@ -190,27 +217,45 @@ def cpu_baseline_llm(args):
     w = LR.make_weights(spec, seed=0, std=0.02)
     ids = BS.make_prompt_ids(1)
     aud = torch.randn(1, BS.FRAMES, 4800)
-    t0 = time.time()
-    LR.forward(w, spec, ids, aud, num_layers=0)
-    t_head = time.time() - t0
-    t0 = time.time()
-    LR.forward(w, spec, ids, aud)
-    t_all = time.time() - t0
+    box = {}
+
+    def head():
+        LR.forward(w, spec, ids, aud, num_layers=0)
+
+    def full():
+        box["out"] = LR.forward(w, spec, ids, aud)
+
+    t_head, t_head_min = _median_time(head, args.cpu_warm, args.cpu_reps)
+    t_all, t_all_min = _median_time(full, args.cpu_warm, args.cpu_reps)
     t_layers = max(t_all - t_head, 1e-6)
     total = t_head + t_layers / layers * 32
-    return total, (f"Llama fwd B=1 S=371 fp32 oracle: embed+projector+lm_head {t_head:.2f}s + {layers} of 32 layers "
-                   f"{t_layers:.2f}s extrapolated to 32")
+    past = box["out"]["past_key_values"]
+    nxt = box["out"]["logits"][:, -1].argmax(-1, keepdim=True)
+
+    def dec_head():
+        LR.forward(w, spec, nxt, None, num_layers=0)
+
+    def dec():
+        LR.forward(w, spec, nxt, None, past_key_values=past)
+
+    t_dh, _ = _median_time(dec_head, 1, args.cpu_reps)
+    t_d, t_d_min = _median_time(dec, 1, args.cpu_reps)
+    t_tok = t_dh + max(t_d - t_dh, 1e-6) / layers * 32
+    return total, (f"Llama fwd B=1 S=371 fp32 oracle: embed+projector+lm_head {t_head:.2f}s ({t_head_min:.2f}) + {layers} of 32 layers "
+                   f"{t_layers:.2f}s extrapolated to 32; one cached decode step {t_tok:.2f}s (head {t_dh:.2f}s + {layers} layers {max(t_d - t_dh, 0):.2f}s x 32/{layers})"), \
+        {"llama_prefill_s": total, "llama_decode_token_s": t_tok}
 
 
-def cpu_baseline_train(args):
+def cpu_baseline_train(args, layers=None):
     """Oracle training step on the host (torch fp32 autograd over oracle/llama_ref.py): 1 clip, S = train_seq,
-    `cpu_layers` of 32 layers + lm_head, extrapolated to 32 layers (optimizer step excluded)."""
+    `cpu_layers` of 32 layers + lm_head, extrapolated to 32 layers (optimizer step excluded).  One timed pass each (a pass is
+    tens of seconds at S = 2048: the bounded-sample rule of the bench contract wins over the repeat count here)."""
     import os
 
     from llark_amd.m2t import bench_support as BS
     from oracle import llama_ref as LR
 
-    layers = max(1, args.cpu_layers)
+    layers = max(1, layers or args.cpu_layers)
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     spec = LR.LlamaSpec(num_hidden_layers=layers, vocab_size=BS.VOCAB, audio_start_token=BS.START, audio_end_token=BS.END,
@@ -326,6 +371,89 @@ def cpu_baseline_clap(wl):
             "sample": f"2 clips: float64 numpy log-mel + torch fp32 HTSAT-base oracle ({dt:.2f}s)"}
 
 
+def extra_generate(args, enc, audio, llm, cpu, steps: int = 3, new_tokens: int = 64):
+    """configs[2] attached to the default line: ONE clip -> Jukebox embed -> projector -> Llama-2-7B prefill (S = 371) + 64 greedy
+    decode steps against the KV cache (m2t/generate.py path; stopping criterion off), `steps` timed repeats after one warm-up.
+    roofline: the decode steps against HBM (every weight byte once per token)."""
+    with torch.no_grad():
+        a1 = audio[:1].contiguous()
+        llm.generate(enc(a1), new_tokens, batch=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec_ms = 0.0
+        for _ in range(steps):
+            llm.generate(enc(a1), new_tokens, batch=1, time_decode=True)
+            torch.cuda.synchronize()
+            dec_ms += llm.decode_events[0].elapsed_time(llm.decode_events[1])
+        dt = (time.perf_counter() - t0) / steps
+    per_tok = dec_ms / steps / (new_tokens - 1)
+    gbs = llm.decode_weight_bytes() / (per_tok * 1e-3) / 1e9
+    out = {"metric": "clips/sec embed + prefill + %d-token greedy decode (B = 1)" % new_tokens, "value": round(1.0 / dt, 4), "unit": "clips/s",
+           "ms_per_clip": round(dt * 1e3, 2), "steps": steps, "warmup": 1, "decode_ms_per_token": round(per_tok, 4),
+           "config": {"workload": "configs[2]: 1 clip -> Jukebox embed -> projector -> Llama-2-7B prefill (S=371) + %d greedy decode steps" % new_tokens,
+                      "llm_precision": args.llm_precision, "prior_precision": args.prior_precision},
+           "roofline": {"bound": "hbm", "kernel": "decode step (weight-streaming Linears: llark_gemv16_dma / gemm_skinny_kernel)", "achieved": round(gbs, 1),
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                        "bytes_per_token": llm.decode_weight_bytes(), "note": "algorithmic bytes = every bf16 weight once per token; time = HIP events around the %d decode steps" % (new_tokens - 1)}}
+    if cpu is not None and "parts_s" in cpu and "llama_decode_token_s" in cpu["parts_s"]:
+        ps = cpu["parts_s"]
+        tot = ps["vqvae_s"] + ps["prior_s"] + ps["llama_prefill_s"] + new_tokens * ps["llama_decode_token_s"]
+        out["cpu_baseline"] = {"value": 1.0 / tot, "unit": "clips/s", "cores": cpu["cores"], "kind": "port",
+                               "sample": "the e2e line's CPU legs (embed + prefill) + %d x one cached oracle decode step (%.2f s, extrapolated from %d layers)"
+                                         % (new_tokens, ps["llama_decode_token_s"], args.cpu_layers)}
+    return out
+
+
+def extra_train(args, device, steps: int = 2):
+    """configs[3] per-GPU share at the reference recipe's micro-batch attached to the default line: 8 clips x 2048 tokens = micro-batch 2 x
+    accumulation 4 (scripts/training/train_llark.sh:25-27,40), fwd + bwd + grad-norm clip + AdamW, one warm-up + `steps` timed."""
+    import copy
+
+    from llark_amd import dist as D
+    from llark_amd.m2t import bench_support
+
+    a = copy.copy(args)
+    a.batch, a.micro_batch, a.train_seq, a.grad_comm, a.grad_checkpoint = 8, 2, 2048, "bf16", False
+    torch.cuda.reset_peak_memory_stats()
+    wl = bench_support.TrainWorkload(a, device, 1)
+    wl.trainer.time_phases = True
+    with torch.no_grad():
+        wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ev = wl.trainer.phase_events
+        fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    d = wl.dims
+    layer_bytes = (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size) * 2.0          # bf16 on the links
+    rest_bytes = (d.hidden_size * d.mm_hidden_size + 2 * d.hidden_size * 33) * 2.0
+    model = {}
+    for name, links in (("one_ring", 1), ("all_7_links", D.XGMI_LINKS_PER_GPU)):
+        tot, exposed = D.model_overlapped_exchange(bwd_ms, d.num_hidden_layers, layer_bytes, rest_bytes, 8, links)
+        model[name] = {"allreduce_ms_at_8": round(tot, 1), "exposed_ms": round(exposed, 1)}
+    out = {"metric": "clips/sec instruction-tuning step (fwd+bwd+grad-norm clip+AdamW), per GPU", "value": round(a.batch / dt, 4), "unit": "clips/s",
+           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": 1, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+           "config": {"workload": "configs[3] per-GPU share: 8 clips x 2048 tokens = micro-batch 2 x accumulation 4, random-init Llama-2-7B + projector on "
+                                  "frozen features; bf16 (fp32 accumulate, fp32 grads + AdamW moments)", "n_gpus": 1},
+           "mfu": round(wl.model_flops_per_step() / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+           "roofline": {"bound": "mfma", "kernel": "whole step (6 x layer params x tokens + 4 x V x H x tokens)", "achieved": round(wl.model_flops_per_step() / dt / 1e12, 1),
+                        "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(wl.model_flops_per_step() / dt / (PEAK_F16_MFMA_TFLOPS * 1e12), 4), "traffic": None},
+           "last_micro_batch_ms": {"forward": round(fwd_ms, 2), "backward": round(bwd_ms, 2)},
+           "allreduce_model_at_8_gpus": {"bytes_bf16": layer_bytes * d.num_hidden_layers + rest_bytes,
+                                         "assumed": "MODEL, not a measurement: ring/direct all-reduce moves 2*(N-1)/N of the buffer per GPU over xGMI links of %.0f GB/s; per-layer slices "
+                                                    "issued as the measured backward of the LAST micro-batch completes them (llark_amd.dist.model_overlapped_exchange)" % D.XGMI_LINK_GBS,
+                                         **model}}
+    if not args.no_cpu_baseline:
+        a.cpu_layers = 1
+        out["cpu_baseline"] = cpu_baseline_train(a, layers=1)
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -347,6 +475,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the second pass that times the prior in the other precision")
     ap.add_argument("--cpu-layers", type=int, default=2)
+    ap.add_argument("--cpu-warm", type=int, default=1, help="cpu_baseline: untimed warm-up runs per stage (BASELINE.md section 2 asks for 3; bounded to keep the default run within minutes)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="cpu_baseline: timed runs per stage, the median is reported (BASELINE.md section 2: 5)")
+    ap.add_argument("--no-extras", action="store_true", help="e2e: skip the configs[2] (generate) and configs[3] (train) legs attached as `extra`")
     ap.add_argument("--prior-precision", default=None, choices=["lo8", "f16x2"],
                     help="how the prior's Conv1D products carry the fp32 activation: f16x2 (library default) = fp16 hi + fp16 lo planes, two "
                          "fp16 MFMA passes, 22 significant bits, 36-layer embedding max-abs-err 5.4e-5; lo8 (opt-in) = fp16 hi plane + E4M3 "
@@ -532,6 +663,36 @@ def main():
                 "note": ("opt-in mode, narrower than the reference's fp32 activations: 36-layer B=8 embedding max-abs-err 5.1e-4 (> the 1e-4 of "
                          "configs[1]; tests/test_fulldepth_gpu.py) -- reported next to the headline, never as it") if other == "lo8" else
                         "the library default (22-bit activations; full-depth embedding max-abs-err 5.4e-5 <= 1e-4)"}
+        if args.stages in ("e2e", "jukebox") and enc is not None and world == 1:
+            # parity of the benchmarked encoder on the bench's own clips, outside the timed region: the default path (fused stages +
+            # near-tie certificate, whose fix-up ran INSIDE the timed region above) against the exact per-layer kernels
+            from llark_amd.jukebox.vqvae import VQVAE
+
+            with torch.no_grad():
+                vq = enc.vqvae
+                got = vq.encode_top(audio)
+                ties = vq.last_near_ties
+                ex = VQVAE(hps, weights, device, exact=True)
+                ex.set_codebook(vq.k)
+                line["vq_codes"] = {"code_mismatches_vs_exact": int((got != ex.encode_top(audio)).sum()), "tokens": int(got.numel()),
+                                    "near_tie_tokens_reevaluated_exactly": int(ties), "tie_e_rel": vq.tie_e_rel, "tie_ulps": vq.tie_ulps,
+                                    "note": "default encoder = fused split-fp16 stages + near-tie certificate; flagged tokens are re-evaluated by the exact "
+                                            "kernels on receptive-field windows inside the timed region (roofline_conv includes it)"}
+                del ex
+        if args.stages == "e2e" and world == 1 and not args.no_extras and not (args.tiny or args.depth or args.llm_layers):
+            line["extra"] = {}
+            try:
+                line["extra"]["generate"] = extra_generate(args, enc, audio, llm, cpu)
+            except Exception as e:  # noqa: BLE001 -- an extra leg must not take the headline line down with it
+                line["extra"]["generate"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                del enc, llm
+                step = None
+                torch.cuda.empty_cache()
+                line["extra"]["train"] = extra_train(args, device)
+            except Exception as e:  # noqa: BLE001
+                line["extra"]["train"] = {"error": f"{type(e).__name__}: {e}"}
+            llm = None
         if args.stages in ("train", "mpt-train"):
             line["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated() / 2**30, 1)
         if args.stages == "train":

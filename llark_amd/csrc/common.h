@@ -23,6 +23,27 @@ inline int check_launch(const char* what) {
     return LLARK_OK;
 }
 
+// One-time setup per (call site, device).  hipFuncSetAttribute acts on the CURRENT device's function object and the
+// occupancy / CU-count queries answer for the current device, so a process that drives several GPUs has to repeat them per
+// device (one process per GPU is the supported flow, this keeps single-process multi-GPU use from failing at launch).
+struct PerDeviceOnce {
+    bool done[64] = {};
+    int value[64] = {};                     // optional per-device result of the setup (e.g. resident workgroups per CU)
+    int dev = 0;                            // device of the last first() / slot() call
+    // true the first time it is called while a given device is current (ids outside 0..63: every time)
+    bool first() {
+        dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+            dev = 0;
+            return true;
+        }
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+    int& slot() { return value[dev]; }
+};
+
 #define LLARK_REQUIRE(cond, ...)                 \
     do {                                         \
         if (!(cond)) {                           \

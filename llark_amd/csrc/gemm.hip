@@ -214,13 +214,14 @@ template <typename T, bool SPLIT, int EPI, typename C>
 static int launch_gemm_persist(GemmParams p, hipStream_t s, llark_workspace* ws) {
     constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
     auto kern = gemm_persist_kernel<T, SPLIT, EPI, C>;
-    static int per_cu = -1;                                        // resident workgroups per CU of THIS instantiation: a property of
-    if (per_cu < 0) {                                              // the code object (same on every gfx950 device), 0 = unusable
+    static PerDeviceOnce once;                                     // resident workgroups per CU of THIS instantiation, per device
+    if (once.first()) {                                            // (0 = unusable)
         int n = 0;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, C::THREADS, LDS) != hipSuccess) n = 0;
-        per_cu = n;
+        once.slot() = n;
     }
+    const int per_cu = once.slot();
     if (!ws || ws->cus % 8) return -1000;
     const int grid = per_cu * ws->cus;
     p.tiles_m = cdiv(p.M, C::BM);
@@ -238,10 +239,9 @@ static int launch_gemm(GemmParams p, hipStream_t s) {
     constexpr int LDS = C::NSTAGE * ((SPLIT ? 2 : 1) * C::A_BYTES + C::B_BYTES);
     static_assert(LDS <= 160 * 1024, "tile does not fit the 160 KiB LDS");
     auto kern = gemm_kernel<T, SPLIT, EPI, C>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
@@ -443,10 +443,9 @@ template <typename T, bool SPLIT, int EPI, typename C>
 static int launch_gemm_bd(GemmParams p, hipStream_t s) {
     constexpr int LDS = 2 * (SPLIT ? 2 : 1) * C::A_BYTES;
     auto kern = gemm_bd_kernel<T, SPLIT, EPI, C>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
@@ -708,13 +707,14 @@ template <typename T, bool SPLIT, int EPI, typename C>
 static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long long scratch_bytes, bool uniform) {
     constexpr int LDS = 2 * (SPLIT ? 2 : 1) * C::A_BYTES;
     auto kern = gemm_bd_sk_kernel<T, SPLIT, EPI, C>;
-    static int per_cu = -1;                                        // resident workgroups per CU: a property of the code object
-    if (per_cu < 0) {
+    static PerDeviceOnce once;                                     // resident workgroups per CU, per device
+    if (once.first()) {
         int n = 0;
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, C::THREADS, LDS) != hipSuccess) n = 0;
-        per_cu = n;
+        once.slot() = n;
     }
+    const int per_cu = once.slot();
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
     const int S = per_cu * cus;

@@ -232,10 +232,9 @@ template <typename T, int EPI>
 static int launch256(GemmParams p, hipStream_t s, int cus) {
     typedef Cfg256 C;
     auto kern = gemm256_kernel<T, EPI>;
-    static bool attr_set = false;                // a property of the code object, not of a device or a stream
-    if (!attr_set) {
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
-        attr_set = true;
     }
     if (cus <= 0 || cus % 8) return -1000;
     p.tiles_m = cdiv(p.M, C::BM);

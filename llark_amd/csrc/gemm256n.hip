@@ -413,10 +413,9 @@ template <typename T, int EPI>
 static int launch256n(GemmParams p, hipStream_t s, int cus) {
     typedef Cfg256NF C;
     auto kern = gemm256n_kernel<T, EPI>;
-    static bool attr_set = false;                // a property of the code object, not of a device or a stream
-    if (!attr_set) {
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
-        attr_set = true;
     }
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);

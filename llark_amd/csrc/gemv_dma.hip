@@ -275,7 +275,8 @@ static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     const int lds = GV_WAVES * (XREG ? 16 : 12) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
     if (lds > 160 * 1024) return -1000;
     auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM, NPCM>;
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    static PerDeviceOnce once;                           // the whole 160 KiB once per (instantiation, device), not per launch
+    if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     kern<<<blocks, GV_WAVES * 64, lds, s>>>(p);
     return check_launch("gemv16_dma");
 }
@@ -295,13 +296,13 @@ static int dispatch_gemv_m(const GemvParams& p, hipStream_t s, int cus) {
 using namespace llark;
 
 static int gemv_device_cus() {
-    static int cus = 0;                                  // a property of the device, not state: queried once
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
+    static PerDeviceOnce once;                           // a property of the device, not state: queried once per device
+    if (once.first()) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, once.dev) != hipSuccess || n <= 0) n = 256;
+        once.slot() = n;
     }
-    return cus;
+    return once.slot();
 }
 
 // c[m][n] = sum_k a[m][k] wt[n][k] (+ bias[n]) for m <= 4 rows, bf16 operands (a as hi + optional lo plane), fp32 accumulate:

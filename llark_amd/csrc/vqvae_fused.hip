@@ -365,13 +365,12 @@ static int launch_vq_stage_n(const VqStageParams& p, hipStream_t s) {
     constexpr int P = NTW * 8 * 32;
     constexpr int lds = (P + 64) * VF_ROW;
     static_assert(lds <= 160 * 1024, "window + guard rows must fit the LDS");
-    static bool attr_set = false;                // a property of the code object
-    if (!attr_set) {
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("vqvae_stage: cannot raise the dynamic LDS limit");
             return LLARK_ERR_LAUNCH;
         }
-        attr_set = true;
     }
     dim3 grid(cdiv(p.t, P - 2 * VF_HALO), p.n);
     kern<<<grid, 512, lds, s>>>(p);

@@ -157,3 +157,34 @@ def all_reduce_sum_async(buf: torch.Tensor, comm_dtype: torch.dtype = torch.floa
         staged = stage.view(buf.shape)
         staged.copy_(buf)
     return _Exchange(dist.all_reduce(staged, op=dist.ReduceOp.SUM, async_op=True), buf, staged)
+
+
+# ---------------------------------------------------------------------------------------------
+# Model of the gradient exchange on an 8-GPU xGMI node (no such node is reachable from the build; the driver measures it)
+# ---------------------------------------------------------------------------------------------
+XGMI_LINKS_PER_GPU = 7          # MI355X: one link to each of the 7 peers of an 8-GPU node
+XGMI_LINK_GBS = 153.0           # per link and direction (task statement: 7 links x ~153 GB/s per GPU)
+
+
+def model_allreduce_ms(nbytes: float, world: int = 8, links: int = 1, link_gbs: float = XGMI_LINK_GBS) -> float:
+    """Bandwidth term of a SUM all-reduce (reduce-scatter + all-gather): every GPU sends 2 (N - 1) / N of the buffer; with
+    `links` of its xGMI links busy at once (1 = a single ring, 7 = every link: seven edge-disjoint rings or the direct
+    algorithm on the fully connected node) that takes 2 (N - 1) / N * bytes / (links * link_gbs).  Latency terms ignored."""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * nbytes / (links * link_gbs * 1e9) * 1e3
+
+
+def model_overlapped_exchange(backward_ms: float, layers: int, layer_bytes: float, rest_bytes: float, world: int = 8, links: int = 1,
+                              link_gbs: float = XGMI_LINK_GBS):
+    """The trainer's schedule replayed on that model: layer i's slice becomes ready when its backward completes (layers are
+    differentiated last to first at an even pace over `backward_ms`), slices go over the links one after another, the rest
+    (embedding rows, norms, projector) after the last layer.  Returns (total exchange ms, ms of it that ends AFTER the backward =
+    what allreduce_grads() would wait for)."""
+    t_link = 0.0
+    per = model_allreduce_ms(layer_bytes, world, links, link_gbs)
+    for k in range(layers):                               # k-th slice to become ready
+        ready = backward_ms * (k + 1) / layers
+        t_link = max(t_link, ready) + per
+    t_link = max(t_link, backward_ms) + model_allreduce_ms(rest_bytes, world, links, link_gbs)
+    return per * layers + model_allreduce_ms(rest_bytes, world, links, link_gbs), max(0.0, t_link - backward_ms)

@@ -16,12 +16,19 @@ from .. import ops
 from .hparams import JukeboxHParams
 
 # Near-tie certificate of the fused encoder (csrc/vqvae.hip: llark_codebook_argmin_tie).  A token is re-evaluated exactly when its
-# best / second-best codebook gap is below  |x| (4 TIE_E_REL sqrt(d_best) + TIE_ULPS 2^-23 |x|):
-#   TIE_E_REL  bound on |x_fused - x_exact|_2 / |x|_2 per token (the fused stages reproduce the encoder output to fp32
-#              accumulation-order noise; measured in profiles/r04_vq_near_tie_stats.txt),
-#   TIE_ULPS   slack, in ulps of |x|^2, for the fp32 rounding of the distance chains (the oracle's own evaluation and this one).
-TIE_E_REL = 2.0e-6
-TIE_ULPS = 16.0
+# best / second-best codebook gap is below  |x| (4 TIE_E_REL sqrt(d_best) + TIE_ULPS 2^-23 |x|).  What the two terms cover, measured
+# over 81 920 tokens of 10 full-size clips (profiles/r04_vq_near_tie_stats.txt; |x| ~ 72, sqrt(d_best) ~ 25, gaps ~ 1e-2 .. 1e2):
+#   * the fused stages' output error e = x_fused - x_exact (fp32 accumulation-order noise): |e| / |x| median 1.06e-6, max 2.07e-6;
+#     it moves the gap of a code pair by 2 e.(k_b - k_a): rms 4.4e-4, max 2.8e-3 (Cauchy-Schwarz, 4 |e| sqrt(d), would allow
+#     1.5e-2: e is not aligned with k_b - k_a);
+#   * the fp32 rounding of the distance chain (xx - 2 dot) + kk at |x|^2 ~ 6000 (ulp 4.9e-4), in the oracle's evaluation AND in this
+#     one: rms 1.5e-3 per distance, max 6.9e-3 -> 3.0e-3 rms on the difference of two gaps.  THIS is the larger term: every one of
+#     the 4 codes (of 65 536) the bare fused argmin gets wrong sits at an exact gap <= 1.3e-3.
+# Together sigma = 3.0e-3; the defaults put the threshold at 2.0e-2 = 6.7 sigma (4 TIE_E_REL |x| sqrt(d) = 1.17e-2 = 4.2x the largest
+# movement observed, TIE_ULPS ulps = 0.86e-2): ~50 of 65 536 tokens are re-evaluated, and with ~3300 tokens per unit of gap the
+# expected number of unresolved flips is ~1e-10 per 8-clip batch.  Wider is safer and slower (15 us per token).
+TIE_E_REL = 1.5e-6
+TIE_ULPS = 12.0
 TIE_LIST_CAP = 4096          # flagged tokens per encode_top call the device list can hold; beyond it the whole batch goes exact
 TIE_CHUNK = 256              # windows re-evaluated per pass (bounds the scratch: 256 windows x 32 channels x 11264 positions fp32)
 
@@ -61,7 +68,7 @@ class VQVAE:
         self.exact = bool(exact)
         self.tie_e_rel = None if tie_e_rel is None else float(tie_e_rel)
         self.tie_ulps = float(tie_ulps)
-        self.halo_tokens = receptive_halo_tokens(hps) + 2
+        self.halo_tokens = receptive_halo_tokens(hps) + 1
         self.win_tokens = min(hps.n_ctx, -(-(2 * self.halo_tokens + 1) // 8) * 8)
         self.last_near_ties = 0                # tokens the last encode_top call re-evaluated exactly
         self.near_ties_total = 0

@@ -55,24 +55,32 @@ class LLMWorkload:
         segs = [(b, 1, emb[b]) for b in range(self.batch)]
         return self.engine.forward_tokens(self.ids, segs)
 
-    def generate(self, emb, new_tokens: int):
+    def generate(self, emb, new_tokens: int, batch=None, time_decode: bool = False):
         """BASELINE configs[2]: prefill (prompt + audio) then `new_tokens` greedy decode steps against the KV cache
-        (argmax on device, stopping criterion disabled for timing -- SURVEY 8d)."""
-        logits = self.forward_last(emb)
+        (argmax on device, stopping criterion disabled for timing -- SURVEY 8d).  batch < self.batch runs the first `batch`
+        prompts (the e2e bench attaches a B = 1 generate leg to its line); time_decode brackets the decode steps with one HIP
+        event pair (``self.decode_events``)."""
+        logits = self.forward_last(emb, batch)
         nxt = logits[:, -1].argmax(-1, keepdim=True)
         out = [nxt]
+        if time_decode:
+            self.decode_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.decode_events[0].record()
         for _ in range(new_tokens - 1):
             logits = self.engine.forward_tokens(nxt, (), pos0=self.engine.cur_len, last_only=True)
             nxt = logits[:, -1].argmax(-1, keepdim=True)
             out.append(nxt)
+        if time_decode:
+            self.decode_events[1].record()
         return torch.cat(out, dim=1)
 
-    def forward_last(self, emb):
+    def forward_last(self, emb, batch=None):
+        b = self.batch if batch is None else batch
         if emb is None:
             self.forward(None)                                   # creates the N(0,1) stand-in
             emb = self._rand_emb
-        segs = [(b, 1, emb[b]) for b in range(self.batch)]
-        return self.engine.forward_tokens(self.ids, segs, last_only=True)
+        segs = [(i, 1, emb[i]) for i in range(b)]
+        return self.engine.forward_tokens(self.ids[:b], segs, last_only=True)
 
     def decode_weight_bytes(self) -> float:
         d = self.dims
@@ -158,11 +166,12 @@ class TrainWorkload:
         return 3.0 * per_layer * d.num_hidden_layers + 2.0 * 2.0 * rows * d.hidden_size * d.vocab_size
 
     def model_flops_per_step(self) -> float:
-        """The usual MFU numerator: 6 x parameters x tokens (fwd + bwd of every weight matrix incl. lm_head, no attention term,
-        no recompute)."""
+        """MFU numerator: 6 x (decoder-layer parameters) x tokens + 4 x V x H x tokens -- every layer matrix has forward + dX + dW,
+        the frozen lm_head forward + dX only, embed_tokens is a gather (no GEMM); no attention term, no recompute.  (Rounds 1-3
+        used the conventional 6 x ALL parameters incl. embedding and lm_head: 2.6 % higher at 7B.)"""
         d = self.dims
-        params = d.num_hidden_layers * (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size) + 2 * d.vocab_size * d.hidden_size
-        return 6.0 * params * self.micro * self.accum * self.seq
+        layer_params = d.num_hidden_layers * (4 * d.hidden_size * d.hidden_size + 3 * d.hidden_size * d.intermediate_size)
+        return (6.0 * layer_params + 4.0 * d.vocab_size * d.hidden_size) * self.micro * self.accum * self.seq
 
     def roofline(self, timers, args):
         if "gemm_bf16" not in timers:

@@ -105,7 +105,7 @@ class HipLlamaEngine:
         # it derives rstd and the hi / lo planes itself under the weight stream that is already flowing: that form (B = 1, weights
         # >= 64 MB: q/k/v, gate/up, lm_head) is the default ("auto"); "1" forces the fusion for every decode shape (the MFMA skinny
         # kernel's per-k-step form for the others), "0" switches it off.
-        self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "auto")
+        self.fuse_decode_norm_a = os.environ.get("LLARK_DECODE_FUSE_NORM_A", "auto")      # property: also takes True / False
         self.decode_graph = os.environ.get("LLARK_DECODE_GRAPH", "0") == "1"      # measured: no gain on ROCm 7.2 (kernel boundaries remain), opt-in
         # decode step as a recorded host launch list over static buffers (ops.LaunchList): removes the per-launch Python cost
         self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
@@ -346,6 +346,20 @@ class HipLlamaEngine:
         st["calls"] += 1
         self.cur_len = pos0 + 1
         return st["logits"].clone().view(B, 1, d.vocab_size)
+
+    @property
+    def fuse_decode_norm_a(self) -> str:
+        """"auto" | "1" | "0" (see __init__); assigning a bool means "1" / "0" (it was a bool before round 3)."""
+        return self._fuse_decode_norm_a
+
+    @fuse_decode_norm_a.setter
+    def fuse_decode_norm_a(self, v) -> None:
+        if isinstance(v, bool):
+            v = "1" if v else "0"
+        v = str(v).strip().lower()
+        if v not in ("auto", "1", "0"):
+            raise ValueError(f"fuse_decode_norm_a must be 'auto', '1', '0' or a bool, got {v!r}")
+        self._fuse_decode_norm_a = v
 
     def reset(self, batch: int) -> None:
         if self.k_cache is not None and self.k_cache.shape[1] != batch:

@@ -411,3 +411,43 @@ try:
     AutoModelForCausalLM.register(WrappedLlamav2Config, WrappedLlamav2ForCausalLM)
 except ValueError:      # already registered (module re-import)
     pass
+
+
+class WrappedLlamav2ReferenceConfig(WrappedLlamav2Config):
+    """The reference's own ``model_type`` (m2t/models/llamav2.py:42,422): a directory saved by the reference
+    (``config.json`` carrying "wrapped_llamav2") resolves to the HIP classes through ``AutoConfig`` /
+    ``AutoModelForCausalLM`` without the caller naming them."""
+
+    model_type = "wrapped_llamav2"
+
+
+class WrappedLlamav2ReferenceForCausalLM(WrappedLlamav2ForCausalLM):
+    config_class = WrappedLlamav2ReferenceConfig
+
+
+def register_reference_names(force: bool = False) -> bool:
+    """Registers the alias above -- only where it cannot collide: when the reference package is not importable (its module
+    registers the same name at import and ``AutoConfig.register`` refuses duplicates), or when forced
+    (``LLARK_REGISTER_REFERENCE_NAMES=1`` / ``force=True``).  Returns whether the alias is registered to the HIP classes."""
+    import importlib.util
+
+    if not force and os.environ.get("LLARK_REGISTER_REFERENCE_NAMES", "") != "1":
+        try:
+            if importlib.util.find_spec("m2t.models.llamav2") is not None:
+                return False
+        except (ImportError, ValueError):
+            pass
+    try:
+        AutoConfig.register("wrapped_llamav2", WrappedLlamav2ReferenceConfig)
+        AutoModelForCausalLM.register(WrappedLlamav2ReferenceConfig, WrappedLlamav2ReferenceForCausalLM)
+    except ValueError:
+        from transformers.models.auto.configuration_auto import CONFIG_MAPPING
+
+        try:
+            return CONFIG_MAPPING["wrapped_llamav2"] is WrappedLlamav2ReferenceConfig
+        except KeyError:
+            return False
+    return True
+
+
+register_reference_names()

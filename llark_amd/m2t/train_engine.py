@@ -97,6 +97,8 @@ class HipLlamaTrainer:
         self._norm_spans: List[Tuple[int, int]] = []
         self._last_sumsq: Optional[torch.Tensor] = None
         self._exchange_events: list = []
+        self.time_phases = False                  # True: forward_backward leaves (start, forward done, backward done) HIP events in phase_events
+        self.phase_events: Optional[list] = None
 
     # ------------------------------------------------------------------------------------------
     def zero_grad(self) -> None:
@@ -214,7 +216,13 @@ class HipLlamaTrainer:
             if self._norm_acc is None:
                 self._norm_acc = torch.zeros((1,), dtype=torch.float64, device=self.flat_grad.device)
             self._norm_acc.zero_()
-            self._norm_spans = []
+        # a collecting call starts from scratch; any OTHER call adds to gradients whose squares an earlier collecting call may
+        # have summed: those partial sums are stale either way
+        self._norm_spans = []
+        ev = None
+        if getattr(self, "time_phases", False) and self.flat_grad.is_cuda:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]        # start | forward done | backward done
+            ev[0].record()
         rows = B * S
         H, I, nh, hd, V = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim, d.vocab_size
         f32 = dict(dtype=torch.float32, device=dev)
@@ -271,6 +279,8 @@ class HipLlamaTrainer:
         loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale)
         del logits
         # ---------------- backward ----------------
+        if ev is not None:
+            ev[1].record()
         g = self.grads
         dtmp = torch.empty((rows, H), **f32)
         self._dx(dlogits, eng.lm_head, dtmp)                           # d(norm output); lm_head itself is frozen
@@ -352,6 +362,9 @@ class HipLlamaTrainer:
                 ops.scatter_add_rows(tmp, ids_flat[ridx].contiguous(), g["embed"])
         self._norm_collect = False
         self.micro_batches += 1
+        if ev is not None:
+            ev[2].record()
+            self.phase_events = ev                      # of the LAST call: bench.py reads forward / backward ms of a micro-batch
         return loss
 
     # ------------------------------------------------------------------------------------------
@@ -404,6 +417,7 @@ class HipLlamaTrainer:
         if world > 1:
             from .. import dist as D
 
+            self._norm_spans = []                        # the exchange changes every gradient: sums of squares taken before it are stale
             comm = getattr(self, "grad_comm", torch.float32)
             n = self.flat_grad.numel()
             pos = 0

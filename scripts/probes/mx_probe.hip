@@ -86,7 +86,7 @@ __global__ void product_kernel(const unsigned char* A, const unsigned char* B, f
 // MIX: 0 = 8 x f16 32x32x16 per iteration (two passes of a K=64 step for one tile: what the split kernel issues today)
 //      1 = 4 x f16 + 1 x scaled fp8 32x32x64   2 = 4 x f16 + 1 x scaled fp6 32x32x64   3 = 4 x f16 only   4 = fp8 only   5 = fp6 only
 //      6 = 16 x f16 16x16x32 (round 4: the same flops as MIX 0 through the other f16 shape, 4 independent accumulators per tile)
-//      7 = 8 x bf16 32x32x16 (round 4: the Llama / training kernels' instruction)
+//      7 = 8 x bf16 32x32x16 (round 4: the Llama / training kernels' instruction)   8 = 16 x bf16 16x16x32
 template <int MIX>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, int iters, unsigned seed) {
     const int lane = threadIdx.x & 63;
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, i
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc4[t][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bh[(k + q) & 3], acc4[t][q], 0, 0, 0);
+            }
+            if (MIX == 8) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc4[t][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[k], bb[(k + q) & 3], acc4[t][q], 0, 0, 0);
             }
             if (MIX == 7) {
 #pragma unroll
@@ -238,5 +244,6 @@ int main(int argc, char** argv) {
     rate<5>("1xfp6(K64)", dout, dcyc, 4 * 4 * f16);
     rate<6>("16xf16 16x16x32", dout, dcyc, 4 * 8 * f16);
     rate<7>("8xbf16 32x32x16", dout, dcyc, 4 * 8 * f16);
+    rate<8>("16xbf16 16x16x32", dout, dcyc, 4 * 8 * f16);
     return 0;
 }

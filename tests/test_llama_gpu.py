@@ -437,13 +437,46 @@ def test_decode_fused_resid_rmsnorm_bit_identical(precision, batch):
     ids = torch.randint(3, 300, (batch, 13), generator=g).cuda()
     toks = torch.randint(3, 300, (5, batch, 1), generator=g).cuda()
     res = []
-    for fuse in ("none", "tail", "norm_a"):                 # separate launches | producer-side tail | consumer-side (default)
+    for fuse in ("none", "tail", "norm_a"):                 # separate launches | producer-side tail | consumer-side, forced for every shape
         eng = HipLlamaEngine(dims, "cuda", batch, 64, precision=precision)
         eng.load_state_dict(w)
-        eng.fuse_decode_norm, eng.fuse_decode_norm_a = fuse == "tail", fuse == "norm_a"
+        eng.fuse_decode_norm, eng.fuse_decode_norm_a = fuse == "tail", fuse == "norm_a"     # bools map to "1" / "0" (property)
+        assert eng.fuse_decode_norm_a == ("1" if fuse == "norm_a" else "0")
         eng.forward_tokens(ids)
         outs = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(5)]
         hid = eng.forward_tokens(toks[0], (), pos0=eng.cur_len, return_hidden=True).clone()
         res.append((torch.stack(outs), hid))
     for other in res[1:]:
         assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+
+
+def test_decode_auto_fused_rmsnorm_engine_level_bit_identical():
+    """the engine's DEFAULT ("auto") decode path at a width where the streaming Linear takes the fused RMSNorm
+    (B = 1, weights >= 64 MB: q/k/v, gate/up, lm_head at hidden 4096) against the same engine with the fusion off: logits and
+    hidden state bit-identical over several steps."""
+    from llark_amd import ops
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    dims = LlamaDims(num_hidden_layers=1, vocab_size=32004)
+    assert ops.gemv_dma_rmsnorm_takes(1, 3 * dims.hidden_size, dims.hidden_size) and ops.gemv_dma_rmsnorm_takes(1, dims.vocab_size, dims.hidden_size)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H, I, V = dims.hidden_size, dims.intermediate_size, dims.vocab_size
+
+    def n(*shape):
+        return (torch.randn(*shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+
+    ws = [n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I)]
+    norm = (1.0 + 0.1 * torch.randn(H, generator=g, device="cuda"))
+    glob = (n(V, H), norm.clone(), n(V, H), n(H, dims.mm_hidden_size), torch.zeros(H, device="cuda"))
+    ids = torch.randint(3, 32000, (1, 9), generator=torch.Generator().manual_seed(2)).cuda()
+    toks = torch.randint(3, 32000, (4, 1, 1), generator=torch.Generator().manual_seed(3)).cuda()
+    res = []
+    for mode in ("auto", "0"):
+        eng = HipLlamaEngine(dims, "cuda", 1, 64, precision="split")
+        eng.set_layer(0, *ws, norm.clone(), norm.clone())
+        eng.set_globals(*glob)
+        eng.fuse_decode_norm_a = mode
+        eng.forward_tokens(ids)
+        outs = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(4)]
+        res.append(torch.stack(outs))
+        del eng
+    assert torch.equal(res[0], res[1])

@@ -519,3 +519,57 @@ def test_grad_norm_clipping_matches_torch():
     tr.forward_backward(ids.cuda(), segs, labels.cuda(), last_micro_batch=True)      # partial sums nobody asks for are dropped
     tr.step()
     assert tr._norm_spans == [] and tr.last_grad_norm is None
+
+
+def test_grad_norm_bookkeeping_invalidated_by_accumulation_and_exchange(monkeypatch):
+    """the sums of squares a collecting forward_backward(last_micro_batch=True) leaves behind are only valid
+    for the gradients as they stood at its end.  (a) a later accumulating call, (b) a gradient exchange without overlap
+    (allreduce_grads(world > 1)) both change the gradients: step(max_grad_norm) must then take the norm of what is in the buffer,
+    not reuse the stale partial sums.  64 tokens per micro-batch so that the dW products take the collecting path."""
+    from llark_amd import dist as D
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    from oracle import llama_ref as LR
+    V, F, S, B = 128, 5, 32, 2
+    spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=V,
+                        mm_hidden_size=96, audio_start_token=V - 2, audio_end_token=V - 1, audio_patch_token=V - 3)
+    w = {k: _bf(v) for k, v in LR.make_weights(spec, seed=0, std=0.08).items()}
+    g = torch.Generator().manual_seed(9)
+    ids = torch.stack([torch.tensor([1] + torch.randint(3, V - 3, (3,), generator=g).tolist() + [V - 2] + [V - 3] * F + [V - 1]
+                                    + torch.randint(3, V - 3, (S - 6 - F,), generator=g).tolist()) for _ in range(B)])
+    assert ids.shape == (B, S)
+    aud = torch.randn(B, F, 96, generator=g)
+    labels = ids.clone()
+    labels[:, :12] = -100
+    dims = LlamaDims(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, vocab_size=V, mm_hidden_size=96)
+    eng = HipLlamaEngine(dims, "cuda", B, 64, precision="bf16")
+    eng.load_state_dict(w)
+    segs = [(b, 4, aud[b].cuda()) for b in range(B)]
+    tr = HipLlamaTrainer(eng, lr=1e-3, weight_decay=0.0, embed_grad_tokens=(V - 2, V - 1))
+    # (a) collect, then accumulate once more
+    tr.forward_backward(ids.cuda(), segs, labels.cuda(), 0.5, last_micro_batch=True)
+    assert tr._norm_spans, "the collecting path did not run: the test does not test anything"
+    tr.forward_backward(ids.flip(0).cuda(), [(b, 4, aud[1 - b].cuda()) for b in range(B)], labels.flip(0).cuda(), 0.5)
+    assert tr._norm_spans == []
+    tr._finalize_grads()
+    full = tr.flat_grad.double().norm().item()
+    tr.step(max_grad_norm=1e9)
+    assert abs(tr.last_grad_norm - full) <= 1e-6 * full, (tr.last_grad_norm, full)
+    # (b) collect without overlap, then an exchange over "2 ranks" (stub: the other rank holds 3x this rank's gradient)
+    class _Done:
+        def wait(self):
+            pass
+
+    def fake_all_reduce(t, comm, stage):
+        t.mul_(4.0)
+        return _Done()
+
+    monkeypatch.setattr(D, "all_reduce_sum_async", fake_all_reduce)
+    tr.forward_backward(ids.cuda(), segs, labels.cuda(), 1.0, last_micro_batch=True)
+    assert tr._norm_spans
+    tr.allreduce_grads(2)
+    assert tr._norm_spans == []
+    tr._finalize_grads()
+    full = tr.flat_grad.double().norm().item() / 2
+    tr.step(world=2, max_grad_norm=1e9)
+    assert abs(tr.last_grad_norm - full) <= 1e-6 * full, (tr.last_grad_norm, full)
