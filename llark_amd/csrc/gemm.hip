@@ -1096,6 +1096,20 @@ static int dispatch_variant(int variant, const GemmParams& p, bool split, int ep
                 case EPI_SWIGLU16: return launch_gemm<T, false, EPI_SWIGLU16, Cfg13>(p, s);
             }
             break;
+        case 32: {                                                  // gemm256n's tile on the 16x16x32 instruction (gemm256x.hip), else 31
+            if (split && ws && ws->cus % 8 == 0) {
+                GemmParams q = p;
+                const int dt = std::is_same<T, half_t>::value ? LLARK_F16 : LLARK_BF16;
+                if (ws_begin(ws, q, s) == 0) {
+                    const int rc = launch_gemm256x(q, dt, epi, s, ws->cus);
+                    if (rc != -1000) {
+                        ws_end(ws, cdiv(p.M, 256) * cdiv(p.N, 256), ws->cus / 8);
+                        return rc;
+                    }
+                }
+            }
+        }
+        [[fallthrough]];
         case 31: {                                                  // 256x256x64 split tile, phases over N with resident A fragments (gemm256n.hip), else 30
             if (split && ws && ws->cus % 8 == 0) {
                 GemmParams q = p;
@@ -1157,7 +1171,8 @@ static int pick_variant(int split, int m, int n, int kp, bool has_ws) {
     // the prior (M = clips x 8192, split fp16): 256x256x64 tile, phases over N with resident A fragments (gemm256n.hip; round 2's
     // M-split LDS ring gemm256.hip = variant 30 stays for A/B) as soon as the
     // problem has two tiles per CU -- also at B = 1 (608 tiles), so a clip's result does not depend on the batch it rides in
-    if (split && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 31;
+    // round 4: the same tile on v_mfma_f32_16x16x32 (gemm256x.hip; falls back to 31 for the shapes / epilogues it does not take)
+    if (split && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 32;
     if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
                                                   // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
     if (m >= 16384 && persist) return 20;                    // very tall products (M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)
@@ -1252,7 +1267,7 @@ extern "C" int llark_workspace_destroy(llark_workspace_t ws) {
 //   a_lo8 e4m3 [m][lda8] (bytes)   = fp8(sat((a - a_hi) * 2^sa)), every 64-k block in the slot order of lo8_pos()
 //   wt    fp16 [n][ldw]; sw such that max|W| * 2^sw <= 448
 //   w8    e4m3 [n][ldw8] (bytes) = fp8(wt * 2^sw) in the same slot order (llark_pack_weight_lo8), staged through LDS next to wt
-//         (required; the form that derived it from wt in registers lost and lives in scripts/experiments/)
+//         (required; the form that derived it from wt in registers lost: git history, scripts/experiments/ before round 4)
 // epilogue: LLARK_EPI_F32 / LLARK_EPI_RESID / LLARK_EPI_QGELU_SPLIT8 (out_hi fp16 [m][ldo], out_lo8 e4m3 [m][ldo8]).
 extern "C" int llark_gemm16_lo8(int epilogue, const void* a_hi, const void* a_lo8, int lda, int lda8, const void* wt, int ldw,
                                 const void* w8, int ldw8, const float* bias, int m, int n, int kp, int sa, int sw, float* c, int ldc, const float* resid,

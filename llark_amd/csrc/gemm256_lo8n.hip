@@ -8,7 +8,7 @@
 // pass.  All four planes stream L2 -> LDS with `buffer_load ... lds` (no VGPR round trip), 16-B chunks XOR-swizzled on the SOURCE
 // address (the DMA destination is lane-linear), counted `s_waitcnt vmcnt(N)` in front of raw `s_barrier`s so the DMA queue never
 // drains; one persistent workgroup of 8 waves per CU (160 KiB of LDS), chunk-synchronous tile order per XCD.  History of the forms
-// that lost (W8 derived in registers; phases split over M) and their sources: DESIGN.md section 4, scripts/experiments/.
+// that lost (W8 derived in registers; phases split over M) and their sources: DESIGN.md section 4 (sources: git history, scripts/experiments/ before round 4).
 // Measured on the M-split form (profiles/r02_lo8_phase_cycles.txt): a phase takes ~2200 cycles for 1536 cycles of matrix
 // work, the DMA stream is never late, and the LDS is the busiest unit: its two phases split M, so every W fragment is read in
 // BOTH phases by all four wave rows -- 480 ds_read_b128 + 96 KiB of DMA writes per K-step and CU.  Here

@@ -1,0 +1,412 @@
+// 256x256x64 split-mode GEMM tile for gfx950 (MI355X) on the 16x16x32 matrix instruction (round 4):
+//     C[M,N] = (Ahi + Alo)[M,K] . Wt[N,K]^T          (two fp16 / bf16 MFMA passes per 32-wide k sub-step, fp32 accumulate)
+//
+// The dominant kernel of the hot path in the DEFAULT precision ("f16x2"): the four Conv1D products per layer of the Jukebox top
+// prior (upstream jukebox `Conv1D.forward` = addmm, reached from jukebox/main.py:108 with fp16=False), M = clips x 8192 rows,
+// N, K in {1200, 3600, 4800}.
+//
+// Why a second form of gemm256n.hip.  Round 3 left that kernel with the matrix pipe 83 % busy at an effective 1.52 GHz: the chip
+// clocks to its power budget, and eight v_mfma_f32_32x32x16_f16 per (32 x 32 tile, 64 k) sustain 1.59 PFLOP/s on the whole chip
+// whatever the loop around them does.  Round 4 measured the OTHER fp16 shape (scripts/probes/mx_probe.hip, profiles/
+// r04_mx_probe_rates*.txt): sixteen v_mfma_f32_16x16x32_f16 for the same flops take 8.6 % more pipe cycles (17.4 instead of 16 per
+// 16 K flop) but the chip holds 1.90 GHz under them instead of 1.52 -- 1.83 .. 1.89 PFLOP/s, +15 .. 18 %.  This file is gemm256n.hip
+// with that instruction: same tile, same LDS map and rings, same LDS-DMA request / wait protocol (scripts/sim_gemm256n.py), same
+// tile order, chunk barrier and tile-to-tile overlap; what differs is everything that touches a fragment:
+//
+//  * a wave (wm, wn) still owns rows wm*64 .. +63 and, per phase, columns wn*64 .. +63 of one 128-column half, now as 4 x 4 tiles of
+//    16 x 16; a K-step's phase has TWO k sub-steps of 32 (one per half-phase) x 16 tiles x {hi, lo} = 64 MFMAs of 16 pipe cycles;
+//  * the product is computed TRANSPOSED: the weight fragment is the instruction's A operand, the activation fragment its B operand,
+//    so a lane's four accumulator registers of a tile are four CONSECUTIVE output columns of ONE row -- the epilogue loads residuals
+//    and stores results 16 bytes at a time (8 bytes for the fp16 planes) straight from the accumulators: a quarter of the store
+//    instructions of the 32x32 form, no LDS transpose;
+//  * the LDS image is unchanged: a fragment of either operand is (16 rows) x (32 k) = lane l reads the 16-byte chunk
+//    (4 s + l / 16) ^ ((l % 16) / 2) of row l % 16 -- the source-side swizzle chosen for the 32x32x16 reads ((row / 2) & 7) is
+//    conflict free for these lane groups too (every ds_read_b128 group of 16 lanes covers 16 distinct 16-byte slots of a 256-byte
+//    bank window: replayed in tests/test_gemm256x_layout_cpu.py);
+//  * fragments: A hi + lo of the whole K-step stay resident across both phases (64 registers, as before); the four weight fragments
+//    of a sub-step are single-buffered -- the pair a group of 16 MFMAs has finished with is re-read for the next sub-step in the
+//    gaps of the following group -- so the register budget is the one of gemm256n.hip.
+// Arithmetic: per accumulator and 32-wide sub-step hi then lo, k ascending.  NOT bit-identical to the 32x32x16 kernels (the
+// instruction sums 32 products per step instead of 16); parity against torch fp64 and the 36-layer oracle fixture, see
+// tests/test_prior_gpu.py and tests/test_fulldepth_gpu.py.
+#include "gemm_core.h"
+
+namespace llark {
+
+struct Cfg256X {
+    static constexpr int BK = 64, BM = 256, BN = 256, NW = 8, THREADS = 512, MINW = 2;
+    static constexpr int TM = 4, TN = 8;                         // 16 x 16 tiles per wave: 4 row tiles x (4 + 4) column tiles (half L | half R)
+    static constexpr int ROWB = 128, UNIT = 128 * ROWB;          // 16 KiB
+    static constexpr int NW_SLOTS = 3, NA_SLOTS = 7;
+    static constexpr int O_W = 0, O_A = NW_SLOTS * UNIT;         // W ring | A ring
+    static constexpr int LDS = O_A + NA_SLOTS * UNIT;            // 160 KiB
+    static_assert(LDS == 160 * 1024, "LDS map");
+};
+
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<half_t> {
+    typedef half8_t frag;
+    typedef half4_t out4;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Mfma16<bf16_t> {
+    typedef bf16x8_t frag;
+    typedef bf16x4_t out4;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+#define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+// Epilogue of the transposed 16x16 accumulators: lane l holds, for tile (tm, tn), row m = wave row + 16 tm + l % 16 and the four
+// columns n = tile column + 4 (l / 16) .. +3.  Column tile tn of half h = tn / 4 starts at h * 128 + wn * 64 + (tn % 4) * 16.
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], const int m0, const int n0,
+                                                const int wm, const int wn, const int lane) {
+    typedef Cfg256X C;
+    typedef typename Mfma16<T>::out4 out4;
+    const int l15 = lane & 15, g4 = (lane >> 4) << 2;
+    const int ncol = n0 + wn * 64 + g4;                              // + (tn / 4) * 128 + (tn % 4) * 16
+    auto coloff = [](int tn) __attribute__((always_inline)) { return (tn >> 2) * 128 + (tn & 3) * 16; };
+    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+    f32x4_t bias[C::TN];
+#pragma unroll
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const int n = ncol + coloff(tn);
+        bias[tn] = (p.bias != nullptr && (full || n < p.N)) ? *(const f32x4_t*)(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int tm = 0; tm < C::TM; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + l15;
+        const bool row_ok = full || m < p.M;
+        // residuals of the whole tile row first, all loads in flight together (R may alias C: a load placed after a store could
+        // never be hoisted above it)
+        f32x4_t res[C::TN];
+        if (EPI == EPI_RESID) {
+            const float* rrow = p.R + (size_t)m * p.ldr + ncol;
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                res[tn] = (row_ok && (full || ncol + coloff(tn) < p.N)) ? *(const f32x4_t*)(rrow + coloff(tn)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!row_ok) continue;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            if (!full && ncol + coloff(tn) >= p.N) continue;          // N % 4 == 0 (checked by the launcher): a vector is all in or all out
+            f32x4_t v = acc[tm][tn] + bias[tn];
+            if (EPI == EPI_F32) {
+                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + coloff(tn)) = v;
+            } else if (EPI == EPI_RESID) {
+                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + coloff(tn)) = res[tn] + v;
+            } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
+                out4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r];
+                    if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
+                    const T h = (T)x;
+                    hi[r] = h;
+                    lo[r] = (T)(x - (float)h);
+                }
+                const size_t o = (size_t)m * p.ldo + ncol + coloff(tn);
+                *(out4*)((T*)p.Ohi + o) = hi;
+                *(out4*)((T*)p.Olo + o) = lo;
+            }
+        }
+    }
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kernel(const GemmParams p) {
+    typedef Cfg256X C;
+    typedef typename Mfma16<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    // ---- fragment-read offsets (lane-constant).  Sub-step s reads chunk ((4 s | lg) ^ sw) of row l15 (+ 16 rows per tile): the s
+    // part only flips bit 6 of the byte offset. ----
+    const int sw = (l15 >> 1) & 7;
+    const int rd0 = l15 * C::ROWB + ((lg ^ sw) << 4);
+    const int rdA0 = C::O_A + rd0;                      // + slot of this wave's quarter; + 2048 per row tile; + 8192 lo plane
+    const int rdW0 = C::O_W + wn * 8192 + rd0;          // weight rows wn*64.. of a 128-row W half; + 2048 per column tile
+    auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+
+    // ---- LDS-DMA lane geometry: one wave instruction = 8 rows x 128 B; lane -> (row rl, 16-B slot pch) ----
+    const int rl = lane >> 3, pch = lane & 7;
+    const int dch = pch ^ ((((w & 1) << 2) + (rl >> 1)) & 7);           // chunk this lane FETCHES (swizzle on the source side)
+    const unsigned RSRC_FLAGS = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ahi, 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc((void*)p.Alo, 0, 0x7FFFFFFF, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wt, 0, 0x7FFFFFFF, RSRC_FLAGS);
+
+    const int nk = p.Kp >> 6;
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int band0, bandn;
+    xcd_band(nwg, xcd, band0, bandn);
+    const int nchunks = ((nwg >> 3) + ((nwg & 7) ? 1 : 0) + p.slots - 1) / p.slots;
+    int* cnt = p.sync + xcd * 32;
+
+    auto tile_of = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        // M-grouped tile order: 4 tile rows, N-major inside a group (a chunk of 32 tiles = 4 x 8 tiles)
+        constexpr int GM = 4;
+        const int gsz = GM * p.tiles_n;
+        const int g = bid / gsz;
+        const int first_m = g * GM;
+        const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+        m0 = (first_m + (bid % gsz) % gm) * C::BM;
+        n0 = ((bid % gsz) / gm) * C::BN;
+    };
+    unsigned voA[4], voW[4];
+    auto set_offsets = [&](int m0, int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int ra = m0 + q * 64 + w * 8 + rl;
+            ra = ra < p.M ? ra : p.M - 1;
+            voA[q] = (unsigned)ra * (unsigned)(p.lda * 2) + (unsigned)(dch << 4);
+            int rw = n0 + q * 64 + w * 8 + rl;
+            rw = rw < p.N ? rw : p.N - 1;
+            voW[q] = (unsigned)rw * (unsigned)(p.ldw * 2) + (unsigned)(dch << 4);
+        }
+    };
+    auto dma = [&](const __amdgpu_buffer_rsrc_t r, unsigned vo, int soff, int dst_off) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + dst_off), 16, vo, soff, 0, 0);
+    };
+    const int wb = w * 1024;                                      // this wave's 1 KiB piece inside every 8 KiB of a unit
+    auto issue_WL = [&](int k, int slot) __attribute__((always_inline)) {
+        dma(rW, voW[0], k << 7, C::O_W + slot * C::UNIT + wb); dma(rW, voW[1], k << 7, C::O_W + slot * C::UNIT + 8192 + wb);
+    };
+    auto issue_WR = [&](int k, int slot) __attribute__((always_inline)) {
+        dma(rW, voW[2], k << 7, C::O_W + slot * C::UNIT + wb); dma(rW, voW[3], k << 7, C::O_W + slot * C::UNIT + 8192 + wb);
+    };
+    auto wrap7 = [](int x) __attribute__((always_inline)) { return x >= C::NA_SLOTS ? x - C::NA_SLOTS : x; };
+    auto issue_Q = [&](auto j_tag, int k, int slot) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        const int b = C::O_A + slot * C::UNIT + wb;
+        dma(rAh, voA[j], k << 7, b);
+        dma(rAl, voA[j], k << 7, b + 8192);
+    };
+    auto prologue = [&]() __attribute__((always_inline)) {
+        issue_WL(0, 0);
+        issue_Q(std::integral_constant<int, 0>{}, 0, 0);
+        issue_Q(std::integral_constant<int, 1>{}, 0, 1);
+        issue_Q(std::integral_constant<int, 2>{}, 0, 2);
+        issue_Q(std::integral_constant<int, 3>{}, 0, 3);
+        issue_WR(0, 1);
+    };
+
+    bool primed = false;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int local = ch * p.slots + slot_id;
+        bool arrived = false;
+        if (local < bandn) {
+            int m0, n0;
+            tile_of(band0 + local, m0, n0);
+            // builtin waits in front of the K loop (hipcc's waitcnt pass has to SEE that only LDS-DMA requests are outstanding: see gemm256n.hip)
+            if (!primed) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                set_offsets(m0, n0);
+                prologue();
+                __builtin_amdgcn_s_waitcnt(0x0F72);                        // everything but WR(0)
+            } else {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            __builtin_amdgcn_s_barrier();
+
+            f32x4_t acc[C::TM][C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+            // activation fragments of the current K-step: [row tile][sub-step], read in phase L, reused in phase R
+            frag ah[4][2], al[4][2];
+
+            // One phase = 64 rows x 64 columns x 64 k of this wave = 2 sub-steps (= half-phases) of 32 MFMAs: two GROUPS of 16 per
+            // sub-step, group c = column tiles 2c, 2c + 1: eight hi products (tn-major) then the eight lo products, so dependent
+            // MFMAs on one accumulator are eight issue slots apart.  Everything else the wave has to issue goes ONE ITEM PER MFMA GAP
+            // behind them (gemm256n.hip's finding): the fragment reads that come next and the phase's LDS-DMA requests.
+            //   HALF 0 (L), sub-step 0: before the first MFMA the four hi activation fragments and the weight fragments of group 0;
+            //                            gaps: lo fragments (needed from MFMA 8), weights of group 1 (from MFMA 16), then the
+            //                            activation fragments of sub-step 1, the phase's four requests, and -- once group 0 is done --
+            //                            group 0's weight fragments of sub-step 1;
+            //           sub-step 1 (after the half-phase barrier): group 1's weight fragments of sub-step 1 (needed from MFMA 16),
+            //                            the two half-phase requests;
+            //   HALF 1 (R): the same without activation reads.
+            auto phase = [&](auto half_tag, auto midw_tag, int aslot, int wslot, auto&& dmaop, auto&& midop) __attribute__((always_inline)) {
+                constexpr int half = decltype(half_tag)::value, midw = decltype(midw_tag)::value;
+                const int vA = rdA0 + aslot, vW = rdW0 + wslot;
+                const int vAs[2] = {vA, opaque(vA) ^ 64};
+                const int vWs[2] = {vW, opaque(vW) ^ 64};
+                frag bf[4];
+                if (half == 0) {
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm) ah[tm][0] = *(const frag*)(smem + vAs[0] + tm * 2048);
+                }
+                bf[0] = *(const frag*)(smem + vWs[0]);
+                bf[1] = *(const frag*)(smem + vWs[0] + 2048);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<2>([&](auto sc) __attribute__((always_inline)) {
+                    constexpr int s = decltype(sc)::value;
+                    if constexpr (s == 1) {        // half-phase boundary: the other wave of the pair starts its next phase here
+                        if constexpr (midw == 6) VMCNT(6);
+                        else if constexpr (midw == 4) VMCNT(4);
+                        else if constexpr (midw == 2) VMCNT(2);
+                        else VMCNT(0);
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    static_for<32>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int grp = i >> 4, j = i & 15, lo_pass = j >> 3, tn2 = (j >> 2) & 1, tm = j & 3;
+                        constexpr int tn = 2 * grp + tn2;                                   // column tile inside the half
+                        if constexpr (lo_pass == 0) acc[tm][4 * half + tn] = Mfma16<T>::run(bf[tn], ah[tm][s], acc[tm][4 * half + tn]);
+                        else acc[tm][4 * half + tn] = Mfma16<T>::run(bf[tn], al[tm][s], acc[tm][4 * half + tn]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // ---- the gap behind MFMA i ----
+                        if constexpr (s == 0) {
+                            // after the half-phase barrier of the PREVIOUS phase the first MFMAs go out back to back (r0): the partner wave
+                            // on the SIMD is waiting for its first fragments just then
+                            constexpr int r0 = 0;
+                            if constexpr (half == 0) {
+                                if constexpr (i >= r0 && i < r0 + 4) al[i - r0][0] = *(const frag*)(smem + vAs[0] + 8192 + (i - r0) * 2048);
+                                if constexpr (i == r0 + 4) bf[2] = *(const frag*)(smem + vWs[0] + 2 * 2048);
+                                if constexpr (i == r0 + 5) bf[3] = *(const frag*)(smem + vWs[0] + 3 * 2048);
+                                if constexpr (i >= r0 + 6 && i < r0 + 10) ah[i - r0 - 6][1] = *(const frag*)(smem + vAs[1] + (i - r0 - 6) * 2048);
+                                if constexpr (i >= r0 + 10 && i < r0 + 14) al[i - r0 - 10][1] = *(const frag*)(smem + vAs[1] + 8192 + (i - r0 - 10) * 2048);
+                                // group 0 finished with bf[0], bf[1] at MFMA 15: their sub-step-1 fragments
+                                if constexpr (i == 16) bf[0] = *(const frag*)(smem + vWs[1]);
+                                if constexpr (i == 17) bf[1] = *(const frag*)(smem + vWs[1] + 2048);
+                                if constexpr (i >= 18 && i < 22) dmaop(std::integral_constant<int, i - 18>{});
+                            } else {
+                                if constexpr (i == r0) bf[2] = *(const frag*)(smem + vWs[0] + 2 * 2048);
+                                if constexpr (i == r0 + 1) bf[3] = *(const frag*)(smem + vWs[0] + 3 * 2048);
+                                if constexpr (i >= r0 + 2 && i < r0 + 6) dmaop(std::integral_constant<int, i - r0 - 2>{});
+                                if constexpr (i == 16) bf[0] = *(const frag*)(smem + vWs[1]);
+                                if constexpr (i == 17) bf[1] = *(const frag*)(smem + vWs[1] + 2048);
+                            }
+                        } else {
+                            // group 1's sub-step-1 weight fragments: bf[2], bf[3] were last used by MFMA 31 of sub-step 0
+                            if constexpr (i == 2) bf[2] = *(const frag*)(smem + vWs[1] + 2 * 2048);
+                            if constexpr (i == 3) bf[3] = *(const frag*)(smem + vWs[1] + 3 * 2048);
+                            if constexpr (i >= 4 && i < 6) midop(std::integral_constant<int, i - 4>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+            };
+
+            // One K-step: the request / wait table of gemm256n.hip's kstep(), unchanged (La = sub-step 0 of phase L, Lb = sub-step 1, ...;
+            // the activation fragments are now all read in La instead of La + Lb: reads only move EARLIER inside the slot they already
+            // started in, so every landing-before-read and no-overwrite-while-read condition of scripts/sim_gemm256n.py still holds).
+            auto kstep = [&](int k, int aq, int wL) __attribute__((always_inline)) {
+                const int kn = k + 1 < nk ? k + 1 : nk - 1;
+                const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // W slots of WR(k), WL(k+1)
+                const int an = wrap7(aq + 4);                                                            // A slot of Q0(k+1)
+                const int amine = wrap7(aq + wm) * C::UNIT;
+                auto reqQ = [&](int j, int lo_plane, int slot) __attribute__((always_inline)) {
+                    const unsigned vo = j == 0 ? voA[0] : j == 1 ? voA[1] : j == 2 ? voA[2] : voA[3];
+                    dma(lo_plane ? rAl : rAh, vo, kn << 7, C::O_A + slot * C::UNIT + wb + (lo_plane ? 8192 : 0));
+                };
+                auto reqW = [&](int right, int piece, int slot) __attribute__((always_inline)) {
+                    dma(rW, voW[2 * right + piece], kn << 7, C::O_W + slot * C::UNIT + piece * 8192 + wb);
+                };
+                // four requests per phase (L: Q0, Q1 of K-step kn; R: Q2, Q3) + two behind each half-phase barrier (L: WL(kn), R: WR(kn)).
+                // Waits: La|Lb vmcnt(4), Ra|Rb vmcnt(4), end of R vmcnt(2).
+                phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, amine, wL * C::UNIT,
+                      [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(i >> 1, i & 1, wrap7(an + (i >> 1))); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(0, decltype(ic)::value, wN); });
+                __builtin_amdgcn_s_barrier();
+                phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, amine, wR * C::UNIT,
+                      [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(2 + (i >> 1), i & 1, wrap7(an + 2 + (i >> 1))); },
+                      [&](auto ic) __attribute__((always_inline)) { reqW(1, decltype(ic)::value, wL); });
+                VMCNT(2);                                                  // Q3(kn) landed (newer: WR(kn) x2)
+                __builtin_amdgcn_s_barrier();
+            };
+
+            if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
+            {
+                int aq = 0, wL = 0;
+                for (int k = 0; k < nk; ++k) {
+                    kstep(k, aq, wL);
+                    aq = wrap7(aq + 4);
+                    wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                }
+            }
+            if (w < 4) __builtin_amdgcn_s_barrier();                       // the trailing waves' last half-phase
+            VMCNT(0);
+            __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
+            if (ch + 1 < nchunks) {
+                if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrived = true;
+                const int nl = (ch + 1) * p.slots + slot_id;
+                primed = nl < bandn;
+                if (primed) {
+                    int m1, n1;
+                    tile_of(band0 + nl, m1, n1);
+                    set_offsets(m1, n1);
+                    prologue();
+                }
+            }
+            gemm_epilogue16<T, EPI>(p, acc, m0, n0, wm, wn, lane);
+        }
+        if (ch + 1 < nchunks) {
+            if (threadIdx.x == 0) {
+                if (!arrived) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int target = p.sync_base + (ch + 1) * p.slots;
+                // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
+                for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_s_barrier();                                  // raw: a fence here would drain the next tile's prologue requests
+        }
+    }
+}
+
+template <typename T, int EPI>
+static int launch256x(GemmParams p, hipStream_t s, int cus) {
+    typedef Cfg256X C;
+    auto kern = gemm256x_kernel<T, EPI>;
+    static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
+    if (once.first()) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    p.slots = cus / 8;
+    kern<<<dim3(cus), C::THREADS, C::LDS, s>>>(p);
+    return check_launch("gemm256x");
+}
+
+template <typename T>
+static int dispatch256x(const GemmParams& p, int epi, hipStream_t s, int cus) {
+    switch (epi) {
+        case EPI_F32: return launch256x<T, EPI_F32>(p, s, cus);
+        case EPI_RESID: return launch256x<T, EPI_RESID>(p, s, cus);
+        case EPI_QGELU_SPLIT: return launch256x<T, EPI_QGELU_SPLIT>(p, s, cus);
+        case EPI_SPLIT16: if (p.act == 0 && p.Ohi2 == nullptr) return launch256x<T, EPI_SPLIT16>(p, s, cus);
+    }
+    return -1000;
+}
+
+int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus) {
+    // split mode only; >= 2 K-steps of 64; operands addressable with 32-bit byte offsets; a sync block; 8 | CUs; no batch;
+    // vector epilogue: N, ldc, ldr, ldo multiples of 4 and 16-byte (8-byte for the planes) aligned bases
+    if (!p.Alo || p.Kp % 64 != 0 || p.Kp < 128 || p.batch > 1 || !p.sync || cus <= 0 || cus % 8) return -1000;
+    if ((long long)p.M * p.lda * 2 >= (1ll << 31) || (long long)p.N * p.ldw * 2 >= (1ll << 31)) return -1000;
+    if (p.N % 4) return -1000;
+    if (p.bias && ((uintptr_t)p.bias & 15)) return -1000;
+    if ((epi == EPI_F32 || epi == EPI_RESID) && (p.ldc % 4 || ((uintptr_t)p.C & 15))) return -1000;
+    if (epi == EPI_RESID && (p.ldr % 4 || ((uintptr_t)p.R & 15))) return -1000;
+    if ((epi == EPI_QGELU_SPLIT || epi == EPI_SPLIT16) && (p.ldo % 4 || ((uintptr_t)p.Ohi & 7) || ((uintptr_t)p.Olo & 7))) return -1000;
+    if (dtype == LLARK_F16) return dispatch256x<half_t>(p, epi, s, cus);
+    if (dtype == LLARK_BF16) return dispatch256x<bf16_t>(p, epi, s, cus);
+    return -1000;
+}
+
+}  // namespace llark

@@ -308,6 +308,11 @@ int launch_gemm256(const GemmParams& p, int dtype, int epi, hipStream_t s, int c
 // tile-to-tile overlap and the two waves of a SIMD half a phase apart (the main loop of gemm256_lo8n.hip with a second fp16 pass
 // instead of the fp8 MFMA).  Bit-identical to launch_gemm256.  Returns -1000 when the problem is not one it handles.
 int launch_gemm256n(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
+// gemm256x.hip (round 4): gemm256n's tile, rings and DMA protocol on v_mfma_f32_16x16x32 (the chip sustains 1.9 GHz under it instead of
+// 1.5 under 32x32x16: profiles/r04_mx_probe_rates*.txt), product computed transposed so the epilogue stores 16 bytes per lane.  Same
+// arithmetic order per accumulator (hi then lo, k ascending) but 32 products per instruction: NOT bit-identical to the 32x32x16 kernels.
+// EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT / plain EPI_SPLIT16, N % 4 == 0.  Returns -1000 when the problem is not one it handles.
+int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
 // gemm256_lo8n.hip: the 256x256 tile with an e4m3 low plane staged through LDS (p.W8), phases split over N, A fragments resident
 // across both (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of the stream's device (8 | cus).  Returns -1000
 // when the problem is not one it handles.

@@ -129,6 +129,56 @@ def test_gemm256_ring_tile_bit_identical(m, n, k, v256):
     assert torch.equal(c2, c3)
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 3600, 1216), (2048, 4800, 4800), (515, 292, 200), (8192, 1200, 640),
+                                   (40000, 600, 448), (70000, 2500, 192), (300, 290, 256)])
+def test_gemm256x_16x16x32_tile(m, n, k):
+    """csrc/gemm256x.hip (variant 32, round 4: the prior's default): gemm256n's tile, rings and LDS-DMA protocol on
+    v_mfma_f32_16x16x32, product computed transposed, 16-byte epilogue stores.  The instruction sums 32 products per step, so it
+    is NOT bit-identical to the 32x32x16 kernels: checked against an fp64 reference within the split scheme's bound, against the
+    128x256 kernel to rounding, run-to-run bit-equal (a race in the rings would come and go), on ragged M / N, 2 .. 75 K-steps,
+    more tiles than CUs, every epilogue the prior uses, fp16 and bf16; n = 290 (n % 4 != 0) must fall back and stay right."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = torch.randn(m, n, generator=g).cuda()
+    for dt in (torch.float16, torch.bfloat16):
+        hi, lo = ops.split16(a.cuda(), dt, kmult=64)
+        wt = ops.pack_weight16(w.cuda(), True, dt, kmult=64)
+        a16 = hi.float().cpu()[:, :k].double() + lo.float().cpu()[:, :k].double()
+        w16 = wt.float().cpu()[:n, :k].double()
+        ref = a16 @ w16.t() + b.cpu().double()
+        bound = 2e-6 * (a16.abs() @ w16.abs().t()) + 1e-6
+        c0 = torch.full((m, n), float("nan"), device="cuda")
+        c1 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c0, variant=12)
+        first = None
+        for rep in range(3):
+            c1.fill_(float("nan"))
+            ops.gemm16(hi, lo, wt, b, n, ops.EPI_F32, c=c1, variant=32)
+            if first is None:
+                first = c1.clone()
+            assert torch.equal(first, c1), f"F32 {dt}: launch {rep} differs from launch 0 in {int((first != c1).sum())} elements"
+        err = (c1.cpu().double() - ref).abs()
+        assert bool((err <= bound).all()), f"gemm256x {dt} vs fp64 reference: worst excess {float((err - bound).max()):.3e}"
+        assert float((c1 - c0).abs().max()) <= 4e-6 * float(ref.abs().max()) + 1e-6
+        c1 = r.clone()
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c1, resid=c1, variant=32)                      # in place, like h += ...
+        assert bool(((c1.cpu().double() - (ref + r.cpu().double())).abs() <= bound + 1e-6).all()), "RESID epilogue"
+        o1 = [torch.full((m, n + 4), float("nan"), dtype=dt, device="cuda") for _ in range(2)]
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o1[0], out_lo=o1[1], variant=32)
+        got = o1[0][:, :n].float().cpu().double() + o1[1][:, :n].float().cpu().double()
+        want = ref * torch.sigmoid(1.702 * ref)
+        q = (2.0 ** -21 if dt == torch.float16 else 2.0 ** -16) * want.abs()                         # what a hi + lo pair of planes cannot carry
+        assert bool(((got - want).abs() <= 3.0 * bound + q + 2e-6 * want.abs() + 1e-6).all()), "QGELU_SPLIT epilogue"
+        assert bool(torch.isnan(o1[0][:, n:]).all() and torch.isnan(o1[1][:, n:]).all()), "QGELU_SPLIT wrote past column n"
+        o0 = [torch.zeros((m, n + 4), dtype=dt, device="cuda") for _ in range(2)]
+        ops.gemm16(hi, lo, wt, b, n, ops.EPI_QGELU_SPLIT, out_hi=o0[0], out_lo=o0[1], variant=12)
+        d = (o0[0][:, :n].float() + o0[1][:, :n].float()) - (o1[0][:, :n].float() + o1[1][:, :n].float())
+        assert float(d.abs().max()) <= 2.0 * float((3.0 * bound + q).max()) + 1e-6               # two correct kernels, each inside the bound
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
