@@ -286,6 +286,68 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
     return LLARK_ERR_INVALID;
 }
 
+// One K-step (64 k = four 16-wide sub-steps) of the B-direct kernels, shared by gemm_bd_kernel and gemm_bd_sk_kernel (round 4).
+// Instruction order = what gemm256n.hip found for the prior's tile (profiles/r03_gemm256n_*.txt), carried over: a sub-step's MFMAs go
+// out FIRST and everything else the wave has to issue rides in their gaps, ONE item per gap -- the weight fragments of sub-step s + 3
+// (global -> VGPR ring; `load_b(slot, tn, q)` loads one of them) and, for plain operands, the A fragments of sub-step s + 1 (LDS ->
+// the second register set) -- instead of a block of loads in front of every sub-step.  The arithmetic and its order per accumulator
+// (k ascending, hi pass then lo pass) are unchanged: results stay bit-identical to the LDS-staged kernels.
+// Measured (profiles/r04_llama_bd_mfma_first_ab.txt, Llama stage, same box, alternating libraries): plain bf16 operands 0.3934 ->
+// 0.4052 of the MFMA peak (forward 44.76 -> 43.64 ms per 8 clips); the hi + lo form LOSES 3 % with its weight loads moved into the gaps
+// (0.2102 -> 0.2028: its MFMAs come in dependent hi / lo pairs and it has one register set only, so there is no latency to hide the
+// loads behind) and keeps round 3's order: loads, then MFMAs.
+template <typename T, bool SPLIT, typename C, typename LB>
+__device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const int lane, typename Mfma<T>::frag (&ring)[4][C::TN],
+                                         f32x16_t (&acc)[C::TM][C::TN], const int q0, LB&& load_b) {
+    typedef typename Mfma<T>::frag frag;
+    constexpr int NM = C::TM * C::TN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if constexpr (!SPLIT) {
+        frag ah[2][C::TM];
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) ah[0][tm] = *(const frag*)(sA + C::off(tm * 32 + l31, lhi));   // sub-step 0 follows the K-step's barrier: exposed
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value, cur = s & 1;
+            constexpr int items = C::TN + (s < 3 ? C::TM : 0);
+            static_for<NM>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, tm = i / C::TN, tn = i % C::TN;
+                acc[tm][tn] = Mfma<T>::run(ah[cur][tm], ring[s][tn], acc[tm][tn]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<items>([&](auto jc) __attribute__((always_inline)) {        // item j rides in gap min(j, NM - 1)
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr ((j < NM ? j : NM - 1) == i) {
+                        if constexpr (j < C::TN) load_b((s + 3) & 3, j, q0 + s + 3);
+                        else ah[cur ^ 1][j - C::TN] = *(const frag*)(sA + C::off((j - C::TN) * 32 + l31, (s + 1) * 2 + lhi));
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) load_b((s + 3) & 3, tn, q0 + s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            frag ah[C::TM], al[C::TM];
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                ah[tm] = *(const frag*)(sA + C::off(tm * 32 + l31, s * 2 + lhi));
+                al[tm] = *(const frag*)(sL + C::off(tm * 32 + l31, s * 2 + lhi));
+            }
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
+                    acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // "B-direct" main loop.  Measured on MI355X (profiles/r01_gemm_ablation.txt): the stage-load latency of the
 // LDS-staged kernel (~2 us per 64 KiB burst) cannot be hidden inside 160 KiB of LDS.  Here the WEIGHT operand
@@ -386,54 +448,16 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
     loadB(2, 2);
     storeA(0);
     __syncthreads();
+    auto load_b1 = [&](int slot, int tn, int q) __attribute__((always_inline)) {
+        q = q < nk16 ? q : nk16 - 1;                                       // tail: harmless re-load of the last chunk
+        ring[slot][tn] = wbase[tn][(size_t)q * 64];
+    };
     for (int kt = 0; kt < nk; ++kt) {
-#if GEMM_ABLATE != 12 && GEMM_ABLATE != 14
         loadA(kt + 1 < nk ? kt + 1 : kt);          // unconditional (tail: harmless re-load) so the counted vmcnt waits stay exact
-#endif
         __builtin_amdgcn_sched_barrier(0);
         const char* sA = smem + (kt & 1) * ASTAGE;
-        const char* sL = sA + OFF_L;
-        // A fragments one k sub-step ahead (plain operands; the split form has no registers left for a second set): the reads of
-        // sub-step s + 1 are in flight while sub-step s multiplies, instead of every sub-step starting with an LDS round trip that
-        // only the other workgroups of the CU could cover.  Sub-step 0 follows the K-step's barrier and stays exposed.
-        constexpr int NAB = SPLIT ? 1 : 2;
-        frag ah[NAB][C::TM], al[NAB][C::TM];
-        auto ldA = [&](int buf, int s) __attribute__((always_inline)) {
-            const int c = s * 2 + (lane >> 5);
-#if GEMM_ABLATE == 13 || GEMM_ABLATE == 14
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) { asm volatile("" : "=v"(ah[buf][tm])); asm volatile("" : "=v"(al[buf][tm])); }
-#else
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) {
-                ah[buf][tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
-                if (SPLIT) al[buf][tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
-            }
-#endif
-        };
-        if (!SPLIT) ldA(0, 0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#if GEMM_ABLATE != 11 && GEMM_ABLATE != 14
-            loadB((s + 3) & 3, kt * 4 + s + 3);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            const int cur = SPLIT ? 0 : (s & 1);
-            if (SPLIT) ldA(0, s);
-            else if (s < 3) ldA(cur ^ 1, s + 1);
-            if (!SPLIT) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < C::TN; ++tn) {
-                    acc[tm][tn] = Mfma<T>::run(ah[cur][tm], ring[s][tn], acc[tm][tn]);
-                    if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[cur][tm], ring[s][tn], acc[tm][tn]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#if GEMM_ABLATE != 12 && GEMM_ABLATE != 14
+        bd_kstep<T, SPLIT, C>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
         if (kt + 1 < nk) storeA((kt + 1) & 1);
-#endif
         __syncthreads();
     }
     gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
@@ -619,31 +643,15 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
         loadB(2, kt0 * 4 + 2);
         storeA(0);
         __syncthreads();
+        auto load_b1 = [&](int slot_, int tn, int q) __attribute__((always_inline)) {
+            q = q < qlast ? q : qlast;                                     // tail: harmless re-load of the piece's last chunk
+            ring[slot_][tn] = wbase[tn][(size_t)q * 64];
+        };
         for (int kt = kt0; kt < kt1; ++kt) {
             loadA(kt + 1 < kt1 ? kt + 1 : kt);
             __builtin_amdgcn_sched_barrier(0);
             const char* sA = smem + ((kt - kt0) & 1) * ASTAGE;
-            const char* sL = sA + OFF_L;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                loadB((s + 3) & 3, kt * 4 + s + 3);
-                __builtin_amdgcn_sched_barrier(0);
-                const int c = s * 2 + (lane >> 5);
-                frag ah[C::TM], al[C::TM];
-#pragma unroll
-                for (int tm = 0; tm < C::TM; ++tm) {
-                    ah[tm] = *(const frag*)(sA + C::off(tm * 32 + (lane & 31), c));
-                    if (SPLIT) al[tm] = *(const frag*)(sL + C::off(tm * 32 + (lane & 31), c));
-                }
-#pragma unroll
-                for (int tm = 0; tm < C::TM; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < C::TN; ++tn) {
-                        acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
-                        if (SPLIT) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            bd_kstep<T, SPLIT, C>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
             if (kt + 1 < kt1) storeA((kt + 1 - kt0) & 1);
             __syncthreads();
         }
@@ -1171,8 +1179,13 @@ static int pick_variant(int split, int m, int n, int kp, bool has_ws) {
     // the prior (M = clips x 8192, split fp16): 256x256x64 tile, phases over N with resident A fragments (gemm256n.hip; round 2's
     // M-split LDS ring gemm256.hip = variant 30 stays for A/B) as soon as the
     // problem has two tiles per CU -- also at B = 1 (608 tiles), so a clip's result does not depend on the batch it rides in
-    // round 4: the same tile on v_mfma_f32_16x16x32 (gemm256x.hip; falls back to 31 for the shapes / epilogues it does not take)
-    if (split && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 512) return 32;
+    // round 4: the same tile on v_mfma_f32_16x16x32 (gemm256x.hip; falls back to 31 for the shapes / epilogues it does not take) for the
+    // deep products: the instruction costs 8.6 % more pipe cycles and buys a 16 % higher sustained clock (1.44 -> 1.68 GHz under the
+    // profiler, profiles/r04_pmc_gemm256x_vs_n.txt): +4 .. 5 % at K = 4800, but -3 % at K = 1216, where a quarter of the tile time is
+    // epilogue and the 32x32x16 loop is not power-bound to begin with (profiles/r04_gemm256x_ab_v2.txt)
+    // (from 384 tiles = 1.5 per CU on: one clip's c_attn has 32 x 15 = 480, and a clip's result must not depend on the batch it rides in --
+    //  variants 31 and 12 are bit-identical to each other, variant 32 is not)
+    if (split && persist && kp >= 128 && (long)cdiv(m, 256) * cdiv(n, 256) >= 384) return kp >= 2048 ? 32 : 31;
     if (kp < 2048) return 12;                     // shallow K (attention c_proj, K = 1216): per-tile 128x256x64 (the chunk barrier of the
                                                   // persistent form does not pay off over 19 K-steps); re-swept after the residual-epilogue fix
     if (m >= 16384 && persist) return 20;                    // very tall products (M = 65536): persistent, chunk-synchronous (L2 hit rate 68 -> 83 %)

@@ -60,45 +60,56 @@ struct Mfma16<bf16_t> {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// Residual epilogue in two halves (row tiles 0, 1 | 2, 3): R may alias C (h += ...), so a load placed after a store can never be
+// hoisted above it -- the residuals of a half (16 x 16 bytes per lane) are all requested before its first store.  The kernel requests
+// the FIRST half right after the K loop, BEFORE the next tile's LDS-DMA prologue goes out: loads return in order, so behind the
+// prologue they would wait for its 192 KiB to land first (epilogue_load_resid / epilogue_store below).
+template <int EPI>
+__device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t (&res)[2][Cfg256X::TN], const int half2, const int m0, const int n0,
+                                                    const int wm, const int wn, const int lane) {
+    typedef Cfg256X C;
+    if (EPI != EPI_RESID) return;
+    const int l15 = lane & 15, g4 = (lane >> 4) << 2;
+    const int ncol = n0 + wn * 64 + g4;
+    const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + wm * 64 + (2 * half2 + t) * 16 + l15;
+        const bool row_ok = full || m < p.M;
+        const float* rrow = p.R + (size_t)(row_ok ? m : 0) * p.ldr + ncol;
+#pragma unroll
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int co = (tn >> 2) * 128 + (tn & 3) * 16;
+            res[t][tn] = (row_ok && (full || ncol + co < p.N)) ? *(const f32x4_t*)(rrow + co) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // Epilogue of the transposed 16x16 accumulators: lane l holds, for tile (tm, tn), row m = wave row + 16 tm + l % 16 and the four
 // columns n = tile column + 4 (l / 16) .. +3.  Column tile tn of half h = tn / 4 starts at h * 128 + wn * 64 + (tn % 4) * 16.
 template <typename T, int EPI>
-__device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], const int m0, const int n0,
-                                                const int wm, const int wn, const int lane) {
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[2][Cfg256X::TN],
+                                               const f32x4_t (&bias)[Cfg256X::TN], const int half2, const int m0, const int n0, const int wm, const int wn,
+                                               const int lane) {
     typedef Cfg256X C;
     typedef typename Mfma16<T>::out4 out4;
     const int l15 = lane & 15, g4 = (lane >> 4) << 2;
-    const int ncol = n0 + wn * 64 + g4;                              // + (tn / 4) * 128 + (tn % 4) * 16
-    auto coloff = [](int tn) __attribute__((always_inline)) { return (tn >> 2) * 128 + (tn & 3) * 16; };
+    const int ncol = n0 + wn * 64 + g4;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
-    f32x4_t bias[C::TN];
 #pragma unroll
-    for (int tn = 0; tn < C::TN; ++tn) {
-        const int n = ncol + coloff(tn);
-        bias[tn] = (p.bias != nullptr && (full || n < p.N)) ? *(const f32x4_t*)(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int tm = 0; tm < C::TM; ++tm) {
+    for (int t = 0; t < 2; ++t) {
+        const int tm = 2 * half2 + t;
         const int m = m0 + wm * 64 + tm * 16 + l15;
-        const bool row_ok = full || m < p.M;
-        // residuals of the whole tile row first, all loads in flight together (R may alias C: a load placed after a store could
-        // never be hoisted above it)
-        f32x4_t res[C::TN];
-        if (EPI == EPI_RESID) {
-            const float* rrow = p.R + (size_t)m * p.ldr + ncol;
-#pragma unroll
-            for (int tn = 0; tn < C::TN; ++tn)
-                res[tn] = (row_ok && (full || ncol + coloff(tn) < p.N)) ? *(const f32x4_t*)(rrow + coloff(tn)) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-        if (!row_ok) continue;
+        if (!full && m >= p.M) continue;
 #pragma unroll
         for (int tn = 0; tn < C::TN; ++tn) {
-            if (!full && ncol + coloff(tn) >= p.N) continue;          // N % 4 == 0 (checked by the launcher): a vector is all in or all out
+            const int co = (tn >> 2) * 128 + (tn & 3) * 16;
+            if (!full && ncol + co >= p.N) continue;                 // N % 4 == 0 (checked by the launcher): a vector is all in or all out
             f32x4_t v = acc[tm][tn] + bias[tn];
             if (EPI == EPI_F32) {
-                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + coloff(tn)) = v;
+                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = v;
             } else if (EPI == EPI_RESID) {
-                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + coloff(tn)) = res[tn] + v;
+                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = res[t][tn] + v;
             } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
                 out4 hi, lo;
 #pragma unroll
@@ -109,11 +120,20 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmParams& p, f32x4_t (&a
                     hi[r] = h;
                     lo[r] = (T)(x - (float)h);
                 }
-                const size_t o = (size_t)m * p.ldo + ncol + coloff(tn);
+                const size_t o = (size_t)m * p.ldo + ncol + co;
                 *(out4*)((T*)p.Ohi + o) = hi;
                 *(out4*)((T*)p.Olo + o) = lo;
             }
         }
+    }
+}
+
+__device__ __forceinline__ void epilogue_load_bias(const GemmParams& p, f32x4_t (&bias)[Cfg256X::TN], const int n0, const int wn, const int lane) {
+    const int ncol = n0 + wn * 64 + ((lane >> 4) << 2);
+#pragma unroll
+    for (int tn = 0; tn < Cfg256X::TN; ++tn) {
+        const int n = ncol + (tn >> 2) * 128 + (tn & 3) * 16;
+        bias[tn] = (p.bias != nullptr && n < p.N) ? *(const f32x4_t*)(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -238,8 +258,20 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             //           sub-step 1 (after the half-phase barrier): group 1's weight fragments of sub-step 1 (needed from MFMA 16),
             //                            the two half-phase requests;
             //   HALF 1 (R): the same without activation reads.
-            auto phase = [&](auto half_tag, auto midw_tag, int aslot, int wslot, auto&& dmaop, auto&& midop) __attribute__((always_inline)) {
+            auto phase = [&](auto half_tag, auto midw_tag, auto compute_tag, int aslot, int wslot, auto&& dmaop, auto&& midop) __attribute__((always_inline)) {
                 constexpr int half = decltype(half_tag)::value, midw = decltype(midw_tag)::value;
+                if constexpr (!decltype(compute_tag)::value) {
+                    // a phase whose 128 columns all lie beyond N (the right half of the last column tile of N = 3600: 16 of its 256 columns
+                    // exist): no fragment reads, no MFMAs -- only its part of the request / wait / barrier protocol
+                    static_for<4>([&](auto ic) __attribute__((always_inline)) { dmaop(ic); });
+                    if constexpr (midw == 6) VMCNT(6);
+                    else if constexpr (midw == 4) VMCNT(4);
+                    else if constexpr (midw == 2) VMCNT(2);
+                    else VMCNT(0);
+                    __builtin_amdgcn_s_barrier();
+                    static_for<2>([&](auto ic) __attribute__((always_inline)) { midop(ic); });
+                    return;
+                }
                 const int vA = rdA0 + aslot, vW = rdW0 + wslot;
                 const int vAs[2] = {vA, opaque(vA) ^ 64};
                 const int vWs[2] = {vW, opaque(vW) ^ 64};
@@ -304,7 +336,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             // One K-step: the request / wait table of gemm256n.hip's kstep(), unchanged (La = sub-step 0 of phase L, Lb = sub-step 1, ...;
             // the activation fragments are now all read in La instead of La + Lb: reads only move EARLIER inside the slot they already
             // started in, so every landing-before-read and no-overwrite-while-read condition of scripts/sim_gemm256n.py still holds).
-            auto kstep = [&](int k, int aq, int wL) __attribute__((always_inline)) {
+            auto kstep = [&](auto right_tag, int k, int aq, int wL) __attribute__((always_inline)) {
                 const int kn = k + 1 < nk ? k + 1 : nk - 1;
                 const int wR = wL + 1 >= 3 ? wL - 2 : wL + 1, wN = wL + 2 >= 3 ? wL - 1 : wL + 2;       // W slots of WR(k), WL(k+1)
                 const int an = wrap7(aq + 4);                                                            // A slot of Q0(k+1)
@@ -318,11 +350,11 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 };
                 // four requests per phase (L: Q0, Q1 of K-step kn; R: Q2, Q3) + two behind each half-phase barrier (L: WL(kn), R: WR(kn)).
                 // Waits: La|Lb vmcnt(4), Ra|Rb vmcnt(4), end of R vmcnt(2).
-                phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, amine, wL * C::UNIT,
+                phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, std::true_type{}, amine, wL * C::UNIT,
                       [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(i >> 1, i & 1, wrap7(an + (i >> 1))); },
                       [&](auto ic) __attribute__((always_inline)) { reqW(0, decltype(ic)::value, wN); });
                 __builtin_amdgcn_s_barrier();
-                phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, amine, wR * C::UNIT,
+                phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{}, right_tag, amine, wR * C::UNIT,
                       [&](auto ic) __attribute__((always_inline)) { constexpr int i = decltype(ic)::value; reqQ(2 + (i >> 1), i & 1, wrap7(an + 2 + (i >> 1))); },
                       [&](auto ic) __attribute__((always_inline)) { reqW(1, decltype(ic)::value, wL); });
                 VMCNT(2);                                                  // Q3(kn) landed (newer: WR(kn) x2)
@@ -332,15 +364,28 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
             {
                 int aq = 0, wL = 0;
-                for (int k = 0; k < nk; ++k) {
-                    kstep(k, aq, wL);
-                    aq = wrap7(aq + 4);
-                    wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                if (n0 + 128 < p.N) {
+                    for (int k = 0; k < nk; ++k) {
+                        kstep(std::true_type{}, k, aq, wL);
+                        aq = wrap7(aq + 4);
+                        wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                    }
+                } else {                                                   // right half of the tile entirely beyond N: phase R carries no products
+                    for (int k = 0; k < nk; ++k) {
+                        kstep(std::false_type{}, k, aq, wL);
+                        aq = wrap7(aq + 4);
+                        wL = wL + 2 >= 3 ? wL - 1 : wL + 2;
+                    }
                 }
             }
             if (w < 4) __builtin_amdgcn_s_barrier();                       // the trailing waves' last half-phase
             VMCNT(0);
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
+            // bias and the first half of the residuals are requested AHEAD of the next tile's prologue (in-order returns)
+            f32x4_t bias[C::TN], res[2][C::TN];
+            epilogue_load_bias(p, bias, n0, wn, lane);
+            epilogue_load_resid<EPI>(p, res, 0, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
             if (ch + 1 < nchunks) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 arrived = true;
@@ -353,7 +398,10 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                     prologue();
                 }
             }
-            gemm_epilogue16<T, EPI>(p, acc, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_store<T, EPI>(p, acc, res, bias, 0, m0, n0, wm, wn, lane);
+            epilogue_load_resid<EPI>(p, res, 1, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI>(p, acc, res, bias, 1, m0, n0, wm, wn, lane);
         }
         if (ch + 1 < nchunks) {
             if (threadIdx.x == 0) {
