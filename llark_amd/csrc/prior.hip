@@ -498,6 +498,290 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATTN_WPE, A
 }
 
 // ------------------------------------------------------------------------------------------
+// Factored attention on the 16-bit matrix cores (round 4).  Same workgroup geometry, staging pipeline, softmax
+// and output stage as prior_attn_kernel above; the two products run as THREE-PASS split-fp16 MFMAs (v_mfma_f32_16x16x32_f16:
+// x = hi + lo fp16, x.y = xh.yh + xh.yl + xl.yh, the dropped xl.yl is 2^-22 relative -- the scheme of the prior's GEMMs and of the
+// Llama attention) instead of exact fp32 MFMAs at 1/16 of that rate, which alone kept the matrix pipe 36 % busy
+// (profiles/r03_pmc_prior_attn.txt).
+//   * K / V tile in LDS = two fp16 planes (hi | lo) of [64 keys][512-byte rows] (160 of 256 halfs used), converted once by the staging
+//     wave; 16-byte chunk `ch` of row `row` sits in slot ch ^ swz(row), swz = attn_bwd.hip's: conflict free both for the b128
+//     fragment reads of the score product (lane (c, g) -> row 8 (c / 4) + c % 4 of its tile, chunk 4 s + g) and for the transposing
+//     reads of the P V product (ds_read_b64_tr_b16: rows r .. r + 3 and r + 8 .. r + 11, chunks 2 dt, 2 dt + 1).
+//   * scores, transposed: S^T = K Q^T per 16-key row tile t of a 64-key tile.  MFMA row i of tile t is key 32 (t / 2) + 8 (i / 4) +
+//     i % 4 + 4 (t % 2), so that lane (c = query, g) ends up with keys 32 u + 8 g + {0 .. 3} (t = 2 u) and + {4 .. 7} (t = 2 u + 1):
+//     eight CONSECUTIVE contraction slots of the P V product -- the probabilities go from the softmax registers straight into its
+//     B operand (hi / lo halves made in registers), no LDS round trip;
+//   * O^T = V^T P^T: A operand = V^T[d][key] fetched from the row-major V planes by two transposing LDS reads per fragment.
+// ------------------------------------------------------------------------------------------
+namespace a16 {
+constexpr int PITCH = 512, PLANE = 64 * PITCH;                       // bytes
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | (row & 8); }
+__device__ __forceinline__ int off(int row, int chunk) { return row * PITCH + ((chunk ^ swz(row)) << 4); }
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+
+// 16 rows of this wave (RowRegs: lane l holds d = 2 l, 2 l + 1 and 128 + 2 l, 128 + 2 l + 1 of every row) -> hi / lo planes
+template <int NK32>
+__device__ __forceinline__ void store_rows16h(const RowRegs& R, char* __restrict__ tile, int row0, int nvalid, int hd, int lane) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = row0 + rr;
+        const bool live = r < nvalid;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int d = 2 * (lane + 64 * it);
+            if (d < 32 * NK32) {
+                const bool ok = live && d < hd;
+                const float x = ok ? R.v[rr][it].x : 0.0f, y = ok ? R.v[rr][it].y : 0.0f;
+                half2v h, l;
+                h[0] = (half_t)x;
+                h[1] = (half_t)y;
+                l[0] = (half_t)(x - (float)h[0]);
+                l[1] = (half_t)(y - (float)h[1]);
+                const int o = off(r, d >> 3) + ((d & 7) << 1);
+                *(half2v*)(tile + o) = h;
+                *(half2v*)(tile + PLANE + o) = l;
+            }
+        }
+    }
+}
+
+// A operand of a 16x16x32 MFMA whose rows are 16 COLUMNS (col0 ..) of the row-major tile and whose 8 contraction slots per lane group
+// g are the ROWS row0 + 8 g .. + 7: two transposing reads (ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of the
+// [4 rows][16 columns] block whose (row r, 4-column group a) is addressed by source lane 4 r + a: scripts/probes/tr_b16_probe.hip)
+__device__ __forceinline__ half8_t tr_frag(const char* tile, int row0, int col0, int g, int c) {
+    const int col = col0 + 4 * (c & 3);
+    const int ra = row0 + 8 * g + (c >> 2), rb = ra + 4;
+    const int oa = ra * PITCH + ((((col >> 3) ^ swz(ra)) << 4) | ((col & 7) << 1));
+    const int ob = rb * PITCH + ((((col >> 3) ^ swz(rb)) << 4) | ((col & 7) << 1));
+    const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + oa));
+    const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(tile + ob));
+    const v8s_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(half8_t, v);
+}
+__device__ __forceinline__ f32x4_t mfma(half8_t a, half8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+}  // namespace a16
+
+template <int NK32>     // 32-wide head-dim steps: hd <= 32 NK32 (pad columns are zero)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prior_attn16_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    char* tile = (char*)sm;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int head = blockIdx.y;
+    const int clip = blockIdx.z;
+    const int hd = p.hd;
+    constexpr int NDT = 2 * NK32;
+
+    int nq, q0, qs, nkeys, k0, ks, coff;
+    bool causal = true, zero_out = false;
+    if (p.pattern == 1) {
+        const int blk = blockIdx.x;
+        nq = p.block_ctx; q0 = blk * p.block_ctx; qs = 1;
+        nkeys = p.block_ctx; k0 = q0; ks = 1; coff = 0;
+    } else if (p.pattern == 2) {
+        const int chunks = p.blocks / p.qc;
+        const int off = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+        nq = p.qc; q0 = ch * p.qc * p.block_ctx + off; qs = p.block_ctx;
+        nkeys = (ch + 1) * p.qc; k0 = off; ks = p.block_ctx; coff = ch * p.qc;
+    } else {
+        const int blk = blockIdx.x;
+        nq = p.block_ctx; q0 = blk * p.block_ctx; qs = 1;
+        nkeys = p.block_ctx; k0 = (blk - 1) * p.block_ctx; ks = 1; coff = 0;
+        causal = false;
+        zero_out = (blk == 0);
+    }
+    const size_t rowbase = (size_t)clip * p.T;
+    const int hcol = head * hd;
+
+    if (zero_out) {   // block 0 of prev_block_attn sees zero-padded K/V: softmax(0)=uniform, V=0 -> 0
+        for (int i = tid; i < nq * hd; i += 256) {
+            const int r = i / hd, d = i - r * hd;
+            const size_t o = (rowbase + q0 + (size_t)r * qs) * p.ldo + hcol + d;
+            p.ohi[o] = (half_t)0.0f;
+            if (p.lo8) ((unsigned char*)p.olo)[(rowbase + q0 + (size_t)r * qs) * p.ldo8 + lo8_pos(hcol + d)] = 0;
+            else p.olo[o] = (half_t)0.0f;
+        }
+        return;
+    }
+    const int ntile = (nkeys + 63) >> 6;
+    const float* kbase = p.qkv + p.n_state + hcol;
+    const float* vbase = p.qkv + 2 * p.n_state + hcol;
+
+    // ---- first K tile in flight, then the Q fragments straight from HBM: lane (c, g) keeps Q[query c][32 s + 8 g .. + 7] as hi / lo ----
+    RowRegs R;
+    load_rows16(R, wv * 16, kbase, rowbase + k0, ks, p.ldq, nkeys, hd, lane);
+    half8_t qh[NK32], ql[NK32];
+    {
+        int qr = wv * 16 + c;
+        qr = qr < nq ? qr : nq - 1;
+        const float* qrow = p.qkv + (rowbase + q0 + (size_t)qr * qs) * p.ldq + hcol;
+#pragma unroll
+        for (int s = 0; s < NK32; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = 32 * s + 8 * g + 2 * e;
+                const bool in = d < hd;                                   // hd is even: a pair is all in or all out
+                const float2 a = *(const float2*)(qrow + (in ? d : 0));
+                const float x = in ? a.x : 0.0f, y = in ? a.y : 0.0f;
+                const half_t hx = (half_t)x, hy = (half_t)y;
+                qh[s][2 * e] = hx;
+                qh[s][2 * e + 1] = hy;
+                ql[s][2 * e] = (half_t)(x - (float)hx);
+                ql[s][2 * e + 1] = (half_t)(y - (float)hy);
+            }
+        }
+    }
+
+    // ---- scores, TRANSPOSED: S^T = scale2 * K Q^T, one 64-key tile = four 16-key row tiles t at a time ----
+    const int krow = 8 * (c >> 2) + (c & 3);                           // + 32 (t / 2) + 4 (t % 2): key of MFMA row c in row tile t
+    const int kswz = a16::swz(krow);                                   // the tile offsets are multiples of 4 and 32: same swizzle for every t
+    f32x4_t sc[2][4];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (kt >= ntile) break;
+        if (kt) __syncthreads();                  // previous K tile fully consumed
+        a16::store_rows16h<NK32>(R, tile, wv * 16, nkeys - kt * 64, hd, lane);
+        __syncthreads();
+        if (kt + 1 < ntile) load_rows16(R, wv * 16, kbase, rowbase + k0 + (size_t)(kt + 1) * 64 * ks, ks, p.ldq, nkeys - (kt + 1) * 64, hd, lane);
+        else load_rows16(R, wv * 16, vbase, rowbase + k0, ks, p.ldq, nkeys, hd, lane);
+        f32x4_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NK32; ++s) {
+            half8_t kh[4], kl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int o = (krow + 32 * (t >> 1) + 4 * (t & 1)) * a16::PITCH + (((4 * s + g) ^ kswz) << 4);
+                kh[t] = *(const half8_t*)(tile + o);
+                kl[t] = *(const half8_t*)(tile + a16::PLANE + o);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = a16::mfma(kh[t], qh[s], acc[t]);        // four independent accumulators between dependent MFMAs
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = a16::mfma(kh[t], ql[s], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = a16::mfma(kl[t], qh[s], acc[t]);
+        }
+        // C layout: col = c (query within the wave's 16), rows 4 g + r = keys 32 (t / 2) + 8 g + 4 (t % 2) + r of the tile
+        const int i = wv * 16 + c;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kt * 64 + 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r;
+                const bool ok = (j < nkeys) && (!causal || (j <= i + coff));
+                sc[kt][t][r] = ok ? acc[t][r] * p.scale2 : -INFINITY;
+            }
+    }
+
+    // ---- fp32 softmax in registers (as in prior_attn_kernel): a lane holds 16 (32) scores of its query, the rest sit in the three
+    //      lanes with the same c in the other lane groups ----
+    {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                mx = fmaxf(fmaxf(fmaxf(sc[kt][t][0], sc[kt][t][1]), fmaxf(sc[kt][t][2], sc[kt][t][3])), mx);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ex = mx > -INFINITY ? expf(sc[kt][t][r] - mx) : 0.0f;
+                    sc[kt][t][r] = ex;
+                    sum += ex;
+                }
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = sum > 0.0f ? 1.0f / sum : 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt >= ntile) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc[kt][t] *= inv;
+        }
+    }
+
+    // ---- O^T = V^T P^T per 64-key tile, two 32-key contraction steps u: B operand = the probabilities of keys 32 u + 8 g .. + 7
+    //      (row tiles 2 u and 2 u + 1 of this lane), A operand = V^T through transposing reads; O^T acc: col = query, rows = d ----
+    f32x4_t o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        if (kt >= ntile) break;
+        __syncthreads();                          // K (or previous V) tile fully consumed by every wave
+        a16::store_rows16h<NK32>(R, tile, wv * 16, nkeys - kt * 64, hd, lane);
+        __syncthreads();
+        if (kt + 1 < ntile) load_rows16(R, wv * 16, vbase, rowbase + k0 + (size_t)(kt + 1) * 64 * ks, ks, p.ldq, nkeys - (kt + 1) * 64, hd, lane);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            half8_t ph, pl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = sc[kt][2 * u + (e >> 2)][e & 3];
+                const half_t h = (half_t)pv;
+                ph[e] = h;
+                pl[e] = (half_t)(pv - (float)h);
+            }
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const half8_t vh = a16::tr_frag(tile, 32 * u, 16 * dt, g, c);
+                const half8_t vl = a16::tr_frag(tile + a16::PLANE, 32 * u, 16 * dt, g, c);
+                o[dt] = a16::mfma(vh, ph, o[dt]);
+                o[dt] = a16::mfma(vh, pl, o[dt]);
+                o[dt] = a16::mfma(vl, ph, o[dt]);
+            }
+        }
+    }
+    // ---- output: as prior_attn_kernel -- O^T through LDS (the V planes are dead once every wave has left the loop), row-major stores ----
+    __syncthreads();
+    float* sT = sm;
+    {
+        float* orow = sT + (wv * 16 + c) * ATT_KP + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) *(f32x4_t*)(orow + dt * 16) = o[dt];
+    }
+    {
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+        const int npair = hd >> 1;                                    // hd is even
+        const float sm8 = __builtin_ldexpf(1.0f, p.sa);
+        for (int idx = lane; idx < 16 * npair; idx += 64) {           // rows of this wave only: no block barrier needed
+            const int rr = idx / npair, pr = idx - rr * npair;
+            const int i = wv * 16 + rr;
+            if (i >= nq) break;
+            const float2 x = *(const float2*)(sT + i * ATT_KP + 2 * pr);
+            const size_t tok = rowbase + q0 + (size_t)i * qs;
+            half2_t h;
+            h[0] = (half_t)x.x;
+            h[1] = (half_t)x.y;
+            *(half2_t*)(p.ohi + tok * p.ldo + hcol + 2 * pr) = h;
+            if (p.lo8) {
+                const unsigned q8 = fp8_e4m3_sat((x.x - (float)h[0]) * sm8) | (fp8_e4m3_sat((x.y - (float)h[1]) * sm8) << 8);
+                *(unsigned short*)((unsigned char*)p.olo + tok * p.ldo8 + lo8_pos(hcol + 2 * pr)) = (unsigned short)q8;
+            } else {
+                half2_t l;
+                l[0] = (half_t)(x.x - (float)h[0]);
+                l[1] = (half_t)(x.y - (float)h[1]);
+                *(half2_t*)(p.olo + tok * p.ldo + hcol + 2 * pr) = l;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // pooling tail (jukebox/main.py:154-167): windowed mean over `frame_len` rows (AvgPool1d, ceil_mode
 // False) or global mean over the first `len` rows.
 // ------------------------------------------------------------------------------------------
@@ -635,12 +919,32 @@ static int prior_attn_impl(const float* qkv, int ldq, int n, int t, int n_state,
     p.hdp = 0;
     p.nk_max = (pattern == 2 && blocks > 64) ? 128 : 64;      // score columns: one or two 64-key tiles
     int gx = (pattern == 2) ? bc * (blocks / p.qc) : blocks;
-    size_t lds = (size_t)64 * ATT_KP * sizeof(float);               // one [64][ATT_KP] tile: 47 KiB
     LLARK_REQUIRE(p.nk_max <= 128, "prior_attn: at most 128 keys per query group (got %d)", p.nk_max);
     LLARK_REQUIRE(hd % 2 == 0 && n_state % 2 == 0 && ldq % 2 == 0 && ldo % 2 == 0,
                   "prior_attn: head_dim, n_state, ldq and ldo must be even (8-byte row loads, 4-byte stores)");
-    LLARK_REQUIRE(lds <= 160 * 1024, "prior_attn: LDS %zu B exceeds 160 KiB", lds);
     dim3 grid(gx, heads, n);
+#ifndef PRIOR_ATTN_FP32
+    {   // default (round 4): three-pass split-fp16 products on v_mfma_f32_16x16x32_f16; LDS = two [64][512 B] planes (the fp32 output tile fits inside)
+        const size_t lds16 = 2 * (size_t)a16::PLANE;
+        static_assert(2 * a16::PLANE >= 64 * ATT_KP * (int)sizeof(float), "the output stage reuses the planes as a [64][ATT_KP] float tile");
+        const int need32 = (hd + 31) / 32;
+#define ATT16_LAUNCH(NK)                                                                                                   \
+    do {                                                                                                                   \
+        static PerDeviceOnce once;                                                                                         \
+        if (once.first()) (void)hipFuncSetAttribute((const void*)prior_attn16_kernel<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); \
+        prior_attn16_kernel<NK><<<grid, 256, lds16, (hipStream_t)stream>>>(p);                                             \
+    } while (0)
+        if (need32 <= 1) ATT16_LAUNCH(1);
+        else if (need32 <= 2) ATT16_LAUNCH(2);
+        else if (need32 <= 3) ATT16_LAUNCH(3);
+        else if (need32 <= 4) ATT16_LAUNCH(4);
+        else ATT16_LAUNCH(5);
+#undef ATT16_LAUNCH
+        return check_launch("prior_attn16");
+    }
+#endif
+    size_t lds = (size_t)64 * ATT_KP * sizeof(float);               // one [64][ATT_KP] tile: 47 KiB
+    LLARK_REQUIRE(lds <= 160 * 1024, "prior_attn: LDS %zu B exceeds 160 KiB", lds);
     const int need = (hd + 15) / 16;
 #define ATT_LAUNCH(NKS)                                                                                              \
     do {                                                                                                             \

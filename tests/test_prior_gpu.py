@@ -386,7 +386,9 @@ def test_layernorm_split(rows, width):
 @pytest.mark.parametrize("pattern", [1, 2, 3])
 @pytest.mark.parametrize("cfg", ["tiny", "full"])
 def test_factored_attention(pattern, cfg):
-    """vs oracle factored_attention (fp32). Bound 6e-6 abs+rel on O(1) values: fp32 MFMA chains + hi/lo (22-bit) output."""
+    """vs oracle factored_attention (fp32).  Round 4: both products are three-pass split-fp16 MFMAs (q, k, v, p carried as fp16 hi + lo,
+    the lo x lo term dropped): per score 2^-22 x sum|q||k| x scale ~ 4e-6 worst case at head_dim 150 with |q|, |k| ~ 1.5, typically a
+    tenth of it (measured: mean 2.3e-7, max 7.3e-6 over 9.8 M outputs).  Bound 1e-5 abs + rel (was 6e-6 with exact fp32 MFMAs)."""
     from llark_amd import ops
     from oracle import jukebox_ref as R
     if cfg == "tiny":
@@ -403,7 +405,7 @@ def test_factored_attention(pattern, cfg):
     lo = torch.zeros_like(hi)
     ops.prior_attn(qkv.view(n * t, 3 * S).cuda(), n, t, S, heads, blocks, pattern, hi, lo)
     got = (hi.float() + lo.float())[:, :S].cpu().view(n, t, S)
-    report_close(f"attn pattern {pattern} {cfg}", got, ref, 6e-6, 6e-6)
+    report_close(f"attn pattern {pattern} {cfg}", got, ref, 1e-5, 1e-5)
     assert (hi[:, S:] == 0).all()
     if pattern == 3:
         assert (got[:, : t // blocks] == 0).all()
