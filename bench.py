@@ -454,6 +454,52 @@ def extra_train(args, device, steps: int = 2):
     return out
 
 
+def extra_mpt(args, device, steps: int = 3, new_tokens: int = 64):
+    """configs[4] per-GPU share attached to the default line: 8 x 10 s 48 kHz clips -> log-mel -> CLAP HTSAT-base -> (1, 512) embedding ->
+    projector -> MPT-1B prefill (S = 132) + 64 greedy decode steps (scripts/clap/clap_embeddings.py:63-153 + m2t/models/mpt.py), and the
+    audio half alone at batch 64.  No CPU leg here (the HTSAT oracle takes ~40 s per clip on the host: `--stages clap` times it)."""
+    import copy
+
+    from llark_amd import ops
+    from llark_amd.m2t import bench_support
+
+    a = copy.copy(args)
+    a.batch, a.with_clap, a.new_tokens = 8, True, new_tokens
+    out = {}
+    with torch.no_grad():
+        wl = bench_support.MptWorkload(a, device)
+        wl.generate(new_tokens)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.generate(new_tokens)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out["mpt_generate"] = {"metric": "clips/sec CLAP embed + MPT-1B prefill + %d-token greedy decode" % new_tokens, "value": round(a.batch / dt, 3), "unit": "clips/s",
+                               "ms_per_step": round(dt * 1e3, 2), "clips_per_step": a.batch, "steps": steps, "warmup": 1,
+                               "config": {"workload": "configs[4] per-GPU share: 8 clips, CLAP HTSAT-base -> (1,512) -> projector -> MPT-1B (S=132) + %d decode steps" % new_tokens,
+                                          "llm_precision": args.llm_precision}}
+        del wl
+        c = copy.copy(args)
+        c.batch = 64
+        cw = bench_support.ClapWorkload(c, device, "fp32" if args.llm_precision == "split" else "bf16")
+        cw.embed()
+        torch.cuda.synchronize()
+        ops.start_kernel_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cw.embed()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        timers = ops.stop_kernel_timing()
+        c.steps = steps
+        out["clap_embed"] = {"metric": "clips/sec CLAP HTSAT-base audio embedding (waveform -> 512-d)", "value": round(c.batch / dt, 1), "unit": "clips/s",
+                             "ms_per_step": round(dt * 1e3, 3), "clips_per_step": c.batch, "steps": steps, "warmup": 1, "roofline": roofline_clap(timers, c, cw)}
+        del cw
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -674,7 +720,25 @@ def main():
                 ties = vq.last_near_ties
                 ex = VQVAE(hps, weights, device, exact=True)
                 ex.set_codebook(vq.k)
-                line["vq_codes"] = {"code_mismatches_vs_exact": int((got != ex.encode_top(audio)).sum()), "tokens": int(got.numel()),
+                exact_codes = ex.encode_top(audio)
+                # the same fused stages WITHOUT the certificate (round 3's default), for the record: what exactness costs
+                raw = VQVAE(hps, weights, device, tie_e_rel=None)
+                raw.set_codebook(vq.k)
+                raw_codes = raw.encode_top(audio)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    raw.encode_top(audio)
+                e1.record()
+                torch.cuda.synchronize()
+                raw_ms = e0.elapsed_time(e1) / 5
+                raw_gbs = raw.algorithmic_bytes(audio.shape[0]) / (raw_ms * 1e-3) / 1e9
+                del raw
+                line["vq_codes"] = {"code_mismatches_vs_exact": int((got != exact_codes).sum()), "tokens": int(got.numel()),
+                                    "without_certificate": {"code_mismatches_vs_exact": int((raw_codes != exact_codes).sum()), "ms": round(raw_ms, 3),
+                                                            "frac_of_hbm_roofline": round(raw_gbs / PEAK_HBM_GBS, 4),
+                                                            "note": "VQVAE(tie_e_rel=None): the fused stages + plain argmin, timed outside the timed region"},
                                     "near_tie_tokens_reevaluated_exactly": int(ties), "tie_e_rel": vq.tie_e_rel, "tie_ulps": vq.tie_ulps,
                                     "note": "default encoder = fused split-fp16 stages + near-tie certificate; flagged tokens are re-evaluated by the exact "
                                             "kernels on receptive-field windows inside the timed region (roofline_conv includes it)"}
@@ -688,6 +752,12 @@ def main():
             try:
                 del enc, llm
                 step = None
+                torch.cuda.empty_cache()
+                line["extra"].update(extra_mpt(args, device))
+            except Exception as e:  # noqa: BLE001
+                line["extra"]["mpt_generate"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                enc = llm = None
                 torch.cuda.empty_cache()
                 line["extra"]["train"] = extra_train(args, device)
             except Exception as e:  # noqa: BLE001

@@ -296,6 +296,10 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 // 0.4052 of the MFMA peak (forward 44.76 -> 43.64 ms per 8 clips); the hi + lo form LOSES 3 % with its weight loads moved into the gaps
 // (0.2102 -> 0.2028: its MFMAs come in dependent hi / lo pairs and it has one register set only, so there is no latency to hide the
 // loads behind) and keeps round 3's order: loads, then MFMAs.
+#ifndef GEMM_BD_SPLIT_ORDER
+#define GEMM_BD_SPLIT_ORDER 0      // 0 = hi / lo pairs back to back (rounds 1-3; default); 1 = all hi products of a sub-step, then all lo:
+                                   // measured 6 % SLOWER on the Llama stage (0.216 -> 0.203, profiles/r04_llama_bd_split_order_ab.txt)
+#endif
 template <typename T, bool SPLIT, typename C, typename LB>
 __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const int lane, typename Mfma<T>::frag (&ring)[4][C::TN],
                                          f32x16_t (&acc)[C::TM][C::TN], const int q0, LB&& load_b) {
@@ -336,6 +340,7 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
                 ah[tm] = *(const frag*)(sA + C::off(tm * 32 + l31, s * 2 + lhi));
                 al[tm] = *(const frag*)(sL + C::off(tm * 32 + l31, s * 2 + lhi));
             }
+#if GEMM_BD_SPLIT_ORDER == 0
 #pragma unroll
             for (int tm = 0; tm < C::TM; ++tm)
 #pragma unroll
@@ -343,6 +348,19 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
                     acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
                     acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
                 }
+#else
+            // all hi products of the sub-step, then all lo products: the two MFMAs on one accumulator are TM x TN issue slots apart
+            // instead of back to back (same order per accumulator: hi then lo, k ascending -- results bit-identical)
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
