@@ -87,6 +87,7 @@ __global__ void product_kernel(const unsigned char* A, const unsigned char* B, f
 //      1 = 4 x f16 + 1 x scaled fp8 32x32x64   2 = 4 x f16 + 1 x scaled fp6 32x32x64   3 = 4 x f16 only   4 = fp8 only   5 = fp6 only
 //      6 = 16 x f16 16x16x32 (round 4: the same flops as MIX 0 through the other f16 shape, 4 independent accumulators per tile)
 //      7 = 8 x bf16 32x32x16 (round 4: the Llama / training kernels' instruction)   8 = 16 x bf16 16x16x32
+//      9 = 4 x f16 32x32x16 + 3 x scaled fp6 32x32x64 (the fp6x2 low plane of scripts/sim_lo_quant_error.py)
 template <int MIX>
 __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, int iters, unsigned seed) {
     const int lane = threadIdx.x & 63;
@@ -136,6 +137,23 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, long long* cyc, i
             }
             if (MIX == 1 || MIX == 4) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 0, 0, 0, 0x70707070, 0, 0x70707070);
             if (MIX == 2 || MIX == 5) acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 2, 2, 0, 0x70707070, 0, 0x70707070);
+            if (MIX == 10) {           // round 4: the same low product with BOTH passes on the 16-wide shapes: 8 x f16 16x16x32 + 6 x fp6 16x16x128 per 32x32x64
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc4[t][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[k], bh[(k + q) & 3], acc4[t][q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc4[t][q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc4[t][q], 2, 2, 0, 0x70707070, 0, 0x70707070);
+                acc4[t][0] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b8, a8, acc4[t][0], 2, 2, 0, 0x70707070, 0, 0x70707070);
+                acc4[t][1] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, a8, acc4[t][1], 2, 2, 0, 0x70707070, 0, 0x70707070);
+            }
+            if (MIX == 9) {            // round 4: the two-plane MXFP6 low product lo_a W_a + lo_b W_a + lo_a W_b next to the fp16 hi pass
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[k], bh[(k + t) & 3], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[t], 2, 2, 0, 0x70707070, 0, 0x70707070);
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, acc[t], 2, 2, 0, 0x70707070, 0, 0x70707070);
+                acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, a8, acc[t], 2, 2, 0, 0x70707070, 0, 0x70707070);
+            }
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -245,5 +263,7 @@ int main(int argc, char** argv) {
     rate<6>("16xf16 16x16x32", dout, dcyc, 4 * 8 * f16);
     rate<7>("8xbf16 32x32x16", dout, dcyc, 4 * 8 * f16);
     rate<8>("16xbf16 16x16x32", dout, dcyc, 4 * 8 * f16);
+    rate<9>("4xf16+3xfp6", dout, dcyc, 4 * 8 * f16);
+    rate<10>("8xf16(16)+6xfp6(16x128)", dout, dcyc, 4 * 8 * f16);
     return 0;
 }
