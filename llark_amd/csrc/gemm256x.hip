@@ -60,6 +60,16 @@ struct Mfma16<bf16_t> {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// A/B knobs (same arithmetic): G256X_R0 = MFMAs that go out back to back at the start of a phase before the first gap carries a
+// fragment read; G256X_PRIO = 1: s_setprio 1 for the later-dispatched half of the workgroup (waves 4..7).  Measured:
+// profiles/r04_gemm256x_knobs.txt.
+#ifndef G256X_R0
+#define G256X_R0 0
+#endif
+#ifndef G256X_PRIO
+#define G256X_PRIO 0
+#endif
+
 // Residual epilogue in two halves (row tiles 0, 1 | 2, 3): R may alias C (h += ...), so a load placed after a store can never be
 // hoisted above it -- the residuals of a half (16 x 16 bytes per lane) are all requested before its first store.  The kernel requests
 // the FIRST half right after the K loop, BEFORE the next tile's LDS-DMA prologue goes out: loads return in order, so behind the
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                         if constexpr (s == 0) {
                             // after the half-phase barrier of the PREVIOUS phase the first MFMAs go out back to back (r0): the partner wave
                             // on the SIMD is waiting for its first fragments just then
-                            constexpr int r0 = 0;
+                            constexpr int r0 = G256X_R0;
                             if constexpr (half == 0) {
                                 if constexpr (i >= r0 && i < r0 + 4) al[i - r0][0] = *(const frag*)(smem + vAs[0] + 8192 + (i - r0) * 2048);
                                 if constexpr (i == r0 + 4) bf[2] = *(const frag*)(smem + vWs[0] + 2 * 2048);
@@ -361,6 +371,9 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 __builtin_amdgcn_s_barrier();
             };
 
+#if G256X_PRIO
+            if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
             if (w >= 4) __builtin_amdgcn_s_barrier();                      // the trailing wave of every pair: half a phase behind
             {
                 int aq = 0, wL = 0;
