@@ -22,6 +22,13 @@ namespace llark {
 
 namespace {
 
+// cache policy of the weight stream's LDS-DMA loads (aux operand): 2 = nt (non-temporal: every weight byte is read once per token by
+// ONE CU; MI355X guide, price-list row "nt-weights"), 0 = default policy.  Round 4 A/B, alternating libraries on one box
+// (profiles/r04_decode_nt_weights.txt): the streaming Linears of a token 3.305 -> 3.13 ms (4.0 -> 4.22 TB/s incl. their launch cost),
+// generate 313.7 -> 301.9 ms per clip.
+#ifndef GV_AUX
+#define GV_AUX 2
+#endif
 constexpr int GV_WAVES = 8;
 constexpr int GV_CHUNK = 4096;                   // k elements per chunk of a weight row = 8 pieces of 1 KiB (64 lanes x 16 B)
 constexpr int GV_MAXCH = 3;                      // k-chunks per weight row: Kp <= 12288
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
         k = k < p.Kp ? k : 0;                                        // beyond Kp: a valid address, its activation entries are zero
         const bf16_t* src = p.wt + (size_t)row * p.ldw + k;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(ring + islot * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(ring + islot * 1024), 16, 0, GV_AUX);
         islot = islot + 1 == GV_NSLOT ? 0 : islot + 1;
         if (++ij == npc) { ij = 0; ++ii; }
     };
