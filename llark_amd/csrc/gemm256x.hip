@@ -69,6 +69,9 @@ struct Mfma16<bf16_t> {
 #ifndef G256X_PRIO
 #define G256X_PRIO 0
 #endif
+#ifndef G256X_STORE_AUX
+#define G256X_STORE_AUX 0          // 16 = sc1 (write-through, line dropped from L2), 2 = nt: epilogue stores through buffer descriptors
+#endif
 
 // Residual epilogue in two halves (row tiles 0, 1 | 2, 3): R may alias C (h += ...), so a load placed after a store can never be
 // hoisted above it -- the residuals of a half (16 x 16 bytes per lane) are all requested before its first store.  The kernel requests
@@ -116,6 +119,33 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4_t (&ac
             const int co = (tn >> 2) * 128 + (tn & 3) * 16;
             if (!full && ncol + co >= p.N) continue;                 // N % 4 == 0 (checked by the launcher): a vector is all in or all out
             f32x4_t v = acc[tm][tn] + bias[tn];
+#if G256X_STORE_AUX
+            // A/B form: the outputs leave through buffer stores with the write-through policy (aux 16 = sc1: the line is NOT kept in the
+            // XCD's L2 -- MI355X guide, "stores of each flavour"), so that 1.26 GB of results per launch stop evicting the A / W panels the
+            // chunk is still re-reading.  32-bit byte offsets: M * ldc * 4 < 2^32 (checked by the launcher)
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            if (EPI == EPI_F32 || EPI == EPI_RESID) {
+                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0xFFFFFFFF, 0x00020000u);
+                const f32x4_t out = EPI == EPI_RESID ? res[t][tn] + v : v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), rc, (int)(((unsigned)m * (unsigned)p.ldc + (unsigned)(ncol + co)) * 4u), 0, G256X_STORE_AUX);
+            } else {
+                out4 hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = v[r];
+                    if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
+                    const T h = (T)x;
+                    hi[r] = h;
+                    lo[r] = (T)(x - (float)h);
+                }
+                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ohi, 0, 0xFFFFFFFF, 0x00020000u);
+                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.Olo, 0, 0xFFFFFFFF, 0x00020000u);
+                const int o = (int)(((unsigned)m * (unsigned)p.ldo + (unsigned)(ncol + co)) * 2u);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rh, o, 0, G256X_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rl, o, 0, G256X_STORE_AUX);
+            }
+#else
             if (EPI == EPI_F32) {
                 *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = v;
             } else if (EPI == EPI_RESID) {
@@ -134,6 +164,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4_t (&ac
                 *(out4*)((T*)p.Ohi + o) = hi;
                 *(out4*)((T*)p.Olo + o) = lo;
             }
+#endif
         }
     }
 }
