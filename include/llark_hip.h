@@ -180,6 +180,22 @@ int llark_gemm16_ex(int variant, int dtype, int split, int epilogue, const void*
 int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                     const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                     int ldr, void* out_hi, void* out_lo, int ldo, llark_workspace_t ws, llark_stream_t stream);
+
+/* LayerNorm folded into the epilogues of the products around it (round 4; replaces the F.layer_norm + Conv1D pairs of upstream
+ * transformer.py ResAttnBlock -- `attn(ln_0(x))`, `mlp(ln_1(x + a))` -- reached from jukebox/main.py:108).  One entry point, two roles:
+ *   producer (ln_part != NULL, LLARK_EPI_RESID): c = resid + a.wt^T + bias as llark_gemm16_ws, plus out_hi / out_lo [m][ldo] = hi / lo of
+ *            c * ln_vec[n] (ln_vec = gamma of the LayerNorm that follows) and ln_part [m][2 * ceil(n / 256)][2] = (sum, sum of squares) of c
+ *            per 128-column slice; llark_ln_stats_finalize reduces them, in slice order, to ln_stat [m][2] = (mean, 1 / sqrt(var + eps));
+ *   consumer (ln_stat != NULL, LLARK_EPI_F32 or LLARK_EPI_QGELU_SPLIT): a_hi / a_lo = those planes;
+ *            out = rstd_m * (acc - mean_m * ln_vec[n]) + bias[n]  with ln_vec[n] = sum_k gamma_k wt[n][k], bias[n] = sum_k beta_k wt[n][k] + b[n]
+ *            (both precomputed by the caller): == Conv1D(layer_norm(x)) without the LayerNorm kernel's read and write of x.
+ * Split operands only; shapes the 256x256 tile does not take (llark_gemm16_ln_takes() == 0) return LLARK_ERR_UNSUPPORTED before anything
+ * is launched.  Partial sums are written, never accumulated atomically: results are run-to-run bit-equal. */
+int llark_gemm16_ln_takes(int m, int n, int kp);
+int llark_gemm16_ln(int dtype, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias, int m,
+                    int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                    const float* ln_stat, const float* ln_vec, float* ln_part, llark_workspace_t ws, llark_stream_t stream);
+int llark_ln_stats_finalize(const float* part, int rows, int nparts, int width, float eps, float* stat, llark_stream_t stream);
 /* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8n.hip; OPT-IN reduced precision, the default is the two-pass fp16
  * form behind llark_gemm16_ws): same call site, upstream Conv1D.forward reached from
  * jukebox/main.py:108 with fp16=False.  The activation is a_hi = fp16(a) plus an E4M3 low plane

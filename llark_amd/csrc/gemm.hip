@@ -1268,6 +1268,48 @@ extern "C" int llark_gemm16_ws(int variant, int dtype, int split, int epilogue, 
                        out_lo, ldo, 0, 0, 0, 0, 0, 0, stream, nullptr, 0, ws);
 }
 
+// LayerNorm folded into the GEMM epilogues around it (round 4; csrc/gemm256x.hip).  One entry point, two roles:
+//   consumer: ln_stat != NULL -- a_hi / a_lo are the planes of x . gamma (written by a producer launch), the epilogue applies the row's
+//             (mean, rstd): out = rstd (acc - mean ln_vec[n]) + bias[n]; ln_vec[n] = sum_k gamma_k W[n][k], bias[n] = sum_k beta_k W[n][k] + b[n];
+//             epilogue LLARK_EPI_F32 (c) or LLARK_EPI_QGELU_SPLIT (out_hi / out_lo)
+//   producer: ln_part != NULL -- LLARK_EPI_RESID: c = resid + acc + bias as usual, plus out_hi / out_lo [m][ldo] = hi / lo of c . ln_vec[n]
+//             (ln_vec = the NEXT LayerNorm's gamma) and ln_part [m][2 * ceil(n / 256)][2] = per-(row, 128-column slice) sum and sum of
+//             squares of c; llark_ln_stats_finalize turns them into [m][2] (mean, rstd)
+// Only the 256x256 tile of gemm256x.hip implements the roles: shapes it does not take return LLARK_ERR_UNSUPPORTED before anything is
+// launched (ask llark_gemm16_ln_takes first).
+extern "C" int llark_gemm16_ln_takes(int m, int n, int kp) { return gemm256x_takes(m, n, kp) ? 1 : 0; }
+
+extern "C" int llark_gemm16_ln(int dtype, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias, int m,
+                               int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                               const float* ln_stat, const float* ln_vec, float* ln_part, llark_workspace_t ws, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && a_lo && wt && ln_vec && ws && m > 0 && n > 0 && kp > 0, "gemm16_ln: null pointer or empty problem");
+    LLARK_REQUIRE((ln_stat != nullptr) != (ln_part != nullptr), "gemm16_ln: exactly one of ln_stat (consumer) / ln_part (producer) must be given");
+    LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16_ln: lda/ldw must be >= kp and multiples of 8");
+    if (ln_part) LLARK_REQUIRE(epilogue == EPI_RESID && c && resid && out_hi && out_lo && ldc >= n && ldr >= n && ldo >= n, "gemm16_ln: the producer role is LLARK_EPI_RESID with c, resid and the operand planes");
+    else LLARK_REQUIRE((epilogue == EPI_F32 && c && ldc >= n) || (epilogue == EPI_QGELU_SPLIT && out_hi && out_lo && ldo >= n), "gemm16_ln: the consumer role is LLARK_EPI_F32 or LLARK_EPI_QGELU_SPLIT");
+    if (!gemm256x_takes(m, n, kp) || ws->cus % 8) {
+        set_error("gemm16_ln: m=%d n=%d kp=%d is not a shape the 256x256 tile takes", m, n, kp);
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
+    p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    p.ln_stat = ln_stat; p.ln_vec = ln_vec; p.ln_part = ln_part;
+    hipStream_t s = (hipStream_t)stream;
+    if (ws_begin(ws, p, s)) {
+        set_error("gemm16_ln: workspace without counters");
+        return LLARK_ERR_INVALID;
+    }
+    const int rc = launch_gemm256x(p, dtype, epilogue, s, ws->cus);
+    if (rc == -1000) {
+        set_error("gemm16_ln: operands do not meet the tile's alignment rules");
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    ws_end(ws, cdiv(m, 256) * cdiv(n, 256), ws->cus / 8);
+    return rc;
+}
+
 extern "C" llark_workspace_t llark_workspace_create(void) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {

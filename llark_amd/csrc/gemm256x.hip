@@ -69,8 +69,46 @@ struct Mfma16<bf16_t> {
 #ifndef G256X_PRIO
 #define G256X_PRIO 0
 #endif
-#ifndef G256X_STORE_AUX
-#define G256X_STORE_AUX 0          // 16 = sc1 (write-through, line dropped from L2), 2 = nt: epilogue stores through buffer descriptors
+
+// The value a hi / lo split starts from has to be ONE fp32 number.  hipcc (ROCm 7.2, even under -ffp-contract=off) selects
+// fp16(a * b) as v_fma_mixlo_f16 a, b, 0 -- the EXACT product rounded once to fp16 -- for the copy of the conversion that feeds the
+// subtraction, and v_cvt_pk_f16_f32 of the fp32 product for the copy that is stored: where the two roundings differ (3e-5 of the
+// elements, measured on gfx950 in round 4) hi + lo misses x by a whole fp16 ulp.  An empty asm on the register makes the product opaque.
+__device__ __forceinline__ float fp_pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// gamma_n for the producer epilogue comes through the LDS.  A vector load placed between the stores would wait for them (vmcnt counts
+// stores, in order: 21 us per tile measured with the loads at the point of use), eight preloaded vectors would need 32 registers that
+// do not exist (spills are scratch = vector memory again), and the scalar cache needs 16 SGPRs per tile (3000 v_writelane / v_readlane
+// when tried).  After the K loop, A-ring slot 6 is idle until the next K loop starts (the prologue fills W 0 - 1 and A 0 - 3): every
+// wave parks the 128 values of its own columns there (lanes 0 .. 31, one float4 each; requested ahead of the bias and the
+// residuals) and reads them back 16 bytes at a time -- lgkmcnt does not care about stores.
+struct Gamma256X {
+    static constexpr int OFF = Cfg256X::O_A + 6 * Cfg256X::UNIT;          // + 1024 per wave
+};
+// (the bias of the producer takes the same road, lanes 32 .. 63 -> the second 512 bytes of the wave's KiB: 32 more registers back)
+__device__ __forceinline__ f32x4_t gamma_load(const GemmParams& p, const int n0, const int wn, const int lane) {
+    const int n = n0 + ((lane >> 4) & 1) * 128 + wn * 64 + (lane & 15) * 4;   // lanes 0 .. 15 (32 .. 47): this wave's columns of half L, 16 .. 31 (48 .. 63): of half R
+    const float* src = lane < 32 ? p.ln_vec : p.bias;
+    return (src != nullptr && n < p.N) ? *(const f32x4_t*)(src + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void gamma_park(char* smem, const f32x4_t gv, const int w, const int lane) {
+    *(f32x4_t*)(smem + Gamma256X::OFF + w * 1024 + lane * 16) = gv;
+}
+__device__ __forceinline__ f32x4_t gamma4(const char* smem, const int w, const int tn, const int g, const int what) {   // what: 0 gamma, 1 bias
+    return *(const f32x4_t*)(smem + Gamma256X::OFF + w * 1024 + what * 512 + (((tn >> 2) << 4) + ((tn & 3) << 2) + g) * 16);
+}
+
+// v_permlane16_swap_b32 a, b: rows (16 lanes) 1 and 3 of a trade places with rows 0 and 2 of b.
+__device__ __forceinline__ void swap_rows16(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+#ifndef G256X_WIDE_PLANES
+#define G256X_WIDE_PLANES 1
 #endif
 
 // Residual epilogue in two halves (row tiles 0, 1 | 2, 3): R may alias C (h += ...), so a load placed after a store can never be
@@ -100,8 +138,10 @@ __device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t
 
 // Epilogue of the transposed 16x16 accumulators: lane l holds, for tile (tm, tn), row m = wave row + 16 tm + l % 16 and the four
 // columns n = tile column + 4 (l / 16) .. +3.  Column tile tn of half h = tn / 4 starts at h * 128 + wn * 64 + (tn % 4) * 16.
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[2][Cfg256X::TN],
+// LN = 1: LayerNorm-folded consumer (mean / rstd of the row applied here), LN = 2: producer of the next LayerNorm's operand planes and
+// of the row statistics' partial sums (GemmParams: ln_stat / ln_vec / ln_part).
+template <typename T, int EPI, int LN>
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* smem, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[2][Cfg256X::TN],
                                                const f32x4_t (&bias)[Cfg256X::TN], const int half2, const int m0, const int n0, const int wm, const int wn,
                                                const int lane) {
     typedef Cfg256X C;
@@ -109,76 +149,158 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, f32x4_t (&ac
     const int l15 = lane & 15, g4 = (lane >> 4) << 2;
     const int ncol = n0 + wn * 64 + g4;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+    f32x4_t lv[LN == 1 ? C::TN : 1];                                 // LN = 1: s_n = sum_k gamma_k W[n][k], kept for both row tiles of the half
+    if (LN == 1) {                                                   // (LN = 2 fetches the next LayerNorm's gamma_n at the point of use: acc +
+#pragma unroll                                                       //  bias + the residual half already fill the register file)
+        for (int tn = 0; tn < C::TN; ++tn) {
+            const int n = ncol + (tn >> 2) * 128 + (tn & 3) * 16;
+            lv[tn] = n < p.N ? *(const f32x4_t*)(p.ln_vec + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // Operand planes leave in 16-byte stores (round 4): a lane owns 4 columns of a 16-column tile = 8 bytes of a 16-bit plane, and 16 rows x
+    // 32 bytes per store instruction made the plane stores the slowest part of the epilogue (issue-bound: requests per instruction, not
+    // bytes).  v_permlane16_swap_b32 trades the tile tn registers of lane groups 1 / 3 for the tile tn + 1 registers of groups 0 / 2: group
+    // g then holds 8 consecutive columns of tile tn + (g & 1), from column 8 (g >> 1) on, and one instruction stores 16 rows x 64 bytes.
+    // Whole tiles only (every lane takes part in the swap); ragged tiles keep the 8-byte stores.
+    constexpr bool PLANES = (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || LN == 2);
+    const bool wide = PLANES && G256X_WIDE_PLANES && full && (p.ldo & 7) == 0;
+    const int gsel = lane >> 4;
+    const int wcol = n0 + wn * 64 + ((gsel & 1) << 4) + ((gsel >> 1) << 3);
+    // every load of this call goes out before its first store: vmcnt counts stores too, so a load behind a store waits for the store's
+    // round trip (the producer's gamma loads inside the column loop cost 21 us per tile that way, measured in round 4)
+    float2 st[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};
+    if (LN == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int m = m0 + wm * 64 + (2 * half2 + t) * 16 + l15;
+            if (full || m < p.M) st[t] = *(const float2*)(p.ln_stat + 2 * (size_t)m);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int tm = 2 * half2 + t;
         const int m = m0 + wm * 64 + tm * 16 + l15;
-        if (!full && m >= p.M) continue;
+        if (!full && m >= p.M) continue;                             // the four lanes of a row (l15, g = 0 .. 3) leave together
+        const float mu = st[t].x, rstd = st[t].y;
+        float sx = 0.f, sq = 0.f;
+        if (wide) {
 #pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int co = (tn >> 2) * 128 + (tn & 3) * 16;
-            if (!full && ncol + co >= p.N) continue;                 // N % 4 == 0 (checked by the launcher): a vector is all in or all out
-            f32x4_t v = acc[tm][tn] + bias[tn];
-#if G256X_STORE_AUX
-            // A/B form: the outputs leave through buffer stores with the write-through policy (aux 16 = sc1: the line is NOT kept in the
-            // XCD's L2 -- MI355X guide, "stores of each flavour"), so that 1.26 GB of results per launch stop evicting the A / W panels the
-            // chunk is still re-reading.  32-bit byte offsets: M * ldc * 4 < 2^32 (checked by the launcher)
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-            if (EPI == EPI_F32 || EPI == EPI_RESID) {
-                const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, 0xFFFFFFFF, 0x00020000u);
-                const f32x4_t out = EPI == EPI_RESID ? res[t][tn] + v : v;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, out), rc, (int)(((unsigned)m * (unsigned)p.ldc + (unsigned)(ncol + co)) * 4u), 0, G256X_STORE_AUX);
-            } else {
-                out4 hi, lo;
+            for (int tp = 0; tp < C::TN / 2; ++tp) {
+                const int co0 = (tp >> 1) * 128 + (tp & 1) * 32;     // tiles tn = 2 tp, 2 tp + 1: 32 consecutive columns
+                uint2 ph[2], pl[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = v[r];
-                    if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
-                    const T h = (T)x;
-                    hi[r] = h;
-                    lo[r] = (T)(x - (float)h);
+                for (int u = 0; u < 2; ++u) {
+                    const int tn = 2 * tp + u;
+                    const int co = co0 + 16 * u;
+                    f32x4_t v;
+                    if (LN == 1) v = (acc[tm][tn] - mu * lv[LN == 1 ? tn : 0]) * rstd + bias[tn];
+                    else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
+                    else v = acc[tm][tn] + bias[tn];
+                    out4 hi, lo;
+                    if (LN == 2) {
+                        const f32x4_t out = res[t][tn] + v;
+                        *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = out;
+                        const f32x4_t gm = gamma4(smem, wm * 2 + wn, tn, gsel, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = fp_pin(out[r] * gm[r]);
+                            const T h = (T)x;
+                            hi[r] = h;
+                            lo[r] = (T)(x - (float)h);
+                            sx += out[r];
+                            sq = fmaf(out[r], out[r], sq);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = v[r];
+                            if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
+                            const T h = (T)x;
+                            hi[r] = h;
+                            lo[r] = (T)(x - (float)h);
+                        }
+                    }
+                    ph[u] = __builtin_bit_cast(uint2, hi);
+                    pl[u] = __builtin_bit_cast(uint2, lo);
                 }
-                const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ohi, 0, 0xFFFFFFFF, 0x00020000u);
-                const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)p.Olo, 0, 0xFFFFFFFF, 0x00020000u);
-                const int o = (int)(((unsigned)m * (unsigned)p.ldo + (unsigned)(ncol + co)) * 2u);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rh, o, 0, G256X_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rl, o, 0, G256X_STORE_AUX);
+                swap_rows16(ph[0].x, ph[1].x);
+                swap_rows16(ph[0].y, ph[1].y);
+                swap_rows16(pl[0].x, pl[1].x);
+                swap_rows16(pl[0].y, pl[1].y);
+                const size_t o = (size_t)m * p.ldo + wcol + co0;
+                *(uint4*)((T*)p.Ohi + o) = make_uint4(ph[0].x, ph[0].y, ph[1].x, ph[1].y);
+                *(uint4*)((T*)p.Olo + o) = make_uint4(pl[0].x, pl[0].y, pl[1].x, pl[1].y);
             }
-#else
-            if (EPI == EPI_F32) {
-                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = v;
-            } else if (EPI == EPI_RESID) {
-                *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = res[t][tn] + v;
-            } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
-                out4 hi, lo;
+        } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = v[r];
-                    if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
-                    const T h = (T)x;
-                    hi[r] = h;
-                    lo[r] = (T)(x - (float)h);
+            for (int tn = 0; tn < C::TN; ++tn) {
+                const int co = (tn >> 2) * 128 + (tn & 3) * 16;
+                if (!full && ncol + co >= p.N) continue;             // N % 4 == 0 (checked by the launcher): a vector is all in or all out
+                f32x4_t v;
+                if (LN == 1) v = (acc[tm][tn] - mu * lv[LN == 1 ? tn : 0]) * rstd + bias[tn];
+                else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
+                else v = acc[tm][tn] + bias[tn];
+                if (EPI == EPI_F32) {
+                    *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = v;
+                } else if (EPI == EPI_RESID) {
+                    const f32x4_t out = res[t][tn] + v;
+                    *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = out;
+                    if (LN == 2) {
+                        const f32x4_t gm = gamma4(smem, wm * 2 + wn, tn, gsel, 0);
+                        out4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = fp_pin(out[r] * gm[r]);
+                            const T h = (T)x;
+                            hi[r] = h;
+                            lo[r] = (T)(x - (float)h);
+                            sx += out[r];
+                            sq = fmaf(out[r], out[r], sq);
+                        }
+                        const size_t o = (size_t)m * p.ldo + ncol + co;
+                        *(out4*)((T*)p.Ohi + o) = hi;
+                        *(out4*)((T*)p.Olo + o) = lo;
+                    }
+                } else if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16) {
+                    out4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = v[r];
+                        if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
+                        const T h = (T)x;
+                        hi[r] = h;
+                        lo[r] = (T)(x - (float)h);
+                    }
+                    const size_t o = (size_t)m * p.ldo + ncol + co;
+                    *(out4*)((T*)p.Ohi + o) = hi;
+                    *(out4*)((T*)p.Olo + o) = lo;
                 }
-                const size_t o = (size_t)m * p.ldo + ncol + co;
-                *(out4*)((T*)p.Ohi + o) = hi;
-                *(out4*)((T*)p.Olo + o) = lo;
             }
-#endif
+        }
+        if (LN == 2) {
+            // this wave's 128 columns of row m: lane groups g = 0 .. 3 hold 32 values each; fixed reduction order -> run-to-run bit-equal
+            sx += __shfl_xor(sx, 16);
+            sq += __shfl_xor(sq, 16);
+            sx += __shfl_xor(sx, 32);
+            sq += __shfl_xor(sq, 32);
+            if (lane < 16) *(float2*)(p.ln_part + ((size_t)m * (2 * p.tiles_n) + 2 * (n0 >> 8) + wn) * 2) = make_float2(sx, sq);
         }
     }
 }
 
-__device__ __forceinline__ void epilogue_load_bias(const GemmParams& p, f32x4_t (&bias)[Cfg256X::TN], const int n0, const int wn, const int lane) {
+__device__ __forceinline__ void epilogue_load_vec(const float* vec, const int N, f32x4_t (&out)[Cfg256X::TN], const int n0, const int wn, const int lane) {
     const int ncol = n0 + wn * 64 + ((lane >> 4) << 2);
 #pragma unroll
     for (int tn = 0; tn < Cfg256X::TN; ++tn) {
         const int n = ncol + (tn >> 2) * 128 + (tn & 3) * 16;
-        bias[tn] = (p.bias != nullptr && n < p.N) ? *(const f32x4_t*)(p.bias + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        out[tn] = (vec != nullptr && n < N) ? *(const f32x4_t*)(vec + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 }
+__device__ __forceinline__ void epilogue_load_bias(const GemmParams& p, f32x4_t (&bias)[Cfg256X::TN], const int n0, const int wn, const int lane) {
+    epilogue_load_vec(p.bias, p.N, bias, n0, wn, lane);
+}
 
-template <typename T, int EPI>
+template <typename T, int EPI, int LN>
 __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kernel(const GemmParams p) {
     typedef Cfg256X C;
     typedef typename Mfma16<T>::frag frag;
@@ -427,8 +549,11 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
             // bias and the first half of the residuals are requested AHEAD of the next tile's prologue (in-order returns)
             f32x4_t bias[C::TN], res[2][C::TN];
-            epilogue_load_bias(p, bias, n0, wn, lane);
+            f32x4_t gv;
+            if (LN == 2) gv = gamma_load(p, n0, wn, lane);
+            else epilogue_load_bias(p, bias, n0, wn, lane);
             epilogue_load_resid<EPI>(p, res, 0, m0, n0, wm, wn, lane);
+            if (LN == 2) gamma_park(smem, gv, w, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 1 < nchunks) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -443,9 +568,9 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_store<T, EPI>(p, acc, res, bias, 0, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, 0, m0, n0, wm, wn, lane);
             epilogue_load_resid<EPI>(p, res, 1, m0, n0, wm, wn, lane);
-            epilogue_store<T, EPI>(p, acc, res, bias, 1, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, 1, m0, n0, wm, wn, lane);
         }
         if (ch + 1 < nchunks) {
             if (threadIdx.x == 0) {
@@ -460,10 +585,10 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, int LN>
 static int launch256x(GemmParams p, hipStream_t s, int cus) {
     typedef Cfg256X C;
-    auto kern = gemm256x_kernel<T, EPI>;
+    auto kern = gemm256x_kernel<T, EPI, LN>;
     static PerDeviceOnce once;                  // per device: the attribute belongs to the device's function object
     if (once.first()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return -1000;
@@ -477,13 +602,27 @@ static int launch256x(GemmParams p, hipStream_t s, int cus) {
 
 template <typename T>
 static int dispatch256x(const GemmParams& p, int epi, hipStream_t s, int cus) {
+    if (p.ln_stat) {                            // LayerNorm-folded consumer
+        if (!p.ln_vec || p.ln_part) return -1000;
+        if (epi == EPI_F32) return launch256x<T, EPI_F32, 1>(p, s, cus);
+        if (epi == EPI_QGELU_SPLIT) return launch256x<T, EPI_QGELU_SPLIT, 1>(p, s, cus);
+        return -1000;
+    }
+    if (p.ln_part) {                            // producer of the next LayerNorm's operand planes + row statistics
+        if (!p.ln_vec || epi != EPI_RESID || !p.Ohi || !p.Olo) return -1000;
+        return launch256x<T, EPI_RESID, 2>(p, s, cus);
+    }
     switch (epi) {
-        case EPI_F32: return launch256x<T, EPI_F32>(p, s, cus);
-        case EPI_RESID: return launch256x<T, EPI_RESID>(p, s, cus);
-        case EPI_QGELU_SPLIT: return launch256x<T, EPI_QGELU_SPLIT>(p, s, cus);
-        case EPI_SPLIT16: if (p.act == 0 && p.Ohi2 == nullptr) return launch256x<T, EPI_SPLIT16>(p, s, cus);
+        case EPI_F32: return launch256x<T, EPI_F32, 0>(p, s, cus);
+        case EPI_RESID: return launch256x<T, EPI_RESID, 0>(p, s, cus);
+        case EPI_QGELU_SPLIT: return launch256x<T, EPI_QGELU_SPLIT, 0>(p, s, cus);
+        case EPI_SPLIT16: if (p.act == 0 && p.Ohi2 == nullptr) return launch256x<T, EPI_SPLIT16, 0>(p, s, cus);
     }
     return -1000;
+}
+
+bool gemm256x_takes(int m, int n, int kp) {
+    return kp % 64 == 0 && kp >= 128 && n % 4 == 0 && m > 0 && (long)cdiv(m, 256) * cdiv(n, 256) >= 384;
 }
 
 int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus) {
@@ -495,7 +634,8 @@ int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int 
     if (p.bias && ((uintptr_t)p.bias & 15)) return -1000;
     if ((epi == EPI_F32 || epi == EPI_RESID) && (p.ldc % 4 || ((uintptr_t)p.C & 15))) return -1000;
     if (epi == EPI_RESID && (p.ldr % 4 || ((uintptr_t)p.R & 15))) return -1000;
-    if ((epi == EPI_QGELU_SPLIT || epi == EPI_SPLIT16) && (p.ldo % 4 || ((uintptr_t)p.Ohi & 7) || ((uintptr_t)p.Olo & 7))) return -1000;
+    if ((epi == EPI_QGELU_SPLIT || epi == EPI_SPLIT16 || p.ln_part) && (p.ldo % 4 || ((uintptr_t)p.Ohi & 7) || ((uintptr_t)p.Olo & 7))) return -1000;
+    if ((p.ln_stat || p.ln_part) && (!p.ln_vec || ((uintptr_t)p.ln_vec & 15) || ((uintptr_t)p.ln_stat & 7) || ((uintptr_t)p.ln_part & 7))) return -1000;
     if (dtype == LLARK_F16) return dispatch256x<half_t>(p, epi, s, cus);
     if (dtype == LLARK_BF16) return dispatch256x<bf16_t>(p, epi, s, cus);
     return -1000;

@@ -108,6 +108,14 @@ struct GemmParams {
     unsigned* sk_flag; // [resident workgroups] hand-off flags, zero between launches
     long long* prof;   // profiling builds only (-DLLARK_LO8_PROF): per-wave cycle counters, nullptr otherwise
     double* sumsq;     // gemm_tn.hip, EPI_F32 / EPI_RESID: += sum of squares of every value the epilogue stores (nullptr = off)
+    // LayerNorm folded into the epilogues around it (gemm256x.hip, round 4; llark_gemm16_ln):
+    //   consumer (ln_stat != nullptr; EPI_F32 / EPI_QGELU_SPLIT): A = planes of x . gamma, out = rstd_m (acc - mu_m ln_vec[n]) + bias[n]
+    //            with ln_vec[n] = sum_k gamma_k W[n][k] and bias[n] = sum_k beta_k W[n][k] + b[n]
+    //   producer (ln_part != nullptr; EPI_RESID): besides C = R + acc + bias: Ohi / Olo [M][ldo] = hi / lo of C . ln_vec[n] (the NEXT
+    //            LayerNorm's gamma) and ln_part[m][2 tile_n + wn][0..1] = (sum, sum of squares) of C over this wave's 128 columns
+    const float* ln_stat;   // [M][2] (mean, rstd)
+    const float* ln_vec;    // [N]
+    float* ln_part;         // [M][2 * tiles_n][2]
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
@@ -313,6 +321,8 @@ int launch_gemm256n(const GemmParams& p, int dtype, int epi, hipStream_t s, int 
 // arithmetic order per accumulator (hi then lo, k ascending) but 32 products per instruction: NOT bit-identical to the 32x32x16 kernels.
 // EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT / plain EPI_SPLIT16, N % 4 == 0.  Returns -1000 when the problem is not one it handles.
 int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
+// does launch_gemm256x take this split product (shape rules only; the LayerNorm-folding host path asks before it commits to it)
+bool gemm256x_takes(int m, int n, int kp);
 // gemm256_lo8n.hip: the 256x256 tile with an e4m3 low plane staged through LDS (p.W8), phases split over N, A fragments resident
 // across both (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of the stream's device (8 | cus).  Returns -1000
 // when the problem is not one it handles.

@@ -189,6 +189,25 @@ __global__ __launch_bounds__(256) void layernorm_split8_kernel(const float* __re
     }
 }
 
+// Row statistics of a LayerNorm whose partial sums came out of a GEMM epilogue (llark_gemm16_ln, producer role): part [rows][nparts][2] =
+// (sum, sum of squares) over 128-column slices, summed here in slice order (fixed: run-to-run bit-equal) in double -> stat [rows][2] =
+// (mean, 1 / sqrt(var + eps)), var = E[x^2] - mean^2 (biased, like torch layer_norm).
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int rows, int nparts, int width, float eps, float* __restrict__ stat) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float2* pr = (const float2*)(part + (size_t)r * nparts * 2);
+    double sx = 0.0, sq = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        const float2 v = pr[i];
+        sx += (double)v.x;
+        sq += (double)v.y;
+    }
+    const double mean = sx / (double)width;
+    double var = sq / (double)width - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    *(float2*)(stat + 2 * (size_t)r) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
 // ------------------------------------------------------------------------------------------
 // Factored attention (block / transpose-block / previous-block), fp32, one workgroup per
 // (64-query group, head, clip).  Q K^T and P V run on the fp32-input matrix cores
@@ -879,6 +898,12 @@ static int layernorm_split_impl(const float* x, int ldx, int rows, int width, co
     }
 #undef LN_CASE
     return check_launch("layernorm_split");
+}
+
+extern "C" int llark_ln_stats_finalize(const float* part, int rows, int nparts, int width, float eps, float* stat, llark_stream_t stream) {
+    LLARK_REQUIRE(part && stat && rows > 0 && nparts > 0 && width > 0, "ln_stats_finalize: bad arguments");
+    ln_stats_finalize_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(part, rows, nparts, width, eps, stat);
+    return check_launch("ln_stats_finalize");
 }
 
 extern "C" int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, const float* gamma,

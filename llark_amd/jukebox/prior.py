@@ -33,6 +33,13 @@ from .hparams import JukeboxHParams
 # precision="lo8" / LLARK_PRIOR_PRECISION=lo8 / bench.py --prior-precision lo8.
 DEFAULT_PRECISION = "f16x2"
 
+# LayerNorm folded into the GEMM epilogues on both sides of it (round 4; include/llark_hip.h, llark_gemm16_ln): the c_proj
+# products write hi/lo planes of (x . gamma) and per-slice (sum, sum of squares) next to the residual stream, the c_attn / c_fc
+# products apply the row's (mean, rstd) in their epilogues --  LN(x) W = rstd ((x . gamma) W - mean (gamma W)) + (beta W + b) --
+# so 71 of the 72 LayerNorm kernels of a 36-layer forward (each one read + one write of the [M][W] stream) disappear.
+# LLARK_PRIOR_LN_FOLD=0 (or PriorTransformer(ln_fold=False)) keeps the separate LayerNorm kernel everywhere.
+DEFAULT_LN_FOLD = True
+
 
 class Labeller:
     """Upstream ``Labeller.get_batch_labels`` for the only metadata the reference ever passes
@@ -57,14 +64,15 @@ class Labeller:
 
 class _LayerWeights:
     __slots__ = ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "w_attn", "b_attn", "w_proj", "b_proj", "w_fc", "b_fc", "w_proj2",
-                 "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2", "w8_attn", "w8_proj", "w8_fc", "w8_proj2")
+                 "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2", "w8_attn", "w8_proj", "w8_fc", "w8_proj2",
+                 "gw_attn", "bw_attn", "gw_fc", "bw_fc")
 
 
 class PriorTransformer:
     """``top_prior.prior``: the ConditionalAutoregressive2D forward in ``only_encode`` mode."""
 
     def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device, depth: Optional[int] = None,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, ln_fold: Optional[bool] = None):
         self.hps = hps
         self.device = torch.device(device)
         self.only_encode = False
@@ -75,6 +83,9 @@ class PriorTransformer:
         if precision not in ("f16x2", "lo8"):
             raise ValueError(f"prior precision must be 'f16x2' or 'lo8', got {precision!r}")
         self.precision = precision
+        if ln_fold is None:
+            ln_fold = os.environ.get("LLARK_PRIOR_LN_FOLD", "1" if DEFAULT_LN_FOLD else "0") != "0"
+        self.ln_fold = bool(ln_fold) and precision == "f16x2"       # the lo8 tile has no folded epilogues
         self.width = hps.prior_width
         self.depth = hps.prior_depth if depth is None else depth
         dev = self.device
@@ -113,9 +124,19 @@ class PriorTransformer:
                 # the E4M3 weight planes e4m3(W 2^sw), staged through LDS next to W (+50 % weight bytes: 5.5 GB for the 36 layers)
                 L.w8_attn, L.w8_proj = ops.pack_weight_lo8(L.w_attn, L.sw_attn), ops.pack_weight_lo8(L.w_proj, L.sw_proj)
                 L.w8_fc, L.w8_proj2 = ops.pack_weight_lo8(L.w_fc, L.sw_fc), ops.pack_weight_lo8(L.w_proj2, L.sw_proj2)
+            if self.ln_fold:
+                # the folded form's per-column vectors, from the fp16 weights as the kernel reads them, summed in float64:
+                #   gw[n] = sum_k gamma_k W[n][k]   (multiplies the row mean),   bw[n] = sum_k beta_k W[n][k] + b[n]
+                W = hps.prior_width
+                for tag, wt, b, g, be in (("attn", L.w_attn, L.b_attn, L.ln0_g, L.ln0_b), ("fc", L.w_fc, L.b_fc, L.ln1_g, L.ln1_b)):
+                    w64 = wt[:, :W].double()
+                    setattr(L, "gw_" + tag, (w64 @ g.double()).float().contiguous())
+                    setattr(L, "bw_" + tag, (w64 @ be.double() + b.double()).float().contiguous())
+                    del w64
             self.layers.append(L)
         self._ws: Dict[str, torch.Tensor] = {}
         self._ws_rows = 0
+        self._fold_rows = False
 
     # ---- workspace ---------------------------------------------------------------------------
     def _workspace(self, rows: int):
@@ -135,19 +156,34 @@ class PriorTransformer:
             ws["att_lo"] = torch.zeros((rows, Sp), dtype=lo_dt, device=dev)
             ws["g_hi"] = torch.zeros((rows, Mp), dtype=torch.float16, device=dev)
             ws["g_lo"] = torch.zeros((rows, Mp), dtype=lo_dt, device=dev)
+            # folded LayerNorm: every product of a block has to be a shape the 256x256 tile takes (5b widths at M >= 2048 rows)
+            self._fold_rows = bool(self.ln_fold and all(ops.gemm16_ln_takes(rows, nn, kk) for nn, kk in
+                                                        ((3 * S, Wp), (W, Sp), (Mw, Wp), (W, Mp))))
+            if self._fold_rows:
+                self._ln_parts = 2 * ((W + 255) // 256)
+                ws["ln_part"] = torch.empty((rows, self._ln_parts, 2), dtype=torch.float32, device=dev)
+                ws["ln_stat"] = torch.empty((rows, 2), dtype=torch.float32, device=dev)
             self._ws, self._ws_rows = ws, rows
         return self._ws
 
     # ---- one ResAttnBlock --------------------------------------------------------------------
-    def layer_forward(self, h2: torch.Tensor, d: int, n: int, taps: Optional[dict] = None) -> None:
+    def layer_forward(self, h2: torch.Tensor, d: int, n: int, taps: Optional[dict] = None, fold_in: bool = False,
+                      fold_out: Optional[int] = None) -> None:
         """h2: [M][W] fp32 residual stream, updated in place:  a = attn(ln_0(h)); h += a;
-        m = mlp(ln_1(h)); h += m   (== upstream ``x + a + m`` evaluated left to right)."""
+        m = mlp(ln_1(h)); h += m   (== upstream ``x + a + m`` evaluated left to right).
+
+        ``fold_in`` / ``fold_out`` chain consecutive blocks in the folded-LayerNorm form (forward() sets them): fold_in = the
+        workspace already holds the planes of h . ln_0.gamma and the row statistics (the previous block's fold_out);
+        fold_out = index of the block that follows, whose ln_0.gamma this block's last product multiplies in."""
         hps, L = self.hps, self.layers[d]
         rows = h2.shape[0]
         ws = self._workspace(rows)
         W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
         if self.precision == "lo8":
             return self._layer_forward_lo8(h2, L, d, n, ws, taps)
+        if self._fold_rows and taps is None:
+            return self._layer_forward_fold(h2, L, d, n, ws, fold_in, fold_out)
+        assert not fold_in, "fold_in without the folded path"
         ops.layernorm_split(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
         ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
         ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
@@ -164,6 +200,30 @@ class PriorTransformer:
             taps["ln1"] = ws["ln_hi"].float() + ws["ln_lo"].float()
             taps["g"] = (ws["g_hi"].float() + ws["g_lo"].float())[:, :Mw]
         ops.gemm16(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
+
+    def _layer_forward_fold(self, h2, L, d: int, n: int, ws, fold_in: bool, fold_out: Optional[int]) -> None:
+        """The block with its LayerNorms folded into the products around them (see DEFAULT_LN_FOLD).  Statistics are per-slice
+        sums written by the producing epilogue and reduced in a fixed order: deterministic, batch-size independent."""
+        hps = self.hps
+        W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
+        rows, part, stat = h2.shape[0], ws["ln_part"], ws["ln_stat"]
+        if fold_in:
+            ops.gemm16_ln(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.bw_attn, 3 * S, ops.EPI_F32, L.gw_attn, ln_stat=stat, c=ws["qkv"])
+        else:
+            ops.layernorm_split(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
+            ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
+        ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
+        ops.gemm16_ln(ws["att_hi"], ws["att_lo"], L.w_proj, L.b_proj, W, ops.EPI_RESID, L.ln1_g, ln_part=part, c=h2, resid=h2,
+                      out_hi=ws["ln_hi"], out_lo=ws["ln_lo"])
+        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat)
+        ops.gemm16_ln(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.bw_fc, Mw, ops.EPI_QGELU_SPLIT, L.gw_fc, ln_stat=stat,
+                      out_hi=ws["g_hi"], out_lo=ws["g_lo"])
+        if fold_out is None:
+            ops.gemm16(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
+            return
+        ops.gemm16_ln(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, self.layers[fold_out].ln0_g, ln_part=part,
+                      c=h2, resid=h2, out_hi=ws["ln_hi"], out_lo=ws["ln_lo"])
+        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat)
 
     def _layer_forward_lo8(self, h2, L, d: int, n: int, ws, taps) -> None:
         """The same block with E4M3 low planes: every producer (LayerNorm, attention, the c_fc epilogue) writes
@@ -211,8 +271,10 @@ class PriorTransformer:
         # x_cond / y_cond are the same for every clip (the reference keeps sample 0 only, main.py:95-96)
         h = self.embed(x, x_cond[0:1] if x_cond.dim() == 3 else x_cond, y_cond)
         h2 = h.view(n * t, self.width)
-        for d in range(self.depth if depth is None else depth):
-            self.layer_forward(h2, d, n)
+        nd = self.depth if depth is None else depth
+        fold = self._workspace(n * t) is not None and self._fold_rows
+        for d in range(nd):
+            self.layer_forward(h2, d, n, fold_in=fold and d > 0, fold_out=d + 1 if fold and d + 1 < nd else None)
         return h
 
     __call__ = forward
@@ -222,14 +284,14 @@ class TopPrior:
     """``top_prior``: conditioning tables + the transformer (upstream SimplePrior, level = top)."""
 
     def __init__(self, hps: JukeboxHParams, weights: Dict[str, torch.Tensor], device="cuda", depth: Optional[int] = None,
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, ln_fold: Optional[bool] = None):
         hps.check()
         self.hps = hps
         self.device = torch.device(device)
         self.raw_to_tokens = hps.raw_to_tokens
         self.n_ctx = hps.n_ctx
         self.labeller = Labeller(hps)
-        self.prior = PriorTransformer(hps, weights, device, depth, precision)
+        self.prior = PriorTransformer(hps, weights, device, depth, precision, ln_fold)
         dev = self.device
         self._y_emb = {k.split(".")[1]: v.detach().to(device=dev, dtype=torch.float32).contiguous()
                        for k, v in weights.items() if k.startswith("y_emb.")}

@@ -494,6 +494,47 @@ def gemm16(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wt: torch.Tensor, b
         out_hi.stride(0) if out_hi is not None else 0, workspace(), _stream()), "gemm16")
 
 
+def gemm16_ln_takes(m: int, n: int, kp: int) -> bool:
+    """True when llark_gemm16_ln (LayerNorm folded into the 256x256 tile's epilogues) takes the shape."""
+    return bool(_lib.lib().llark_gemm16_ln_takes(int(m), int(n), int(kp)))
+
+
+def gemm16_ln(a_hi: torch.Tensor, a_lo: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], n: int, epilogue: int,
+              ln_vec: torch.Tensor, ln_stat: Optional[torch.Tensor] = None, ln_part: Optional[torch.Tensor] = None,
+              c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None,
+              out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
+    """The split product with a LayerNorm folded into its epilogue (include/llark_hip.h, llark_gemm16_ln): ``ln_stat`` given =
+    consumer (the operand planes hold x . gamma; the epilogue applies the row's mean / rstd), ``ln_part`` given = producer
+    (EPI_RESID; also writes the planes of c . ln_vec and the per-slice sums the next LayerNorm's statistics come from)."""
+    dtype = a_hi.dtype
+    assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype and a_lo is not None
+    m = a_hi.shape[0] if m is None else m
+    kp = wt.shape[1]
+    assert a_hi.shape[1] >= kp and wt.shape[0] >= n and ln_vec.numel() >= n
+    if ln_part is not None:
+        assert ln_part.numel() >= m * 2 * ((n + 255) // 256) * 2, "gemm16_ln: ln_part is [m][2 * ceil(n / 256)][2]"
+    if ln_stat is not None:
+        assert ln_stat.numel() >= 2 * m
+    name = "gemm_split_" + ("f16" if dtype == torch.float16 else "bf16")
+    with _timed(name, 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_ln(
+            _DT[dtype], epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype), a_hi.stride(0), _dev(wt, "wt"), wt.stride(0),
+            _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp,
+            _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
+            _dev(resid, "resid", torch.float32) if resid is not None else None, resid.stride(0) if resid is not None else 0,
+            _dev(out_hi, "out_hi", dtype) if out_hi is not None else None, _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
+            out_hi.stride(0) if out_hi is not None else 0,
+            _dev(ln_stat, "ln_stat", torch.float32) if ln_stat is not None else None, _dev(ln_vec, "ln_vec", torch.float32),
+            _dev(ln_part, "ln_part", torch.float32) if ln_part is not None else None, workspace(), _stream()), "gemm16_ln")
+
+
+def ln_stats_finalize(part: torch.Tensor, rows: int, nparts: int, width: int, eps: float, stat: torch.Tensor) -> None:
+    """part [rows][nparts][2] (sum, sum of squares per column slice) -> stat [rows][2] (mean, rstd)."""
+    assert part.numel() >= rows * nparts * 2 and stat.numel() >= rows * 2
+    check(_lib.lib().llark_ln_stats_finalize(_dev(part, "part", torch.float32), rows, nparts, width, float(eps),
+                                             _dev(stat, "stat", torch.float32), _stream()), "ln_stats_finalize")
+
+
 def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a: bool, trans_b: bool, c: torch.Tensor,
              accumulate: bool = False, sumsq: Optional[torch.Tensor] = None) -> None:
     """c[m][n] (= | +=) sum_k A(m, k) W(n, k) with operands that may be stored contraction-major (csrc/gemm_tn.hip;

@@ -179,6 +179,90 @@ def test_gemm256x_16x16x32_tile(m, n, k):
         assert float(d.abs().max()) <= 2.0 * float((3.0 * bound + q).max()) + 1e-6               # two correct kernels, each inside the bound
 
 
+@pytest.mark.parametrize("m,n,k", [(8192, 4800, 192), (8200, 3648, 256), (20000, 1216, 320)])
+def test_gemm16_ln_folded_layernorm_roles(m, n, k):
+    """llark_gemm16_ln (round 4): the LayerNorm folded into the 256x256 tile's epilogues.
+    Producer (EPI_RESID): the stream it writes is BIT-equal to the plain product's; the planes are the hi / lo split of c . gamma;
+    the per-slice sums, reduced by llark_ln_stats_finalize, are the row's mean and 1 / sqrt(var + eps); run-to-run bit-equal.
+    Consumer: rstd (acc - mean gw) + bw  ==  LayerNorm(c) W + b evaluated in float64, inside the split scheme's bound, for the
+    F32 and the QGELU_SPLIT epilogue; ragged M, ragged last column tile; shapes the tile does not take are refused."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m + 3 * n + k)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.2).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = (torch.randn(m, n, generator=g) * 3.0 + 0.7).cuda()             # a row mean that is not ~0: the -mean.gw term matters
+    gamma = (1.0 + 0.3 * torch.randn(n, generator=g)).cuda()
+    beta = (0.2 * torch.randn(n, generator=g)).cuda()
+    assert ops.gemm16_ln_takes(m, n, ops.round_up(k, 64)) and not ops.gemm16_ln_takes(512, 512, 256)
+    hi, lo = ops.split16(a.cuda(), torch.float16, kmult=64)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16, kmult=64)
+    # ---- producer
+    c0 = r.clone()
+    ops.gemm16(hi, lo, wt, b, n, ops.EPI_RESID, c=c0, resid=c0, variant=32)
+    nparts = 2 * ((n + 255) // 256)
+    first = None
+    for rep in range(2):
+        c1 = r.clone()
+        ph, pl = (torch.full((m, n + 8), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+        part = torch.full((m, nparts, 2), float("nan"), device="cuda")
+        stat = torch.full((m, 2), float("nan"), device="cuda")
+        ops.gemm16_ln(hi, lo, wt, b, n, ops.EPI_RESID, gamma, ln_part=part, c=c1, resid=c1, out_hi=ph, out_lo=pl)
+        ops.ln_stats_finalize(part, m, nparts, n, 1e-5, stat)
+        if first is None:
+            first = (c1.clone(), ph.clone(), pl.clone(), stat.clone())
+    assert torch.equal(c1, c0), f"producer stream differs from the plain RESID product in {int((c1 != c0).sum())} elements"
+    assert torch.equal(first[0], c1) and torch.equal(first[1][:, :n], ph[:, :n]) and torch.equal(first[2][:, :n], pl[:, :n]) and torch.equal(first[3], stat)
+    assert bool(torch.isnan(ph[:, n:]).all() and torch.isnan(pl[:, n:]).all()), "producer wrote planes past column n"
+    xg = c1 * gamma
+    want_hi = xg.half()
+    # (bit-equal: found the toolchain's v_fma_mixlo_f16 double-rounding mismatch in round 4 -- csrc/gemm256x.hip fp_pin)
+    assert torch.equal(ph[:, :n], want_hi) and torch.equal(pl[:, :n], (xg - want_hi.float()).half()), "planes are not split16(c . gamma)"
+    c64 = c1.double()
+    mean64, var64 = c64.mean(1), c64.var(1, unbiased=False)
+    assert float((stat[:, 0].double() - mean64).abs().max()) <= 2e-6 * float(c64.abs().max())
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    assert float((stat[:, 1].double() / rstd64 - 1.0).abs().max()) <= 3e-6
+    # ---- consumer: a second product whose operand is LayerNorm(c1); K = n, N = n2
+    n2 = 4800 if m < 16384 else 2048
+    w2 = (torch.randn(n, n2, generator=g) * 0.05).half()
+    b2 = torch.randn(n2, generator=g).cuda()
+    wt2 = ops.pack_weight16(w2.cuda(), True, torch.float16, kmult=64)
+    kp2 = wt2.shape[1]
+    if ph.shape[1] < kp2 or not ops.gemm16_ln_takes(m, n2, kp2):
+        return
+    w64 = wt2[:, :n].double()
+    gw = (w64 @ gamma.double()).float()
+    bw = (w64 @ beta.double() + b2.double()).float()
+    ph0, pl0 = (torch.zeros((m, kp2), dtype=torch.float16, device="cuda") for _ in range(2))
+    ph0[:, :n], pl0[:, :n] = ph[:, :n], pl[:, :n]
+    ln64 = (c64 - mean64[:, None]) * rstd64[:, None] * gamma.double() + beta.double()
+    ref = ln64 @ w64.t() + b2.double()
+    # the error of the form: the planes carry x . gamma to 2^-21, the products sum in fp32, the mean term cancels against the sum
+    xg_abs = (c64 * gamma.double()).abs()
+    bound = rstd64[:, None] * (3e-6 * (xg_abs @ w64.abs().t()) + 3e-6 * mean64.abs()[:, None] * gw.double().abs()) + 2e-6 * ref.abs() + 1e-6
+    out = torch.full((m, n2), float("nan"), device="cuda")
+    ops.gemm16_ln(ph0, pl0, wt2, bw, n2, ops.EPI_F32, gw, ln_stat=stat, c=out)
+    err = (out.double() - ref).abs()
+    assert bool((err <= bound).all()), f"consumer F32 vs float64 LayerNorm + product: worst excess {float((err - bound).max()):.3e}, worst err {float(err.max()):.3e}"
+    # and against the unfolded path (LayerNorm kernel + plain product): two correct evaluations of the same thing
+    lh, ll = (torch.zeros((m, kp2), dtype=torch.float16, device="cuda") for _ in range(2))
+    ops.layernorm_split(c1, gamma, beta, 1e-5, lh, ll)
+    out_u = torch.empty((m, n2), device="cuda")
+    ops.gemm16(lh, ll, wt2, b2, n2, ops.EPI_F32, c=out_u, variant=32)
+    print(f"\n[ln-fold] m={m} k={n} n={n2}: folded vs float64 {float(err.max()):.2e}, unfolded vs float64 {float((out_u.double() - ref).abs().max()):.2e}, "
+          f"max|out| {float(ref.abs().max()):.1f}")
+    oh, ol = (torch.full((m, n2 + 8), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+    ops.gemm16_ln(ph0, pl0, wt2, bw, n2, ops.EPI_QGELU_SPLIT, gw, ln_stat=stat, out_hi=oh, out_lo=ol)
+    got = oh[:, :n2].double() + ol[:, :n2].double()
+    want = ref * torch.sigmoid(1.702 * ref)
+    assert bool(((got - want).abs() <= 1.2 * bound + 2.0 ** -21 * want.abs() + 2e-6 * want.abs() + 1e-6).all()), "consumer QGELU_SPLIT"
+    assert bool(torch.isnan(oh[:, n2:]).all()), "consumer wrote past column n"
+    # refused, not mis-computed
+    with pytest.raises(RuntimeError):
+        ops.gemm16_ln(ph0[:512], pl0[:512], wt2, bw, n2, ops.EPI_F32, gw, ln_stat=stat, c=out[:512])
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
@@ -469,6 +553,36 @@ def test_prior_full_width_depth3():
     """5b widths (4800 / 8 heads x 150 / 8192 tokens), 3 layers = all three attention patterns."""
     rel = _run_prior(hparams_5b_depth(3), 3, 1)
     print(f"full-width prior (3 layers) rel err {rel:.3e}")
+
+
+def test_prior_folded_layernorm_matches_unfolded_and_oracle():
+    """The 5b-width prior, 3 layers (all attention patterns), with the LayerNorms folded into the products (the default) against
+    (a) the CPU oracle at 1e-4 of max|h|, (b) the same engine with LLARK_PRIOR_LN_FOLD off -- two roundings of one graph -- and
+    (c) itself at batch 2: row statistics come from fixed-order partial sums, so clip 0 of a batch is BIT-equal to clip 0 alone."""
+    from llark_amd.jukebox.prior import TopPrior
+    from llark_amd.jukebox import extract as E
+    from oracle import jukebox_ref as R
+    hps = hparams_5b_depth(3)
+    w = make_prior_weights(hps, 5, depth=3)
+    z = torch.randint(0, hps.l_bins, (2, hps.n_ctx), generator=torch.Generator().manual_seed(11))
+    tp_f = TopPrior(hps, w, "cuda", depth=3, ln_fold=True)
+    tp_u = TopPrior(hps, w, "cuda", depth=3, ln_fold=False)
+    x_cond, y_cond = E.get_cond(hps, tp_f)
+    a_f1 = E.get_final_activations(z[:1].cuda(), x_cond, y_cond, tp_f)
+    assert tp_f.prior._fold_rows and not tp_u.prior.ln_fold, "the folded path was not taken at 8192 rows"
+    a_u1 = E.get_final_activations(z[:1].cuda(), x_cond, y_cond, tp_u)
+    a_f2 = E.get_final_activations(z.cuda(), x_cond, y_cond, tp_f)
+    assert torch.equal(a_f2[0], a_f1[0]), "folded LayerNorm: clip 0 of a batch of 2 differs from clip 0 alone"
+    x_cond_r, y_cond_r = R.get_cond(w, hps)
+    h = R.prior_embed(w, z[:1], x_cond_r, y_cond_r, hps)
+    for d in range(3):
+        h = R.prior_layer(w, h, d, hps)
+    scale = float(h.abs().max())
+    e_f = report_close("folded prior vs oracle", a_f1.cpu(), h, 1e-4 * scale)
+    e_u = report_close("unfolded prior vs oracle", a_u1.cpu(), h, 1e-4 * scale)
+    e_fu = float((a_f1 - a_u1).abs().max())
+    print(f"\n[ln-fold] 3 layers at 5b widths: folded vs oracle {e_f:.2e}, unfolded vs oracle {e_u:.2e}, folded vs unfolded {e_fu:.2e}, max|h| {scale:.2f}")
+    assert e_fu <= 2e-5 * scale
 
 
 def test_prior_rejects_unsupported():
