@@ -88,7 +88,8 @@ __device__ __forceinline__ float fp_pin(float x) {
 struct Gamma256X {
     static constexpr int OFF = Cfg256X::O_A + 6 * Cfg256X::UNIT;          // + 1024 per wave
 };
-// (the bias of the producer takes the same road, lanes 32 .. 63 -> the second 512 bytes of the wave's KiB: 32 more registers back)
+// (the bias takes the same road, lanes 32 .. 63 -> the second 512 bytes of the wave's KiB: 32 more registers back; the consumer parks
+//  its two vectors -- gamma.W and bias' -- the same way)
 __device__ __forceinline__ f32x4_t gamma_load(const GemmParams& p, const int n0, const int wn, const int lane) {
     const int n = n0 + ((lane >> 4) & 1) * 128 + wn * 64 + (lane & 15) * 4;   // lanes 0 .. 15 (32 .. 47): this wave's columns of half L, 16 .. 31 (48 .. 63): of half R
     const float* src = lane < 32 ? p.ln_vec : p.bias;
@@ -142,21 +143,13 @@ __device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t
 // of the row statistics' partial sums (GemmParams: ln_stat / ln_vec / ln_part).
 template <typename T, int EPI, int LN>
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* smem, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[2][Cfg256X::TN],
-                                               const f32x4_t (&bias)[Cfg256X::TN], const int half2, const int m0, const int n0, const int wm, const int wn,
-                                               const int lane) {
+                                               const f32x4_t (&bias)[Cfg256X::TN], const float2 (&st)[Cfg256X::TM], const int half2, const int m0, const int n0,
+                                               const int wm, const int wn, const int lane) {
     typedef Cfg256X C;
     typedef typename Mfma16<T>::out4 out4;
     const int l15 = lane & 15, g4 = (lane >> 4) << 2;
     const int ncol = n0 + wn * 64 + g4;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
-    f32x4_t lv[LN == 1 ? C::TN : 1];                                 // LN = 1: s_n = sum_k gamma_k W[n][k], kept for both row tiles of the half
-    if (LN == 1) {                                                   // (LN = 2 fetches the next LayerNorm's gamma_n at the point of use: acc +
-#pragma unroll                                                       //  bias + the residual half already fill the register file)
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int n = ncol + (tn >> 2) * 128 + (tn & 3) * 16;
-            lv[tn] = n < p.N ? *(const f32x4_t*)(p.ln_vec + n) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
-    }
     // Operand planes leave in 16-byte stores (round 4): a lane owns 4 columns of a 16-column tile = 8 bytes of a 16-bit plane, and 16 rows x
     // 32 bytes per store instruction made the plane stores the slowest part of the epilogue (issue-bound: requests per instruction, not
     // bytes).  v_permlane16_swap_b32 trades the tile tn registers of lane groups 1 / 3 for the tile tn + 1 registers of groups 0 / 2: group
@@ -166,22 +159,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
     const bool wide = PLANES && G256X_WIDE_PLANES && full && (p.ldo & 7) == 0;
     const int gsel = lane >> 4;
     const int wcol = n0 + wn * 64 + ((gsel & 1) << 4) + ((gsel >> 1) << 3);
-    // every load of this call goes out before its first store: vmcnt counts stores too, so a load behind a store waits for the store's
-    // round trip (the producer's gamma loads inside the column loop cost 21 us per tile that way, measured in round 4)
-    float2 st[2] = {make_float2(0.f, 1.f), make_float2(0.f, 1.f)};
-    if (LN == 1) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int m = m0 + wm * 64 + (2 * half2 + t) * 16 + l15;
-            if (full || m < p.M) st[t] = *(const float2*)(p.ln_stat + 2 * (size_t)m);
-        }
-    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int tm = 2 * half2 + t;
         const int m = m0 + wm * 64 + tm * 16 + l15;
         if (!full && m >= p.M) continue;                             // the four lanes of a row (l15, g = 0 .. 3) leave together
-        const float mu = st[t].x, rstd = st[t].y;
+        const float mu = st[tm].x, rstd = st[tm].y;
         float sx = 0.f, sq = 0.f;
         if (wide) {
 #pragma unroll
@@ -193,7 +176,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                     const int tn = 2 * tp + u;
                     const int co = co0 + 16 * u;
                     f32x4_t v;
-                    if (LN == 1) v = (acc[tm][tn] - mu * lv[LN == 1 ? tn : 0]) * rstd + bias[tn];
+                    if (LN == 1) v = (acc[tm][tn] - mu * gamma4(smem, wm * 2 + wn, tn, gsel, 0)) * rstd + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                     else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                     else v = acc[tm][tn] + bias[tn];
                     out4 hi, lo;
@@ -237,7 +220,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                 const int co = (tn >> 2) * 128 + (tn & 3) * 16;
                 if (!full && ncol + co >= p.N) continue;             // N % 4 == 0 (checked by the launcher): a vector is all in or all out
                 f32x4_t v;
-                if (LN == 1) v = (acc[tm][tn] - mu * lv[LN == 1 ? tn : 0]) * rstd + bias[tn];
+                if (LN == 1) v = (acc[tm][tn] - mu * gamma4(smem, wm * 2 + wn, tn, gsel, 0)) * rstd + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                 else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                 else v = acc[tm][tn] + bias[tn];
                 if (EPI == EPI_F32) {
@@ -549,11 +532,23 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
             // bias and the first half of the residuals are requested AHEAD of the next tile's prologue (in-order returns)
             f32x4_t bias[C::TN], res[2][C::TN];
+            // Folded LayerNorm: every load of the epilogue goes out HERE, before its first store -- vmcnt counts stores too, in order, so a
+            // load behind a store waits for the store's round trip.  The per-column vectors (LN = 2: gamma | bias, LN = 1: gamma.W | bias')
+            // are parked in the LDS, the row statistics of the consumer (4 row tiles) stay in registers.
             f32x4_t gv;
-            if (LN == 2) gv = gamma_load(p, n0, wn, lane);
+            float2 st[C::TM];
+            if (LN != 0) gv = gamma_load(p, n0, wn, lane);
             else epilogue_load_bias(p, bias, n0, wn, lane);
+            if (LN == 1) {
+                const bool whole = m0 + C::BM <= p.M;
+#pragma unroll
+                for (int tm = 0; tm < C::TM; ++tm) {
+                    const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
+                    st[tm] = (whole || m < p.M) ? *(const float2*)(p.ln_stat + 2 * (size_t)m) : make_float2(0.f, 1.f);
+                }
+            }
             epilogue_load_resid<EPI>(p, res, 0, m0, n0, wm, wn, lane);
-            if (LN == 2) gamma_park(smem, gv, w, lane);
+            if (LN != 0) gamma_park(smem, gv, w, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 1 < nchunks) {
                 if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -568,9 +563,9 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, 0, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 0, m0, n0, wm, wn, lane);
             epilogue_load_resid<EPI>(p, res, 1, m0, n0, wm, wn, lane);
-            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, 1, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 1, m0, n0, wm, wn, lane);
         }
         if (ch + 1 < nchunks) {
             if (threadIdx.x == 0) {

@@ -12,6 +12,8 @@ Data layout in HBM (per batch of N clips, M = N*n_ctx rows):
   qkv      fp32 [M][3S]
   att_hi/lo fp16 [M][Sp]   (Sp = S rounded up to 32, pad columns stay zero)
   g_hi/lo  fp16 [M][Mp]                     QuickGELU output
+  ln_part  fp32 [M][2*ceil(W/256)][2]       folded LayerNorm: per-slice (sum, sum of squares) written by the producing epilogue
+  ln_stat  fp32 [M][2]                      folded LayerNorm: (mean, rstd) of the row; ln_hi/lo then hold h . gamma, not LN(h)
   weights  fp16 [N_out][Kp]                 transposed (K-contiguous) copies of upstream Conv1D.w
 In the opt-in "lo8" precision the three lo planes are E4M3 byte planes (uint8 [M][K rounded up to 64], MFMA slot order, scale 2^12).
 """
