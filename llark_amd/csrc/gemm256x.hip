@@ -156,7 +156,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
     // g then holds 8 consecutive columns of tile tn + (g & 1), from column 8 (g >> 1) on, and one instruction stores 16 rows x 64 bytes.
     // Whole tiles only (every lane takes part in the swap); ragged tiles keep the 8-byte stores.
     constexpr bool PLANES = (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || LN == 2);
-    const bool wide = PLANES && G256X_WIDE_PLANES && full && (p.ldo & 7) == 0;
+    const bool wide = PLANES && G256X_WIDE_PLANES && full && (p.ldo & 7) == 0 && (((uintptr_t)p.Ohi | (uintptr_t)p.Olo) & 15) == 0;
     const int gsel = lane >> 4;
     const int wcol = n0 + wn * 64 + ((gsel & 1) << 4) + ((gsel >> 1) << 3);
 #pragma unroll

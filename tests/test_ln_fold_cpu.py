@@ -1,0 +1,61 @@
+"""CPU checks of the folded-LayerNorm algebra the HIP path uses (llark_gemm16_ln, llark_amd/jukebox/prior.py): no GPU, no library
+compute call.  The GPU parity tests (tests/test_prior_gpu.py) compare the kernels with this same restatement in float64."""
+import numpy as np
+import torch
+
+from oracle import jukebox_ref as R
+
+
+def test_folded_layernorm_identity_against_oracle_ops():
+    """LN(x) W + b  ==  rstd (x . gamma) W - rstd mean (gamma W) + (beta W + b), with the oracle's own layer_norm / Conv1D
+    (oracle/jukebox_ref.py -- the functions the 36-layer fixtures were generated with) on the left-hand side."""
+    g = torch.Generator().manual_seed(0)
+    m, k, n = 37, 96, 80
+    x = torch.randn(m, k, generator=g, dtype=torch.float64) * 3 + 0.5
+    gamma = 1 + 0.3 * torch.randn(k, generator=g, dtype=torch.float64)
+    beta = 0.2 * torch.randn(k, generator=g, dtype=torch.float64)
+    w = torch.randn(k, n, generator=g, dtype=torch.float64) * 0.1            # upstream Conv1D.w: [n_in][n_out]
+    b = torch.randn(n, generator=g, dtype=torch.float64)
+    ln = torch.nn.functional.layer_norm(x, (k,), gamma, beta, 1e-5)
+    want = R._conv1d_linear(ln, w, b, dtype=torch.float64)
+    mean = x.mean(1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    gw = gamma @ w                                                            # ln_vec of the consumer
+    bw = beta @ w + b                                                         # its bias
+    got = rstd * ((x * gamma) @ w - mean * gw) + bw
+    assert float((got - want).abs().max()) < 1e-12
+
+
+def test_partial_sum_partition_matches_the_kernel_layout():
+    """The producer writes, per row, one (sum, sum of squares) pair per 256-column tile and wave column wn: wave wn of tile j owns
+    columns 256 j + 64 wn + {0 .. 63} and 256 j + 128 + 64 wn + {0 .. 63} (csrc/gemm256x.hip: two halves of 128 columns, the wave's
+    64 columns in each).  Every column of [0, N) is in exactly one slice, also in the ragged last tile, so the slice-ordered sum
+    llark_ln_stats_finalize forms is the row sum -- for ANY N % 4 == 0."""
+    for n in (4800, 1216, 3648, 260, 4):
+        tiles = (n + 255) // 256
+        owner = -np.ones(n, dtype=np.int64)
+        for j in range(tiles):
+            for wn in range(2):
+                for half in range(2):
+                    c0 = 256 * j + 128 * half + 64 * wn
+                    cols = np.arange(c0, min(c0 + 64, n))
+                    assert (owner[cols] == -1).all()
+                    owner[cols] = 2 * j + wn
+        assert (owner >= 0).all() and owner.max() <= 2 * tiles - 1
+        x = np.random.default_rng(n).standard_normal(n)
+        parts = np.array([[x[owner == s].sum(), (x[owner == s] ** 2).sum()] for s in range(2 * tiles)])
+        mean = parts[:, 0].sum() / n
+        var = parts[:, 1].sum() / n - mean * mean
+        assert abs(mean - x.mean()) < 1e-12 and abs(var - x.var()) < 1e-12
+
+
+def test_fold_takes_only_big_tiles_signature_exported():
+    """The C-ABI names the Python layer binds (no compute call): present in the header and in the ctypes table."""
+    import os
+    import re
+
+    from llark_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "llark_hip.h")).read()
+    for name in ("llark_gemm16_ln", "llark_gemm16_ln_takes", "llark_ln_stats_finalize"):
+        assert re.search(r"\b%s\s*\(" % name, hdr), name
+        assert name in _lib._SIGS, name
