@@ -17,8 +17,12 @@
 //    16 x 16; a K-step's phase has TWO k sub-steps of 32 (one per half-phase) x 16 tiles x {hi, lo} = 64 MFMAs of 16 pipe cycles;
 //  * the product is computed TRANSPOSED: the weight fragment is the instruction's A operand, the activation fragment its B operand,
 //    so a lane's four accumulator registers of a tile are four CONSECUTIVE output columns of ONE row -- the epilogue loads residuals
-//    and stores results 16 bytes at a time (8 bytes for the fp16 planes) straight from the accumulators: a quarter of the store
-//    instructions of the 32x32 form, no LDS transpose;
+//    and stores results 16 bytes at a time straight from the accumulators (the 16-bit planes too, after one v_permlane16_swap per
+//    register pair -- see epilogue_store): a quarter of the store instructions of the 32x32 form, no LDS transpose;
+//  * the epilogue has two more roles (template parameter LN; llark_gemm16_ln in gemm.hip): LN = 2 writes, next to the residual
+//    stream, the operand planes of the LayerNorm that follows (h . gamma) and the row statistics' partial sums; LN = 1 applies a
+//    row's (mean, rstd) to a product whose operand is such a pair of planes.  71 of the 72 LayerNorm kernels of a 36-layer forward
+//    live here (llark_amd/jukebox/prior.py, _layer_forward_fold);
 //  * the LDS image is unchanged: a fragment of either operand is (16 rows) x (32 k) = lane l reads the 16-byte chunk
 //    (4 s + l / 16) ^ ((l % 16) / 2) of row l % 16 -- the source-side swizzle chosen for the 32x32x16 reads ((row / 2) & 7) is
 //    conflict free for these lane groups too (every ds_read_b128 group of 16 lanes covers 16 distinct 16-byte slots of a 256-byte
