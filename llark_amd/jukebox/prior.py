@@ -31,7 +31,7 @@ from .hparams import JukeboxHParams
 
 # How the Conv1D products carry the fp32 activation (see PriorTransformer.__init__).  The reference runs them in fp32
 # (jukebox/main.py:108, fp16=False): the default is the 22-bit two-pass form, whose 36-layer B = 8 embedding is within the
-# ABSOLUTE 1e-4 of BASELINE configs[1] (5.4e-5 measured); "lo8" (15-16 bits, 5.1e-4 absolute = 3e-5 of max|acts|) is opt-in:
+# ABSOLUTE 1e-4 of BASELINE configs[1] (5.0e-5 measured); "lo8" (15-16 bits, 5.8e-4 absolute = 3e-5 of max|acts|) is opt-in:
 # precision="lo8" / LLARK_PRIOR_PRECISION=lo8 / bench.py --prior-precision lo8.
 DEFAULT_PRECISION = "f16x2"
 
