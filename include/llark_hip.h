@@ -68,6 +68,16 @@ const char* llark_last_error(void);
 int llark_device_info(int device, char* arch_name, int arch_name_len);
 
 /* ---------------------------------------------------------------------------------------------
+ * Audio front end: the sample-rate conversion inside `lr.load(fpath, sr=44100)` at jukebox/main.py:31 (librosa 0.7.2
+ * -- the version openai/jukebox @ 08efbbc pins, docker/jukebox-embed.dockerfile:56 -- resamples with resampy's
+ * "kaiser_best" band-limited sinc interpolation).  HOST entry point on HOST pointers, no stream, no device work:
+ * x [n_in] -> y [n_out] at ratio = sr_new / sr_orig; win / dwin [nwin] = right half of the interpolation window with
+ * num_table samples per zero crossing (scaled by ratio when ratio < 1) and its forward difference.
+ * ------------------------------------------------------------------------------------------- */
+int llark_resample_sinc_host(const float* x, int64_t n_in, double ratio, const double* win, const double* dwin, int nwin,
+                             int num_table, float* y, int64_t n_out);
+
+/* ---------------------------------------------------------------------------------------------
  * Jukebox VQ-VAE level-2 encoder: replaces `vqvae.encode(...)` at jukebox/main.py:61
  * (upstream openai/jukebox vqvae/encdec.py EncoderConvBlock, resnet.py ResConv1DBlock,
  * bottleneck.py BottleneckBlock.encode).  Activations: fp32 [n][C][T] (torch NCT).

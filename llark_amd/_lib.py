@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLARK_HIP_LIB") or os.path.join(_HERE, "libllark_hip.so")   # override: profiling builds only
@@ -42,6 +42,7 @@ _P = c_void_p
 _SIGS = {
     "llark_version": [],
     "llark_device_info": [c_int, c_char_p, c_int],
+    "llark_resample_sinc_host": [_P, c_int64, c_double, _P, _P, c_int, c_int, _P, c_int64],
     "llark_pack_conv_weight": [_P, _P, c_int, c_int, c_int, _P],
     "llark_conv1d_f32": [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_resblock_f32": [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P],

@@ -52,18 +52,22 @@ def _normalize(audio: np.ndarray) -> np.ndarray:
     return audio.flatten()
 
 
-def load_audio_from_file(fpath) -> np.ndarray:
+def load_audio_from_file(fpath, res_type: Optional[str] = None) -> np.ndarray:
     """Reads a wav file, resamples to 44.1 kHz, converts to mono, peak-normalises.
 
     ``fpath``: a path or a binary file object (the Beam worker passes ``io.BytesIO(wav_bytes)``,
     jukebox/dataflow_inference.py:101-103).  The reference calls ``librosa.load(fpath, sr=44100)`` (librosa / soundfile /
-    soxr are not installed here): wav decoding uses ``scipy.io.wavfile`` with soundfile's integer scaling (int16 / 2^15,
+    resampy are not installed here): wav decoding uses ``scipy.io.wavfile`` with soundfile's integer scaling (int16 / 2^15,
     int32 and 24-bit-in-int32 / 2^31, uint8 -> (x - 128) / 2^7), mono = channel mean BEFORE resampling like
-    ``librosa.load``, and polyphase resampling -- resampled clips therefore differ from librosa's ``soxr_hq`` output at
-    filter-design level; 44.1 kHz files are bit-identical.  Formats other than wav (librosa's audioread fallback) are
-    not decoded.
+    ``librosa.load``.  Resampling (``res_type``, default ``$LLARK_RES_TYPE`` or "kaiser_best"): the band-limited sinc
+    interpolation of the librosa 0.7.2 / resampy pair the reference's image installs, or "soxr_hq" for newer librosa's default
+    -- both restated in :mod:`llark_amd.jukebox.resample`, neither pinnable offline; 44.1 kHz files are bit-identical.
+    The reference's pipeline is wav-only on both sides (``read_wav_bytes``, ``input_filename.replace(".wav", ".npy")``,
+    jukebox/main.py:251); other containers are not decoded.
     """
     from scipy.io import wavfile
+
+    from .resample import resample
 
     try:
         sr, data = wavfile.read(fpath)
@@ -80,12 +84,7 @@ def load_audio_from_file(fpath) -> np.ndarray:
     if audio.ndim == 2:
         audio = audio.mean(axis=0)                         # librosa.load defaults to mono=True
     if sr != JUKEBOX_SAMPLE_RATE:
-        from math import gcd
-
-        from scipy.signal import resample_poly
-
-        g = gcd(int(sr), JUKEBOX_SAMPLE_RATE)
-        audio = resample_poly(audio, JUKEBOX_SAMPLE_RATE // g, int(sr) // g).astype(np.float32)
+        audio = resample(audio, int(sr), JUKEBOX_SAMPLE_RATE, res_type or os.environ.get("LLARK_RES_TYPE", "kaiser_best"))
     return _normalize(audio).astype(np.float32)
 
 

@@ -70,6 +70,77 @@ def test_resampling_to_44100(tmp_path):
     assert len(E.load_audio_from_file(p48)) == 4410
 
 
+def _multitone(sr, n, top_hz, seed):
+    rng = np.random.default_rng(seed)
+    f, a, ph = rng.uniform(50, top_hz, 12), rng.uniform(0.05, 0.2, 12), rng.uniform(0, 2 * np.pi, 12)
+
+    def at(rate, m):
+        t = np.arange(m) / rate
+        return sum(ai * np.sin(2 * np.pi * fi * t + pi) for fi, ai, pi in zip(f, a, ph))
+    return at(sr, n).astype(np.float32), at
+
+
+@pytest.mark.parametrize("sr", [8000, 16000, 22050, 32000, 88200])
+@pytest.mark.parametrize("res_type", ["kaiser_best", "soxr_hq"])
+def test_resamplers_reproduce_a_band_limited_signal(sr, res_type):
+    """Both restated resamplers are transparent on content below 0.88 of the lower Nyquist rate: the output equals the SAME
+    continuous signal sampled at 44.1 kHz (away from the zero-extended edges) -- which is what any correct implementation of
+    librosa's kaiser_best / soxr_hq produces to its own precision."""
+    from llark_amd.jukebox import resample as R
+
+    x, at = _multitone(sr, 2 * sr, 0.88 * min(sr, 44100) / 2, seed=sr)
+    y = R.resample(x, sr, 44100, res_type)
+    assert y.dtype == np.float32 and len(y) == int(np.ceil(len(x) * 44100 / sr))
+    err = np.abs(y[4000:-4000] - at(44100, len(y))[4000:-4000]).max()
+    assert err < 1e-5, err
+
+
+def test_kaiser_best_follows_resampy_including_its_integer_table_step():
+    """resampy walks its filter table in steps of int(scale * 512); at 48 kHz -> 44.1 kHz (scale 0.91875, 470.4 -> 470) the
+    truncation stretches the filter by 0.085 %: a -60 dB deviation from the ideal that the restatement keeps (it is the
+    reference image's arithmetic), while the soxr_hq-specification filter has none.  Also: output length rule, empty-edge
+    behaviour, rejection of content above the new Nyquist rate, the errors of the C entry point."""
+    from llark_amd import _lib
+    from llark_amd.jukebox import resample as R
+
+    x, at = _multitone(48000, 96000, 0.85 * 22050, seed=3)
+    ref = at(44100, 88200)[4000:-4000]
+    yk, ys = R.resample(x, 48000, 44100, "kaiser_best"), R.resample(x, 48000, 44100, "soxr_hq")
+    assert len(yk) == len(ys) == 88200
+    ek, es = np.abs(yk[4000:-4000] - ref).max(), np.abs(ys[4000:-4000] - ref).max()
+    assert 1e-4 < ek < 3e-3 and es < 1e-5, (ek, es)
+    # a tone above the new Nyquist rate (23 kHz in a 96 kHz file) is removed: to -70 dB by the truncated-step table walk
+    # (235.2 -> 235 table samples per input sample), to the design rejection by the soxr_hq-specification filter
+    t = np.arange(96000) / 96000
+    hi = (0.5 * np.sin(2 * np.pi * 23000 * t)).astype(np.float32)
+    assert np.abs(R.resample(hi, 96000, 44100, "kaiser_best")[4000:-4000]).max() < 5e-4
+    assert np.abs(R.resample(hi, 96000, 44100, "soxr_hq")[4000:-4000]).max() < 2e-6
+    # int(n * ratio) outputs, padded to ceil(n * ratio) (librosa.core.resample's fix_length)
+    y = R.resample(np.ones(1001, dtype=np.float32), 48000, 44100, "kaiser_best")
+    assert len(y) == 920 and y[-1] == 0.0 and abs(y[500] - 1.0) < 2e-3
+    assert R.resample(x, 44100, 44100) is x or np.array_equal(R.resample(x, 44100, 44100), x)
+    with pytest.raises(ValueError, match="too small"):
+        R.resample(np.ones(1, dtype=np.float32), 48000, 8000)
+    with pytest.raises(ValueError, match="res_type"):
+        R.resample(x, 48000, 44100, "linear")
+    L = _lib.lib()
+    assert L.llark_resample_sinc_host(None, 1, 1.0, None, None, 2, 1, None, 1) == -1
+    assert b"resample_sinc_host" in L.llark_last_error()
+    half, nt = R.sinc_window(**R.KAISER_BEST)
+    assert half.shape == (64 * 512 + 1,) and nt == 512 and abs(half[0] - R.KAISER_BEST["rolloff"]) < 1e-15 and abs(half[-1]) < 1e-7
+
+
+def test_load_audio_res_type_selection(tmp_path, monkeypatch):
+    x = (_tone(48000, 48000, 1000.0) * 32767).astype(np.int16)
+    p = tmp_path / "a48.wav"
+    wavfile.write(p, 48000, x)
+    a, b = E.load_audio_from_file(p), E.load_audio_from_file(p, res_type="soxr_hq")
+    assert len(a) == len(b) == 44100 and np.abs(a).max() == 1.0 and np.abs(b).max() == 1.0
+    assert 0 < np.abs(a - b).max() < 5e-2                          # two different filters, the same audio
+    monkeypatch.setenv("LLARK_RES_TYPE", "soxr_hq")
+    np.testing.assert_array_equal(E.load_audio_from_file(p), b)
+
+
 def test_file_object_input_like_the_beam_worker(tmp_path):
     x = (_tone(9000, 44100) * 20000).astype(np.int16)
     p = tmp_path / "b.wav"

@@ -108,3 +108,27 @@ def test_unsafe_pickle_is_opt_in(tmp_path, monkeypatch):
     assert torch.equal(sd["prior.x_emb.weight"], w["prior.x_emb.weight"])
     monkeypatch.setenv(CK.UNSAFE_PICKLE_ENV, "1")
     assert "prior.x_emb.weight" in CK.read_pth_tar(_save(pr_ck))
+
+
+def test_legacy_torch14_serialisation_with_fp16_conv_weights(tmp_path):
+    """The released 5b files were written by torch 1.4 (docker/jukebox-embed.dockerfile:42): the pre-zipfile container, and
+    -- ``fp16_params=True`` -- every prior ``Conv1D.w`` as a HalfTensor.  Both must come through the restricted reader
+    unchanged (TopPrior rounds fp32 inputs to fp16 itself; fp16 inputs are taken as they are)."""
+    hps = hparams_tiny()
+    vq_ck, pr_ck, w = upstream_style_checkpoints(hps, ckpt_depth=hps.prior_depth)
+    pr_ck["model"] = {k: (v.half() if k.endswith((".c_attn.w", ".c_proj.w", ".c_fc.w")) else v) for k, v in pr_ck["model"].items()}
+    pv, pp = tmp_path / "vqvae.pth.tar", tmp_path / "prior_level_2.pth.tar"
+    torch.save(vq_ck, pv, _use_new_zipfile_serialization=False)
+    torch.save(pr_ck, pp, _use_new_zipfile_serialization=False)
+    import zipfile
+
+    assert not zipfile.is_zipfile(pv) and not zipfile.is_zipfile(pp)
+    got, _ = CK.load_checkpoint_weights("5b", hps, None, str(pv), str(pp))
+    n_half = 0
+    for k, v in got.items():
+        if k.endswith((".c_attn.w", ".c_proj.w", ".c_fc.w")):
+            assert v.dtype == torch.float16 and torch.equal(v, w[k].half()), k
+            n_half += 1
+        else:
+            assert v.dtype == w[k].dtype and torch.equal(v, w[k]), k
+    assert n_half == 4 * hps.prior_depth
