@@ -4,14 +4,14 @@
 this shards the sorted file list over the launched ranks (one process per GPU, RANK / WORLD_SIZE from the launcher, no
 collective: clips are independent) and embeds ``--batch-size`` clips per pass on the GPU.
 
-Audio reading: RIFF wav via scipy (int16 / int32 / float), mixed down to mono, resampled to 48 kHz with a polyphase
-filter when the file's rate differs (the reference uses librosa's resampler inside ``read_wav``: same rate, different
-filter -- feed 48 kHz files for exact agreement)."""
+Audio reading: RIFF wav via scipy (int16 / int32 / float), mixed down to mono, resampled to 48 kHz when the file's rate
+differs with a polyphase filter to libsoxr's HQ specification (the reference calls ``librosa.resample`` of an unpinned librosa
+inside ``read_wav``, m2t/gcs_utils.py:133-135 = soxr_hq: same pass band / rejection, not the same taps -- feed 48 kHz files for
+exact agreement)."""
 from __future__ import annotations
 
 import argparse
 import os
-from math import gcd
 from typing import Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -32,7 +32,8 @@ def shard(paths: List[str], rank: int, world: int) -> List[str]:
 
 def read_wav_48k(path: str) -> np.ndarray:
     from scipy.io import wavfile
-    from scipy.signal import resample_poly
+
+    from ..jukebox.resample import resample
 
     sr, x = wavfile.read(path)
     if x.dtype == np.int16:
@@ -46,8 +47,8 @@ def read_wav_48k(path: str) -> np.ndarray:
     if x.ndim == 2:
         x = x.mean(axis=1)
     if sr != SAMPLE_RATE:
-        g = gcd(int(sr), SAMPLE_RATE)
-        x = resample_poly(x, SAMPLE_RATE // g, int(sr) // g).astype(np.float32)
+        # m2t/gcs_utils.py:133-135: librosa.resample(samples, orig_sr, target_sr) of an unpinned (current) librosa = soxr_hq
+        x = resample(x, int(sr), SAMPLE_RATE, "soxr_hq")
     return x
 
 
