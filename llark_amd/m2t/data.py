@@ -9,8 +9,10 @@ through ``preprocess_multimodal_mappable`` / ``preprocess_for_lm_mappable`` and 
 Here: a pure-``tarfile`` reader for local shards (``.npy`` members are read natively; ``.pyd`` pickles only with
 ``allow_pickle=True`` -- unpickling is code execution, the caller must trust the shards), brace expansion of
 ``name-{000..127}.tar`` lists (:436-438), the per-rank shard split of ``wds.split_by_node``, and a micro-batch generator
-for ``llark_amd.m2t.train.train``.  GCS URLs, resampling with task probabilities and the HF ``IterableDataset`` wrapper
-are not built (I/O glue outside the hot path).
+for ``llark_amd.m2t.train.train``; with ``task_sample_probs`` the shard order of an epoch is drawn WITH replacement, each shard
+weighted by the probability of the task whose name its path contains (``repeat_shards``, :441-463; off unless
+``--apply_task_sample_probs``, as in m2t/arguments.py:61-68).  GCS URLs and the HF ``IterableDataset`` wrapper are not built
+(I/O glue outside the hot path).
 """
 from __future__ import annotations
 
@@ -48,6 +50,26 @@ def expand_urls(url: str) -> List[str]:
             lo, hi, width = int(m.group(1)), int(m.group(2)), len(m.group(1))
             todo = [cur[: m.start()] + str(i).zfill(width) + cur[m.end():] for i in range(lo, hi + 1)] + todo
     return out
+
+
+DEFAULT_TASK_SAMPLE_PROBS = {"captioning": 0.15, "reasoning": 0.55, "mir": 0.3}      # m2t/arguments.py:61-67
+
+
+def shard_probs(urls: Sequence[str], task_sample_probs: Dict[str, float]) -> List[float]:
+    """``repeat_shards`` (m2t/data_modules.py:441-457): a shard's weight is the probability of the FIRST task key contained in
+    its name, normalised over the list; a shard matching no key is an error."""
+    probs = []
+    for shard in urls:
+        for k, prob in task_sample_probs.items():
+            if k in shard:
+                probs.append(float(prob))
+                break
+        else:
+            raise ValueError(f"probability for shard {shard} not defined in probs {task_sample_probs}")
+    total = sum(probs)
+    if total <= 0:
+        raise ValueError(f"task probabilities {task_sample_probs} give the shard list zero total weight")
+    return [p / total for p in probs]
 
 
 def split_by_rank(urls: Sequence[str], rank: int, world: int) -> List[str]:
@@ -126,7 +148,8 @@ def _shuffled(items: Iterator[Dict[str, Any]], rng: random.Random, size: int) ->
 
 def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any], batch_size: int, model_max_length: int,
                   rank: int = 0, world: int = 1, seed: int = 0, epochs: Optional[int] = None, allow_pickle: bool = False,
-                  shuffle_buffer: int = SHUFFLE_BUFFER, skip_micro_batches: int = 0):
+                  shuffle_buffer: int = SHUFFLE_BUFFER, skip_micro_batches: int = 0,
+                  task_sample_probs: Optional[Dict[str, float]] = None):
     """Collated micro-batches (``input_ids``, ``labels``, ``attention_mask``, ``audio_encodings``) of THIS rank, forever
     (``epochs=None``, like the reference's ``repeat()``) or for a number of passes over its shards.
 
@@ -134,15 +157,20 @@ def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any
     bounded shuffle buffer of ``shuffle_buffer`` conversations so that the pairs of one clip are not emitted back to back;
     both generators are seeded per rank AND per epoch.  ``skip_micro_batches`` fast-forwards the stream (resume: the
     trainer passes ``step * gradient_accumulation_steps``) so a resumed run continues where the interrupted one stopped
-    instead of replaying its first samples."""
+    instead of replaying its first samples.  ``task_sample_probs``: see :func:`shard_probs` -- an epoch then reads as many shards
+    as the rank owns, drawn with replacement by task weight (the reference draws 1024 x len(urls) up front and resamples)."""
     shards = split_by_rank(expand_urls(train_data_path), rank, world)
+    weights = shard_probs(shards, task_sample_probs) if task_sample_probs else None
     collate = DataCollatorForSupervisedDataset(tokenizer)
     epoch = 0
     to_skip = max(0, int(skip_micro_batches))                         # whole micro-batches still to fast-forward over
     while epochs is None or epoch < epochs:
         rng = random.Random((seed * 1000003 + rank) * 7919 + epoch)
-        order = list(shards)
-        rng.shuffle(order)                                            # shardshuffle
+        if weights is None:
+            order = list(shards)
+            rng.shuffle(order)                                        # shardshuffle
+        else:
+            order = rng.choices(shards, weights=weights, k=len(shards))
 
         def conversations():
             for elem in iter_tar_samples(order, allow_pickle):

@@ -157,6 +157,8 @@ def main(argv=None):
     ap.add_argument("--grad_comm", default="bf16", choices=["fp32", "bf16"], help="transport dtype of the gradient all-reduce (reference: bf16)")
     ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
     ap.add_argument("--gradient_checkpointing", type=boolean, default=False, help="train_llark.sh:25: recompute each decoder layer in the backward")
+    ap.add_argument("--apply_task_sample_probs", type=boolean, default=False, help="m2t/arguments.py:68: weight shards by the task in their name")
+    ap.add_argument("--task_sample_probs", default=None, help='JSON dict task -> probability (default: m2t/arguments.py:61-67)')
     ap.add_argument("--freeze_backbone", type=boolean, default=False)
     ap.add_argument("--lr_scheduler_type", default="cosine")
     ap.add_argument("--bf16", type=boolean, default=True)
@@ -197,9 +199,18 @@ def main(argv=None):
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
                       max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm,
                       gradient_checkpointing=args.gradient_checkpointing, max_grad_norm=args.max_grad_norm)
+    task_probs = None
+    if args.apply_task_sample_probs:
+        import json as _json
+
+        from .data import DEFAULT_TASK_SAMPLE_PROBS
+
+        task_probs = _json.loads(args.task_sample_probs) if args.task_sample_probs else dict(DEFAULT_TASK_SAMPLE_PROBS)
+
     def batches(skip_micro_batches: int):
         return micro_batches(args.train_data_path, tok, mm_cfg, args.per_device_train_batch_size, args.model_max_length, rank, world,
-                             seed=args.seed, allow_pickle=args.allow_pickle, skip_micro_batches=skip_micro_batches)
+                             seed=args.seed, allow_pickle=args.allow_pickle, skip_micro_batches=skip_micro_batches,
+                             task_sample_probs=task_probs)
 
     log = (lambda rec: print(rec, flush=True)) if rank == 0 else None
     train(eng, batches, audio_cfg, cfg, world=world, max_optimizer_steps=args.max_steps, log=log, output_dir=args.output_dir,

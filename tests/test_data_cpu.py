@@ -103,3 +103,28 @@ def test_resume_fast_forward_matches_uninterrupted_stream_across_epochs(tmp_path
         assert len(rest) == len(full) - skip
         for a, b in zip(rest, full[skip:]):
             assert torch.equal(a["input_ids"], b["input_ids"]) and torch.equal(a["labels"], b["labels"])
+
+
+def test_task_sample_probs_weight_the_shard_draw(tmp_path):
+    """``repeat_shards`` (m2t/data_modules.py:441-463, behind --apply_task_sample_probs): shards are drawn with replacement,
+    weighted by the probability of the task named in their path; a shard of no known task is an error."""
+    assert D.shard_probs(["a/captioning-000.tar", "b/mir-000.tar", "b/mir-001.tar"], {"captioning": 0.2, "mir": 0.4}) == [0.2, 0.4, 0.4]
+    assert D.DEFAULT_TASK_SAMPLE_PROBS == {"captioning": 0.15, "reasoning": 0.55, "mir": 0.3}
+    with pytest.raises(ValueError, match="not defined in probs"):
+        D.shard_probs(["x/unknown-000.tar"], {"mir": 1.0})
+    _make_shard(tmp_path / "mir-000.tar", ["m0"])                          # 1 clip x 2 QA pairs
+    _make_shard(tmp_path / "captioning-000.tar", ["c0"])
+    tok = ToyTokenizer()
+    tok.add_tokens(["<audio_patch>", "<audio_start>", "<audio_end>"], special_tokens=True)
+    mm = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    pattern = f"{tmp_path}/mir-000.tar,{tmp_path}/captioning-000.tar"
+    only_mir = list(D.micro_batches(pattern, tok, mm, batch_size=2, model_max_length=64, epochs=6, seed=1,
+                                    task_sample_probs={"mir": 1.0, "captioning": 0.0}))
+    assert len(only_mir) == 12                                             # 2 draws per epoch, always the mir shard: 2 x 2 pairs
+    plain = list(D.micro_batches(pattern, tok, mm, batch_size=2, model_max_length=64, epochs=6, seed=1))
+    assert len(plain) == 12
+    ids = lambda bs: sorted({tuple(r.tolist()) for b in bs for r in b["input_ids"]})
+    assert len(ids(only_mir)) < len(ids(plain))                            # the captioning clip never appears
+    a = list(D.micro_batches(pattern, tok, mm, 2, 64, epochs=3, seed=4, task_sample_probs={"mir": 0.5, "captioning": 0.5}))
+    b = list(D.micro_batches(pattern, tok, mm, 2, 64, epochs=3, seed=4, task_sample_probs={"mir": 0.5, "captioning": 0.5}))
+    assert all(torch.equal(x["input_ids"], y["input_ids"]) for x, y in zip(a, b)) and len(a) == len(b)    # seeded: reproducible
