@@ -233,6 +233,16 @@ int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, 
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                        int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* The Llama q|k|v product of a PREFILL with RoPE, the head split, the K-cache append and the transposed V-cache append in its
+ * epilogue: one launch instead of llark_gemm16_fragw (fp32 qkv) + llark_rope_split_heads (m2t/models/llamav2.py:224-234 -> HF
+ * LlamaAttention q_proj / k_proj / v_proj, apply_rotary_pos_emb, cache update).  bf16 only; head_dim 128, nh even, s >= 32.
+ * a_hi / a_lo [batch * s][lda]: RMSNorm output planes (a_lo NULL = plain bf16 mode: the three *_lo outputs must be NULL too).
+ * wfrag: llark_pack_weight16_frag of the [3 * nh * 128][kp] q|k|v weight with the q and k rows of every head reordered to
+ * [0..31 | 64..95 | 32..63 | 96..127] (v rows natural), so that a rotation pair (d, d + 64) shares a lane and register.
+ * Outputs as llark_rope_split_heads writes them; bit-equal to the two-launch path wherever that runs whole 128x256 tiles. */
+int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, int lda, const void* wfrag, int kp, int batch, int s, int nh, int hd,
+                                int pos0, const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache,
+                                void* q_lo, void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream);
 /* llark_gemm16_fragw with the K range of a tile cut over several workgroups, for products whose tile count is not a whole
  * number of rounds of the resident workgroups (Llama prefill at M = 2968: 384 / 1152 / 2064 tiles of 128x256 against 512
  * resident workgroups; one clip, M = 371: 48 .. 258 tiles -- m2t/models/llamav2.py:224-234 -> the q/k/v, o, gate/up, down

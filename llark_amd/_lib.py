@@ -81,6 +81,7 @@ _SIGS = {
                            _P, _P, c_int, _P],
     "llark_gemm16_fragw_sk": [c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int,
                               _P, _P, c_int, _P, c_int64, _P],
+    "llark_gemm16_fragw_rope_qkv": [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P],
     "llark_gemm16_resid_rmsnorm": [c_int, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_float, _P, _P,
                                    c_int, _P],
     "llark_gemm16_rmsnorm_a": [c_int, c_int, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P,

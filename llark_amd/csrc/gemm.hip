@@ -367,6 +367,133 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
 }
 
 // ------------------------------------------------------------------------------------------
+// Epilogue of the Llama q|k|v product with RoPE, the head split and both cache writes folded in (EPI_ROPE_QKV; replaces the fp32
+// qkv tensor and the rope_split_kernel launch of llama.hip in the prefill: m2t/models/llamav2.py:224-234 -> HF LlamaAttention
+// q_proj / k_proj / v_proj + apply_rotary_pos_emb + the cache append).  Written for the 128x256 B-direct tile (4 waves side by side,
+// two 32-column MFMA tiles each): a 256-column tile is two heads of ONE of the q / k / v regions (nh even), wave wn holds 64 columns
+// of head n0 / 128 + wn / 2.  The q / k weight rows of every head are PERMUTED at pack time to [0..31 | 64..95 | 32..63 | 96..127]
+// (ops.rope_qkv_row_order), the same trick as the SwiGLU gate / up interleave: MFMA tile 0 of the wave then holds x1 = x[d],
+// tile 1 holds x2 = x[d + 64] for d = 32 (wn % 2) + (lane & 31), in the same lane and register -- the rotation
+//     out[d] = x1 cos - x2 sin,   out[d + 64] = x2 cos + x1 sin          (rotate_half = cat(-x2, x1))
+// needs no cross-lane traffic.  A column's dot product does not depend on where its weight row sits, and the arithmetic below is
+// rope_split_kernel's operation for operation, so q, the K cache and V^T are BIT-equal to the two-kernel path whenever that path
+// runs the same whole-tile kernel (tests/test_llama_gpu.py).  V rows keep their natural order; its transposed cache layout makes
+// the V stores 2-byte scatters along d (one third of the tiles; the data of 4 consecutive rows shares a 64-byte line).
+// cos / sin come from the [max_pos][64] tables (L2-resident); the loads of row block tm + 1 are issued before the stores of
+// block tm so that no load waits behind a store.
+// ------------------------------------------------------------------------------------------
+template <typename T, bool SPLIT, typename C, bool FULL>
+__device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
+                                                            const int wn, const int lane) {
+    static_assert(C::WM == 1 && C::WN == 4 && C::TN == 2 && C::BN == 256, "rope epilogue: 128x256 tile, waves 1 x 4, two column tiles per wave");
+    static_assert(std::is_same<T, bf16_t>::value, "rope epilogue: bf16 planes");
+    const int H = p.rope_nh * 128;
+    // 0 = q, 1 = k, 2 = v (uniform: H % 256 == 0).  The division runs on the vector ALU; readfirstlane puts region / head back into
+    // scalar registers, or the buffer descriptors selected by `region` count as divergent and every store becomes a waterfall loop.
+    const int region = __builtin_amdgcn_readfirstlane(n0 / H);
+    const int head = __builtin_amdgcn_readfirstlane((n0 - region * H) / 128 + (wn >> 1));
+    const int lc = lane & 31, lr = 4 * (lane >> 5);
+    const int S = p.rope_s, smax = p.rope_smax;
+    const int mlane = m0 + lr;                                   // this lane's first row
+    // All addresses are 32-bit byte offsets into whole-tensor buffer descriptors (the host checks that every plane is < 2 GiB):
+    // no 64-bit vector arithmetic in the epilogue.  A row block of 28 consecutive rows crosses at most one sequence boundary
+    // (the host requires S >= 32): one integer division per 32-row block, a compare + select per row.
+    constexpr unsigned RSRC_FLAGS = 0x00020000u;
+    if (region < 2) {
+        const int dbase = 32 * (wn & 1) + lc;                    // rotation pair index d: x1 = column d, x2 = column d + 64
+        const int rph = region == 0 ? S : smax;                  // rows per head: q [b][nh][S][128], K cache [b][nh][smax][128]
+        const unsigned head_bytes = (unsigned)rph * 256u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
+        __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(region == 0 ? p.rope_q : p.rope_k, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? (region == 0 ? p.rope_q_lo : p.rope_k_lo) : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)p.rope_cos, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.rope_sin, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        const unsigned out_lane = (unsigned)head * head_bytes + (region == 0 ? 0u : (unsigned)p.rope_pos0 * 256u) + (unsigned)dbase * 2u;
+        const unsigned tab_lane = (unsigned)p.rope_pos0 * 256u + (unsigned)dbase * 4u;
+        float cs[2][16], sn[2][16];
+        // row block tm of this lane: (batch, position) of its first row; the 16 rows are offsets 0..3, 8..11, 16..19, 24..27 further on
+        auto block_origin = [&](int tm, int& bt, int& st) __attribute__((always_inline)) {
+            const int mt = mlane + C::tile_row(tm);
+            bt = mt / S;
+            st = mt - bt * S;
+        };
+        auto load_tables = [&](int tm, int buf) __attribute__((always_inline)) {   // issued one row block ahead of its use
+            int bt, st;
+            block_origin(tm, bt, st);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sr = st + (r & 3) + 8 * (r >> 2);
+                const unsigned to = tab_lane + (unsigned)(sr >= S ? sr - S : sr) * 256u;
+                cs[buf][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, to, 0, 0));
+                sn[buf][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, to, 0, 0));
+            }
+        };
+        load_tables(0, 0);
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) {
+            if (tm + 1 < C::TM) load_tables(tm + 1, (tm + 1) & 1);
+            int bt, st;
+            block_origin(tm, bt, st);
+            const unsigned base = out_lane + (unsigned)bt * batch_bytes;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);
+                if (!FULL && mlane + ml >= p.M) continue;
+                const int sr = st + (r & 3) + 8 * (r >> 2);
+                const bool wrap = sr >= S;
+                const unsigned o = base + (unsigned)(wrap ? sr - S : sr) * 256u + (wrap ? batch_bytes : 0u);    // byte offset of the row's x1 element
+                const float x1 = acc[tm][0][r], x2 = acc[tm][1][r];
+                const float c = cs[tm & 1][r], sv = sn[tm & 1][r];
+                const float ya = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sv));         // rope_split_kernel's operations, in its order
+                const float yb = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sv));
+                const bf16_t ha = (bf16_t)ya, hb = (bf16_t)yb;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, ha), rH, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hb), rH, o + 128u, 0, 0);
+                if (SPLIT) {
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(ya - (float)ha)), rL, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(yb - (float)hb)), rL, o + 128u, 0, 0);
+                }
+            }
+        }
+    } else {
+        // V^T cache [b][nh][128][smax]: lane = column d (natural order), rows run along the key axis
+        const unsigned head_bytes = 128u * (unsigned)smax * 2u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
+        __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.rope_v, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? p.rope_v_lo : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        const unsigned d0 = 64u * (wn & 1) + (unsigned)lc;
+        const unsigned out_lane = (unsigned)head * head_bytes + d0 * (unsigned)smax * 2u + (unsigned)p.rope_pos0 * 2u;
+        const unsigned tn_step = 32u * (unsigned)smax * 2u;      // column tile 1 = d + 32
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) {
+            const int mt = mlane + C::tile_row(tm);
+            const int bt = mt / S, st = mt - bt * S;
+            const unsigned base = out_lane + (unsigned)bt * batch_bytes;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                if (!FULL && mt + off >= p.M) continue;
+                const int sr = st + off;
+                const bool wrap = sr >= S;
+                const unsigned o = base + (unsigned)(wrap ? sr - S : sr) * 2u + (wrap ? batch_bytes : 0u);
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const float v = acc[tm][tn][r];
+                    const bf16_t h = (bf16_t)v;
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rH, o + tn * tn_step, 0, 0);
+                    if (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(v - (float)h)), rL, o + tn * tn_step, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool SPLIT, typename C>
+__device__ __forceinline__ void gemm_epilogue_rope_qkv(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
+                                                       const int wn, const int lane) {
+    if (m0 + C::BM <= p.M) gemm_epilogue_rope_qkv_impl<T, SPLIT, C, true>(p, acc, m0, n0, wn, lane);     // interior tile: no row checks
+    else gemm_epilogue_rope_qkv_impl<T, SPLIT, C, false>(p, acc, m0, n0, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // "B-direct" main loop.  Measured on MI355X (profiles/r01_gemm_ablation.txt): the stage-load latency of the
 // LDS-staged kernel (~2 us per 64 KiB burst) cannot be hidden inside 160 KiB of LDS.  Here the WEIGHT operand
 // never touches LDS: it is pre-packed fragment-major (llark_pack_weight16_frag: one contiguous 1 KiB chunk per
@@ -478,7 +605,8 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
         if (kt + 1 < nk) storeA((kt + 1) & 1);
         __syncthreads();
     }
-    gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
+    if constexpr (EPI == EPI_ROPE_QKV) gemm_epilogue_rope_qkv<T, SPLIT, C>(p, acc, m0, n0, wn, lane);
+    else gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
 }
 
 template <typename T, bool SPLIT, int EPI, typename C>
@@ -1488,6 +1616,37 @@ extern "C" int llark_gemm16_fragw_sk(int variant, int dtype, int split, int epil
     LLARK_REQUIRE(!scratch || ((uintptr_t)scratch & 15) == 0, "gemm16_fragw_sk: scratch must be 16-byte aligned");
     return gemm16_fragw_impl(variant, dtype, split, epilogue, a_hi, a_lo, lda, wfrag, bias, m, n, kp, c, ldc, resid, ldr, out_hi, out_lo,
                              ldo, scratch, scratch_bytes, stream);
+}
+
+// The Llama q|k|v product of a prefill with RoPE, the head split, the K-cache append and the transposed V-cache append in its
+// epilogue (gemm_epilogue_rope_qkv): one launch instead of llark_gemm16_fragw (fp32 qkv) + llark_rope_split_heads.  bf16 only.
+// a_hi / a_lo [batch * s][lda]: RMSNorm output planes (a_lo NULL = plain bf16 mode; then the three *_lo outputs must be NULL too).
+// wfrag: llark_pack_weight16_frag of the [3 * nh * 128][kp] q|k|v weight whose q and k rows are permuted per head to
+// [0..31 | 64..95 | 32..63 | 96..127] (v rows in natural order).  Always whole 128x256 tiles (no K cut): callers that want results
+// bit-equal to the two-launch path use it where that path runs whole tiles too (m >= 2 rounds of tiles, see gemm16_fragw_impl).
+extern "C" int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, int lda, const void* wfrag, int kp, int batch, int s, int nh,
+                                           int hd, int pos0, const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache,
+                                           void* vt_cache, void* q_lo, void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && wfrag && cos_t && sin_t && q && k_cache && vt_cache, "gemm16_fragw_rope_qkv: null pointer");
+    LLARK_REQUIRE(hd == 128, "gemm16_fragw_rope_qkv: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(nh > 0 && nh % 2 == 0, "gemm16_fragw_rope_qkv: a 256-column tile holds two heads: nh must be even, got %d", nh);
+    LLARK_REQUIRE(batch > 0 && s > 0 && pos0 >= 0 && pos0 + s <= smax && pos0 + s <= max_pos && smax % 8 == 0,
+                  "gemm16_fragw_rope_qkv: bad shape batch=%d s=%d pos0=%d smax=%d max_pos=%d", batch, s, pos0, smax, max_pos);
+    LLARK_REQUIRE(kp > 0 && kp % 64 == 0 && lda % 8 == 0 && lda >= kp, "gemm16_fragw_rope_qkv: kp must be a multiple of 64, lda >= kp and a multiple of 8");
+    LLARK_REQUIRE(s >= 32, "gemm16_fragw_rope_qkv: a 32-row block may cross one sequence boundary only: s must be >= 32, got %d", s);
+    LLARK_REQUIRE((long long)batch * nh * smax * 256 < (1ll << 31) && (long long)max_pos * 256 < (1ll << 31) && (long long)batch * s < (1ll << 30),
+                  "gemm16_fragw_rope_qkv: the planes are addressed with 32-bit byte offsets: batch * nh * smax * 256 must stay below 2 GiB");
+    const bool split = a_lo != nullptr;
+    LLARK_REQUIRE(split == (q_lo != nullptr) && split == (k_cache_lo != nullptr) && split == (vt_cache_lo != nullptr),
+                  "gemm16_fragw_rope_qkv: give a_lo and all three lo outputs (fp32-class mode) or none");
+    LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)wfrag & 15) == 0 && (!a_lo || ((uintptr_t)a_lo & 15) == 0),
+                  "gemm16_fragw_rope_qkv: operands must be 16-byte aligned");
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.M = batch * s; p.N = 3 * nh * 128; p.Kp = kp;
+    p.rope_cos = cos_t; p.rope_sin = sin_t; p.rope_s = s; p.rope_nh = nh; p.rope_pos0 = pos0; p.rope_smax = smax;
+    p.rope_q = q; p.rope_q_lo = q_lo; p.rope_k = k_cache; p.rope_k_lo = k_cache_lo; p.rope_v = vt_cache; p.rope_v_lo = vt_cache_lo;
+    hipStream_t st = (hipStream_t)stream;
+    return split ? launch_gemm_bd<bf16_t, true, EPI_ROPE_QKV, CfgBD0>(p, st) : launch_gemm_bd<bf16_t, false, EPI_ROPE_QKV, CfgBD0>(p, st);
 }
 
 // Decode-step form of `h += x . W^T` followed by RMSNorm(h) -> bf16 planes, in ONE launch (m <= 16 rows): the skinny

@@ -116,10 +116,20 @@ struct GemmParams {
     const float* ln_stat;   // [M][2] (mean, rstd)
     const float* ln_vec;    // [N]
     float* ln_part;         // [M][2 * tiles_n][2]
+    // EPI_ROPE_QKV (gemm.hip, B-direct kernel only; llark_gemm16_fragw_rope_qkv): the Llama q|k|v product whose epilogue rotates q / k
+    // and writes q planes, the K cache and the transposed V cache directly (no fp32 qkv round trip, no rope_split_kernel launch).
+    // Rows m = b * rope_s + s; N = 3 * rope_nh * 128 with the q / k weight rows of every head permuted [0..31 | 64..95 | 32..63 | 96..127].
+    const float* rope_cos;  // [max_pos][64]
+    const float* rope_sin;
+    int rope_s, rope_nh, rope_pos0, rope_smax;
+    void *rope_q, *rope_q_lo;      // bf16 [batch][nh][rope_s][128]
+    void *rope_k, *rope_k_lo;      // bf16 [batch][nh][rope_smax][128]
+    void *rope_v, *rope_v_lo;      // bf16 [batch][nh][128][rope_smax]  (V transposed)
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
-       EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8n.hip only) */ };
+       EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8n.hip only) */,
+       EPI_ROPE_QKV = 8 /* internal (no public value): gemm_bd_kernel + gemm_epilogue_rope_qkv, llark_gemm16_fragw_rope_qkv */ };
 #define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
 
 template <typename T>

@@ -49,7 +49,7 @@ def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
 
 
 class _Layer:
-    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2")
+    __slots__ = ("wqkv", "wo", "wgu", "wdown", "ln1", "ln2", "wqkv_rope")
 
 
 class HipLlamaEngine:
@@ -111,6 +111,16 @@ class HipLlamaEngine:
         self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
         # decode: RoPE + KV-cache append inside the attention launch (one launch per layer fewer); LLARK_DECODE_FUSE_ROPE=0 = two launches
         self.fuse_decode_rope = os.environ.get("LLARK_DECODE_FUSE_ROPE", "1") != "0"
+        # prefill: RoPE + head split + K / V^T cache writes inside the q|k|v GEMM's epilogue (llark_gemm16_fragw_rope_qkv: no fp32 qkv
+        # tensor, no rope_split_kernel launch).  "0" (default until measured on the GPU: written at the end of round 4 without GPU
+        # time left) = two launches; "auto" = fused wherever the two-launch path runs the same whole-tile kernel, so q / K / V^T
+        # and the logits stay bit-equal; "1" = fused for every prefill of >= 32 positions.  Needs a second fragment-major copy
+        # of the q|k|v weight in the epilogue's row order (+ 3 H^2 x 2 bytes per layer: 3.2 GB at 7B), built at load time unless "0".
+        self.fuse_prefill_rope = os.environ.get("LLARK_PREFILL_FUSE_ROPE", "0")
+        if self.fuse_prefill_rope not in ("0", "1", "auto"):
+            raise ValueError(f"LLARK_PREFILL_FUSE_ROPE must be 0, 1 or auto, got {self.fuse_prefill_rope!r}")
+        self._resident_wgs = None
+        self._rope_rows = None                                      # gather index of the epilogue's q|k|v row order (built on first use)
         self._dec: Dict[int, dict] = {}
 
     # ---- weights -------------------------------------------------------------------------------
@@ -135,6 +145,11 @@ class HipLlamaEngine:
         if self.frag_weights:
             for t in (L.wqkv, L.wo, L.wgu, L.wdown):
                 ops.attach_frag(t, t.shape[0])
+        L.wqkv_rope = None
+        if self.frag_weights and self.fuse_prefill_rope != "0" and self.dims.num_attention_heads % 2 == 0 and self.dims.hidden_size % 64 == 0:
+            if self._rope_rows is None:
+                self._rope_rows = ops.rope_qkv_row_order(self.dims.num_attention_heads, self.dims.head_dim).to(self.device)
+            L.wqkv_rope = ops.pack_weight16_frag(L.wqkv.index_select(0, self._rope_rows).contiguous(), L.wqkv.shape[0])
         self.layers[i] = L
 
     def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
@@ -174,6 +189,7 @@ class HipLlamaEngine:
             if L is not None:
                 for t in (L.wqkv, L.wo, L.wgu, L.wdown):
                     ops.detach_frag(t)
+                L.wqkv_rope = None
         if self.lm_head is not None:
             ops.detach_frag(self.lm_head)
 
@@ -236,6 +252,22 @@ class HipLlamaEngine:
             self.k_cache_lo = torch.zeros(shape_k, dtype=torch.bfloat16, device=self.device) if self.split else None
             self.vt_cache_lo = torch.zeros(shape_v, dtype=torch.bfloat16, device=self.device) if self.split else None
 
+    def _prefill_rope_fused(self, batch: int, s: int) -> bool:
+        """Does this prefill take the q|k|v product with RoPE in its epilogue?  "auto" = only where llark_gemm16_fragw would run the
+        same whole 128x256 tiles (its K-cutting rule restated: csrc/gemm.hip gemm16_fragw_impl), so results stay bit-equal."""
+        if self.fuse_prefill_rope == "0" or s < 32 or batch * s < ops.FRAG_MIN_ROWS:
+            return False
+        if self.fuse_prefill_rope == "1":
+            return True
+        H = self.dims.hidden_size
+        tiles = -(-batch * s // 128) * -(-3 * H // 256)
+        if self._resident_wgs is None:
+            self._resident_wgs = 2 * ops.device_info(self.device.index or 0)[0]      # two 128x256 workgroups per CU
+        resident = self._resident_wgs
+        if self.split:
+            return tiles >= resident
+        return not (4 * tiles <= resident or (tiles < resident and H >= 8192))
+
     # ---- forward -------------------------------------------------------------------------------
     def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None) -> bool:
         """Runs the decoder layers on ws["h"].  Returns True when ws["x16"] already holds RMSNorm_final(h) (the fused
@@ -251,6 +283,7 @@ class HipLlamaEngine:
                   (self.fuse_decode_norm_a == "1" or (self.fuse_decode_norm_a == "auto" and ops.gemv_dma_rmsnorm_takes(batch, 3 * H, H))))
         if fused:
             ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+        rope_fused = s > 1 and pos_dev is None and self._prefill_rope_fused(batch, s)
         for i in range(n_layers):
             L = self.layers[i]
             kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
@@ -258,13 +291,19 @@ class HipLlamaEngine:
             vcl = self.vt_cache_lo[i, :batch] if sp else None
             if not kc.is_contiguous():            # batch smaller than the allocated cache
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
-            if norm_a:                               # decode: RMSNorm fused into the consuming weight-streaming GEMM
+            if rope_fused and L.wqkv_rope is not None:  # prefill: RoPE / head split / cache writes in the q|k|v epilogue
+                ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+                ops.gemm16_fragw_rope_qkv(ws["x16"], ws["x16_lo"], L.wqkv_rope, H, batch, s, nh, pos0, self.cos, self.sin, ws["q"], kc, vc,
+                                          ws["q_lo"], kcl, vcl)
+            elif norm_a:                             # decode: RMSNorm fused into the consuming weight-streaming GEMM
                 ops.gemm16_rmsnorm_a(h, L.ln1, d.rms_norm_eps, L.wqkv, 3 * H, ops.EPI_F32, sp, c=ws["qkv"])
             else:
                 if not fused:
                     ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
                 ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
-            if s == 1 and self.fuse_decode_rope:
+            if rope_fused and L.wqkv_rope is not None:
+                ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
+            elif s == 1 and self.fuse_decode_rope:
                 ops.attn_decode_rope(ws["qkv"], batch, nh, hd, pos_dev if pos_dev is not None else pos0, self.cos, self.sin, kc, vc,
                                      ws["att"], kcl, vcl, ws["att_lo"])
             elif pos_dev is not None:               # decode step, position in device memory (graph-capturable)

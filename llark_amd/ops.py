@@ -689,6 +689,36 @@ def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.
         scratch.data_ptr() if scratch is not None else None, scratch.numel() * 4 if scratch is not None else 0, _stream()), "gemm16_fragw")
 
 
+def rope_qkv_row_order(nh: int, hd: int = 128) -> torch.Tensor:
+    """Row order of the fused q|k|v weight for llark_gemm16_fragw_rope_qkv: inside every q and k head the rows go
+    [0..31 | 64..95 | 32..63 | 96..127] (a rotation pair d, d + 64 then sits in MFMA tiles 2j, 2j + 1 of one wave: same lane, same
+    register); v rows keep their order.  Returns the int64 gather index over the 3 * nh * hd rows (a permutation)."""
+    assert hd == 128
+    inside = torch.cat((torch.arange(0, 32), torch.arange(64, 96), torch.arange(32, 64), torch.arange(96, 128)))
+    qk = (torch.arange(2 * nh)[:, None] * hd + inside[None, :]).reshape(-1)
+    return torch.cat((qk, torch.arange(2 * nh * hd, 3 * nh * hd)))
+
+
+def gemm16_fragw_rope_qkv(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.Tensor, kp: int, batch: int, s: int, nh: int,
+                          pos0: int, cos_t: torch.Tensor, sin_t: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor,
+                          q_lo=None, k_cache_lo=None, vt_cache_lo=None) -> None:
+    """Prefill q|k|v product with RoPE + head split + both cache writes in the epilogue (include/llark_hip.h,
+    llark_gemm16_fragw_rope_qkv); ``wfrag`` = pack_weight16_frag of the weight gathered with :func:`rope_qkv_row_order`."""
+    bf = torch.bfloat16
+    hd = 128
+    smax = k_cache.shape[-2]
+    n = 3 * nh * hd
+    assert a_hi.dtype == bf and wfrag.dtype == bf and wfrag.numel() == n * kp and a_hi.shape[0] >= batch * s and a_hi.shape[1] >= kp
+    assert k_cache.shape[-1] == hd and vt_cache.shape[-1] == smax and q.numel() >= batch * nh * s * hd
+    name = "gemm_split_bf16" if a_lo is not None else "gemm_bf16"
+    with _timed(name, 2.0 * batch * s * n * kp):
+        check(_lib.lib().llark_gemm16_fragw_rope_qkv(
+            _dev(a_hi, "a_hi", bf), _opt(a_lo, "a_lo", bf), a_hi.stride(0), _dev(wfrag, "wfrag", bf), kp, batch, s, nh, hd, pos0,
+            _dev(cos_t, "cos", torch.float32), _dev(sin_t, "sin", torch.float32), cos_t.shape[0], _dev(q, "q", bf),
+            _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf), _opt(q_lo, "q_lo", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+            _opt(vt_cache_lo, "vt_cache_lo", bf), smax, _stream()), "gemm16_fragw_rope_qkv")
+
+
 # ------------------------------------------------------------------------------------------------
 # Llama
 # ------------------------------------------------------------------------------------------------

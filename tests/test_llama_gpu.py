@@ -480,3 +480,83 @@ def test_decode_auto_fused_rmsnorm_engine_level_bit_identical():
         res.append(torch.stack(outs))
         del eng
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("batch,s,pos0,smax", [(3, 371, 0, 384), (2, 40, 8, 64), (1, 1000, 24, 1024), (5, 33, 0, 40)])
+def test_rope_qkv_epilogue_bit_equal_to_two_launches(split, batch, s, pos0, smax):
+    """llark_gemm16_fragw_rope_qkv (q|k|v product with RoPE, head split, K-cache and V^T-cache writes in its epilogue) against
+    llark_gemm16_fragw (whole 128x256 tiles, fp32 qkv) + llark_rope_split_heads: q, the K cache and V^T -- hi and lo planes --
+    are BIT-equal, rows of ragged last tiles and positions outside [pos0, pos0 + s) untouched.  Sequence boundaries fall inside
+    row blocks (s = 371, 40, 33), pos0 > 0, m not a multiple of 128."""
+    from llark_amd import ops
+    nh, hd, kp = 4, 128, 192
+    H = nh * hd
+    m = batch * s
+    g = torch.Generator().manual_seed(1000 * batch + s)
+    bf = torch.bfloat16
+    x = torch.randn(m, kp, generator=g).cuda()
+    x_hi = x.to(bf)
+    x_lo = (x - x_hi.float()).to(bf) if split else None
+    w = (torch.randn(3 * H, kp, generator=g) * 0.2).to(bf).cuda()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(smax, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = fr.cos().contiguous().cuda(), fr.sin().contiguous().cuda()
+
+    def outs():
+        mk = lambda *shape: torch.full(shape, 7.0, dtype=bf, device="cuda")
+        o = dict(q=mk(batch, nh, s, hd), k=mk(batch, nh, smax, hd), v=mk(batch, nh, hd, smax))
+        if split:
+            o.update(q_lo=mk(batch, nh, s, hd), k_lo=mk(batch, nh, smax, hd), v_lo=mk(batch, nh, hd, smax))
+        return o
+
+    ref = outs()
+    qkv = torch.empty(m, 3 * H, dtype=torch.float32, device="cuda")
+    ops.gemm16_fragw(x_hi, x_lo, ops.pack_weight16_frag(w, 3 * H), None, 3 * H, kp, ops.EPI_F32, c=qkv, variant=0, stream_k=False)
+    ops.rope_split_heads(qkv, batch, s, nh, hd, pos0, cos, sin, ref["q"], ref["k"], ref["v"], ref.get("q_lo"), ref.get("k_lo"), ref.get("v_lo"))
+    got = outs()
+    order = ops.rope_qkv_row_order(nh, hd)
+    assert sorted(order.tolist()) == list(range(3 * H))
+    wf = ops.pack_weight16_frag(w.index_select(0, order.cuda()).contiguous(), 3 * H)
+    ops.gemm16_fragw_rope_qkv(x_hi, x_lo, wf, kp, batch, s, nh, pos0, cos, sin, got["q"], got["k"], got["v"], got.get("q_lo"), got.get("k_lo"),
+                              got.get("v_lo"))
+    torch.cuda.synchronize()
+    for name in ref:
+        bad = int((ref[name].view(torch.int16) != got[name].view(torch.int16)).sum())
+        assert bad == 0, f"{name}: {bad} of {ref[name].numel()} elements differ"
+    assert float(ref["k"][:, :, pos0:pos0 + s].float().abs().max()) > 0.1        # the comparison saw real values, not only the sentinel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+def test_engine_prefill_rope_fused_bit_equal_at_7b_width(precision):
+    """One decoder layer at Llama-2-7B widths, B = 8 x S = 371 (the bench shape): with LLARK_PREFILL_FUSE_ROPE=auto the engine takes
+    the fused q|k|v launch (1152 whole tiles in both paths) and logits, K cache and V^T cache equal the two-launch path's bit for
+    bit; one clip of the batch alone (144 tiles) stays on the two-launch path in split mode, whose K-cutting kernel sums in
+    another order."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    dims = LlamaDims(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32, vocab_size=512, mm_hidden_size=96)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = lambda *shape: (torch.randn(*shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    H, I = 4096, 11008
+    layer = (n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I), torch.ones(H, device="cuda"), torch.ones(H, device="cuda"))
+    glob = (n(512, H), torch.ones(H, device="cuda"), n(512, H))
+    ids = torch.randint(3, 500, (8, 371), generator=torch.Generator().manual_seed(2)).cuda()
+    res = []
+    for mode in ("0", "auto"):
+        eng = HipLlamaEngine(dims, "cuda", 8, 384, precision=precision)
+        eng.fuse_prefill_rope = mode
+        eng.set_layer(0, *layer)
+        eng.set_globals(*glob)
+        assert (eng.layers[0].wqkv_rope is not None) == (mode == "auto")
+        assert eng._prefill_rope_fused(8, 371) == (mode == "auto")
+        assert eng._prefill_rope_fused(1, 371) == (mode == "auto" and precision == "bf16")
+        logits = eng.forward_tokens(ids).clone()
+        res.append((logits, eng.k_cache.clone(), eng.vt_cache.clone(), eng.k_cache_lo.clone() if eng.split else None))
+        del eng
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if precision == "split":
+        assert torch.equal(a[3], b[3])
+    assert float(a[0].abs().max()) > 0
