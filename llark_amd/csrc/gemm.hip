@@ -377,14 +377,14 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
 //     out[d] = x1 cos - x2 sin,   out[d + 64] = x2 cos + x1 sin          (rotate_half = cat(-x2, x1))
 // needs no cross-lane traffic.  A column's dot product does not depend on where its weight row sits, and the arithmetic below is
 // rope_split_kernel's operation for operation, so q, the K cache and V^T are BIT-equal to the two-kernel path whenever that path
-// runs the same whole-tile kernel (tests/test_llama_gpu.py).  V rows keep their natural order; its transposed cache layout makes
-// the V stores 2-byte scatters along d (one third of the tiles; the data of 4 consecutive rows shares a 64-byte line).
+// runs the same whole-tile kernel (tests/test_llama_gpu.py).  V rows keep their natural order; the V tiles are transposed through
+// wave-private LDS patches so that their stores run along the cache's contiguous (position) axis.
 // cos / sin come from the [max_pos][64] tables (L2-resident); the loads of row block tm + 1 are issued before the stores of
 // block tm so that no load waits behind a store.
 // ------------------------------------------------------------------------------------------
 template <typename T, bool SPLIT, typename C, bool FULL>
 __device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                                            const int wn, const int lane) {
+                                                            const int wn, const int lane, char* smem) {
     static_assert(C::WM == 1 && C::WN == 4 && C::TN == 2 && C::BN == 256, "rope epilogue: 128x256 tile, waves 1 x 4, two column tiles per wave");
     static_assert(std::is_same<T, bf16_t>::value, "rope epilogue: bf16 planes");
     const int H = p.rope_nh * 128;
@@ -455,31 +455,41 @@ __device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p,
             }
         }
     } else {
-        // V^T cache [b][nh][128][smax]: lane = column d (natural order), rows run along the key axis
+        // V^T cache [b][nh][128][smax]: positions are the contiguous axis, but an accumulator lane holds ONE column d -- stored from
+        // there, a wave instruction scatters 64 two-byte pieces over 64 cache lines (measured, first version of this epilogue: the
+        // V tiles alone cost what rope_split_kernel costs, profiles/r04_rope_fuse_ab_v1.txt).  So every 32 x 32 MFMA tile goes
+        // through a wave-private LDS patch [column][33 dwords] (the A stages are free after the K loop's last barrier; writes and
+        // reads are conflict-free: bank = (column + row) mod 32) and comes back with lanes along the ROWS: an instruction then
+        // stores 2 columns x 32 consecutive positions = two 64-byte runs.
         const unsigned head_bytes = 128u * (unsigned)smax * 2u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
         __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.rope_v, 0, 0x7FFFFFFF, RSRC_FLAGS);
         __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? p.rope_v_lo : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        const unsigned d0 = 64u * (wn & 1) + (unsigned)lc;
-        const unsigned out_lane = (unsigned)head * head_bytes + d0 * (unsigned)smax * 2u + (unsigned)p.rope_pos0 * 2u;
-        const unsigned tn_step = 32u * (unsigned)smax * 2u;      // column tile 1 = d + 32
+        float* patch = (float*)smem + (threadIdx.x >> 6) * (32 * 33);
+        const int rrow = lane & 31, rcol = lane >> 5;            // read-back role: row of the 32-row block, first of this lane's columns
+        const unsigned col_bytes = (unsigned)smax * 2u;
+        const unsigned out_lane = (unsigned)head * head_bytes + (64u * (wn & 1) + (unsigned)rcol) * col_bytes + (unsigned)p.rope_pos0 * 2u;
 #pragma unroll
         for (int tm = 0; tm < C::TM; ++tm) {
-            const int mt = mlane + C::tile_row(tm);
-            const int bt = mt / S, st = mt - bt * S;
-            const unsigned base = out_lane + (unsigned)bt * batch_bytes;
+            const int mr = m0 + C::tile_row(tm) + rrow;          // the row this lane stores
+            const int bt = mr / S, st = mr - bt * S;
+            const unsigned vo = out_lane + (unsigned)bt * batch_bytes + (unsigned)st * 2u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                if (!FULL && mt + off >= p.M) continue;
-                const int sr = st + off;
-                const bool wrap = sr >= S;
-                const unsigned o = base + (unsigned)(wrap ? sr - S : sr) * 2u + (wrap ? batch_bytes : 0u);
+            for (int tn = 0; tn < 2; ++tn) {
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    const float v = acc[tm][tn][r];
-                    const bf16_t h = (bf16_t)v;
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rH, o + tn * tn_step, 0, 0);
-                    if (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(v - (float)h)), rL, o + tn * tn_step, 0, 0);
+                for (int r = 0; r < 16; ++r) patch[lc * 33 + (r & 3) + 8 * (r >> 2) + lr] = acc[tm][tn][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float vals[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) vals[j] = patch[(rcol + 2 * j) * 33 + rrow];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (FULL || mr < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const unsigned so = (unsigned)(32 * tn + 2 * j) * col_bytes;       // uniform: scalar offset of the instruction
+                        const bf16_t h = (bf16_t)vals[j];
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rH, vo, so, 0);
+                        if (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(vals[j] - (float)h)), rL, vo, so, 0);
+                    }
                 }
             }
         }
@@ -488,9 +498,10 @@ __device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p,
 
 template <typename T, bool SPLIT, typename C>
 __device__ __forceinline__ void gemm_epilogue_rope_qkv(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                                       const int wn, const int lane) {
-    if (m0 + C::BM <= p.M) gemm_epilogue_rope_qkv_impl<T, SPLIT, C, true>(p, acc, m0, n0, wn, lane);     // interior tile: no row checks
-    else gemm_epilogue_rope_qkv_impl<T, SPLIT, C, false>(p, acc, m0, n0, wn, lane);
+                                                       const int wn, const int lane, char* smem) {
+    static_assert(4 * 32 * 33 * 4 <= 2 * C::A_BYTES, "rope epilogue: the V transposition patches must fit the A stages");
+    if (m0 + C::BM <= p.M) gemm_epilogue_rope_qkv_impl<T, SPLIT, C, true>(p, acc, m0, n0, wn, lane, smem);     // interior tile: no row checks
+    else gemm_epilogue_rope_qkv_impl<T, SPLIT, C, false>(p, acc, m0, n0, wn, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
         if (kt + 1 < nk) storeA((kt + 1) & 1);
         __syncthreads();
     }
-    if constexpr (EPI == EPI_ROPE_QKV) gemm_epilogue_rope_qkv<T, SPLIT, C>(p, acc, m0, n0, wn, lane);
+    if constexpr (EPI == EPI_ROPE_QKV) gemm_epilogue_rope_qkv<T, SPLIT, C>(p, acc, m0, n0, wn, lane, smem);
     else gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
 }
 

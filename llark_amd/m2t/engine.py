@@ -112,11 +112,14 @@ class HipLlamaEngine:
         # decode: RoPE + KV-cache append inside the attention launch (one launch per layer fewer); LLARK_DECODE_FUSE_ROPE=0 = two launches
         self.fuse_decode_rope = os.environ.get("LLARK_DECODE_FUSE_ROPE", "1") != "0"
         # prefill: RoPE + head split + K / V^T cache writes inside the q|k|v GEMM's epilogue (llark_gemm16_fragw_rope_qkv: no fp32 qkv
-        # tensor, no rope_split_kernel launch).  "0" (default until measured on the GPU: written at the end of round 4 without GPU
-        # time left) = two launches; "auto" = fused wherever the two-launch path runs the same whole-tile kernel, so q / K / V^T
-        # and the logits stay bit-equal; "1" = fused for every prefill of >= 32 positions.  Needs a second fragment-major copy
-        # of the q|k|v weight in the epilogue's row order (+ 3 H^2 x 2 bytes per layer: 3.2 GB at 7B), built at load time unless "0".
-        self.fuse_prefill_rope = os.environ.get("LLARK_PREFILL_FUSE_ROPE", "0")
+        # tensor, no rope_split_kernel launch).  "auto" (default) = fused wherever the two-launch path runs the same whole-tile kernel,
+        # so q / K / V^T and the logits stay BIT-equal (tests/test_llama_gpu.py); "1" = fused for every prefill of >= 32 positions;
+        # "0" = two launches.  Measured at 7B, 8 x 371 (profiles/r04_rope_fuse_ab_v2.txt, same engine, interleaved): forward 42.48 ->
+        # 40.97 ms bf16, 79.03 -> 77.82 ms split.  (The first version stored the V tiles straight from the accumulator lanes -- 64
+        # two-byte pieces on 64 cache lines per instruction -- and lost what the removed launch gained: 42.63 -> 42.24 / 79.10 -> 80.31,
+        # profiles/r04_rope_fuse_ab_v1.txt; the V tiles now go through a wave-private LDS transposition.)  Costs a second fragment-major
+        # copy of the q|k|v weight in the epilogue's row order (+ 3 H^2 x 2 bytes per layer: 3.2 GB at 7B), built at load time unless "0".
+        self.fuse_prefill_rope = os.environ.get("LLARK_PREFILL_FUSE_ROPE", "auto")
         if self.fuse_prefill_rope not in ("0", "1", "auto"):
             raise ValueError(f"LLARK_PREFILL_FUSE_ROPE must be 0, 1 or auto, got {self.fuse_prefill_rope!r}")
         self._resident_wgs = None

@@ -61,15 +61,33 @@ def replay_epilogue(acc_full: np.ndarray, batch: int, s: int, nh: int, pos0: int
                             dst[idx], dst[idx + 64] = ya[ok], yb[ok]
                             writes["q" if region == 0 else "k"] += 2 * int(ok.sum())
                         else:
-                            head_bytes, batch_bytes = 128 * smax * 2, nh * 128 * smax * 2
-                            d0 = 64 * (wn & 1) + lc
-                            out_lane = head * head_bytes + d0 * smax * 2 + pos0 * 2
-                            o = out_lane + bt * batch_bytes + s2 * 2 + np.where(wrap, batch_bytes, 0)
-                            for tn, a in ((0, a0), (1, a1)):
-                                idx = (o[ok] + tn * 32 * smax * 2) // 2
+                            pass                                        # V tiles: replayed per 32 x 32 MFMA tile below
+                if region == 2:
+                    # V^T: every MFMA tile goes through a wave-private LDS patch [column][33 dwords] and is stored with lanes along
+                    # the rows: lane -> row lane & 31 of the 32-row block, columns (lane >> 5) + 2 j
+                    head_bytes, batch_bytes, col_bytes = 128 * smax * 2, nh * 128 * smax * 2, smax * 2
+                    rrow, rcol = lane & 31, lane >> 5
+                    out_lane = head * head_bytes + (64 * (wn & 1) + rcol) * col_bytes + pos0 * 2
+                    for tm in range(TM):
+                        mr = m0 + 32 * tm + rrow
+                        bt, st = mr // s, mr % s
+                        vo = out_lane + bt * batch_bytes + st * 2
+                        ok = mr < m
+                        for tn in range(2):
+                            patch = np.full(32 * 33, np.nan, np.float32)
+                            for r in range(16):                        # write phase: lane = (column lc, row half lr)
+                                rows = np.minimum(m0 + 32 * tm + (r & 3) + 8 * (r >> 2) + lr, m - 1)
+                                waddr = lc * 33 + (r & 3) + 8 * (r >> 2) + lr
+                                assert len(set((waddr[:32] % 32).tolist())) == 32 and len(set((waddr[32:] % 32).tolist())) == 32   # no bank conflict
+                                patch[waddr] = acc_full[rows, n0 + wn * 64 + 32 * tn + lc]
+                            for j in range(16):                        # read phase + store
+                                raddr = (rcol + 2 * j) * 33 + rrow
+                                assert len(set((raddr[:32] % 32).tolist())) == 32 and len(set((raddr[32:] % 32).tolist())) == 32
+                                vals = patch[raddr]
+                                idx = (vo[ok] + (32 * tn + 2 * j) * col_bytes) // 2
                                 assert np.isnan(v[idx]).all(), "an element was written twice"
-                                v[idx] = a[ok]
-                            writes["v"] += 2 * int(ok.sum())
+                                v[idx] = vals[ok]
+                                writes["v"] += int(ok.sum())
     return q.reshape(batch, nh, s, 128), k.reshape(batch, nh, smax, 128), v.reshape(batch, nh, 128, smax), writes
 
 
