@@ -102,7 +102,18 @@ class LLMWorkload:
         return {"bound": "mfma", "kernel": "gemm_kernel<bf16%s>" % (",split" if self.engine.split else ""),
                 "mfma_passes": 2 if self.engine.split else 1, "achieved": round(achieved, 2), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None, "launches": launches,
-                "avg_launch_ms": round(ms / launches, 4)}
+                "avg_launch_ms": round(ms / launches, 4),
+                "rope_in_qkv_epilogue": bool(self.engine._prefill_rope_fused(self.batch, self.ids.shape[1])),
+                "whole_forward_flops_t": round((self.flops_per_step() + self.attention_flops_per_step()) / 1e12, 2),
+                "note": ("GEMM launches only (HIP events); with rope_in_qkv_epilogue the q|k|v launches also rotate q / k and append the K / V^T "
+                         "caches (no rope_split_kernel, no fp32 qkv) -- that work is inside the event time, its flops are not counted; "
+                         "whole-forward fraction = whole_forward_flops_t / llama forward time / peak")}
+
+    def attention_flops_per_step(self) -> float:
+        """Dense-counted attention flops of the prefill (4 S^2 H per layer and clip)."""
+        d = self.dims
+        s = self.ids.shape[1]
+        return 4.0 * s * s * d.hidden_size * d.num_hidden_layers * self.batch
 
 
 class TrainWorkload:
