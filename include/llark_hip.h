@@ -77,6 +77,13 @@ int llark_device_info(int device, char* arch_name, int arch_name_len);
 int llark_resample_sinc_host(const float* x, int64_t n_in, double ratio, const double* win, const double* dwin, int nwin,
                              int num_table, float* y, int64_t n_out);
 
+/* FLAC streams (the other container libsndfile -- `lr.load` at jukebox/main.py:31, `sf.read` at m2t/gcs_utils.py:123 -- reads without
+ * further dependencies), decoded from memory on the HOST.  info: STREAMINFO fields (total_samples 0 = not recorded).  decode:
+ * interleaved int32 [frames][channels] into out (NULL = count only), at most cap_frames frames; every frame's CRC-8 / CRC-16 is
+ * checked and, with verify_md5, the MD5 signature of the decoded samples against STREAMINFO's (a FLAC stream certifies its decode). */
+int llark_flac_info_host(const uint8_t* data, int64_t n, int* sample_rate, int* channels, int* bits_per_sample, int64_t* total_samples);
+int llark_flac_decode_host(const uint8_t* data, int64_t n, int32_t* out, int64_t cap_frames, int64_t* decoded_frames, int verify_md5);
+
 /* ---------------------------------------------------------------------------------------------
  * Jukebox VQ-VAE level-2 encoder: replaces `vqvae.encode(...)` at jukebox/main.py:61
  * (upstream openai/jukebox vqvae/encdec.py EncoderConvBlock, resnet.py ResConv1DBlock,

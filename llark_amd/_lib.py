@@ -43,6 +43,8 @@ _SIGS = {
     "llark_version": [],
     "llark_device_info": [c_int, c_char_p, c_int],
     "llark_resample_sinc_host": [_P, c_int64, c_double, _P, _P, c_int, c_int, _P, c_int64],
+    "llark_flac_info_host": [_P, c_int64, _P, _P, _P, _P],
+    "llark_flac_decode_host": [_P, c_int64, _P, c_int64, _P, c_int],
     "llark_pack_conv_weight": [_P, _P, c_int, c_int, c_int, _P],
     "llark_conv1d_f32": [_P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P],
     "llark_resblock_f32": [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P],
