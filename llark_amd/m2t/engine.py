@@ -149,7 +149,9 @@ class HipLlamaEngine:
             for t in (L.wqkv, L.wo, L.wgu, L.wdown):
                 ops.attach_frag(t, t.shape[0])
         L.wqkv_rope = None
-        if self.frag_weights and self.fuse_prefill_rope != "0" and self.dims.num_attention_heads % 2 == 0 and self.dims.hidden_size % 64 == 0:
+        # only next to the fragment-major twin the two-launch path uses (LLARK_FRAG=0 switches both off: same kernel family either way)
+        if (self.frag_weights and hasattr(L.wqkv, "_llark_frag") and self.fuse_prefill_rope != "0" and self.dims.num_attention_heads % 2 == 0
+                and self.dims.hidden_size % 64 == 0):
             if self._rope_rows is None:
                 self._rope_rows = ops.rope_qkv_row_order(self.dims.num_attention_heads, self.dims.head_dim).to(self.device)
             L.wqkv_rope = ops.pack_weight16_frag(L.wqkv.index_select(0, self._rope_rows).contiguous(), L.wqkv.shape[0])
