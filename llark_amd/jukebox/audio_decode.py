@@ -1,6 +1,7 @@
-"""File decoding of ``load_audio_from_file`` (jukebox/main.py:31): what ``librosa.load`` gets from libsndfile for the two containers
-handled here -- RIFF wav (``scipy.io.wavfile`` + soundfile's integer scaling) and FLAC (``llark_flac_decode_host``: a native decoder
-whose output is checked against the stream's own MD5 signature) -- as ``(sample_rate, float32 [frames] or [frames][channels])``.
+"""File decoding of ``load_audio_from_file`` (jukebox/main.py:31): what ``librosa.load`` gets from libsndfile for the containers it
+reads without further codecs -- RIFF wav (``scipy.io.wavfile`` + soundfile's integer scaling), FLAC (``llark_flac_decode_host``: a
+native decoder whose output is checked against the stream's own MD5 signature), and the plain-PCM containers AIFF / AIFF-C
+(``NONE`` / ``sowt`` / ``fl32`` / ``fl64``) and Sun / NeXT ``.au`` -- as ``(sample_rate, float32 [frames] or [frames][channels])``.
 Anything else (mp3 / ogg: librosa's audioread fallback, which needs ffmpeg or gstreamer codecs) is not decoded."""
 from __future__ import annotations
 
@@ -52,6 +53,87 @@ def decode_wav(f) -> Tuple[int, np.ndarray]:
     return int(sr), data.astype(np.float32)
 
 
+def _pcm_to_float(raw: bytes, bits: int, channels: int, big_endian: bool, is_float: bool = False, signed8: bool = True) -> np.ndarray:
+    """Interleaved PCM bytes -> float32 [frames][channels] with libsndfile's scaling (integers / 2^(bits - 1))."""
+    e = ">" if big_endian else "<"
+    if is_float:
+        x = np.frombuffer(raw, dtype=e + ("f4" if bits == 32 else "f8")).astype(np.float32)
+    elif bits == 8:
+        x = np.frombuffer(raw, dtype=np.int8 if signed8 else np.uint8).astype(np.float32)
+        x = x / 128.0 if signed8 else (x - 128.0) / 128.0
+    elif bits == 16:
+        x = np.frombuffer(raw, dtype=e + "i2").astype(np.float32) / 32768.0
+    elif bits == 24:
+        b = np.frombuffer(raw[: len(raw) // 3 * 3], dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        hi, mid, lo = (b[:, 0], b[:, 1], b[:, 2]) if big_endian else (b[:, 2], b[:, 1], b[:, 0])
+        v = (hi << 16) | (mid << 8) | lo
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif bits == 32:
+        x = np.frombuffer(raw, dtype=e + "i4").astype(np.float32) / 2147483648.0
+    else:
+        raise ValueError(f"unsupported PCM sample size {bits}")
+    n = x.shape[0] // channels
+    return x[: n * channels].reshape(n, channels)
+
+
+def _ieee_extended(b: bytes) -> float:
+    """The 80-bit extended float AIFF stores its sample rate in."""
+    exp = ((b[0] & 0x7F) << 8) | b[1]
+    mant = int.from_bytes(b[2:10], "big")
+    if exp == 0 and mant == 0:
+        return 0.0
+    return (-1.0 if b[0] & 0x80 else 1.0) * mant * 2.0 ** (exp - 16383 - 63)
+
+
+def decode_aiff(data: bytes) -> Tuple[int, np.ndarray]:
+    """AIFF / AIFF-C: big-endian chunks; ``COMM`` (channels, frames, sample size, 80-bit rate[, compression]) + ``SSND`` (offset,
+    block size, samples).  Compression ``NONE`` / ``twos`` (big-endian PCM), ``sowt`` (little-endian), ``fl32`` / ``fl64``."""
+    if len(data) < 12 or data[:4] != b"FORM" or data[8:12] not in (b"AIFF", b"AIFC"):
+        raise ValueError("aiff: no FORM/AIFF header")
+    aifc = data[8:12] == b"AIFC"
+    p, comm, ssnd = 12, None, None
+    while p + 8 <= len(data):
+        cid, size = data[p:p + 4], int.from_bytes(data[p + 4:p + 8], "big")
+        body = data[p + 8:p + 8 + size]
+        if cid == b"COMM":
+            comm = body
+        elif cid == b"SSND":
+            ssnd = body
+        p += 8 + size + (size & 1)
+    if comm is None or len(comm) < 18:
+        raise ValueError("aiff: no COMM chunk")
+    channels, frames, bits = int.from_bytes(comm[0:2], "big"), int.from_bytes(comm[2:6], "big"), int.from_bytes(comm[6:8], "big")
+    sr = int(round(_ieee_extended(comm[8:18])))
+    comp = comm[18:22] if aifc and len(comm) >= 22 else b"NONE"
+    if comp not in (b"NONE", b"twos", b"sowt", b"fl32", b"FL32", b"fl64", b"FL64"):
+        raise ValueError(f"aiff: compression {comp!r} is not decoded")
+    if channels < 1 or sr <= 0:
+        raise ValueError("aiff: bad COMM chunk")
+    if ssnd is None or frames == 0:
+        return sr, np.zeros((0, channels), np.float32)
+    off = int.from_bytes(ssnd[0:4], "big")
+    raw = ssnd[8 + off:]
+    is_float = comp.lower() in (b"fl32", b"fl64")
+    width = 64 if comp.lower() == b"fl64" else 32 if is_float else (bits + 7) // 8 * 8
+    x = _pcm_to_float(raw[: frames * channels * width // 8], width, channels, big_endian=comp != b"sowt", is_float=is_float)
+    return sr, x[:frames]
+
+
+def decode_au(data: bytes) -> Tuple[int, np.ndarray]:
+    """Sun / NeXT .au: ``.snd``, header size, data size, encoding (2..7 = 8 / 16 / 24 / 32-bit PCM, float32, float64), rate, channels;
+    big-endian."""
+    if len(data) < 24 or data[:4] != b".snd":
+        raise ValueError("au: no .snd header")
+    hdr, size, enc, sr, channels = (int.from_bytes(data[i:i + 4], "big") for i in (4, 8, 12, 16, 20))
+    fmt = {2: (8, False), 3: (16, False), 4: (24, False), 5: (32, False), 6: (32, True), 7: (64, True)}.get(enc)
+    if fmt is None:
+        raise ValueError(f"au: encoding {enc} is not decoded")
+    if channels < 1 or sr <= 0 or hdr < 24:
+        raise ValueError("au: bad header")
+    raw = data[hdr:] if size in (0xFFFFFFFF, 0) else data[hdr:hdr + size]
+    return sr, _pcm_to_float(raw, fmt[0], channels, big_endian=True, is_float=fmt[1])
+
+
 def decode_audio(f) -> Tuple[int, np.ndarray]:
     """Path or binary file object -> (sample_rate, float32 [frames] or [frames][channels]); the container is told from its first bytes."""
     data = _read_all(f)
@@ -60,4 +142,8 @@ def decode_audio(f) -> Tuple[int, np.ndarray]:
         return decode_flac(data)
     if head in (b"RIFF", b"RIFX", b"RF64") or len(data) == 0:
         return decode_wav(io.BytesIO(data))
-    raise ValueError(f"unsupported audio container (first bytes {head!r}): wav and FLAC are decoded")
+    if head == b"FORM":
+        return decode_aiff(data)
+    if head == b".snd":
+        return decode_au(data)
+    raise ValueError(f"unsupported audio container (first bytes {head!r}): wav, FLAC, AIFF and .au are decoded")

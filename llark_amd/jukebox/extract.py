@@ -53,7 +53,7 @@ def _normalize(audio: np.ndarray) -> np.ndarray:
 
 
 def load_audio_from_file(fpath, res_type: Optional[str] = None) -> np.ndarray:
-    """Reads a wav or FLAC file, resamples to 44.1 kHz, converts to mono, peak-normalises.
+    """Reads a wav / FLAC / AIFF / .au file, resamples to 44.1 kHz, converts to mono, peak-normalises.
 
     ``fpath``: a path or a binary file object (the Beam worker passes ``io.BytesIO(wav_bytes)``,
     jukebox/dataflow_inference.py:101-103).  The reference calls ``librosa.load(fpath, sr=44100)`` (librosa / soundfile /
@@ -64,8 +64,8 @@ def load_audio_from_file(fpath, res_type: Optional[str] = None) -> np.ndarray:
     interpolation of the librosa 0.7.2 / resampy pair the reference's image installs, or "soxr_hq" for newer librosa's default
     -- both restated in :mod:`llark_amd.jukebox.resample`, neither pinnable offline; 44.1 kHz files are bit-identical.
     The reference's pipeline names its files wav on both sides (``read_wav_bytes``, ``input_filename.replace(".wav", ".npy")``,
-    jukebox/main.py:251); what libsndfile would also read without further codecs -- FLAC -- is decoded, mp3 / ogg (librosa's
-    audioread fallback) are not.
+    jukebox/main.py:251); what libsndfile would also read without further codecs -- FLAC, AIFF / AIFF-C, .au -- is decoded,
+    mp3 / ogg (librosa's audioread fallback) are not.
     """
     from .audio_decode import decode_audio
     from .resample import resample

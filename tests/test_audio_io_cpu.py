@@ -196,3 +196,62 @@ def test_file_list_and_result_writer(tmp_path):
     assert not (out / "b.npy").exists()
     with pytest.raises(NotImplementedError):
         D.get_input_file_list("gs://bucket/dir")
+
+
+def _ext80(v: float) -> bytes:
+    """80-bit extended float of a positive integer-valued sample rate (AIFF COMM chunk)."""
+    import math
+    e = int(math.floor(math.log2(v)))
+    mant = int(round(v / 2.0 ** e * 2 ** 63))
+    return (e + 16383).to_bytes(2, "big") + mant.to_bytes(8, "big")
+
+
+def _aiff(x, sr, bits, comp=None):
+    """x int [n][ch] -> AIFF (comp None) / AIFF-C bytes; comp in {b"sowt", b"fl32"}."""
+    n, ch = x.shape
+    if comp == b"fl32":
+        raw = (x.astype(np.float32) / 2.0 ** (bits - 1)).astype(">f4").tobytes()
+        width = 32
+    else:
+        width = bits
+        big = comp != b"sowt"
+        raw = b"".join(int(v).to_bytes(bits // 8, "big" if big else "little", signed=True) for v in x.reshape(-1))
+    comm = ch.to_bytes(2, "big") + n.to_bytes(4, "big") + width.to_bytes(2, "big") + _ext80(sr)
+    if comp:
+        comm += comp + b"\x00\x00"
+    ssnd = (0).to_bytes(4, "big") + (0).to_bytes(4, "big") + raw
+    chunks = b"COMM" + len(comm).to_bytes(4, "big") + comm + (b"\x00" if len(comm) & 1 else b"")
+    chunks += b"SSND" + len(ssnd).to_bytes(4, "big") + ssnd + (b"\x00" if len(ssnd) & 1 else b"")
+    form = b"AIFC" if comp else b"AIFF"
+    return b"FORM" + (4 + len(chunks)).to_bytes(4, "big") + form + chunks
+
+
+def test_aiff_and_au_containers_decode_like_wav(tmp_path):
+    """The other plain-PCM containers libsndfile hands to ``lr.load`` (jukebox/main.py:31): same samples -> same float32 audio."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((5000, 2)) * 6000).astype(np.int64)
+    pw = tmp_path / "a.wav"
+    wavfile.write(pw, 44100, x.astype(np.int16))
+    want = E.load_audio_from_file(pw)
+    for name, data in (("a.aiff", _aiff(x, 44100, 16)), ("b.aifc", _aiff(x, 44100, 16, b"sowt")), ("c.aifc", _aiff(x, 44100, 16, b"fl32"))):
+        (tmp_path / name).write_bytes(data)
+        np.testing.assert_array_equal(E.load_audio_from_file(tmp_path / name), want, err_msg=name)
+    x24 = (rng.standard_normal((3000, 1)) * 2.0 ** 20).astype(np.int64)
+    (tmp_path / "d.aiff").write_bytes(_aiff(x24, 48000, 24))
+    got = E.load_audio_from_file(tmp_path / "d.aiff", res_type="soxr_hq")
+    assert len(got) == int(np.ceil(3000 * 44100 / 48000)) and np.abs(got).max() == 1.0
+    from llark_amd.jukebox import audio_decode as AD
+    sr, y = AD.decode_audio(tmp_path / "d.aiff")
+    assert sr == 48000
+    np.testing.assert_array_equal(np.round(y[:, 0].astype(np.float64) * 2 ** 23).astype(np.int64), x24[:, 0])
+    # .au: 16-bit PCM (encoding 3) and float32 (encoding 6), big-endian
+    hdr = lambda enc, nbytes: b".snd" + (24).to_bytes(4, "big") + nbytes.to_bytes(4, "big") + enc.to_bytes(4, "big") + (44100).to_bytes(4, "big") + (2).to_bytes(4, "big")
+    pcm = x.astype(">i2").tobytes()
+    (tmp_path / "e.au").write_bytes(hdr(3, len(pcm)) + pcm)
+    np.testing.assert_array_equal(E.load_audio_from_file(tmp_path / "e.au"), want)
+    fl = (x.astype(np.float32) / 32768.0).astype(">f4").tobytes()
+    (tmp_path / "f.au").write_bytes(hdr(6, 0xFFFFFFFF) + fl)
+    np.testing.assert_array_equal(E.load_audio_from_file(tmp_path / "f.au"), want)
+    (tmp_path / "g.au").write_bytes(hdr(1, 10) + bytes(10))                  # mu-law: not decoded -> the reference's ValueError path
+    with pytest.raises(E.EmptyFileError):
+        E.load_audio_from_file(tmp_path / "g.au")
