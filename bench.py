@@ -668,6 +668,8 @@ def main():
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[1] / args.steps, 3) for k, v in timers.items()},
         }
+        if args.stages == "llama" and line.get("roofline_llm") and line["roofline_llm"].get("whole_forward_flops_t"):
+            line["roofline_llm"]["whole_forward_frac"] = round(line["roofline_llm"]["whole_forward_flops_t"] / (elapsed / args.steps) / PEAK_F16_MFMA_TFLOPS, 4)
         if args.stages in ("generate", "mpt"):
             line["kernel_ms_from"] = "second pass with per-op events (the timed region runs without them)"
         if args.stages in ("e2e", "llama") and llm is not None and world == 1:
@@ -687,6 +689,9 @@ def main():
                 llm.engine.set_precision(args.llm_precision)
             if roof_other is not None:
                 roof_other.update({"llm_precision": other, "llama_ms_per_step": round(ms_other, 3)})
+                wf = roof_other.get("whole_forward_flops_t")
+                if wf and ms_other > 0:             # north_star's ">= 40 % of the MFMA roofline on the Llama forward": all flops / forward time
+                    roof_other["whole_forward_frac"] = round(wf / (ms_other * 1e-3) / PEAK_F16_MFMA_TFLOPS, 4)
             line["roofline_llm_" + other] = roof_other
         if args.stages in ("e2e", "jukebox") and enc is not None and world == 1 and not args.no_alt_precision:
             # The SAME step with the prior in the OTHER precision (same weights, second encoder object), outside the timed region, so
