@@ -30,6 +30,22 @@ import numpy as np
 import torch
 
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def _load_fulldepth_llm_parity():
+    """Errors of the Llama flows against the fp32 CPU oracle at the benchmarked depth (7B x 32 layers, S = 371, B = 8), as recorded by
+    tests/test_fulldepth_gpu.py on a GPU box (profiles/r05_llama_fulldepth_parity.json).  Annotation only: nothing timed reads it."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_llama_fulldepth_parity.json")) as f:
+            rec = json.load(f)
+        return {k: {"logits_err_over_max": v.get("logits_err_over_max"), "greedy_tokens_matching": v.get("greedy_tokens_matching"),
+                    "greedy_tokens": v.get("greedy_tokens"), "source": "tests/test_fulldepth_gpu.py -> profiles/r05_llama_fulldepth_parity.json"}
+                for k, v in rec.items()}
+    except (OSError, ValueError):
+        return {}
+
+
+FULLDEPTH_LLM_PARITY = _load_fulldepth_llm_parity()
 PEAK_HBM_GBS = 8000.0
 
 
@@ -676,9 +692,21 @@ def main():
             # the Llama half in the OTHER activation precision (same weights), outside the timed region: both MFMA fractions in one line
             other = "bf16" if args.llm_precision == "split" else "split"
             with torch.no_grad():
+                ref_logits = llm.forward(None).clone()              # this precision's logits on the bench prompts (N(0,1) audio stand-in)
                 llm.engine.set_precision(other)
-                llm.forward(None)
+                oth_logits = llm.forward(None)
                 torch.cuda.synchronize()
+                # live parity pair: the two flows on the SAME weights and inputs.  "split" is pinned to the fp32
+                # oracle at 6.2e-5 of max|logits| (tests/test_fulldepth_gpu.py), so this difference IS the bf16 flow's error to that accuracy.
+                lmax = float(ref_logits.abs().max())
+                diff = (oth_logits - ref_logits).abs()
+                parity_pair = {"against": args.llm_precision, "logits_max_abs_diff": round(float(diff.max()), 6), "logits_max_abs": round(lmax, 4),
+                               "diff_over_max": round(float(diff.max()) / lmax, 6),
+                               "rms_diff_over_max": round(float(diff.pow(2).mean().sqrt()) / lmax, 7),
+                               "argmax_agree_frac": round(float((oth_logits.argmax(-1) == ref_logits.argmax(-1)).float().mean()), 5),
+                               "positions": int(ref_logits.shape[0] * ref_logits.shape[1]),
+                               "fulldepth_fixture": FULLDEPTH_LLM_PARITY.get(other)}
+                del ref_logits, oth_logits, diff
                 ops.start_kernel_timing()
                 t1 = time.perf_counter()
                 for _ in range(args.steps):
@@ -688,7 +716,7 @@ def main():
                 roof_other = llm.roofline(ops.stop_kernel_timing(), args)
                 llm.engine.set_precision(args.llm_precision)
             if roof_other is not None:
-                roof_other.update({"llm_precision": other, "llama_ms_per_step": round(ms_other, 3)})
+                roof_other.update({"llm_precision": other, "llama_ms_per_step": round(ms_other, 3), "parity": parity_pair})
                 wf = roof_other.get("whole_forward_flops_t")
                 if wf and ms_other > 0:             # north_star's ">= 40 % of the MFMA roofline on the Llama forward": all flops / forward time
                     roof_other["whole_forward_frac"] = round(wf / (ms_other * 1e-3) / PEAK_F16_MFMA_TFLOPS, 4)

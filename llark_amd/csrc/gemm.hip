@@ -1458,6 +1458,9 @@ extern "C" llark_workspace_t llark_workspace_create(void) {
     llark_workspace* ws = new (std::nothrow) llark_workspace();
     if (!ws) { set_error("workspace_create: out of host memory"); return nullptr; }
     ws->device = dev; ws->cus = cus; ws->base = 0; ws->counters = nullptr;
+#ifdef G256X_PROF      // profiling build only (gemm256x.hip): fewer resident workgroups per XCD, to size the epilogue bursts
+    if (const char* e = getenv("LLARK_G256X_CUS")) ws->cus = atoi(e);
+#endif
     if (hipMalloc((void**)&ws->counters, LLARK_WS_BYTES) != hipSuccess || hipMemset(ws->counters, 0, LLARK_WS_BYTES) != hipSuccess) {
         set_error("workspace_create: cannot allocate %d bytes of device memory", LLARK_WS_BYTES);
         if (ws->counters) (void)hipFree(ws->counters);

@@ -64,6 +64,16 @@ struct Mfma16<bf16_t> {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
+// Profiling build only (-DG256X_PROF; scripts/gpu_runs/r05/build_prof.sh, never shipped): wave 0 of every workgroup stamps the
+// constant-rate clock (s_memrealtime, 100 MHz) at the start of a tile's K loop, at its end and after the epilogue's last store has
+// been issued -- p.prof[(workgroup * 64 + tile) * 4 + {0, 1, 2}] -- so that the exposed epilogue (stores acknowledged + chunk barrier =
+// next K-loop start minus K-loop end) and the alignment of the workgroups of an XCD can be read off (profiles/r05_gemm256x_tile_times*).
+#ifdef G256X_PROF
+#define PROF_STAMP(slot) do { if (p.prof && threadIdx.x == 0) p.prof[((size_t)blockIdx.x * 64 + prof_tile) * 4 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define PROF_STAMP(slot) do { } while (0)
+#endif
+
 // A/B knobs (same arithmetic): G256X_R0 = MFMAs that go out back to back at the start of a phase before the first gap carries a
 // fragment read; G256X_PRIO = 1: s_setprio 1 for the later-dispatched half of the workgroup (waves 4..7).  Measured:
 // profiles/r04_gemm256x_knobs.txt.
@@ -72,6 +82,17 @@ struct Mfma16<bf16_t> {
 #endif
 #ifndef G256X_PRIO
 #define G256X_PRIO 0
+#endif
+// G256X_RUNAHEAD = 1: the chunk barrier waits for the arrivals of the PREVIOUS chunk only -- a workgroup may run one tile ahead of the
+// slowest workgroup of its XCD instead of meeting it at every tile.  Round 5's per-tile time stamps (profiles/r05_gemm256x_tile_times.txt):
+// the workgroups of an XCD end their K loops 15 us apart (median of max - min), so the strict barrier makes the fast ones wait, and it
+// re-aligns the epilogue bursts of all 32 workgroups (exposed gap 37 us per producer tile with 32 workgroups per XCD against 25 with 4).
+// G256X_STAGGER_TICKS > 0: workgroup slot s of an XCD starts (s % 4) x ticks x 10 ns late (seeds the spread from the first tile on).
+#ifndef G256X_RUNAHEAD
+#define G256X_RUNAHEAD 0
+#endif
+#ifndef G256X_STAGGER_TICKS
+#define G256X_STAGGER_TICKS 0
 #endif
 
 // The value a hi / lo split starts from has to be ONE fp32 number.  hipcc (ROCm 7.2, even under -ffp-contract=off) selects
@@ -371,6 +392,14 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
     };
 
     bool primed = false;
+    int prof_tile = 0;
+#if G256X_STAGGER_TICKS > 0
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64(), dt = (long long)(slot_id & 3) * G256X_STAGGER_TICKS;
+        while ((long long)wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_s_barrier();
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
         const int local = ch * p.slots + slot_id;
         bool arrived = false;
@@ -387,6 +416,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 __builtin_amdgcn_s_waitcnt(0x0F70);
             }
             __builtin_amdgcn_s_barrier();
+            PROF_STAMP(0);
 
             f32x4_t acc[C::TM][C::TN];
 #pragma unroll
@@ -534,6 +564,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             if (w < 4) __builtin_amdgcn_s_barrier();                       // the trailing waves' last half-phase
             VMCNT(0);
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
+            PROF_STAMP(1);
             // bias and the first half of the residuals are requested AHEAD of the next tile's prologue (in-order returns)
             f32x4_t bias[C::TN], res[2][C::TN];
             // Folded LayerNorm: every load of the epilogue goes out HERE, before its first store -- vmcnt counts stores too, in order, so a
@@ -570,11 +601,13 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 0, m0, n0, wm, wn, lane);
             epilogue_load_resid<EPI>(p, res, 1, m0, n0, wm, wn, lane);
             epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 1, m0, n0, wm, wn, lane);
+            PROF_STAMP(2);
+            ++prof_tile;
         }
         if (ch + 1 < nchunks) {
             if (threadIdx.x == 0) {
                 if (!arrived) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int target = p.sync_base + (ch + 1) * p.slots;
+                const int target = p.sync_base + (ch + 1 - G256X_RUNAHEAD) * p.slots;
                 // bounded spin: the chunk barrier only aligns tile starts for L2 locality, never a correctness dependency
                 for (int it = 0; it < 100000 && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0; ++it)
                     __builtin_amdgcn_s_sleep(8);
@@ -582,6 +615,11 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             __builtin_amdgcn_s_barrier();                                  // raw: a fence here would drain the next tile's prologue requests
         }
     }
+#ifdef G256X_PROF
+    VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    PROF_STAMP(0);                                                         // "start" of the tile after the last = every store acknowledged
+#endif
 }
 
 template <typename T, int EPI, int LN>
@@ -594,6 +632,9 @@ static int launch256x(GemmParams p, hipStream_t s, int cus) {
     }
     p.tiles_m = cdiv(p.M, C::BM);
     p.tiles_n = cdiv(p.N, C::BN);
+#ifdef G256X_PROF
+    if (const char* e = getenv("LLARK_G256X_PROF_BUF")) p.prof = (long long*)strtoull(e, nullptr, 0);
+#endif
     p.slots = cus / 8;
     kern<<<dim3(cus), C::THREADS, C::LDS, s>>>(p);
     return check_launch("gemm256x");

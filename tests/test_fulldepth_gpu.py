@@ -211,15 +211,36 @@ def test_jukebox_36_layers_outlier_weights_vs_oracle():
     torch.cuda.empty_cache()
 
 
-@pytest.fixture(scope="module")
-def llm():
+# Bars of the two activation flows of the Llama half at FULL depth.  "split" = the default / headline flow
+# (fp32-class, bar = north_star's 1e-3 of max|logits|).  "bf16" = single bf16 rounding at every Linear input / q / k / v / attention
+# output (the dtype FLOW of the reference's GPU path, which itself runs 16-bit: m2t/models/utils.py:129 torch_dtype=float16): its
+# error against the fp32 oracle is MEASURED and recorded here and in profiles/r05_llama_fulldepth_parity.json; the assertion is a
+# regression guard at 2x the recorded figure, not a claim that the flow meets 1e-3.
+LLM_BARS = {"split": 1e-3, "bf16": 8e-2}     # bf16: measured 3.7e-2 of max|logits| (round 5, profiles/r05_llama_fulldepth_parity.json)
+_LLM_REPORT = {}
+
+
+def _llm_report(precision, **kv):
+    """Collects the measured figures per precision; written to gpurun_out/ (copied to profiles/ by the run script)."""
+    import json
+    import os
+
+    _LLM_REPORT.setdefault(precision, {}).update(kv)
+    out = os.path.join(FD.ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "llama_fulldepth_parity.json"), "w") as f:
+        json.dump(_LLM_REPORT, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module", params=["split", "bf16"])
+def llm(request):
     from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
 
     z = np.load(FD.LLAMA_NPZ)
     spec = FD.llama_spec(32)
     w = FD.llama_weights_cpu(spec)
     dims = LlamaDims(vocab_size=spec.vocab_size)
-    eng = HipLlamaEngine(dims, "cuda", max_batch=8, max_seq=512, precision="split")
+    eng = HipLlamaEngine(dims, "cuda", max_batch=8, max_seq=512, precision=request.param)
     eng.load_state_dict(w)
     del w
     yield z, spec, eng
@@ -238,41 +259,65 @@ def test_llama7b_32_layers_logits_vs_oracle(llm):
     logits = eng.forward_tokens(ids8, [(b, 1, audc) for b in range(B)])
     rows = torch.from_numpy(z["rows"]).cuda()
     scale = float(z["logits_maxabs"])
-    err = report_close("7B 32-layer logits (sampled rows, full vocab) vs fp32 oracle", logits[3][rows].cpu(), z["logits_rows"], 1e-3 * scale)
-    print(f"\n[fulldepth] llama-2-7B 32 layers S=371: logits max|err| {err:.3e} = {err / scale:.2e} of max|logits| {scale:.3f}")
+    prec = eng.precision
+    got, ref = logits[3][rows].cpu().double(), torch.from_numpy(z["logits_rows"]).double()
+    err = float((got - ref).abs().max())
+    rms = float((got - ref).pow(2).mean().sqrt())
+    agree = float((got.argmax(-1) == ref.argmax(-1)).double().mean())
+    print(f"\n[fulldepth] llama-2-7B 32 layers S=371 B=8 ({prec}): logits max|err| {err:.3e} = {err / scale:.2e} of max|logits| {scale:.3f}; "
+          f"rms err {rms:.3e}; argmax of the sampled rows equal to the oracle's: {agree:.4f}")
+    _llm_report(prec, logits_max_abs_err=err, logits_max_abs=scale, logits_err_over_max=err / scale, logits_rms_err=rms,
+                sampled_rows_argmax_agree=agree, bar_over_max=LLM_BARS[prec], layers=32, seq=371, batch=8)
+    report_close(f"7B 32-layer logits (sampled rows, full vocab) vs fp32 oracle [{prec}]", got, ref, LLM_BARS[prec] * scale)
     # rows of the batch hold the same prompt: bit-identical results (batch invariance of every kernel)
     assert torch.equal(logits[0], logits[7])
     # B = 1 goes through different tile counts and K cuts (o_proj / down_proj: 4 K ranges per tile instead of 2); same values
     # to the rounding of the fp32 accumulation and of the bf16 hi/lo operand planes downstream (measured 3.1e-5 of max|logits|)
     l1 = eng.forward_tokens(ids.cuda(), [(0, 1, audc)])
-    report_close("B=1 vs B=8 logits", l1[0][rows].cpu(), logits[0][rows].cpu(), 6e-5 * scale)
+    # (bf16 flow: a K cut that moves changes which fp32 sum gets rounded to bf16 downstream -- differences of the size of the flow's own error)
+    report_close("B=1 vs B=8 logits", l1[0][rows].cpu(), logits[0][rows].cpu(), (6e-5 if prec == "split" else LLM_BARS[prec]) * scale)
 
 
 def test_llama7b_64_greedy_tokens_vs_oracle(llm):
-    """configs[2]: prefill + 64 greedy decode steps against the KV cache; tokens equal the oracle's, and the
-    last-position logits of decode steps 0 / 1 / 31 / 63 stay within 1e-3 * max|logits|."""
+    """configs[2]: prefill + 64 greedy decode steps against the KV cache.  "split": tokens equal the oracle's, and the
+    last-position logits of decode steps 0 / 1 / 31 / 63 stay within 1e-3 * max|logits|.  "bf16": the number of the 64 positions
+    whose argmax equals the oracle's token is COUNTED (teacher-forced on the oracle's tokens, so that one early flip does not hide
+    the other 63 comparisons) and recorded with the worst checked decode-logit error; positions that differ must be near-ties of
+    the oracle (its top-1 / top-2 gap below twice the flow's measured logit error)."""
     z, spec, eng = llm
     ids, aud = FD.llama_inputs(1)
     audc = aud[0].cuda()
     gold, gaps = z["tokens"], z["gaps"]
     step_idx = [int(v) for v in z["step_idx"]]
     scale = float(z["logits_maxabs"])
+    prec = eng.precision
+    bar = LLM_BARS[prec] * scale
     eng.reset(1)
     logits = eng.forward_tokens(ids.cuda(), [(0, 1, audc)], last_only=True)
-    toks, worst = [], 0.0
+    toks, worst, flips = [], 0.0, []
     for t in range(len(gold)):
         last = logits[0, -1]
         if t in step_idx:
-            e = report_close(f"decode step {t} logits", last.cpu(), z["step_logits"][step_idx.index(t)], 1e-3 * scale)
+            e = float((last.cpu().double() - torch.from_numpy(z["step_logits"][step_idx.index(t)]).double()).abs().max())
             worst = max(worst, e)
         tok = int(last.argmax())
         toks.append(tok)
         if tok != int(gold[t]):
-            raise AssertionError(f"greedy token {t}: got {tok}, oracle {int(gold[t])} (oracle top-1/top-2 gap {gaps[t]:.3e}, "
-                                 f"logit error bound so far {worst:.3e})")
+            if prec == "split":
+                raise AssertionError(f"greedy token {t}: got {tok}, oracle {int(gold[t])} (oracle top-1/top-2 gap {gaps[t]:.3e}, "
+                                     f"logit error bound so far {worst:.3e})")
+            flips.append((t, float(gaps[t])))
         if t + 1 < len(gold):
-            nxt = torch.tensor([[tok]], device="cuda")
+            nxt = torch.tensor([[int(gold[t])]], device="cuda")          # == tok for "split"; teacher-forced for "bf16"
             logits = eng.forward_tokens(nxt, (), pos0=eng.cur_len, last_only=True)
-    assert toks == [int(v) for v in gold]
-    print(f"\n[fulldepth] 64 greedy tokens equal the oracle's; smallest oracle top-1/top-2 gap {gaps.min():.3e}, "
-          f"worst checked decode-logit error {worst:.3e} ({worst / scale:.2e} of max|logits|)")
+    match = len(gold) - len(flips)
+    _llm_report(prec, greedy_tokens_matching=match, greedy_tokens=len(gold), decode_logits_worst_err_over_max=worst / scale,
+                greedy_flips=[{"step": t, "oracle_gap": g} for t, g in flips], oracle_min_gap=float(gaps.min()))
+    print(f"\n[fulldepth] ({prec}) {match} of {len(gold)} greedy tokens equal the oracle's; smallest oracle top-1/top-2 gap {gaps.min():.3e}, "
+          f"worst checked decode-logit error {worst:.3e} ({worst / scale:.2e} of max|logits|); flips (step, oracle gap): {flips}")
+    assert worst <= bar, f"({prec}) worst checked decode-logit error {worst:.3e} > {bar:.3e}"
+    if prec == "split":
+        assert toks == [int(v) for v in gold]
+    else:
+        for t, g in flips:
+            assert g <= 2.0 * bar, f"bf16 flow flips greedy token {t} although the oracle's gap {g:.3e} is far above the flow's error"
