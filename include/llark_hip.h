@@ -213,6 +213,18 @@ int llark_gemm16_ln(int dtype, int epilogue, const void* a_hi, const void* a_lo,
                     int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
                     const float* ln_stat, const float* ln_vec, float* ln_part, llark_workspace_t ws, llark_stream_t stream);
 int llark_ln_stats_finalize(const float* part, int rows, int nparts, int width, float eps, float* stat, llark_stream_t stream);
+/* Round 5: the producer role with PREDICTED row statistics.  ln_pred [m][2] = (shift_m, scale_m), scale a power of two: out_hi / out_lo then
+ * hold hi / lo of ((c - shift_m) scale_m) ln_vec[n] -- values of order one, so that rows whose level is far from their spread (|mean| >> std)
+ * or whose spread is far from one (std ~ 1e-3: the fp16 lo plane would sit in its subnormals; std ~ 1e3: the hi plane would overflow) keep the
+ * planes' 22 bits -- and ln_part the sums of (c - shift_m) and of its square.  llark_ln_stats_finalize_p reduces them to the pair the
+ * UNCHANGED consumer role applies, ln_stat = ((mean - shift) scale, rstd / scale), and replaces ln_pred by the prediction for the next
+ * LayerNorm of the same rows, (mean, nearest power of two of rstd).  llark_ln_row_pred makes the first prediction of a forward from the rows
+ * of x themselves.  ln_pred = NULL: llark_gemm16_ln.  Same call sites (upstream ResAttnBlock ln_0 / ln_1 around the Conv1D products). */
+int llark_gemm16_ln_p(int dtype, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias, int m,
+                      int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                      const float* ln_stat, const float* ln_vec, float* ln_part, const float* ln_pred, llark_workspace_t ws, llark_stream_t stream);
+int llark_ln_stats_finalize_p(const float* part, int rows, int nparts, int width, float eps, float* stat, float* pred, llark_stream_t stream);
+int llark_ln_row_pred(const float* x, int ldx, int rows, int width, float eps, float* pred, llark_stream_t stream);
 /* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8n.hip; OPT-IN reduced precision, the default is the two-pass fp16
  * form behind llark_gemm16_ws): same call site, upstream Conv1D.forward reached from
  * jukebox/main.py:108 with fp16=False.  The activation is a_hi = fp16(a) plus an E4M3 low plane

@@ -296,6 +296,9 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 // 0.4052 of the MFMA peak (forward 44.76 -> 43.64 ms per 8 clips); the hi + lo form LOSES 3 % with its weight loads moved into the gaps
 // (0.2102 -> 0.2028: its MFMAs come in dependent hi / lo pairs and it has one register set only, so there is no latency to hide the
 // loads behind) and keeps round 3's order: loads, then MFMAs.
+#ifndef GEMM_BD_SPLIT_PAIRS
+#define GEMM_BD_SPLIT_PAIRS 0      // 1 = the hi + lo form's A fragments as two half sets read one half ahead (round 5; see bd_kstep)
+#endif
 #ifndef GEMM_BD_SPLIT_ORDER
 #define GEMM_BD_SPLIT_ORDER 0      // 0 = hi / lo pairs back to back (rounds 1-3; default); 1 = all hi products of a sub-step, then all lo:
                                    // measured 6 % SLOWER on the Llama stage (0.216 -> 0.203, profiles/r04_llama_bd_split_order_ab.txt)
@@ -326,6 +329,42 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    } else if constexpr (GEMM_BD_SPLIT_PAIRS && C::TM == 4) {
+        // Round 5: the hi + lo form has ONE set of A fragments (32 registers; 244 of 256 are taken), so rounds 1-4 read all eight
+        // fragments of a sub-step in front of its MFMAs and waited for the LDS four times per K-step.  Here the set is used as two
+        // HALVES (row tiles 0, 1 | 2, 3): while the MFMAs of one half run, the fragments of the other half -- of this sub-step or the
+        // next -- are read into the registers the previous half has just released.  Same registers, same arithmetic and order per
+        // accumulator (hi then lo, k ascending): bit-identical; the LDS latency is exposed once per K-step (behind its barrier).
+        frag ah[2][2], al[2][2];
+        auto rd = [&](int set, int tm, int s) __attribute__((always_inline)) {
+            ah[set][tm & 1] = *(const frag*)(sA + C::off(tm * 32 + l31, s * 2 + lhi));
+            al[set][tm & 1] = *(const frag*)(sL + C::off(tm * 32 + l31, s * 2 + lhi));
+        };
+        rd(0, 0, 0);
+        rd(0, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<4>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn) load_b((s + 3) & 3, tn, q0 + s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<2>([&](auto hc) __attribute__((always_inline)) {
+                constexpr int hf = decltype(hc)::value;                    // row tiles 2 hf, 2 hf + 1 from set hf
+                static_for<2 * C::TN>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int i = decltype(ic)::value, t2 = i / C::TN, tn = i % C::TN, tm = 2 * hf + t2;
+                    acc[tm][tn] = Mfma<T>::run(ah[hf][t2], ring[s][tn], acc[tm][tn]);
+                    acc[tm][tn] = Mfma<T>::run(al[hf][t2], ring[s][tn], acc[tm][tn]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // gaps behind the first two products of this half: the OTHER half's fragments (its registers were released by the
+                    // previous half's last product)
+                    if constexpr (i < 2) {
+                        if constexpr (hf == 0) rd(1, 2 + i, s);
+                        else if constexpr (s < 3) rd(0, i, s + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             });
         });
     } else {
@@ -1421,7 +1460,18 @@ extern "C" int llark_gemm16_ln_takes(int m, int n, int kp) { return gemm256x_tak
 extern "C" int llark_gemm16_ln(int dtype, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias, int m,
                                int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
                                const float* ln_stat, const float* ln_vec, float* ln_part, llark_workspace_t ws, llark_stream_t stream) {
+    return llark_gemm16_ln_p(dtype, epilogue, a_hi, a_lo, lda, wt, ldw, bias, m, n, kp, c, ldc, resid, ldr, out_hi, out_lo, ldo, ln_stat, ln_vec, ln_part,
+                             nullptr, ws, stream);
+}
+
+// The same two roles; the producer may be given the rows' PREDICTED statistics ln_pred [m][2] = (shift, scale) -- see GemmParams::ln_pred --
+// so that the planes it writes are of order one: pair it with llark_ln_stats_finalize_p.  ln_pred = NULL is llark_gemm16_ln.
+extern "C" int llark_gemm16_ln_p(int dtype, int epilogue, const void* a_hi, const void* a_lo, int lda, const void* wt, int ldw, const float* bias, int m,
+                                 int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
+                                 const float* ln_stat, const float* ln_vec, float* ln_part, const float* ln_pred, llark_workspace_t ws,
+                                 llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && a_lo && wt && ln_vec && ws && m > 0 && n > 0 && kp > 0, "gemm16_ln: null pointer or empty problem");
+    LLARK_REQUIRE(ln_pred == nullptr || ln_part != nullptr, "gemm16_ln: ln_pred belongs to the producer role (ln_part)");
     LLARK_REQUIRE((ln_stat != nullptr) != (ln_part != nullptr), "gemm16_ln: exactly one of ln_stat (consumer) / ln_part (producer) must be given");
     LLARK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && lda >= kp && ldw >= kp, "gemm16_ln: lda/ldw must be >= kp and multiples of 8");
     if (ln_part) LLARK_REQUIRE(epilogue == EPI_RESID && c && resid && out_hi && out_lo && ldc >= n && ldr >= n && ldo >= n, "gemm16_ln: the producer role is LLARK_EPI_RESID with c, resid and the operand planes");
@@ -1434,7 +1484,7 @@ extern "C" int llark_gemm16_ln(int dtype, int epilogue, const void* a_hi, const 
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wt; p.ldw = ldw; p.bias = bias;
     p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
     p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
-    p.ln_stat = ln_stat; p.ln_vec = ln_vec; p.ln_part = ln_part;
+    p.ln_stat = ln_stat; p.ln_vec = ln_vec; p.ln_part = ln_part; p.ln_pred = ln_pred;
     hipStream_t s = (hipStream_t)stream;
     if (ws_begin(ws, p, s)) {
         set_error("gemm16_ln: workspace without counters");

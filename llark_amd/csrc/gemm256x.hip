@@ -211,12 +211,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                         const f32x4_t gm = gamma4(smem, wm * 2 + wn, tn, gsel, 0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float x = fp_pin(out[r] * gm[r]);
+                            const float d = out[r] - mu;                       // mu / rstd = the row's predicted (shift, scale): (0, 1) without ln_pred
+                            const float x = fp_pin((d * rstd) * gm[r]);
                             const T h = (T)x;
                             hi[r] = h;
                             lo[r] = (T)(x - (float)h);
-                            sx += out[r];
-                            sq = fmaf(out[r], out[r], sq);
+                            sx += d;
+                            sq = fmaf(d, d, sq);
                         }
                     } else {
 #pragma unroll
@@ -258,12 +259,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                         out4 hi, lo;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float x = fp_pin(out[r] * gm[r]);
+                            const float d = out[r] - mu;
+                            const float x = fp_pin((d * rstd) * gm[r]);
                             const T h = (T)x;
                             hi[r] = h;
                             lo[r] = (T)(x - (float)h);
-                            sx += out[r];
-                            sq = fmaf(out[r], out[r], sq);
+                            sx += d;
+                            sq = fmaf(d, d, sq);
                         }
                         const size_t o = (size_t)m * p.ldo + ncol + co;
                         *(out4*)((T*)p.Ohi + o) = hi;
@@ -574,12 +576,13 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             float2 st[C::TM];
             if (LN != 0) gv = gamma_load(p, n0, wn, lane);
             else epilogue_load_bias(p, bias, n0, wn, lane);
-            if (LN == 1) {
+            if (LN == 1 || LN == 2) {                                       // consumer: the row's (mean, rstd); producer: its predicted (shift, scale)
                 const bool whole = m0 + C::BM <= p.M;
+                const float* rowst = LN == 1 ? p.ln_stat : p.ln_pred;
 #pragma unroll
                 for (int tm = 0; tm < C::TM; ++tm) {
                     const int m = m0 + wm * 64 + tm * 16 + (lane & 15);
-                    st[tm] = (whole || m < p.M) ? *(const float2*)(p.ln_stat + 2 * (size_t)m) : make_float2(0.f, 1.f);
+                    st[tm] = (rowst != nullptr && (whole || m < p.M)) ? *(const float2*)(rowst + 2 * (size_t)m) : make_float2(0.f, 1.f);
                 }
             }
             epilogue_load_resid<EPI>(p, res, 0, m0, n0, wm, wn, lane);
@@ -675,7 +678,7 @@ int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int 
     if ((epi == EPI_F32 || epi == EPI_RESID) && (p.ldc % 4 || ((uintptr_t)p.C & 15))) return -1000;
     if (epi == EPI_RESID && (p.ldr % 4 || ((uintptr_t)p.R & 15))) return -1000;
     if ((epi == EPI_QGELU_SPLIT || epi == EPI_SPLIT16 || p.ln_part) && (p.ldo % 4 || ((uintptr_t)p.Ohi & 7) || ((uintptr_t)p.Olo & 7))) return -1000;
-    if ((p.ln_stat || p.ln_part) && (!p.ln_vec || ((uintptr_t)p.ln_vec & 15) || ((uintptr_t)p.ln_stat & 7) || ((uintptr_t)p.ln_part & 7))) return -1000;
+    if ((p.ln_stat || p.ln_part) && (!p.ln_vec || ((uintptr_t)p.ln_vec & 15) || ((uintptr_t)p.ln_stat & 7) || ((uintptr_t)p.ln_part & 7) || ((uintptr_t)p.ln_pred & 7))) return -1000;
     if (dtype == LLARK_F16) return dispatch256x<half_t>(p, epi, s, cus);
     if (dtype == LLARK_BF16) return dispatch256x<bf16_t>(p, epi, s, cus);
     return -1000;

@@ -116,6 +116,12 @@ struct GemmParams {
     const float* ln_stat;   // [M][2] (mean, rstd)
     const float* ln_vec;    // [N]
     float* ln_part;         // [M][2 * tiles_n][2]
+    // producer with PREDICTED row statistics (round 5; llark_gemm16_ln_p): ln_pred [M][2] = (shift_m, scale_m), scale a power of two.  The
+    // planes then hold hi / lo of ((C - shift_m) . scale_m) . ln_vec[n] -- values of order one whatever the row's level and spread, so the
+    // fp16 lo plane never runs into its subnormals and a row mean far from zero does not eat the planes' bits -- and ln_part holds the sums
+    // of (C - shift_m) and of its square.  llark_ln_stats_finalize_p folds shift / scale into the (mean, rstd) pair the consumer applies,
+    // so the consumer role is unchanged.  nullptr = shift 0, scale 1 (round 4's form).
+    const float* ln_pred;
     // EPI_ROPE_QKV (gemm.hip, B-direct kernel only; llark_gemm16_fragw_rope_qkv): the Llama q|k|v product whose epilogue rotates q / k
     // and writes q planes, the K cache and the transposed V cache directly (no fp32 qkv round trip, no rope_split_kernel launch).
     // Rows m = b * rope_s + s; N = 3 * rope_nh * 128 with the q / k weight rows of every head permuted [0..31 | 64..95 | 32..63 | 96..127].

@@ -208,6 +208,59 @@ __global__ void ln_stats_finalize_kernel(const float* __restrict__ part, int row
     *(float2*)(stat + 2 * (size_t)r) = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
 }
 
+// The same reduction for a producer that was given PREDICTED row statistics pred [rows][2] = (shift, scale) (llark_gemm16_ln_p): the partial
+// sums are of d = x - shift and d^2, so mean = shift + sum(d) / width and var = E[d^2] - E[d]^2 (no cancellation against a large mean), and
+// the planes hold ((x - shift) scale) gamma.  What the consumer's epilogue needs to turn acc = sum_k plane_k W_nk into
+// rstd (sum_k x_k gamma_k W_nk - mean gw_n) is the pair ((mean - shift) scale, rstd / scale): written to stat.  pred is then REPLACED by the
+// prediction for the next LayerNorm of the same row -- (mean, 2^round(log2 rstd)) of the statistics just measured: the residual stream of a
+// row moves slowly from one LayerNorm to the next.  One thread per row, fixed order: run-to-run and batch-size bit-equal.
+__device__ __forceinline__ float pow2_near(float v) {          // nearest power of two, clamped to 2^-24 .. 2^24 (exact scalings of fp16 planes)
+    int e;
+    const float m = frexpf(v, &e);                               // v = m 2^e, m in [0.5, 1)
+    e = m > 0.70710678f ? e : e - 1;
+    e = e < -24 ? -24 : (e > 24 ? 24 : e);
+    return ldexpf(1.0f, e);
+}
+__global__ void ln_stats_finalize_p_kernel(const float* __restrict__ part, int rows, int nparts, int width, float eps, float* __restrict__ stat,
+                                           float* __restrict__ pred) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float2* pr = (const float2*)(part + (size_t)r * nparts * 2);
+    double sx = 0.0, sq = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        const float2 v = pr[i];
+        sx += (double)v.x;
+        sq += (double)v.y;
+    }
+    const float2 pd = *(const float2*)(pred + 2 * (size_t)r);
+    const double dm = sx / (double)width;
+    double var = sq / (double)width - dm * dm;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    *(float2*)(stat + 2 * (size_t)r) = make_float2((float)(dm * (double)pd.y), (float)(rstd / (double)pd.y));
+    *(float2*)(pred + 2 * (size_t)r) = make_float2((float)((double)pd.x + dm), pow2_near((float)rstd));
+}
+
+// First prediction of a forward: (mean, 2^round(log2 rstd)) of the rows of x (the embedded sequence), one wave per row.
+__global__ __launch_bounds__(256) void ln_row_pred_kernel(const float* __restrict__ x, int ldx, int rows, int width, float eps, float* __restrict__ pred) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = (const float4*)(x + (size_t)row * ldx);
+    const int w4 = width >> 2;
+    float s = 0.f, q = 0.f;
+    for (int c = lane; c < w4; c += 64) {
+        const float4 v = xr[c];
+        s += (v.x + v.y) + (v.z + v.w);
+        q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const double sum = (double)wave_sum(s), sq = (double)wave_sum(q);
+    const double mean = sum / (double)width;
+    double var = sq / (double)width - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    if (lane == 0) *(float2*)(pred + 2 * (size_t)row) = make_float2((float)mean, pow2_near((float)(1.0 / sqrt(var + (double)eps))));
+}
+
 // ------------------------------------------------------------------------------------------
 // Factored attention (block / transpose-block / previous-block), fp32, one workgroup per
 // (64-query group, head, clip).  Q K^T and P V run on the fp32-input matrix cores
@@ -904,6 +957,19 @@ extern "C" int llark_ln_stats_finalize(const float* part, int rows, int nparts, 
     LLARK_REQUIRE(part && stat && rows > 0 && nparts > 0 && width > 0, "ln_stats_finalize: bad arguments");
     ln_stats_finalize_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(part, rows, nparts, width, eps, stat);
     return check_launch("ln_stats_finalize");
+}
+
+extern "C" int llark_ln_stats_finalize_p(const float* part, int rows, int nparts, int width, float eps, float* stat, float* pred, llark_stream_t stream) {
+    LLARK_REQUIRE(part && stat && pred && rows > 0 && nparts > 0 && width > 0, "ln_stats_finalize_p: bad arguments");
+    ln_stats_finalize_p_kernel<<<cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>(part, rows, nparts, width, eps, stat, pred);
+    return check_launch("ln_stats_finalize_p");
+}
+
+extern "C" int llark_ln_row_pred(const float* x, int ldx, int rows, int width, float eps, float* pred, llark_stream_t stream) {
+    LLARK_REQUIRE(x && pred && rows > 0 && width > 0 && width % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0,
+                  "ln_row_pred: bad arguments (width, ldx multiples of 4, x 16-byte aligned)");
+    ln_row_pred_kernel<<<cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, ldx, rows, width, eps, pred);
+    return check_launch("ln_row_pred");
 }
 
 extern "C" int llark_layernorm_split_f16(const float* x, int ldx, int rows, int width, const float* gamma,

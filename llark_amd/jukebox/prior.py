@@ -41,6 +41,14 @@ DEFAULT_PRECISION = "f16x2"
 # so 71 of the 72 LayerNorm kernels of a 36-layer forward (each one read + one write of the [M][W] stream) disappear.
 # LLARK_PRIOR_LN_FOLD=0 (or PriorTransformer(ln_fold=False)) keeps the separate LayerNorm kernel everywhere.
 DEFAULT_LN_FOLD = True
+# Round 5: the folded planes are pre-normalised with the row's PREDICTED statistics -- the producing
+# epilogue writes hi / lo of ((x - shift) scale) . gamma with (shift, scale) = (mean, nearest power of two of rstd) of the same row at its
+# previous LayerNorm (llark_gemm16_ln_p / llark_ln_stats_finalize_p; the first prediction of a forward comes from the embedded sequence,
+# llark_ln_row_pred), and the finalize kernel hands the consumer ((mean - shift) scale, rstd / scale).  Without it the planes hold x . gamma
+# at the residual stream's own level: rows with std ~ 3e-3 (the embedding's scale at layer 0) push the fp16 lo plane into its subnormals
+# (2.7e-5 error per product instead of 2e-7, CPU simulation in tests/test_ln_fold_cpu.py), a row mean of 50 sigma costs 6 bits, |x| > 65504 /
+# gamma overflows.  LLARK_PRIOR_LN_PRED=0 = round 4's unscaled planes.
+DEFAULT_LN_PRED = True
 
 
 class Labeller:
@@ -88,6 +96,7 @@ class PriorTransformer:
         if ln_fold is None:
             ln_fold = os.environ.get("LLARK_PRIOR_LN_FOLD", "1" if DEFAULT_LN_FOLD else "0") != "0"
         self.ln_fold = bool(ln_fold) and precision == "f16x2"       # the lo8 tile has no folded epilogues
+        self.ln_pred = self.ln_fold and os.environ.get("LLARK_PRIOR_LN_PRED", "1" if DEFAULT_LN_PRED else "0") != "0"
         self.width = hps.prior_width
         self.depth = hps.prior_depth if depth is None else depth
         dev = self.device
@@ -165,6 +174,7 @@ class PriorTransformer:
                 self._ln_parts = 2 * ((W + 255) // 256)
                 ws["ln_part"] = torch.empty((rows, self._ln_parts, 2), dtype=torch.float32, device=dev)
                 ws["ln_stat"] = torch.empty((rows, 2), dtype=torch.float32, device=dev)
+                ws["ln_pred"] = torch.empty((rows, 2), dtype=torch.float32, device=dev) if self.ln_pred else None
             self._ws, self._ws_rows = ws, rows
         return self._ws
 
@@ -208,7 +218,9 @@ class PriorTransformer:
         sums written by the producing epilogue and reduced in a fixed order: deterministic, batch-size independent."""
         hps = self.hps
         W, S, Mw = hps.prior_width, hps.n_state, hps.mlp_state
-        rows, part, stat = h2.shape[0], ws["ln_part"], ws["ln_stat"]
+        rows, part, stat, pred = h2.shape[0], ws["ln_part"], ws["ln_stat"], ws["ln_pred"]
+        if pred is not None and not fold_in:
+            ops.ln_row_pred(h2, 1e-5, pred)                  # first block of a chain: predict from the stream as it stands
         if fold_in:
             ops.gemm16_ln(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.bw_attn, 3 * S, ops.EPI_F32, L.gw_attn, ln_stat=stat, c=ws["qkv"])
         else:
@@ -216,16 +228,16 @@ class PriorTransformer:
             ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
         ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
         ops.gemm16_ln(ws["att_hi"], ws["att_lo"], L.w_proj, L.b_proj, W, ops.EPI_RESID, L.ln1_g, ln_part=part, c=h2, resid=h2,
-                      out_hi=ws["ln_hi"], out_lo=ws["ln_lo"])
-        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat)
+                      out_hi=ws["ln_hi"], out_lo=ws["ln_lo"], ln_pred=pred)
+        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat, pred)
         ops.gemm16_ln(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.bw_fc, Mw, ops.EPI_QGELU_SPLIT, L.gw_fc, ln_stat=stat,
                       out_hi=ws["g_hi"], out_lo=ws["g_lo"])
         if fold_out is None:
             ops.gemm16(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, c=h2, resid=h2)
             return
         ops.gemm16_ln(ws["g_hi"], ws["g_lo"], L.w_proj2, L.b_proj2, W, ops.EPI_RESID, self.layers[fold_out].ln0_g, ln_part=part,
-                      c=h2, resid=h2, out_hi=ws["ln_hi"], out_lo=ws["ln_lo"])
-        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat)
+                      c=h2, resid=h2, out_hi=ws["ln_hi"], out_lo=ws["ln_lo"], ln_pred=pred)
+        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat, pred)
 
     def _layer_forward_lo8(self, h2, L, d: int, n: int, ws, taps) -> None:
         """The same block with E4M3 low planes: every producer (LayerNorm, attention, the c_fc epilogue) writes

@@ -122,6 +122,15 @@ class HipLlamaEngine:
         self.fuse_prefill_rope = os.environ.get("LLARK_PREFILL_FUSE_ROPE", "auto")
         if self.fuse_prefill_rope not in ("0", "1", "auto"):
             raise ValueError(f"LLARK_PREFILL_FUSE_ROPE must be 0, 1 or auto, got {self.fuse_prefill_rope!r}")
+        # prefill of an even batch as TWO half-batches on two HIP streams (round 5; LLARK_PREFILL_STREAMS=2, default 1 until measured):
+        # every kernel of the layer stack leaves part of the chip idle in its last round of tiles (M = 8 x 371 = 2968 rows: q|k|v 2.25
+        # rounds of the 512 resident workgroups, o_proj / down_proj 0.75) and none of them overlaps its successor on ONE stream; two
+        # independent half-batches let the hardware dispatcher fill the tail of one stream's kernel with the other stream's workgroups.
+        # Same kernels, same per-row arithmetic; the K cuts of o_proj / down_proj follow the half-batch's tile count (see ops.gemm16_fragw).
+        self.prefill_streams = int(os.environ.get("LLARK_PREFILL_STREAMS", "1"))
+        if self.prefill_streams not in (1, 2):
+            raise ValueError(f"LLARK_PREFILL_STREAMS must be 1 or 2, got {self.prefill_streams}")
+        self._side_streams = None
         self._resident_wgs = None
         self._rope_rows = None                                      # gather index of the epilogue's q|k|v row order (built on first use)
         self._dec: Dict[int, dict] = {}
@@ -289,6 +298,10 @@ class HipLlamaEngine:
         if fused:
             ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         rope_fused = s > 1 and pos_dev is None and self._prefill_rope_fused(batch, s)
+        if (self.prefill_streams == 2 and rope_fused and batch >= 2 and batch % 2 == 0 and self._prefill_rope_fused(batch // 2, s)
+                and all(self.layers[i].wqkv_rope is not None for i in range(n_layers)) and not torch.cuda.is_current_stream_capturing()):
+            self._prefill_two_streams(ws, batch, s, pos0, n_layers)
+            return False
         for i in range(n_layers):
             L = self.layers[i]
             kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
@@ -340,6 +353,46 @@ class HipLlamaEngine:
             else:
                 ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
         return fused
+
+    def _prefill_layer_rows(self, ws, L, i: int, b0: int, b1: int, s: int, pos0: int) -> None:
+        """One decoder layer of a PREFILL on batch rows b0 .. b1 - 1 (the fused-RoPE path of _layers_forward on row slices)."""
+        d = self.dims
+        H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
+        sp, nb = self.split, b1 - b0
+        r0, r1 = b0 * s, b1 * s
+        h = ws["h"][r0:r1]
+        x16, att, act, q = ws["x16"][r0:r1], ws["att"][r0:r1], ws["act"][r0:r1], ws["q"][b0:b1]
+        x16l = ws["x16_lo"][r0:r1] if sp else None
+        attl = ws["att_lo"][r0:r1] if sp else None
+        actl = ws["act_lo"][r0:r1] if sp else None
+        ql = ws["q_lo"][b0:b1] if sp else None
+        kc, vc = self.k_cache[i, b0:b1], self.vt_cache[i, b0:b1]
+        kcl = self.k_cache_lo[i, b0:b1] if sp else None
+        vcl = self.vt_cache_lo[i, b0:b1] if sp else None
+        ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x16, x16l)
+        ops.gemm16_fragw_rope_qkv(x16, x16l, L.wqkv_rope, H, nb, s, nh, pos0, self.cos, self.sin, q, kc, vc, ql, kcl, vcl)
+        ops.attn_prefill(q, kc, vc, nb, s, nh, hd, pos0, att, ql, kcl, vcl, attl)
+        ops.gemm16(att, attl, L.wo, None, H, ops.EPI_RESID, c=h, resid=h)
+        ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x16, x16l)
+        ops.gemm16(x16, x16l, L.wgu, None, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16, out_hi=act, out_lo=actl)
+        ops.gemm16(act, actl, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+
+    def _prefill_two_streams(self, ws, batch: int, s: int, pos0: int, n_layers: int) -> None:
+        """The layer stack of a prefill as two half-batches, each on its own stream, enqueued layer by layer in alternation."""
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        cur = torch.cuda.current_stream()
+        half = batch // 2
+        parts = ((0, half), (half, batch))
+        for st in self._side_streams:
+            st.wait_stream(cur)
+        for i in range(n_layers):
+            L = self.layers[i]
+            for st, (b0, b1) in zip(self._side_streams, parts):
+                with torch.cuda.stream(st):
+                    self._prefill_layer_rows(ws, L, i, b0, b1, s, pos0)
+        for st in self._side_streams:
+            cur.wait_stream(st)
 
     def _decode_body(self, st) -> None:
         """One decode step on static buffers: ids -> logits, new K/V written at *pos."""

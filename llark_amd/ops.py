@@ -502,10 +502,12 @@ def gemm16_ln_takes(m: int, n: int, kp: int) -> bool:
 def gemm16_ln(a_hi: torch.Tensor, a_lo: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], n: int, epilogue: int,
               ln_vec: torch.Tensor, ln_stat: Optional[torch.Tensor] = None, ln_part: Optional[torch.Tensor] = None,
               c: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, out_hi: Optional[torch.Tensor] = None,
-              out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None) -> None:
-    """The split product with a LayerNorm folded into its epilogue (include/llark_hip.h, llark_gemm16_ln): ``ln_stat`` given =
-    consumer (the operand planes hold x . gamma; the epilogue applies the row's mean / rstd), ``ln_part`` given = producer
-    (EPI_RESID; also writes the planes of c . ln_vec and the per-slice sums the next LayerNorm's statistics come from)."""
+              out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None, ln_pred: Optional[torch.Tensor] = None) -> None:
+    """The split product with a LayerNorm folded into its epilogue (include/llark_hip.h, llark_gemm16_ln / llark_gemm16_ln_p):
+    ``ln_stat`` given = consumer (the operand planes hold x . gamma; the epilogue applies the row's mean / rstd), ``ln_part`` given =
+    producer (EPI_RESID; also writes the planes of c . ln_vec and the per-slice sums the next LayerNorm's statistics come from);
+    ``ln_pred`` [m][2] (producer only) = the rows' predicted (shift, power-of-two scale): planes of ((c - shift) scale) . ln_vec,
+    sums of (c - shift) -- to be reduced by :func:`ln_stats_finalize` with the same ``pred``."""
     dtype = a_hi.dtype
     assert dtype in (torch.float16, torch.bfloat16) and wt.dtype == dtype and a_lo is not None
     m = a_hi.shape[0] if m is None else m
@@ -515,9 +517,11 @@ def gemm16_ln(a_hi: torch.Tensor, a_lo: torch.Tensor, wt: torch.Tensor, bias: Op
         assert ln_part.numel() >= m * 2 * ((n + 255) // 256) * 2, "gemm16_ln: ln_part is [m][2 * ceil(n / 256)][2]"
     if ln_stat is not None:
         assert ln_stat.numel() >= 2 * m
+    if ln_pred is not None:
+        assert ln_part is not None and ln_pred.numel() >= 2 * m and ln_pred.is_contiguous()
     name = "gemm_split_" + ("f16" if dtype == torch.float16 else "bf16")
     with _timed(name, 2.0 * m * n * kp):
-        check(_lib.lib().llark_gemm16_ln(
+        check(_lib.lib().llark_gemm16_ln_p(
             _DT[dtype], epilogue, _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype), a_hi.stride(0), _dev(wt, "wt"), wt.stride(0),
             _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp,
             _dev(c, "c", torch.float32) if c is not None else None, c.stride(0) if c is not None else 0,
@@ -525,14 +529,32 @@ def gemm16_ln(a_hi: torch.Tensor, a_lo: torch.Tensor, wt: torch.Tensor, bias: Op
             _dev(out_hi, "out_hi", dtype) if out_hi is not None else None, _dev(out_lo, "out_lo", dtype) if out_lo is not None else None,
             out_hi.stride(0) if out_hi is not None else 0,
             _dev(ln_stat, "ln_stat", torch.float32) if ln_stat is not None else None, _dev(ln_vec, "ln_vec", torch.float32),
-            _dev(ln_part, "ln_part", torch.float32) if ln_part is not None else None, workspace(), _stream()), "gemm16_ln")
+            _dev(ln_part, "ln_part", torch.float32) if ln_part is not None else None,
+            _dev(ln_pred, "ln_pred", torch.float32) if ln_pred is not None else None, workspace(), _stream()), "gemm16_ln")
 
 
-def ln_stats_finalize(part: torch.Tensor, rows: int, nparts: int, width: int, eps: float, stat: torch.Tensor) -> None:
-    """part [rows][nparts][2] (sum, sum of squares per column slice) -> stat [rows][2] (mean, rstd)."""
+def ln_stats_finalize(part: torch.Tensor, rows: int, nparts: int, width: int, eps: float, stat: torch.Tensor,
+                      pred: Optional[torch.Tensor] = None) -> None:
+    """part [rows][nparts][2] (sum, sum of squares per column slice) -> stat [rows][2] (mean, rstd).  With ``pred`` [rows][2] (the
+    (shift, scale) the producer was given): stat = ((mean - shift) scale, rstd / scale) -- what the consumer role needs for planes of
+    ((x - shift) scale) gamma -- and pred is replaced by (mean, nearest power of two of rstd) for the next LayerNorm of these rows."""
     assert part.numel() >= rows * nparts * 2 and stat.numel() >= rows * 2
+    if pred is not None:
+        assert pred.numel() >= rows * 2 and pred.is_contiguous()
+        check(_lib.lib().llark_ln_stats_finalize_p(_dev(part, "part", torch.float32), rows, nparts, width, float(eps),
+                                                   _dev(stat, "stat", torch.float32), _dev(pred, "pred", torch.float32), _stream()), "ln_stats_finalize_p")
+        return
     check(_lib.lib().llark_ln_stats_finalize(_dev(part, "part", torch.float32), rows, nparts, width, float(eps),
                                              _dev(stat, "stat", torch.float32), _stream()), "ln_stats_finalize")
+
+
+def ln_row_pred(x: torch.Tensor, eps: float, pred: torch.Tensor) -> None:
+    """pred [rows][2] = (mean, nearest power of two of 1 / sqrt(var + eps)) of the rows of x (fp32 [rows][width]): the first prediction
+    of a forward for the producers of :func:`gemm16_ln` (ln_pred)."""
+    rows, width = x.shape
+    assert pred.numel() >= 2 * rows and pred.is_contiguous()
+    check(_lib.lib().llark_ln_row_pred(_dev(x, "x", torch.float32), x.stride(0), rows, width, float(eps), _dev(pred, "pred", torch.float32),
+                                       _stream()), "ln_row_pred")
 
 
 def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a: bool, trans_b: bool, c: torch.Tensor,

@@ -560,3 +560,40 @@ def test_engine_prefill_rope_fused_bit_equal_at_7b_width(precision):
     if precision == "split":
         assert torch.equal(a[3], b[3])
     assert float(a[0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+def test_prefill_two_streams_matches_one_stream(precision):
+    """Round 5: the prefill's layer stack as two half-batches on two HIP streams (HipLlamaEngine.prefill_streams = 2) against the
+    single-stream order, 7B width, 2 layers, B = 8 x S = 371.  Same kernels on the same rows; only the K cuts of o_proj / down_proj
+    follow the half-batch's tile count, so logits agree to the fp32 summation order ("split": <= 6e-5 of max|logits|, the B = 1
+    vs B = 8 bar of the full-depth fixture; "bf16": a moved cut moves bf16 rounding points downstream).  Rows holding the same
+    prompt stay bit-equal across the two halves, and the KV cache of both halves is written (decode step afterwards agrees)."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    dims = LlamaDims(num_hidden_layers=2, vocab_size=512)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = lambda *shape: (torch.randn(*shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    H, I = 4096, 11008
+    eng = HipLlamaEngine(dims, "cuda", 8, 384, precision=precision)
+    for i in range(2):
+        eng.set_layer(i, n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I), torch.ones(H, device="cuda"), torch.ones(H, device="cuda"))
+    eng.set_globals(n(512, H), torch.ones(H, device="cuda"), n(512, H))
+    row = torch.randint(3, 500, (1, 371), generator=torch.Generator().manual_seed(2))
+    ids = torch.cat((row.expand(4, -1), torch.randint(3, 500, (3, 371), generator=torch.Generator().manual_seed(3)), row), 0).cuda()
+    nxt = torch.randint(3, 500, (8, 1), generator=torch.Generator().manual_seed(4)).cuda()
+    res = []
+    for streams in (1, 2):
+        eng.prefill_streams = streams
+        logits = eng.forward_tokens(ids).clone()
+        step = eng.forward_tokens(nxt, (), pos0=eng.cur_len, last_only=True).clone()
+        torch.cuda.synchronize()
+        res.append((logits, step, eng.k_cache.clone(), eng.vt_cache.clone()))
+    assert eng._side_streams is not None, "the two-stream path was not taken"
+    (l1, s1, k1, v1), (l2, s2, k2, v2) = res
+    scale = float(l1.abs().max())
+    tol = (6e-5 if precision == "split" else 4e-2) * scale
+    report_close(f"two-stream vs one-stream prefill logits [{precision}]", l2.cpu(), l1.cpu(), tol)
+    report_close(f"decode step after a two-stream prefill [{precision}]", s2.cpu(), s1.cpu(), tol)
+    assert torch.equal(l2[0], l2[3]) and torch.equal(l2[0], l2[7]), "equal prompts in the two halves must give bit-equal logits"
+    report_close("K cache", k2.float().cpu(), k1.float().cpu(), 2e-2 * float(k1.float().abs().max()))
+    assert float(k2[:, 4:].float().abs().max()) > 0 and float(v2[:, 4:].float().abs().max()) > 0

@@ -59,3 +59,56 @@ def test_fold_takes_only_big_tiles_signature_exported():
     for name in ("llark_gemm16_ln", "llark_gemm16_ln_takes", "llark_ln_stats_finalize"):
         assert re.search(r"\b%s\s*\(" % name, hdr), name
         assert name in _lib._SIGS, name
+
+
+def _split16(v32):
+    """fp16 hi / lo planes of an fp32 array (numpy float16 rounds to nearest even and keeps subnormals, like the kernels)."""
+    hi = v32.astype(np.float16)
+    lo = (v32 - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64) + lo.astype(np.float64)
+
+
+def _pow2_near(v):
+    m, e = np.frexp(v)
+    e = np.where(m > 0.70710678, e, e - 1)
+    return np.ldexp(1.0, np.clip(e, -24, 24))
+
+
+def test_predicted_statistics_keep_the_planes_bits_on_adversarial_rows():
+    """Round 5: what the folded planes lose on rows whose level / spread is far from one, and what pre-normalising them
+    with PREDICTED statistics recovers (llark_gemm16_ln_p + llark_ln_stats_finalize_p, restated here in numpy with fp16 planes).
+    Rows: std 1e-3 (the lo plane in its subnormals), std 1e3 with a mean of 50 sigma (hi plane overflows without the shift), mean of
+    50 sigma at std 1.  The prediction is deliberately off (mean by 0.3 sigma, scale by a factor 1.7) -- it only has to be close.
+    Identity checked on the way: with stat = ((mean - shift) scale, rstd / scale) the consumer formula is unchanged."""
+    rng = np.random.default_rng(0)
+    K, N = 4800, 128
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16).astype(np.float64)
+    gamma = (1 + 0.3 * rng.standard_normal(K)).astype(np.float32)
+    beta = 0.2 * rng.standard_normal(K)
+    gw, bw = W @ gamma.astype(np.float64), W @ beta
+    worst = {}
+    for name, scale, off in (("unit", 1.0, 0.0), ("std 1e-3", 1e-3, 0.0), ("std 3e-3", 3e-3, 0.0), ("mean 50 sigma", 1.0, 50.0),
+                             ("std 1e3, mean 50 sigma", 1e3, 50.0), ("std 1e-3, mean 50 sigma", 1e-3, 50.0)):
+        x = (rng.standard_normal((16, K)) * scale + off * scale).astype(np.float32)
+        x64 = x.astype(np.float64)
+        mu, var = x64.mean(1, keepdims=True), x64.var(1, keepdims=True)
+        rstd = 1.0 / np.sqrt(var + 1e-5)
+        ref = ((x64 - mu) * rstd * gamma + beta) @ W.T
+        with np.errstate(over="ignore", invalid="ignore"):
+            plain = rstd * (_split16(x * gamma) @ W.T - mu * gw) + bw                      # round 4: planes of x . gamma
+        shift = (mu + 0.3 / rstd).astype(np.float32)                                        # a prediction that is off
+        sc = _pow2_near(1.7 * rstd).astype(np.float32)
+        planes = _split16(((x - shift) * sc) * gamma)
+        assert np.isfinite(planes).all(), name
+        d = (x - shift).astype(np.float64)                                                  # what the producer sums
+        dm = d.mean(1, keepdims=True)
+        var_p = (d * d).mean(1, keepdims=True) - dm * dm
+        rstd_p = 1.0 / np.sqrt(np.maximum(var_p, 0) + 1e-5)
+        stat = (dm * sc, rstd_p / sc)                                                       # ((mean - shift) scale, rstd / scale)
+        pred = stat[1] * (planes @ W.T - stat[0] * gw) + bw                                 # the UNCHANGED consumer formula
+        s = np.abs(ref).max()
+        worst[name] = (np.nanmax(np.abs(plain - ref)) / s if np.isfinite(plain).all() else np.inf, np.abs(pred - ref).max() / s)
+        assert worst[name][1] <= 3e-7, f"{name}: predicted-statistics planes {worst[name][1]:.2e} of max|out|"
+    assert worst["unit"][0] <= 3e-7                                                         # nothing to fix on well-scaled rows
+    assert worst["std 1e-3"][0] >= 3e-6 and worst["mean 50 sigma"][0] >= 1e-6               # the losses the prediction removes
+    assert not np.isfinite(worst["std 1e3, mean 50 sigma"][0])                              # fp16 overflow of the unscaled hi plane

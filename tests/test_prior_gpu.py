@@ -263,6 +263,117 @@ def test_gemm16_ln_folded_layernorm_roles(m, n, k):
         ops.gemm16_ln(ph0[:512], pl0[:512], wt2, bw, n2, ops.EPI_F32, gw, ln_stat=stat, c=out[:512])
 
 
+def test_gemm16_ln_predicted_statistics_adversarial_rows():
+    """llark_gemm16_ln_p / llark_ln_stats_finalize_p / llark_ln_row_pred (round 5): the folded LayerNorm with planes
+    pre-normalised by PREDICTED row statistics, on rows the unscaled planes lose bits on -- std 1e-3 (fp16 lo plane subnormal), std 1e3
+    (hi plane near overflow), mean = 50 sigma, and ordinary rows -- against float64 and against the unfolded path (LayerNorm kernel +
+    plain product).  Checks: the stream c is BIT-equal to the plain product's; the planes are split16(((c - shift) scale) gamma);
+    stat = ((mean - shift) scale, rstd / scale); pred is replaced by (mean, nearest power of two of rstd); the consumer (unchanged
+    kernel) is as close to float64 as the unfolded path on EVERY row class, where round 4's unscaled planes are 8x further out on
+    the small rows; run-to-run bit-equal."""
+    from llark_amd import ops
+    m, n, k = 8192, 4800, 192
+    g = torch.Generator().manual_seed(99)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.2).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = torch.randn(m, n, generator=g) * 3.0
+    cls = torch.arange(m) % 4                          # 0 ordinary, 1 std ~1e-3, 2 std ~1e3, 3 mean 50 sigma
+    a[cls == 1] *= 3e-4
+    r[cls == 1] *= 3e-4
+    a[cls == 2] *= 300.0
+    r[cls == 2] *= 300.0
+    r[cls == 3] += 50.0 * 4.0
+    r = r.cuda()
+    bsel = torch.zeros_like(b)                          # an N(0, 1) bias would lift the 1e-3 rows back to order one
+    gamma = (1.0 + 0.3 * torch.randn(n, generator=g)).cuda()
+    beta = (0.2 * torch.randn(n, generator=g)).cuda()
+    hi, lo = ops.split16(a.cuda(), torch.float16, kmult=64)
+    wt = ops.pack_weight16(w.cuda(), True, torch.float16, kmult=64)
+    c0 = r.clone()
+    ops.gemm16(hi, lo, wt, bsel, n, ops.EPI_RESID, c=c0, resid=c0, variant=32)
+    # prediction from a DIFFERENT (earlier) state of the rows: the residual before this product -- off, as in the real chain
+    pred0 = torch.empty((m, 2), device="cuda")
+    ops.ln_row_pred(r, 1e-5, pred0)
+    r64 = r.double()
+    assert float((pred0[:, 0].double() - r64.mean(1)).abs().max()) <= 2e-6 * float(r64.abs().max())
+    ratio = pred0[:, 1].double() * torch.sqrt(r64.var(1, unbiased=False) + 1e-5)
+    assert float(ratio.max()) <= 1.4143 and float(ratio.min()) >= 0.7071, "scale is not the nearest power of two of rstd"
+    assert bool((torch.frexp(pred0[:, 1])[0] == 0.5).all()), "scale must be an exact power of two"
+    nparts = 2 * ((n + 255) // 256)
+    first = None
+    for rep in range(2):
+        c1 = r.clone()
+        pred = pred0.clone()
+        ph, pl = (torch.full((m, n + 8), float("nan"), dtype=torch.float16, device="cuda") for _ in range(2))
+        part = torch.full((m, nparts, 2), float("nan"), device="cuda")
+        stat = torch.full((m, 2), float("nan"), device="cuda")
+        ops.gemm16_ln(hi, lo, wt, bsel, n, ops.EPI_RESID, gamma, ln_part=part, c=c1, resid=c1, out_hi=ph, out_lo=pl, ln_pred=pred)
+        ops.ln_stats_finalize(part, m, nparts, n, 1e-5, stat, pred)
+        if first is None:
+            first = (c1.clone(), ph[:, :n].clone(), pl[:, :n].clone(), stat.clone(), pred.clone())
+    assert torch.equal(c1, c0), "producer stream differs from the plain RESID product"
+    assert all(torch.equal(x, y) for x, y in zip(first, (c1, ph[:, :n], pl[:, :n], stat, pred))), "not run-to-run bit-equal"
+    assert bool(torch.isnan(ph[:, n:]).all() and torch.isnan(pl[:, n:]).all()), "producer wrote planes past column n"
+    shift, scale = pred0[:, 0:1], pred0[:, 1:2]
+    xg = ((c1 - shift) * scale) * gamma
+    want_hi = xg.half()
+    assert torch.isfinite(want_hi.float()).all()
+    assert torch.equal(ph[:, :n], want_hi) and torch.equal(pl[:, :n], (xg - want_hi.float()).half()), "planes are not split16(((c - shift) scale) gamma)"
+    c64 = c1.double()
+    mean64, var64 = c64.mean(1), c64.var(1, unbiased=False)
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    sd = torch.sqrt(var64 + 1e-5)
+    assert float(((stat[:, 0].double() / scale[:, 0].double() + shift[:, 0].double() - mean64).abs() / sd).max()) <= 1e-5, "stat.x != (mean - shift) scale"
+    assert float((stat[:, 1].double() * scale[:, 0].double() / rstd64 - 1.0).abs().max()) <= 1e-5, "stat.y != rstd / scale"
+    assert float(((pred[:, 0].double() - mean64).abs() / sd).max()) <= 1e-5, "pred was not replaced by the measured mean"
+    rr = pred[:, 1].double() / rstd64
+    assert float(rr.max()) <= 1.4143 and float(rr.min()) >= 0.7071
+    # ---- consumer (the round-4 kernel, unchanged) on the pre-normalised planes vs round 4's planes vs the unfolded path
+    n2 = 4800
+    w2 = (torch.randn(n, n2, generator=g) * 0.05).half()
+    b2 = torch.randn(n2, generator=g).cuda()
+    wt2 = ops.pack_weight16(w2.cuda(), True, torch.float16, kmult=64)
+    kp2 = wt2.shape[1]
+    assert ops.gemm16_ln_takes(m, n2, kp2)
+    w64 = wt2[:, :n].double()
+    gw = (w64 @ gamma.double()).float()
+    bw = (w64 @ beta.double() + b2.double()).float()
+    ref = ((c64 - mean64[:, None]) * rstd64[:, None] * gamma.double() + beta.double()) @ w64.t() + b2.double()
+
+    def consume(planes_hi, planes_lo, st):
+        p0, p1 = (torch.zeros((m, kp2), dtype=torch.float16, device="cuda") for _ in range(2))
+        p0[:, :n], p1[:, :n] = planes_hi[:, :n], planes_lo[:, :n]
+        out = torch.full((m, n2), float("nan"), device="cuda")
+        ops.gemm16_ln(p0, p1, wt2, bw, n2, ops.EPI_F32, gw, ln_stat=st, c=out)
+        return out.double()
+
+    out_p = consume(ph, pl, stat)
+    # round 4's form on the same rows (no prediction)
+    c2 = r.clone()
+    ph4, pl4 = (torch.zeros((m, n + 8), dtype=torch.float16, device="cuda") for _ in range(2))
+    part4, stat4 = torch.zeros((m, nparts, 2), device="cuda"), torch.zeros((m, 2), device="cuda")
+    ops.gemm16_ln(hi, lo, wt, bsel, n, ops.EPI_RESID, gamma, ln_part=part4, c=c2, resid=c2, out_hi=ph4, out_lo=pl4)
+    ops.ln_stats_finalize(part4, m, nparts, n, 1e-5, stat4)
+    out_4 = consume(ph4, pl4, stat4)
+    lh, ll = (torch.zeros((m, kp2), dtype=torch.float16, device="cuda") for _ in range(2))
+    ops.layernorm_split(c1, gamma, beta, 1e-5, lh, ll)
+    out_u = torch.empty((m, n2), device="cuda")
+    ops.gemm16(lh, ll, wt2, b2, n2, ops.EPI_F32, c=out_u, variant=32)
+    scale_out = float(ref.abs().max())
+    names = ("ordinary", "std 1e-3", "std 1e3", "mean 50 sigma")
+    for ci, nm in enumerate(names):
+        sel = (cls == ci).cuda()
+        e_p = float((out_p[sel] - ref[sel]).abs().max()) / scale_out
+        e_4 = float((out_4[sel] - ref[sel]).abs().nan_to_num(float("inf")).max()) / scale_out
+        e_u = float((out_u[sel].double() - ref[sel]).abs().max()) / scale_out
+        print(f"\n[ln-pred] rows {nm:14s}: predicted-statistics planes {e_p:.2e} | round-4 planes {e_4:.2e} | unfolded {e_u:.2e}  (of max|out| {scale_out:.1f})")
+        assert e_p <= max(3.0 * e_u, 1e-6), f"{nm}: predicted-statistics fold {e_p:.2e} vs unfolded {e_u:.2e}"
+    sel = (cls == 1).cuda()
+    assert float((out_4[sel] - ref[sel]).abs().max()) >= 4.0 * float((out_p[sel] - ref[sel]).abs().max()), \
+        "expected round 4's unscaled planes to be several times further from float64 on the std 1e-3 rows (measured 8x)"
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
