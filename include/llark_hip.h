@@ -252,6 +252,10 @@ int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, 
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
                        int ldr, void* out_hi, void* out_lo, int ldo, llark_stream_t stream);
+/* 1 when llark_gemm16_fragw_sk's library choice (variant -1, a scratch given) runs the product as whole 128x256 tiles of the per-tile
+ * kernel -- no K cut, not the 128x128 tiles: the case in which llark_gemm16_fragw_rope_qkv (always whole 128x256 tiles) is BIT-equal to
+ * llark_gemm16_fragw_sk + llark_rope_split_heads.  Shape rule only (no launch); callers ask it instead of restating the rule. */
+int llark_gemm16_fragw_whole_tiles(int split, int epilogue, int m, int n, int kp);
 /* The Llama q|k|v product of a PREFILL with RoPE, the head split, the K-cache append and the transposed V-cache append in its
  * epilogue: one launch instead of llark_gemm16_fragw (fp32 qkv) + llark_rope_split_heads (m2t/models/llamav2.py:224-234 -> HF
  * LlamaAttention q_proj / k_proj / v_proj, apply_rotary_pos_emb, cache update).  bf16 only; head_dim 128, nh even, s >= 32.

@@ -75,6 +75,7 @@ _SIGS = {
     "llark_gemm16_ln_takes": [c_int, c_int, c_int],
     "llark_gemm16_ln": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P],
     "llark_ln_stats_finalize": [_P, c_int, c_int, c_int, c_float, _P, _P],
+    "llark_gemm16_fragw_whole_tiles": [c_int, c_int, c_int, c_int, c_int],
     "llark_gemm16_ln_p": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P],
     "llark_ln_stats_finalize_p": [_P, c_int, c_int, c_int, c_float, _P, _P, _P],
     "llark_ln_row_pred": [_P, c_int, c_int, c_int, c_float, _P, _P],

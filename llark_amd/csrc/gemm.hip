@@ -1599,6 +1599,25 @@ static int llark_device_cus() {
     return cached[dev];
 }
 
+// Library choice (variant -1) of llark_gemm16_fragw_sk: is the product cut along K?
+// plain 16-bit operands at < 1 round: the two-way K cut pays only on a deep K (down_proj, K = 11008: 903 -> 974 TFLOP/s; o_proj,
+// K = 4096: 866 -> 756 against the 128x128 tiles) -- profiles/r02_streamk.txt
+static bool fragw_sk_rule(bool split, int m, int n, int kp) {
+    const long long tiles_bd0 = (long long)cdiv(m, CfgBD0::BM) * cdiv(n, CfgBD0::BN);
+    return (split && tiles_bd0 < 2LL * llark_device_cus()) ||
+           (!split && (4 * tiles_bd0 <= 2LL * llark_device_cus() || (tiles_bd0 < 2LL * llark_device_cus() && kp >= 8192)));
+}
+static bool fragw_small_tiles(bool split, int epilogue, int n) { return !split && !IS_SWIGLU(epilogue) && n <= 4096; }
+
+// 1 when the library choice of llark_gemm16_fragw_sk runs this product as WHOLE 128x256 tiles of the per-tile kernel (no K cut, not the
+// 128x128 tiles): the case in which llark_gemm16_fragw_rope_qkv -- which always runs whole 128x256 tiles -- is bit-equal to the two-launch
+// path.  The one place this rule lives (the Python layer used to restate it).  Conservative: a product the K-cutting
+// kernels would decline at launch time is reported as 0.
+extern "C" int llark_gemm16_fragw_whole_tiles(int split, int epilogue, int m, int n, int kp) {
+    if (m <= 0 || n <= 0 || kp <= 0) return 0;
+    return (!fragw_sk_rule(split != 0, m, n, kp) && !fragw_small_tiles(split != 0, epilogue, n)) ? 1 : 0;
+}
+
 static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                              const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc,
                              const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, void* scratch, long long scratch_bytes,
@@ -1627,11 +1646,7 @@ static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, co
     // +6 %); with one or more whole rounds ahead of the remainder the hardware's dynamic dispatch of one workgroup per tile
     // already hides the ragged last round (qkv, gate/up: +-1 %; lm_head: -6 %), and plain 16-bit operands at N <= 4096 are
     // better served by the 128x128 tiles below.  variant -1 applies that rule, variant 0 + scratch cuts whenever it can.
-    const long long tiles_bd0 = (long long)cdiv(m, CfgBD0::BM) * cdiv(n, CfgBD0::BN);
-    // plain 16-bit operands at < 1 round: the two-way K cut pays only on a deep K (down_proj, K = 11008: 903 -> 974 TFLOP/s; o_proj,
-    // K = 4096: 866 -> 756 against the 128x128 tiles) -- profiles/r02_streamk.txt
-    const bool sk_rule = (split && tiles_bd0 < 2LL * llark_device_cus()) ||
-                         (!split && (4 * tiles_bd0 <= 2LL * llark_device_cus() || (tiles_bd0 < 2LL * llark_device_cus() && kp >= 8192)));
+    const bool sk_rule = fragw_sk_rule(split != 0, m, n, kp);
     if (scratch && (variant == 0 || (variant < 0 && sk_rule)) && epilogue != EPI_QGELU_SPLIT) {
         int rc = -1000;                                             // -1000 = whole rounds / too small to cut -> the per-tile kernels below
         const bool uniform = variant < 0;                          // library choice: the position-independent cut
@@ -1639,7 +1654,7 @@ static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, co
         else if (dtype == LLARK_BF16) rc = dispatch_bd_sk<bf16_t, CfgBD0>(p, split != 0, epilogue, s, scratch, scratch_bytes, uniform);
         if (rc != -1000) return rc;
     }
-    if (variant < 0) variant = (!split && !IS_SWIGLU(epilogue) && n <= 4096) ? 1 : 0;
+    if (variant < 0) variant = fragw_small_tiles(split != 0, epilogue, n) ? 1 : 0;
     if (variant == 1) {
         if (IS_SWIGLU(epilogue)) { set_error("gemm16_fragw: variant 1 (128x128 tiles) has no SwiGLU epilogue"); return LLARK_ERR_UNSUPPORTED; }
         if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD1>(p, split != 0, epilogue, s);

@@ -12,6 +12,12 @@ from typing import Tuple
 import numpy as np
 
 
+
+class UnsupportedContainerError(RuntimeError):
+    """The bytes are not one of the containers decoded here.  NOT a ValueError on purpose: load_audio_from_file turns ValueError into
+    EmptyFileError ("probably empty", jukebox/main.py:29-34) and its callers skip such files silently -- an mp3 must not be reported
+    as an empty file."""
+
 def _read_all(f) -> bytes:
     if hasattr(f, "read"):
         return f.read()
@@ -137,8 +143,15 @@ def decode_au(data: bytes) -> Tuple[int, np.ndarray]:
 def decode_audio(f) -> Tuple[int, np.ndarray]:
     """Path or binary file object -> (sample_rate, float32 [frames] or [frames][channels]); the container is told from its first bytes."""
     data = _read_all(f)
+    if data[:3] == b"ID3" and len(data) >= 10:          # ID3v2 tag in front of the stream (almost always mp3, sometimes FLAC): skip it, sniff what follows
+        size = ((data[6] & 0x7F) << 21) | ((data[7] & 0x7F) << 14) | ((data[8] & 0x7F) << 7) | (data[9] & 0x7F)
+        body = data[10 + size + (10 if data[5] & 0x10 else 0):]
+        if body[:4] != b"fLaC":
+            raise UnsupportedContainerError(f"unsupported audio container: ID3v2 tag followed by {body[:4]!r} (mp3 is not decoded): "
+                                            "wav, FLAC, AIFF and .au are")
+        data = body
     head = data[:4]
-    if head == b"fLaC" or head[:3] == b"ID3":
+    if head == b"fLaC":
         return decode_flac(data)
     if head in (b"RIFF", b"RIFX", b"RF64") or len(data) == 0:
         return decode_wav(io.BytesIO(data))
@@ -146,4 +159,4 @@ def decode_audio(f) -> Tuple[int, np.ndarray]:
         return decode_aiff(data)
     if head == b".snd":
         return decode_au(data)
-    raise ValueError(f"unsupported audio container (first bytes {head!r}): wav, FLAC, AIFF and .au are decoded")
+    raise UnsupportedContainerError(f"unsupported audio container (first bytes {head!r}): wav, FLAC, AIFF and .au are decoded")

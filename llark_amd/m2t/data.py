@@ -158,9 +158,14 @@ def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any
     both generators are seeded per rank AND per epoch.  ``skip_micro_batches`` fast-forwards the stream (resume: the
     trainer passes ``step * gradient_accumulation_steps``) so a resumed run continues where the interrupted one stopped
     instead of replaying its first samples.  ``task_sample_probs``: see :func:`shard_probs` -- an epoch then reads as many shards
-    as the rank owns, drawn with replacement by task weight (the reference draws 1024 x len(urls) up front and resamples)."""
-    shards = split_by_rank(expand_urls(train_data_path), rank, world)
-    weights = shard_probs(shards, task_sample_probs) if task_sample_probs else None
+    as the rank owns, drawn with replacement by task weight over the WHOLE shard list (one draw shared by all ranks, then split
+    r::world; the reference draws 1024 x len(urls) up front, before split_by_node)."""
+    all_shards = expand_urls(train_data_path)
+    shards = split_by_rank(all_shards, rank, world)
+    # task weights are normalised over the GLOBAL shard list and the weighted order is drawn over it with a RANK-INDEPENDENT seed, then
+    # split by rank -- the reference's repeat_shards() runs before split_by_node (m2t/data_modules.py:441-462, 560-640), so every rank
+    # sees the task mix of the whole list, also when its own r::world subset is skewed or lacks a task (ADVICE r04)
+    weights = shard_probs(all_shards, task_sample_probs) if task_sample_probs else None
     collate = DataCollatorForSupervisedDataset(tokenizer)
     epoch = 0
     to_skip = max(0, int(skip_micro_batches))                         # whole micro-batches still to fast-forward over
@@ -170,7 +175,8 @@ def micro_batches(train_data_path: str, tokenizer, multimodal_cfg: Dict[str, Any
             order = list(shards)
             rng.shuffle(order)                                        # shardshuffle
         else:
-            order = rng.choices(shards, weights=weights, k=len(shards))
+            grng = random.Random(seed * 1000003 * 7919 + epoch)          # the same draw on every rank
+            order = grng.choices(all_shards, weights=weights, k=len(shards) * world)[rank::world]
 
         def conversations():
             for elem in iter_tar_samples(order, allow_pickle):

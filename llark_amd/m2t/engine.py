@@ -157,14 +157,22 @@ class HipLlamaEngine:
         if self.frag_weights:
             for t in (L.wqkv, L.wo, L.wgu, L.wdown):
                 ops.attach_frag(t, t.shape[0])
-        L.wqkv_rope = None
+        L.wqkv_rope = None                                    # built on the first prefill that takes the fused epilogue (_rope_weight)
+        self.layers[i] = L
+
+    def _rope_capable(self, L) -> bool:
         # only next to the fragment-major twin the two-launch path uses (LLARK_FRAG=0 switches both off: same kernel family either way)
-        if (self.frag_weights and hasattr(L.wqkv, "_llark_frag") and self.fuse_prefill_rope != "0" and self.dims.num_attention_heads % 2 == 0
-                and self.dims.hidden_size % 64 == 0):
+        return (self.frag_weights and hasattr(L.wqkv, "_llark_frag") and self.fuse_prefill_rope != "0" and self.dims.num_attention_heads % 2 == 0
+                and self.dims.hidden_size % 64 == 0)
+
+    def _rope_weight(self, L):
+        """The q|k|v weight in the fused epilogue's row order, fragment-major: + 3 H^2 x 2 bytes per layer (3.2 GB at 7B), so it is
+        built LAZILY -- engines that only decode, prefill short prompts or train never pay for it."""
+        if L.wqkv_rope is None and self._rope_capable(L):
             if self._rope_rows is None:
                 self._rope_rows = ops.rope_qkv_row_order(self.dims.num_attention_heads, self.dims.head_dim).to(self.device)
             L.wqkv_rope = ops.pack_weight16_frag(L.wqkv.index_select(0, self._rope_rows).contiguous(), L.wqkv.shape[0])
-        self.layers[i] = L
+        return L.wqkv_rope
 
     def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
         self._dec.clear()
@@ -268,22 +276,16 @@ class HipLlamaEngine:
 
     def _prefill_rope_fused(self, batch: int, s: int) -> bool:
         """Does this prefill take the q|k|v product with RoPE in its epilogue?  "auto" = only where llark_gemm16_fragw would run the
-        same whole 128x256 tiles (its K-cutting rule restated: csrc/gemm.hip gemm16_fragw_impl), so results stay bit-equal."""
+        same whole 128x256 tiles (the library answers: llark_gemm16_fragw_whole_tiles), so results stay bit-equal."""
         if self.fuse_prefill_rope == "0" or s < 32 or batch * s < ops.FRAG_MIN_ROWS:
             return False
         if self.fuse_prefill_rope == "1":
             return True
         H = self.dims.hidden_size
-        tiles = -(-batch * s // 128) * -(-3 * H // 256)
-        if self._resident_wgs is None:
-            self._resident_wgs = 2 * ops.device_info(self.device.index or 0)[0]      # two 128x256 workgroups per CU
-        resident = self._resident_wgs
-        if self.split:
-            return tiles >= resident
-        return not (4 * tiles <= resident or (tiles < resident and H >= 8192))
+        return ops.gemm16_fragw_whole_tiles(self.split, ops.EPI_F32, batch * s, 3 * H, H)
 
     # ---- forward -------------------------------------------------------------------------------
-    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None) -> bool:
+    def _layers_forward(self, ws, batch: int, s: int, pos0: int, num_layers: Optional[int] = None, pos_dev=None, hidden_sink=None) -> bool:
         """Runs the decoder layers on ws["h"].  Returns True when ws["x16"] already holds RMSNorm_final(h) (the fused
         decode path normalises inside the producing GEMM), False when the caller still has to apply the final norm."""
         d = self.dims
@@ -292,24 +294,28 @@ class HipLlamaEngine:
         n_layers = d.num_hidden_layers if num_layers is None else num_layers
         sp = self.split
         # decode (one token per sequence): o_proj / down_proj carry the FOLLOWING RMSNorm in their launch
-        fused = s == 1 and batch <= 16 and n_layers > 0 and self.fuse_decode_norm and H <= 8192
+        fused = s == 1 and batch <= 16 and n_layers > 0 and self.fuse_decode_norm and H <= 8192 and hidden_sink is None
         norm_a = (s == 1 and batch <= 16 and not fused and H % 32 == 0 and
                   (self.fuse_decode_norm_a == "1" or (self.fuse_decode_norm_a == "auto" and ops.gemv_dma_rmsnorm_takes(batch, 3 * H, H))))
         if fused:
             ops.rmsnorm_bf16(h, self.layers[0].ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
         rope_fused = s > 1 and pos_dev is None and self._prefill_rope_fused(batch, s)
+        if rope_fused:
+            rope_fused = all(self._rope_weight(self.layers[i]) is not None for i in range(n_layers))
         if (self.prefill_streams == 2 and rope_fused and batch >= 2 and batch % 2 == 0 and self._prefill_rope_fused(batch // 2, s)
-                and all(self.layers[i].wqkv_rope is not None for i in range(n_layers)) and not torch.cuda.is_current_stream_capturing()):
+                and hidden_sink is None and not torch.cuda.is_current_stream_capturing()):
             self._prefill_two_streams(ws, batch, s, pos0, n_layers)
             return False
         for i in range(n_layers):
             L = self.layers[i]
+            if hidden_sink is not None:                       # HF output_hidden_states: the stream as it ENTERS every layer
+                hidden_sink.append(h.view(batch, s, H).clone())
             kc, vc = self.k_cache[i, :batch], self.vt_cache[i, :batch]
             kcl = self.k_cache_lo[i, :batch] if sp else None
             vcl = self.vt_cache_lo[i, :batch] if sp else None
             if not kc.is_contiguous():            # batch smaller than the allocated cache
                 raise ops._lib.LlarkHipError("KV cache batch mismatch: call reset(batch) before prefill")
-            if rope_fused and L.wqkv_rope is not None:  # prefill: RoPE / head split / cache writes in the q|k|v epilogue
+            if rope_fused:                           # prefill: RoPE / head split / cache writes in the q|k|v epilogue
                 ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
                 ops.gemm16_fragw_rope_qkv(ws["x16"], ws["x16_lo"], L.wqkv_rope, H, batch, s, nh, pos0, self.cos, self.sin, ws["q"], kc, vc,
                                           ws["q_lo"], kcl, vcl)
@@ -319,7 +325,7 @@ class HipLlamaEngine:
                 if not fused:
                     ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
                 ops.gemm16(ws["x16"], ws["x16_lo"], L.wqkv, None, 3 * H, ops.EPI_F32, c=ws["qkv"])
-            if rope_fused and L.wqkv_rope is not None:
+            if rope_fused:
                 ops.attn_prefill(ws["q"], kc, vc, batch, s, nh, hd, pos0, ws["att"], ws["q_lo"], kcl, vcl, ws["att_lo"])
             elif s == 1 and self.fuse_decode_rope:
                 ops.attn_decode_rope(ws["qkv"], batch, nh, hd, pos_dev if pos_dev is not None else pos0, self.cos, self.sin, kc, vc,
@@ -466,7 +472,7 @@ class HipLlamaEngine:
 
     def forward_tokens(self, input_ids: torch.Tensor, audio_segments: Sequence[Tuple[int, int, torch.Tensor]] = (),
                        pos0: int = 0, last_only: bool = False, num_layers: Optional[int] = None,
-                       return_hidden: bool = False) -> torch.Tensor:
+                       return_hidden: bool = False, hidden_sink: Optional[list] = None) -> torch.Tensor:
         """input_ids (B,S) int64 on device.  audio_segments: (batch index, position of <audio_start>,
         frames fp32 (F, mm) on device): projected frames overwrite rows start+1 .. start+F of the
         embedded sequence (the splice of m2t/models/llamav2.py:141-222).  Returns fp32 logits
@@ -481,7 +487,7 @@ class HipLlamaEngine:
         if pos0 + S > self.smax:
             raise ValueError(f"sequence of {pos0 + S} exceeds the engine's max_seq {self.smax}")
         if (S == 1 and pos0 > 0 and (self.decode_graph or self.decode_replay) and not audio_segments and num_layers is None
-                and not return_hidden and (self.decode_replay or not ops.kernel_timing_active())):
+                and not return_hidden and hidden_sink is None and (self.decode_replay or not ops.kernel_timing_active())):
             return self._decode_step_graph(input_ids, pos0)
         ws = self._workspace(B, S)
         h = ws["h"]
@@ -492,8 +498,15 @@ class HipLlamaEngine:
             a16, a16_lo = ops.split16(frames.contiguous(), torch.bfloat16, want_lo=self.split)
             r0 = b * S + start + 1
             ops.gemm16(a16, a16_lo, self.proj_w, self.proj_b, d.hidden_size, ops.EPI_F32, c=h[r0: r0 + F])
-        normed = self._layers_forward(ws, B, S, pos0, num_layers)
+        normed = self._layers_forward(ws, B, S, pos0, num_layers, hidden_sink=hidden_sink)
         self.cur_len = pos0 + S
+        if hidden_sink is not None:
+            # HF appends model.norm(h) last (LlamaModel.forward): here the kernel's output planes, hi (+ lo) -- 16 significant bits in the
+            # "split" flow, the bf16 value in the "bf16" flow
+            ops.rmsnorm_bf16(h, self.norm, d.rms_norm_eps, ws["x16"], ws["x16_lo"])
+            nh_ = ws["x16"].float() + (ws["x16_lo"].float() if ws["x16_lo"] is not None else 0.0)
+            hidden_sink.append(nh_.view(B, S, d.hidden_size))
+            normed = True
         if return_hidden:
             return h.view(B, S, d.hidden_size)
         if last_only and S > 1:

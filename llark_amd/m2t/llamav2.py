@@ -223,8 +223,9 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
         """m2t/models/llamav2.py:259-337.  Returns CausalLMOutputWithPast(loss, logits, past_key_values)."""
         if torch.is_grad_enabled() and labels is not None and any(p.requires_grad for p in self.parameters()):
             return self._forward_train(input_ids, labels, audio_encodings, attention_mask, return_dict)
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused kernels")
+        if output_attentions:
+            raise NotImplementedError("output_attentions: the flash-style attention kernels never materialise the S x S probabilities "
+                                      "(unused by m2t/; m2t/models/llamav2.py:259-270 only forwards the flag)")
         if position_ids is not None:
             raise NotImplementedError("custom position_ids are not used by the reference path")
         return_dict = True if return_dict is None else return_dict
@@ -251,15 +252,17 @@ class WrappedLlamav2ForCausalLM(LlamaForCausalLM):
             segs = plan_audio_splice(input_ids, feats, cfg, has_past)
         else:
             segs = []
-        logits = eng.forward_tokens(input_ids, segs, pos0=pos0)
+        hidden = [] if output_hidden_states else None      # HF layout: the stream entering every layer, then norm(last) -- (L + 1) x (B, S, H)
+        logits = eng.forward_tokens(input_ids, segs, pos0=pos0, hidden_sink=hidden)
         loss = None
         if labels is not None:
             loss = ops.cross_entropy_shifted(logits, labels.to(eng.device))
         cache = EngineCache(eng)
+        hs = tuple(hidden) if hidden is not None else None
         if not return_dict:
-            out = (logits, cache)
+            out = (logits, cache) + ((hs,) if hs is not None else ())
             return (loss,) + out if loss is not None else out
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=None, attentions=None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=hs, attentions=None)
 
     # ---- training (m2t/train.py path) ---------------------------------------------------------
     def _hip_trainer(self):

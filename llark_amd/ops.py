@@ -711,6 +711,11 @@ def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.
         scratch.data_ptr() if scratch is not None else None, scratch.numel() * 4 if scratch is not None else 0, _stream()), "gemm16_fragw")
 
 
+def gemm16_fragw_whole_tiles(split: bool, epilogue: int, m: int, n: int, kp: int) -> bool:
+    """Does the library's own choice run this fragment-major product as whole 128x256 tiles (llark_gemm16_fragw_whole_tiles)?"""
+    return bool(_lib.lib().llark_gemm16_fragw_whole_tiles(int(bool(split)), int(epilogue), int(m), int(n), int(kp)))
+
+
 def rope_qkv_row_order(nh: int, hd: int = 128) -> torch.Tensor:
     """Row order of the fused q|k|v weight for llark_gemm16_fragw_rope_qkv: inside every q and k head the rows go
     [0..31 | 64..95 | 32..63 | 96..127] (a rotation pair d, d + 64 then sits in MFMA tiles 2j, 2j + 1 of one wave: same lane, same

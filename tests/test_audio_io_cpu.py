@@ -255,3 +255,33 @@ def test_aiff_and_au_containers_decode_like_wav(tmp_path):
     (tmp_path / "g.au").write_bytes(hdr(1, 10) + bytes(10))                  # mu-law: not decoded -> the reference's ValueError path
     with pytest.raises(E.EmptyFileError):
         E.load_audio_from_file(tmp_path / "g.au")
+
+
+def test_id3_tagged_files_are_sniffed_behind_the_tag(tmp_path):
+    """an ID3v2 tag is skipped and the stream behind it decides -- FLAC is decoded, anything else (in practice mp3) raises
+    UnsupportedContainerError, which load_audio_from_file does NOT turn into EmptyFileError ("probably empty": jukebox/main.py:29-34)."""
+    import pytest
+    from llark_amd.jukebox import extract as E
+    from llark_amd.jukebox.audio_decode import UnsupportedContainerError, decode_audio
+
+    def id3(n):                                      # ID3v2.3 header + n bytes of tag body (sync-safe size)
+        return b"ID3\x03\x00\x00" + bytes([(n >> 21) & 0x7F, (n >> 14) & 0x7F, (n >> 7) & 0x7F, n & 0x7F]) + b"\x00" * n
+
+    mp3 = tmp_path / "song.mp3"
+    mp3.write_bytes(id3(300) + b"\xff\xfb\x90\x64" + b"\x00" * 400)
+    with pytest.raises(UnsupportedContainerError, match="mp3"):
+        decode_audio(str(mp3))
+    with pytest.raises(UnsupportedContainerError):
+        E.load_audio_from_file(str(mp3))
+    assert not issubclass(UnsupportedContainerError, ValueError)
+    ogg = tmp_path / "a.ogg"
+    ogg.write_bytes(b"OggS" + b"\x00" * 100)
+    with pytest.raises(UnsupportedContainerError):
+        E.load_audio_from_file(str(ogg))
+    # FLAC behind an ID3 tag: decoded like the bare stream
+    import flac_writer as FW
+    x = np.round(np.sin(np.arange(4000) * 0.05) * 12000).astype(np.int64)
+    bare = FW.write_flac(x[:, None], 44100, 16)
+    sr0, a0 = decode_audio(io.BytesIO(bare))
+    sr1, a1 = decode_audio(io.BytesIO(id3(77) + bare))
+    assert sr0 == sr1 == 44100 and np.array_equal(a0, a1)

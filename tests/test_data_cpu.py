@@ -128,3 +128,31 @@ def test_task_sample_probs_weight_the_shard_draw(tmp_path):
     a = list(D.micro_batches(pattern, tok, mm, 2, 64, epochs=3, seed=4, task_sample_probs={"mir": 0.5, "captioning": 0.5}))
     b = list(D.micro_batches(pattern, tok, mm, 2, 64, epochs=3, seed=4, task_sample_probs={"mir": 0.5, "captioning": 0.5}))
     assert all(torch.equal(x["input_ids"], y["input_ids"]) for x, y in zip(a, b)) and len(a) == len(b)    # seeded: reproducible
+
+
+def test_task_sample_probs_are_global_not_per_rank(tmp_path):
+    """the reference's repeat_shards() weights and samples the GLOBAL url list and split_by_node comes afterwards
+    (m2t/data_modules.py:441-462): a rank whose r::world subset holds no shard of a task must still see that task.  Two ranks,
+    shards [mir, captioning, mir, captioning]: rank 0's own subset is all-mir, rank 1's all-captioning; with weights mir 0.5 /
+    captioning 0.5 both ranks read both tasks over a few epochs, the two ranks' draws are disjoint positions of ONE shared order,
+    and a zero-weight task never appears on any rank."""
+    names = ["mir-000", "captioning-000", "mir-001", "captioning-001"]
+    for i, nm in enumerate(names):
+        _make_shard(tmp_path / f"{nm}.tar", [f"{nm[0]}{i}"])
+    tok = ToyTokenizer()
+    tok.add_tokens(["<audio_patch>", "<audio_start>", "<audio_end>"], special_tokens=True)
+    mm = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=True)
+    pattern = ",".join(f"{tmp_path}/{nm}.tar" for nm in names)
+    ids = lambda bs: {tuple(r.tolist()) for b in bs for r in b["input_ids"]}
+    per_task = {}
+    for task in ("mir", "captioning"):
+        only = list(D.micro_batches(pattern, tok, mm, 2, 64, epochs=8, seed=2, task_sample_probs={task: 1.0, "mir" if task != "mir" else "captioning": 0.0}))
+        per_task[task] = ids(only)
+    common = per_task["mir"] & per_task["captioning"]                      # the "tempo ?" pair every clip carries
+    mir_only, cap_only = per_task["mir"] - common, per_task["captioning"] - common
+    assert mir_only and cap_only
+    for rank in (0, 1):
+        got = ids(D.micro_batches(pattern, tok, mm, 2, 64, rank=rank, world=2, epochs=12, seed=2, task_sample_probs={"mir": 0.5, "captioning": 0.5}))
+        assert got & mir_only and got & cap_only, f"rank {rank} never saw one of the tasks"
+        zero = ids(D.micro_batches(pattern, tok, mm, 2, 64, rank=rank, world=2, epochs=6, seed=2, task_sample_probs={"mir": 1.0, "captioning": 0.0}))
+        assert zero and not (zero & cap_only), f"rank {rank} read a zero-weight task"

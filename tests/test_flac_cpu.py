@@ -128,5 +128,5 @@ def test_load_audio_from_file_reads_flac_like_wav(tmp_path):
     wavfile.write(tmp_path / "lo.wav", 22050, x22[:, 0].astype(np.int16))
     np.testing.assert_array_equal(E.load_audio_from_file(tmp_path / "lo.flac"), E.load_audio_from_file(tmp_path / "lo.wav"))
     (tmp_path / "x.ogg").write_bytes(b"OggS" + bytes(64))
-    with pytest.raises(E.EmptyFileError):                                # an undecodable container surfaces like the reference's ValueError path
+    with pytest.raises(AD.UnsupportedContainerError):                    # a container that is not decoded here is NOT reported as an empty file
         E.load_audio_from_file(tmp_path / "x.ogg")

@@ -246,6 +246,19 @@ def test_wrapped_model_api_loss_generate_errors():
     report_close("wrapped logits vs reference golden", r.logits.cpu(), gold, 1e-3 * gold.abs().max().item())
     assert abs(r.loss.item() - float(z["c1_loss"])) < 1e-3 * max(1.0, float(z["c1_loss"]))
     assert torch.equal(r_list.logits, r.logits)
+    # output_hidden_states (m2t/models/llamav2.py:259-270 -> HF LlamaModel.forward): the stream entering every layer, then norm(last);
+    # checked against the oracle truncated at each depth (return_hidden = the stream after `num_layers` layers) and its final RMSNorm
+    with torch.no_grad():
+        rh = m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), output_hidden_states=True)
+        with pytest.raises(NotImplementedError):
+            m(input_ids=ids.cuda(), audio_encodings=aud.cuda(), output_attentions=True)
+    assert torch.equal(rh.logits, r.logits) and len(rh.hidden_states) == spec.num_hidden_layers + 1
+    wf = {k: v.float() for k, v in w.items()}
+    for depth in range(spec.num_hidden_layers + 1):
+        ref_h = LR.forward(wf, spec, ids, aud, num_layers=depth, return_hidden=True)["hidden"]
+        if depth == spec.num_hidden_layers:
+            ref_h = LR.rmsnorm(ref_h, wf["model.norm.weight"], spec.rms_norm_eps)
+        report_close(f"hidden_states[{depth}]", rh.hidden_states[depth].cpu(), ref_h, 1e-3 * float(ref_h.abs().max()))
     # state-dict keys are the reference's
     keys = set(m.state_dict().keys())
     assert {"model.mm_projector.weight", "model.mm_projector.bias", "model.embed_tokens.weight", "lm_head.weight"} <= keys
@@ -549,10 +562,11 @@ def test_engine_prefill_rope_fused_bit_equal_at_7b_width(precision):
         eng.fuse_prefill_rope = mode
         eng.set_layer(0, *layer)
         eng.set_globals(*glob)
-        assert (eng.layers[0].wqkv_rope is not None) == (mode == "auto")
+        assert eng.layers[0].wqkv_rope is None                      # built lazily, by the first prefill that takes the fused epilogue
         assert eng._prefill_rope_fused(8, 371) == (mode == "auto")
         assert eng._prefill_rope_fused(1, 371) == (mode == "auto" and precision == "bf16")
         logits = eng.forward_tokens(ids).clone()
+        assert (eng.layers[0].wqkv_rope is not None) == (mode == "auto")
         res.append((logits, eng.k_cache.clone(), eng.vt_cache.clone(), eng.k_cache_lo.clone() if eng.split else None))
         del eng
     a, b = res
