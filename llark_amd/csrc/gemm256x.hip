@@ -64,7 +64,7 @@ struct Mfma16<bf16_t> {
 
 #define VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
-// Profiling build only (-DG256X_PROF; scripts/gpu_runs/r05/build_prof.sh, never shipped): wave 0 of every workgroup stamps the
+// Profiling build only (-DG256X_PROF; scripts/build_variant.sh prof "-DG256X_PROF" gemm.hip gemm256x.hip, never shipped): wave 0 of every workgroup stamps the
 // constant-rate clock (s_memrealtime, 100 MHz) at the start of a tile's K loop, at its end and after the epilogue's last store has
 // been issued -- p.prof[(workgroup * 64 + tile) * 4 + {0, 1, 2}] -- so that the exposed epilogue (stores acknowledged + chunk barrier =
 // next K-loop start minus K-loop end) and the alignment of the workgroups of an XCD can be read off (profiles/r05_gemm256x_tile_times*).
@@ -104,6 +104,19 @@ __device__ __forceinline__ float fp_pin(float x) {
     return x;
 }
 
+// x - (float)h in one instruction: v_fma_mix_f32 takes the fp16 operand as it is (no v_cvt_f32_f16 back); h * -1 is exact, so the value is
+// bit for bit the (x - (float)h) of rounds 1-4.
+template <typename T>
+__device__ __forceinline__ float sub_hi(float x, T h) { return __builtin_fmaf((float)h, -1.0f, x); }
+// Consumer of a folded LayerNorm: rstd (acc - mu g) + b evaluated as acc rstd + (b - (mu rstd) g) -- two fused multiply-adds per element
+// instead of mul, sub, mul, add (the epilogue is VALU-bound: 7 us of issue per 256 x 256 tile, profiles/r05_gemm256x_tile_times.txt).
+__device__ __forceinline__ f32x4_t ln_apply(const f32x4_t a, const float mu_rstd, const float rstd, const f32x4_t g, const f32x4_t b) {
+    f32x4_t v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(a[r], rstd, __builtin_fmaf(-mu_rstd, g[r], b[r]));
+    return v;
+}
+
 // gamma_n for the producer epilogue comes through the LDS.  A vector load placed between the stores would wait for them (vmcnt counts
 // stores, in order: 21 us per tile measured with the loads at the point of use), eight preloaded vectors would need 32 registers that
 // do not exist (spills are scratch = vector memory again), and the scalar cache needs 16 SGPRs per tile (3000 v_writelane / v_readlane
@@ -137,28 +150,29 @@ __device__ __forceinline__ void swap_rows16(unsigned& a, unsigned& b) {
 #define G256X_WIDE_PLANES 1
 #endif
 
-// Residual epilogue in two halves (row tiles 0, 1 | 2, 3): R may alias C (h += ...), so a load placed after a store can never be
-// hoisted above it -- the residuals of a half (16 x 16 bytes per lane) are all requested before its first store.  The kernel requests
-// the FIRST half right after the K loop, BEFORE the next tile's LDS-DMA prologue goes out: loads return in order, so behind the
-// prologue they would wait for its 192 KiB to land first (epilogue_load_resid / epilogue_store below).
+// Residual epilogue by row tiles (16 rows = 8 x 16 bytes per lane each), two register sets: R may alias C (h += ...), so a load placed
+// after a store can never be hoisted above it, and vmcnt retires loads and stores in issue order -- a load issued behind a store cannot
+// be consumed before that store is acknowledged.  Rounds 3-4 ran two halves: load (0, 1) | store (0, 1) | load (2, 3) | store (2, 3), so the
+// second pair of loads sat behind 32 just-issued stores and the wave waited out their whole round trip.  Round 5 (the per-tile stamps of
+// profiles/r05_gemm256x_tile_times.txt: 23 us to ISSUE a producer epilogue, 7 of them VALU) staggers them: load 0, 1 | store 0 | load 2 |
+// store 1 | load 3 | store 2 | store 3 -- the loads of row tile t + 2 go out behind the stores of row tile t and are consumed only after the
+// stores of t + 1 have been computed and issued.  Row tiles 0, 1 are requested right after the K loop, BEFORE the next tile's LDS-DMA
+// prologue goes out: loads return in order, so behind the prologue they would wait for its 192 KiB to land first.
 template <int EPI>
-__device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t (&res)[2][Cfg256X::TN], const int half2, const int m0, const int n0,
+__device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t (&res)[Cfg256X::TN], const int tm, const int m0, const int n0,
                                                     const int wm, const int wn, const int lane) {
     typedef Cfg256X C;
     if (EPI != EPI_RESID) return;
     const int l15 = lane & 15, g4 = (lane >> 4) << 2;
     const int ncol = n0 + wn * 64 + g4;
     const bool full = (m0 + C::BM <= p.M) && (n0 + C::BN <= p.N);
+    const int m = m0 + wm * 64 + tm * 16 + l15;
+    const bool row_ok = full || m < p.M;
+    const float* rrow = p.R + (size_t)(row_ok ? m : 0) * p.ldr + ncol;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + wm * 64 + (2 * half2 + t) * 16 + l15;
-        const bool row_ok = full || m < p.M;
-        const float* rrow = p.R + (size_t)(row_ok ? m : 0) * p.ldr + ncol;
-#pragma unroll
-        for (int tn = 0; tn < C::TN; ++tn) {
-            const int co = (tn >> 2) * 128 + (tn & 3) * 16;
-            res[t][tn] = (row_ok && (full || ncol + co < p.N)) ? *(const f32x4_t*)(rrow + co) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int tn = 0; tn < C::TN; ++tn) {
+        const int co = (tn >> 2) * 128 + (tn & 3) * 16;
+        res[tn] = (row_ok && (full || ncol + co < p.N)) ? *(const f32x4_t*)(rrow + co) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -167,8 +181,8 @@ __device__ __forceinline__ void epilogue_load_resid(const GemmParams& p, f32x4_t
 // LN = 1: LayerNorm-folded consumer (mean / rstd of the row applied here), LN = 2: producer of the next LayerNorm's operand planes and
 // of the row statistics' partial sums (GemmParams: ln_stat / ln_vec / ln_part).
 template <typename T, int EPI, int LN>
-__device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* smem, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[2][Cfg256X::TN],
-                                               const f32x4_t (&bias)[Cfg256X::TN], const float2 (&st)[Cfg256X::TM], const int half2, const int m0, const int n0,
+__device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* smem, f32x4_t (&acc)[Cfg256X::TM][Cfg256X::TN], f32x4_t (&res)[Cfg256X::TN],
+                                               const f32x4_t (&bias)[Cfg256X::TN], const float2 (&st)[Cfg256X::TM], const int tm, const int m0, const int n0,
                                                const int wm, const int wn, const int lane) {
     typedef Cfg256X C;
     typedef typename Mfma16<T>::out4 out4;
@@ -184,12 +198,10 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
     const bool wide = PLANES && G256X_WIDE_PLANES && full && (p.ldo & 7) == 0 && (((uintptr_t)p.Ohi | (uintptr_t)p.Olo) & 15) == 0;
     const int gsel = lane >> 4;
     const int wcol = n0 + wn * 64 + ((gsel & 1) << 4) + ((gsel >> 1) << 3);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tm = 2 * half2 + t;
+    {
         const int m = m0 + wm * 64 + tm * 16 + l15;
-        if (!full && m >= p.M) continue;                             // the four lanes of a row (l15, g = 0 .. 3) leave together
-        const float mu = st[tm].x, rstd = st[tm].y;
+        if (!full && m >= p.M) return;                               // the four lanes of a row (l15, g = 0 .. 3) leave together
+        const float mu = st[tm].x, rstd = st[tm].y, mu_rstd = mu * rstd;
         float sx = 0.f, sq = 0.f;
         if (wide) {
 #pragma unroll
@@ -201,12 +213,12 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                     const int tn = 2 * tp + u;
                     const int co = co0 + 16 * u;
                     f32x4_t v;
-                    if (LN == 1) v = (acc[tm][tn] - mu * gamma4(smem, wm * 2 + wn, tn, gsel, 0)) * rstd + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
+                    if (LN == 1) v = ln_apply(acc[tm][tn], mu_rstd, rstd, gamma4(smem, wm * 2 + wn, tn, gsel, 0), gamma4(smem, wm * 2 + wn, tn, gsel, 1));
                     else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                     else v = acc[tm][tn] + bias[tn];
                     out4 hi, lo;
                     if (LN == 2) {
-                        const f32x4_t out = res[t][tn] + v;
+                        const f32x4_t out = res[tn] + v;
                         *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = out;
                         const f32x4_t gm = gamma4(smem, wm * 2 + wn, tn, gsel, 0);
 #pragma unroll
@@ -215,7 +227,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                             const float x = fp_pin((d * rstd) * gm[r]);
                             const T h = (T)x;
                             hi[r] = h;
-                            lo[r] = (T)(x - (float)h);
+                            lo[r] = (T)sub_hi<T>(x, h);
                             sx += d;
                             sq = fmaf(d, d, sq);
                         }
@@ -226,7 +238,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                             if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
                             const T h = (T)x;
                             hi[r] = h;
-                            lo[r] = (T)(x - (float)h);
+                            lo[r] = (T)sub_hi<T>(x, h);
                         }
                     }
                     ph[u] = __builtin_bit_cast(uint2, hi);
@@ -246,13 +258,13 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                 const int co = (tn >> 2) * 128 + (tn & 3) * 16;
                 if (!full && ncol + co >= p.N) continue;             // N % 4 == 0 (checked by the launcher): a vector is all in or all out
                 f32x4_t v;
-                if (LN == 1) v = (acc[tm][tn] - mu * gamma4(smem, wm * 2 + wn, tn, gsel, 0)) * rstd + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
+                if (LN == 1) v = ln_apply(acc[tm][tn], mu_rstd, rstd, gamma4(smem, wm * 2 + wn, tn, gsel, 0), gamma4(smem, wm * 2 + wn, tn, gsel, 1));
                 else if (LN == 2) v = acc[tm][tn] + gamma4(smem, wm * 2 + wn, tn, gsel, 1);
                 else v = acc[tm][tn] + bias[tn];
                 if (EPI == EPI_F32) {
                     *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = v;
                 } else if (EPI == EPI_RESID) {
-                    const f32x4_t out = res[t][tn] + v;
+                    const f32x4_t out = res[tn] + v;
                     *(f32x4_t*)(p.C + (size_t)m * p.ldc + ncol + co) = out;
                     if (LN == 2) {
                         const f32x4_t gm = gamma4(smem, wm * 2 + wn, tn, gsel, 0);
@@ -263,7 +275,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                             const float x = fp_pin((d * rstd) * gm[r]);
                             const T h = (T)x;
                             hi[r] = h;
-                            lo[r] = (T)(x - (float)h);
+                            lo[r] = (T)sub_hi<T>(x, h);
                             sx += d;
                             sq = fmaf(d, d, sq);
                         }
@@ -279,7 +291,7 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, const char* 
                         if (EPI == EPI_QGELU_SPLIT) x = quick_gelu(x);
                         const T h = (T)x;
                         hi[r] = h;
-                        lo[r] = (T)(x - (float)h);
+                        lo[r] = (T)sub_hi<T>(x, h);
                     }
                     const size_t o = (size_t)m * p.ldo + ncol + co;
                     *(out4*)((T*)p.Ohi + o) = hi;
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
             __builtin_amdgcn_s_barrier();                                  // every wave's last (re-)requests have landed: the LDS is free
             PROF_STAMP(1);
             // bias and the first half of the residuals are requested AHEAD of the next tile's prologue (in-order returns)
-            f32x4_t bias[C::TN], res[2][C::TN];
+            f32x4_t bias[C::TN], res0[C::TN], res1[C::TN];
             // Folded LayerNorm: every load of the epilogue goes out HERE, before its first store -- vmcnt counts stores too, in order, so a
             // load behind a store waits for the store's round trip.  The per-column vectors (LN = 2: gamma | bias, LN = 1: gamma.W | bias')
             // are parked in the LDS, the row statistics of the consumer (4 row tiles) stay in registers.
@@ -585,7 +597,8 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                     st[tm] = (rowst != nullptr && (whole || m < p.M)) ? *(const float2*)(rowst + 2 * (size_t)m) : make_float2(0.f, 1.f);
                 }
             }
-            epilogue_load_resid<EPI>(p, res, 0, m0, n0, wm, wn, lane);
+            epilogue_load_resid<EPI>(p, res0, 0, m0, n0, wm, wn, lane);
+            epilogue_load_resid<EPI>(p, res1, 1, m0, n0, wm, wn, lane);
             if (LN != 0) gamma_park(smem, gv, w, lane);
             __builtin_amdgcn_sched_barrier(0);
             if (ch + 1 < nchunks) {
@@ -601,9 +614,16 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 0, m0, n0, wm, wn, lane);
-            epilogue_load_resid<EPI>(p, res, 1, m0, n0, wm, wn, lane);
-            epilogue_store<T, EPI, LN>(p, smem, acc, res, bias, st, 1, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res0, bias, st, 0, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_load_resid<EPI>(p, res0, 2, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res1, bias, st, 1, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_load_resid<EPI>(p, res1, 3, m0, n0, wm, wn, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res0, bias, st, 2, m0, n0, wm, wn, lane);
+            epilogue_store<T, EPI, LN>(p, smem, acc, res1, bias, st, 3, m0, n0, wm, wn, lane);
             PROF_STAMP(2);
             ++prof_tile;
         }
