@@ -307,7 +307,7 @@ PRIOR_DT = {"f16x2": "fp16x2-split(fp32-class)", "lo8": "fp16+e4m3-split(fp32 ac
 # fp16 MFMA rate (f16x2 = two fp16 passes; lo8 = one fp16 pass + one MX-fp8 MFMA per 64 k, 64 cycles against the 128 of four fp16
 # MFMAs = 1.5), and the committed PMC record of that kernel (separate --pmc passes: FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
 PRIOR_GEMM = {
-    "f16x2": ("gemm_split_f16", "gemm256x_kernel<f16> (v_mfma_f32_16x16x32_f16: the K = 4800 products, and the K = 1216 product when its epilogue produces the next LayerNorm's operand) / gemm256n_kernel<f16> (K = 1216 without the fold; 32x32x16): two fp16 MFMA passes, fp32 accumulate", 2.0, "r04_pmc_gemm256x.json"),
+    "f16x2": ("gemm_split_f16", "gemm256x_kernel<f16> (v_mfma_f32_16x16x32_f16: the K = 4800 products, and the K = 1216 product when its epilogue produces the next LayerNorm's operand) / gemm256n_kernel<f16> (K = 1216 without the fold; 32x32x16): two fp16 MFMA passes, fp32 accumulate", 2.0, "r05_pmc_gemm256x.json"),
     "lo8": ("gemm_lo8_f16", "gemm256_lo8n_kernel (fp16 hi pass + MX-fp8 low plane)", 1.5, "r02_pmc_gemm_lo8.json"),
 }
 
