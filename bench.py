@@ -348,8 +348,17 @@ def conv_roofline(timers, args):
         return None
     launches, ms, work = timers["vqvae_encode"]
     gbs = work / (ms * 1e-3) / 1e9
+    traffic, traffic_note = None, "no PMC record committed"
+    try:                                                              # committed record of the same kernels (annotation: nothing timed reads it)
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_conv.json")))
+        traffic = int(rec["traffic_bytes_per_call"] * args.batch / rec["clips_per_call"])
+        traffic_note = ("NOT measured in this run: memory-side bytes of one encode_top call (scaled to this batch) from the committed rocprofv3 --pmc passes in "
+                        "profiles/r05_pmc_conv.json (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE): %.2fx the per-layer-fused algorithmic bytes -- the fused stages keep "
+                        "intermediate activations in LDS" % rec["traffic_over_algorithmic"])
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "hbm", "kernel": "llark_vqvae_encode (conv / resblock chain + codebook argmin, one event pair per batch)",
-            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "algorithmic_gb_per_clip": round(work / launches / args.batch / 1e9, 4), "launches": launches,
             "ms_per_clip": round(ms / launches / args.batch, 4)}
 

@@ -296,6 +296,12 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 // 0.4052 of the MFMA peak (forward 44.76 -> 43.64 ms per 8 clips); the hi + lo form LOSES 3 % with its weight loads moved into the gaps
 // (0.2102 -> 0.2028: its MFMAs come in dependent hi / lo pairs and it has one register set only, so there is no latency to hide the
 // loads behind) and keeps round 3's order: loads, then MFMAs.
+#ifndef GEMM_BD_TAIL_SKIP
+#define GEMM_BD_TAIL_SKIP 0        // 1 = a last row tile with <= 32 live rows issues one row block's MFMAs only (round 5; see bd_kstep).
+                                   // Bit-identical, and measured SLOWER (profiles/r05_llama_bd_tail_skip_ab.txt: Llama stage 83.0 -> 89.7 ms split,
+                                   // 43.9 -> 45.7 ms bf16 on one box): the second loop body costs the 128x256 kernel registers it does not have
+                                   // (bf16 227 -> 248 VGPRs, split 244 -> 256 + 2 spilled) -- more than the 2.6 % of MFMA work it removes.  Off.
+#endif
 #ifndef GEMM_BD_SPLIT_PAIRS
 #define GEMM_BD_SPLIT_PAIRS 0      // 1 = the hi + lo form's A fragments as two half sets read one half ahead (round 5; see bd_kstep)
 #endif
@@ -303,20 +309,24 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 #define GEMM_BD_SPLIT_ORDER 0      // 0 = hi / lo pairs back to back (rounds 1-3; default); 1 = all hi products of a sub-step, then all lo:
                                    // measured 6 % SLOWER on the Llama stage (0.216 -> 0.203, profiles/r04_llama_bd_split_order_ab.txt)
 #endif
-template <typename T, bool SPLIT, typename C, typename LB>
+// NTM (round 5) = how many of the tile's TM row blocks of 32 hold rows below M: the LAST row tile of a product whose M is not a multiple
+// of the tile height (the Llama prefill: M = 8 x 371 = 2968 = 23 x 128 + 24) issues the MFMAs and fragment reads of its live row blocks
+// only -- a quarter of the matrix work for that tile instead of all of it for 24 of 128 rows (3.4 % of every product).  The dead blocks'
+// accumulators stay zero and the epilogue masks their rows as before: results unchanged bit for bit.
+template <typename T, bool SPLIT, typename C, int NTM = C::TM, typename LB>
 __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const int lane, typename Mfma<T>::frag (&ring)[4][C::TN],
                                          f32x16_t (&acc)[C::TM][C::TN], const int q0, LB&& load_b) {
     typedef typename Mfma<T>::frag frag;
-    constexpr int NM = C::TM * C::TN;
+    constexpr int NM = NTM * C::TN;
     const int l31 = lane & 31, lhi = lane >> 5;
     if constexpr (!SPLIT) {
-        frag ah[2][C::TM];
+        frag ah[2][NTM];
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) ah[0][tm] = *(const frag*)(sA + C::off(tm * 32 + l31, lhi));   // sub-step 0 follows the K-step's barrier: exposed
+        for (int tm = 0; tm < NTM; ++tm) ah[0][tm] = *(const frag*)(sA + C::off(tm * 32 + l31, lhi));   // sub-step 0 follows the K-step's barrier: exposed
         __builtin_amdgcn_sched_barrier(0);
         static_for<4>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value, cur = s & 1;
-            constexpr int items = C::TN + (s < 3 ? C::TM : 0);
+            constexpr int items = C::TN + (s < 3 ? NTM : 0);
             static_for<NM>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value, tm = i / C::TN, tn = i % C::TN;
                 acc[tm][tn] = Mfma<T>::run(ah[cur][tm], ring[s][tn], acc[tm][tn]);
@@ -331,7 +341,7 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-    } else if constexpr (GEMM_BD_SPLIT_PAIRS && C::TM == 4) {
+    } else if constexpr (GEMM_BD_SPLIT_PAIRS && C::TM == 4 && NTM == 4) {
         // Round 5: the hi + lo form has ONE set of A fragments (32 registers; 244 of 256 are taken), so rounds 1-4 read all eight
         // fragments of a sub-step in front of its MFMAs and waited for the LDS four times per K-step.  Here the set is used as two
         // HALVES (row tiles 0, 1 | 2, 3): while the MFMAs of one half run, the fragments of the other half -- of this sub-step or the
@@ -373,15 +383,15 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
 #pragma unroll
             for (int tn = 0; tn < C::TN; ++tn) load_b((s + 3) & 3, tn, q0 + s + 3);
             __builtin_amdgcn_sched_barrier(0);
-            frag ah[C::TM], al[C::TM];
+            frag ah[NTM], al[NTM];
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm) {
+            for (int tm = 0; tm < NTM; ++tm) {
                 ah[tm] = *(const frag*)(sA + C::off(tm * 32 + l31, s * 2 + lhi));
                 al[tm] = *(const frag*)(sL + C::off(tm * 32 + l31, s * 2 + lhi));
             }
 #if GEMM_BD_SPLIT_ORDER == 0
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
+            for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn) {
                     acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
@@ -391,12 +401,12 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
             // all hi products of the sub-step, then all lo products: the two MFMAs on one accumulator are TM x TN issue slots apart
             // instead of back to back (same order per accumulator: hi then lo, k ascending -- results bit-identical)
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
+            for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(ah[tm], ring[s][tn], acc[tm][tn]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tm = 0; tm < C::TM; ++tm)
+            for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(al[tm], ring[s][tn], acc[tm][tn]);
 #endif
@@ -647,14 +657,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_kernel(const Gemm
         q = q < nk16 ? q : nk16 - 1;                                       // tail: harmless re-load of the last chunk
         ring[slot][tn] = wbase[tn][(size_t)q * 64];
     };
-    for (int kt = 0; kt < nk; ++kt) {
-        loadA(kt + 1 < nk ? kt + 1 : kt);          // unconditional (tail: harmless re-load) so the counted vmcnt waits stay exact
-        __builtin_amdgcn_sched_barrier(0);
-        const char* sA = smem + (kt & 1) * ASTAGE;
-        bd_kstep<T, SPLIT, C>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
-        if (kt + 1 < nk) storeA((kt + 1) & 1);
-        __syncthreads();
-    }
+    auto kloop = [&](auto ntm_tag) __attribute__((always_inline)) {
+        constexpr int NTM = decltype(ntm_tag)::value;
+        for (int kt = 0; kt < nk; ++kt) {
+            loadA(kt + 1 < nk ? kt + 1 : kt);          // unconditional (tail: harmless re-load) so the counted vmcnt waits stay exact
+            __builtin_amdgcn_sched_barrier(0);
+            const char* sA = smem + (kt & 1) * ASTAGE;
+            bd_kstep<T, SPLIT, C, NTM>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
+            if (kt + 1 < nk) storeA((kt + 1) & 1);
+            __syncthreads();
+        }
+    };
+    if (GEMM_BD_TAIL_SKIP && C::TM > 1 && p.M - m0 <= 32) kloop(std::integral_constant<int, 1>{});      // ragged last row tile: one live row block
+    else kloop(std::integral_constant<int, C::TM>{});
     if constexpr (EPI == EPI_ROPE_QKV) gemm_epilogue_rope_qkv<T, SPLIT, C>(p, acc, m0, n0, wn, lane, smem);
     else gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, bz);
 }
@@ -843,14 +858,19 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
             q = q < qlast ? q : qlast;                                     // tail: harmless re-load of the piece's last chunk
             ring[slot_][tn] = wbase[tn][(size_t)q * 64];
         };
-        for (int kt = kt0; kt < kt1; ++kt) {
-            loadA(kt + 1 < kt1 ? kt + 1 : kt);
-            __builtin_amdgcn_sched_barrier(0);
-            const char* sA = smem + ((kt - kt0) & 1) * ASTAGE;
-            bd_kstep<T, SPLIT, C>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
-            if (kt + 1 < kt1) storeA((kt + 1 - kt0) & 1);
-            __syncthreads();
-        }
+        auto kloop = [&](auto ntm_tag) __attribute__((always_inline)) {
+            constexpr int NTM = decltype(ntm_tag)::value;
+            for (int kt = kt0; kt < kt1; ++kt) {
+                loadA(kt + 1 < kt1 ? kt + 1 : kt);
+                __builtin_amdgcn_sched_barrier(0);
+                const char* sA = smem + ((kt - kt0) & 1) * ASTAGE;
+                bd_kstep<T, SPLIT, C, NTM>(sA, sA + OFF_L, lane, ring, acc, kt * 4, load_b1);
+                if (kt + 1 < kt1) storeA((kt + 1 - kt0) & 1);
+                __syncthreads();
+            }
+        };
+        if (GEMM_BD_TAIL_SKIP && C::TM > 1 && p.M - m0 <= 32) kloop(std::integral_constant<int, 1>{});  // ragged last row tile (see bd_kstep)
+        else kloop(std::integral_constant<int, C::TM>{});
 
         // Who finishes a shared tile.  Uniform split: the piece with the LAST K range -- the block order is piece-major (see `slot`
         // above), so it has a higher block id than the other pieces of its tile: it only ever waits for workgroups that were

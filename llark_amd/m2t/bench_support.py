@@ -99,9 +99,20 @@ class LLMWorkload:
             return None
         launches, ms, _ = timers[key]
         achieved = self.flops_per_step() * args.steps / (ms * 1e-3) / 1e12
+        traffic = None
+        try:                                                          # committed PMC record (7B, 8 x 371 only): average bytes per GEMM launch of a forward
+            import json
+            import os
+            rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles", "r05_pmc_llm.json")))
+            if self.batch == 8 and self.dims.num_hidden_layers == 32:
+                traffic = rec["per_forward"]["split" if self.engine.split else "bf16"]["traffic_bytes_per_launch_avg"]
+        except (OSError, ValueError, KeyError):
+            pass
         return {"bound": "mfma", "kernel": "gemm_kernel<bf16%s>" % (",split" if self.engine.split else ""),
                 "mfma_passes": 2 if self.engine.split else 1, "achieved": round(achieved, 2), "peak": 2500.0,
-                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": None, "launches": launches,
+                "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "traffic": traffic,
+                "traffic_note": "memory-side bytes per GEMM launch (average over the 129 launches of a forward) from the committed --pmc passes in profiles/r05_pmc_llm.json; not measured in this run" if traffic else None,
+                "launches": launches,
                 "avg_launch_ms": round(ms / launches, 4),
                 "rope_in_qkv_epilogue": bool(self.engine._prefill_rope_fused(self.batch, self.ids.shape[1])),
                 "whole_forward_flops_t": round((self.flops_per_step() + self.attention_flops_per_step()) / 1e12, 2),
