@@ -247,7 +247,8 @@ int llark_pack_weight_lo8(const void* wt, int ldw, int n, int kp, int sw, void* 
  * ceil(n/32)*32 * kp elements laid out as 1-KiB chunks [row tile][k16 step][lane 0..63][8 elements] = one MFMA
  * B fragment per chunk (rows >= n are zero).  llark_gemm16_fragw computes the same product as llark_gemm16 but
  * streams these chunks L2 -> VGPR (the weight never goes through LDS); variant: -1 library choice,
- * 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogues). */
+ * 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogues).   variant 2 (round 5, csrc/gemm_bda.hip; hi + lo bf16 operands, kp >= 192): the same 128x256 tiles
+ * with A staged by LDS-DMA and the A fragments read one sub-step ahead -- results bit-identical to variant 0. */
 int llark_pack_weight16_frag(const void* wt, int ldw, int n, int kp, void* dst, llark_stream_t stream);
 int llark_gemm16_fragw(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
                        const void* wfrag, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,

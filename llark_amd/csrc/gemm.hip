@@ -31,6 +31,8 @@
 #include <new>
 
 #include "gemm_core.h"
+#include "gemm_rope_epi.h"
+#include "gemm_bda_loop.h"
 
 namespace llark {
 
@@ -296,6 +298,9 @@ static int dispatch(const GemmParams& p, bool split, int epi, hipStream_t s) {
 // 0.4052 of the MFMA peak (forward 44.76 -> 43.64 ms per 8 clips); the hi + lo form LOSES 3 % with its weight loads moved into the gaps
 // (0.2102 -> 0.2028: its MFMAs come in dependent hi / lo pairs and it has one register set only, so there is no latency to hide the
 // loads behind) and keeps round 3's order: loads, then MFMAs.
+#ifndef GEMM_BDA
+#define GEMM_BDA 2                 // 2 (default since round 5) = bf16 products on 128x256 tiles, hi + lo AND plain, take gemm_bda.hip / gemm_bda_loop.h; 1 = hi + lo only; (A by LDS-DMA, fragments read ahead: +15 .. 19 %, bit-identical); 0 = gemm_bd_kernel
+#endif
 #ifndef GEMM_BD_TAIL_SKIP
 #define GEMM_BD_TAIL_SKIP 0        // 1 = a last row tile with <= 32 live rows issues one row block's MFMAs only (round 5; see bd_kstep).
                                    // Bit-identical, and measured SLOWER (profiles/r05_llama_bd_tail_skip_ab.txt: Llama stage 83.0 -> 89.7 ms split,
@@ -413,144 +418,6 @@ __device__ __forceinline__ void bd_kstep(const char* sA, const char* sL, const i
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// Epilogue of the Llama q|k|v product with RoPE, the head split and both cache writes folded in (EPI_ROPE_QKV; replaces the fp32
-// qkv tensor and the rope_split_kernel launch of llama.hip in the prefill: m2t/models/llamav2.py:224-234 -> HF LlamaAttention
-// q_proj / k_proj / v_proj + apply_rotary_pos_emb + the cache append).  Written for the 128x256 B-direct tile (4 waves side by side,
-// two 32-column MFMA tiles each): a 256-column tile is two heads of ONE of the q / k / v regions (nh even), wave wn holds 64 columns
-// of head n0 / 128 + wn / 2.  The q / k weight rows of every head are PERMUTED at pack time to [0..31 | 64..95 | 32..63 | 96..127]
-// (ops.rope_qkv_row_order), the same trick as the SwiGLU gate / up interleave: MFMA tile 0 of the wave then holds x1 = x[d],
-// tile 1 holds x2 = x[d + 64] for d = 32 (wn % 2) + (lane & 31), in the same lane and register -- the rotation
-//     out[d] = x1 cos - x2 sin,   out[d + 64] = x2 cos + x1 sin          (rotate_half = cat(-x2, x1))
-// needs no cross-lane traffic.  A column's dot product does not depend on where its weight row sits, and the arithmetic below is
-// rope_split_kernel's operation for operation, so q, the K cache and V^T are BIT-equal to the two-kernel path whenever that path
-// runs the same whole-tile kernel (tests/test_llama_gpu.py).  V rows keep their natural order; the V tiles are transposed through
-// wave-private LDS patches so that their stores run along the cache's contiguous (position) axis.
-// cos / sin come from the [max_pos][64] tables (L2-resident); the loads of row block tm + 1 are issued before the stores of
-// block tm so that no load waits behind a store.
-// ------------------------------------------------------------------------------------------
-template <typename T, bool SPLIT, typename C, bool FULL>
-__device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                                            const int wn, const int lane, char* smem) {
-    static_assert(C::WM == 1 && C::WN == 4 && C::TN == 2 && C::BN == 256, "rope epilogue: 128x256 tile, waves 1 x 4, two column tiles per wave");
-    static_assert(std::is_same<T, bf16_t>::value, "rope epilogue: bf16 planes");
-    const int H = p.rope_nh * 128;
-    // 0 = q, 1 = k, 2 = v (uniform: H % 256 == 0).  The division runs on the vector ALU; readfirstlane puts region / head back into
-    // scalar registers, or the buffer descriptors selected by `region` count as divergent and every store becomes a waterfall loop.
-    const int region = __builtin_amdgcn_readfirstlane(n0 / H);
-    const int head = __builtin_amdgcn_readfirstlane((n0 - region * H) / 128 + (wn >> 1));
-    const int lc = lane & 31, lr = 4 * (lane >> 5);
-    const int S = p.rope_s, smax = p.rope_smax;
-    const int mlane = m0 + lr;                                   // this lane's first row
-    // All addresses are 32-bit byte offsets into whole-tensor buffer descriptors (the host checks that every plane is < 2 GiB):
-    // no 64-bit vector arithmetic in the epilogue.  A row block of 28 consecutive rows crosses at most one sequence boundary
-    // (the host requires S >= 32): one integer division per 32-row block, a compare + select per row.
-    constexpr unsigned RSRC_FLAGS = 0x00020000u;
-    if (region < 2) {
-        const int dbase = 32 * (wn & 1) + lc;                    // rotation pair index d: x1 = column d, x2 = column d + 64
-        const int rph = region == 0 ? S : smax;                  // rows per head: q [b][nh][S][128], K cache [b][nh][smax][128]
-        const unsigned head_bytes = (unsigned)rph * 256u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
-        __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(region == 0 ? p.rope_q : p.rope_k, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? (region == 0 ? p.rope_q_lo : p.rope_k_lo) : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)p.rope_cos, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.rope_sin, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        const unsigned out_lane = (unsigned)head * head_bytes + (region == 0 ? 0u : (unsigned)p.rope_pos0 * 256u) + (unsigned)dbase * 2u;
-        const unsigned tab_lane = (unsigned)p.rope_pos0 * 256u + (unsigned)dbase * 4u;
-        float cs[2][16], sn[2][16];
-        // row block tm of this lane: (batch, position) of its first row; the 16 rows are offsets 0..3, 8..11, 16..19, 24..27 further on
-        auto block_origin = [&](int tm, int& bt, int& st) __attribute__((always_inline)) {
-            const int mt = mlane + C::tile_row(tm);
-            bt = mt / S;
-            st = mt - bt * S;
-        };
-        auto load_tables = [&](int tm, int buf) __attribute__((always_inline)) {   // issued one row block ahead of its use
-            int bt, st;
-            block_origin(tm, bt, st);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int sr = st + (r & 3) + 8 * (r >> 2);
-                const unsigned to = tab_lane + (unsigned)(sr >= S ? sr - S : sr) * 256u;
-                cs[buf][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, to, 0, 0));
-                sn[buf][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, to, 0, 0));
-            }
-        };
-        load_tables(0, 0);
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            if (tm + 1 < C::TM) load_tables(tm + 1, (tm + 1) & 1);
-            int bt, st;
-            block_origin(tm, bt, st);
-            const unsigned base = out_lane + (unsigned)bt * batch_bytes;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);
-                if (!FULL && mlane + ml >= p.M) continue;
-                const int sr = st + (r & 3) + 8 * (r >> 2);
-                const bool wrap = sr >= S;
-                const unsigned o = base + (unsigned)(wrap ? sr - S : sr) * 256u + (wrap ? batch_bytes : 0u);    // byte offset of the row's x1 element
-                const float x1 = acc[tm][0][r], x2 = acc[tm][1][r];
-                const float c = cs[tm & 1][r], sv = sn[tm & 1][r];
-                const float ya = __fadd_rn(__fmul_rn(x1, c), __fmul_rn(-x2, sv));         // rope_split_kernel's operations, in its order
-                const float yb = __fadd_rn(__fmul_rn(x2, c), __fmul_rn(x1, sv));
-                const bf16_t ha = (bf16_t)ya, hb = (bf16_t)yb;
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, ha), rH, o, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hb), rH, o + 128u, 0, 0);
-                if (SPLIT) {
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(ya - (float)ha)), rL, o, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(yb - (float)hb)), rL, o + 128u, 0, 0);
-                }
-            }
-        }
-    } else {
-        // V^T cache [b][nh][128][smax]: positions are the contiguous axis, but an accumulator lane holds ONE column d -- stored from
-        // there, a wave instruction scatters 64 two-byte pieces over 64 cache lines (measured, first version of this epilogue: the
-        // V tiles alone cost what rope_split_kernel costs, profiles/r04_rope_fuse_ab_v1.txt).  So every 32 x 32 MFMA tile goes
-        // through a wave-private LDS patch [column][33 dwords] (the A stages are free after the K loop's last barrier; writes and
-        // reads are conflict-free: bank = (column + row) mod 32) and comes back with lanes along the ROWS: an instruction then
-        // stores 2 columns x 32 consecutive positions = two 64-byte runs.
-        const unsigned head_bytes = 128u * (unsigned)smax * 2u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
-        __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.rope_v, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? p.rope_v_lo : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
-        float* patch = (float*)smem + (threadIdx.x >> 6) * (32 * 33);
-        const int rrow = lane & 31, rcol = lane >> 5;            // read-back role: row of the 32-row block, first of this lane's columns
-        const unsigned col_bytes = (unsigned)smax * 2u;
-        const unsigned out_lane = (unsigned)head * head_bytes + (64u * (wn & 1) + (unsigned)rcol) * col_bytes + (unsigned)p.rope_pos0 * 2u;
-#pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) {
-            const int mr = m0 + C::tile_row(tm) + rrow;          // the row this lane stores
-            const int bt = mr / S, st = mr - bt * S;
-            const unsigned vo = out_lane + (unsigned)bt * batch_bytes + (unsigned)st * 2u;
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) patch[lc * 33 + (r & 3) + 8 * (r >> 2) + lr] = acc[tm][tn][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                float vals[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) vals[j] = patch[(rcol + 2 * j) * 33 + rrow];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (FULL || mr < p.M) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const unsigned so = (unsigned)(32 * tn + 2 * j) * col_bytes;       // uniform: scalar offset of the instruction
-                        const bf16_t h = (bf16_t)vals[j];
-                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), rH, vo, so, 0);
-                        if (SPLIT) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)(vals[j] - (float)h)), rL, vo, so, 0);
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <typename T, bool SPLIT, typename C>
-__device__ __forceinline__ void gemm_epilogue_rope_qkv(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
-                                                       const int wn, const int lane, char* smem) {
-    static_assert(4 * 32 * 33 * 4 <= 2 * C::A_BYTES, "rope epilogue: the V transposition patches must fit the A stages");
-    if (m0 + C::BM <= p.M) gemm_epilogue_rope_qkv_impl<T, SPLIT, C, true>(p, acc, m0, n0, wn, lane, smem);     // interior tile: no row checks
-    else gemm_epilogue_rope_qkv_impl<T, SPLIT, C, false>(p, acc, m0, n0, wn, lane, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -690,6 +557,12 @@ static int launch_gemm_bd(GemmParams p, hipStream_t s) {
 
 template <typename T, typename C>
 static int dispatch_bd(const GemmParams& p, bool split, int epi, hipStream_t s) {
+    if constexpr (GEMM_BDA && std::is_same<T, bf16_t>::value && C::BM == 128 && C::BN == 256) {
+        if (split == (p.Alo != nullptr) && (split || GEMM_BDA >= 2)) {
+            const int rc = launch_gemm_bda(p, LLARK_BF16, epi, s);
+            if (rc != -1000) return rc;
+        }
+    }
 #define CASE(E)                                                      \
     case E:                                                          \
         return split ? launch_gemm_bd<T, true, E, C>(p, s) : launch_gemm_bd<T, false, E, C>(p, s);
@@ -848,6 +721,12 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+        // hi + lo bf16 pieces on the 128x256 tile run gemm_bda_loop.h's K loop (A by LDS-DMA, fragments read ahead): same arithmetic and
+        // order per accumulator, so the slabs and the combined tiles are bit-identical to the register-staged loop below
+        constexpr bool USE_BDA = GEMM_BDA && (SPLIT || GEMM_BDA >= 2) && std::is_same<T, bf16_t>::value && C::BM == 128 && C::BN == 256 && C::TM == 4 && C::TN == 2;
+        if constexpr (USE_BDA) {
+            bda_kloop<T, SPLIT>(p, smem, m0, n0, w, lane, kt0, kt1, acc);
+        } else {
         loadA(kt0);
         loadB(0, kt0 * 4);
         loadB(1, kt0 * 4 + 1);
@@ -871,6 +750,7 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_bd_sk_kernel(const G
         };
         if (GEMM_BD_TAIL_SKIP && C::TM > 1 && p.M - m0 <= 32) kloop(std::integral_constant<int, 1>{});  // ragged last row tile (see bd_kstep)
         else kloop(std::integral_constant<int, C::TM>{});
+        }
 
         // Who finishes a shared tile.  Uniform split: the piece with the LAST K range -- the block order is piece-major (see `slot`
         // above), so it has a higher block id than the other pieces of its tile: it only ever waits for workgroups that were
@@ -939,6 +819,8 @@ static int launch_gemm_bd_sk(GemmParams p, hipStream_t s, void* scratch, long lo
         once.slot() = n;
     }
     const int per_cu = once.slot();
+    if (GEMM_BDA && (SPLIT || GEMM_BDA >= 2) && std::is_same<T, bf16_t>::value && C::BM == 128 && C::BN == 256 && ((long long)p.M * p.lda * 2 >= (1ll << 31) || p.Kp < 192))
+        return -1000;                                              // the DMA loop addresses A with 32-bit byte offsets: the per-tile kernels take it
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1000;
     const int S = per_cu * cus;
@@ -1627,7 +1509,12 @@ static bool fragw_sk_rule(bool split, int m, int n, int kp) {
     return (split && tiles_bd0 < 2LL * llark_device_cus()) ||
            (!split && (4 * tiles_bd0 <= 2LL * llark_device_cus() || (tiles_bd0 < 2LL * llark_device_cus() && kp >= 8192)));
 }
-static bool fragw_small_tiles(bool split, int epilogue, int n) { return !split && !IS_SWIGLU(epilogue) && n <= 4096; }
+// plain operands, narrow output: the 128x128 tiles (3 workgroups per CU) -- except for bf16 once the DMA loop takes plain operands
+// (GEMM_BDA >= 2): its 128x256 whole tiles beat them (o_proj at M = 2968: 104 vs 111 us, profiles/r05_gemm_bda_plain_ab.txt)
+static bool fragw_small_tiles(int dtype, bool split, int epilogue, int n) {
+    if (GEMM_BDA >= 2 && dtype == LLARK_BF16) return false;
+    return !split && !IS_SWIGLU(epilogue) && n <= 4096;
+}
 
 // 1 when the library choice of llark_gemm16_fragw_sk runs this product as WHOLE 128x256 tiles of the per-tile kernel (no K cut, not the
 // 128x128 tiles): the case in which llark_gemm16_fragw_rope_qkv -- which always runs whole 128x256 tiles -- is bit-equal to the two-launch
@@ -1635,7 +1522,7 @@ static bool fragw_small_tiles(bool split, int epilogue, int n) { return !split &
 // kernels would decline at launch time is reported as 0.
 extern "C" int llark_gemm16_fragw_whole_tiles(int split, int epilogue, int m, int n, int kp) {
     if (m <= 0 || n <= 0 || kp <= 0) return 0;
-    return (!fragw_sk_rule(split != 0, m, n, kp) && !fragw_small_tiles(split != 0, epilogue, n)) ? 1 : 0;
+    return (!fragw_sk_rule(split != 0, m, n, kp) && !fragw_small_tiles(LLARK_BF16, split != 0, epilogue, n)) ? 1 : 0;      // (asked by the bf16 Llama engine)
 }
 
 static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, const void* a_hi, const void* a_lo, int lda,
@@ -1656,7 +1543,12 @@ static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, co
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.ldw = 0; p.bias = bias; p.M = m; p.N = n; p.Kp = kp;
     p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
     hipStream_t s = (hipStream_t)stream;
-    if (variant > 1) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
+    if (variant == 2) {                                             // gemm_bda.hip: hi + lo bf16 operands, A by LDS-DMA (same results as variant 0)
+        const int rc = launch_gemm_bda(p, dtype, epilogue, s);
+        if (rc == -1000) { set_error("gemm16_fragw: variant 2 takes bf16 operands with kp >= 192 and its epilogues only"); return LLARK_ERR_UNSUPPORTED; }
+        return rc;
+    }
+    if (variant > 2) { set_error("gemm16_fragw: unknown variant %d", variant); return LLARK_ERR_INVALID; }
     // variant 1 (128x128 tiles, 3 workgroups per CU) fills the chip where the big tile leaves a ragged wave.  Measured
     // at M = 2968, bf16 (profiles/r01_gemm_variants.txt): it wins only on the narrow outputs -- o_proj 844 vs 798,
     // down_proj 939 vs 903 TFLOP/s (N = 4096: 768 small tiles = exactly one wave) -- and loses on qkv / lm_head
@@ -1674,7 +1566,7 @@ static int gemm16_fragw_impl(int variant, int dtype, int split, int epilogue, co
         else if (dtype == LLARK_BF16) rc = dispatch_bd_sk<bf16_t, CfgBD0>(p, split != 0, epilogue, s, scratch, scratch_bytes, uniform);
         if (rc != -1000) return rc;
     }
-    if (variant < 0) variant = fragw_small_tiles(split != 0, epilogue, n) ? 1 : 0;
+    if (variant < 0) variant = fragw_small_tiles(dtype, split != 0, epilogue, n) ? 1 : 0;
     if (variant == 1) {
         if (IS_SWIGLU(epilogue)) { set_error("gemm16_fragw: variant 1 (128x128 tiles) has no SwiGLU epilogue"); return LLARK_ERR_UNSUPPORTED; }
         if (dtype == LLARK_F16) return dispatch_bd<half_t, CfgBD1>(p, split != 0, epilogue, s);
@@ -1745,6 +1637,10 @@ extern "C" int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, i
     p.rope_cos = cos_t; p.rope_sin = sin_t; p.rope_s = s; p.rope_nh = nh; p.rope_pos0 = pos0; p.rope_smax = smax;
     p.rope_q = q; p.rope_q_lo = q_lo; p.rope_k = k_cache; p.rope_k_lo = k_cache_lo; p.rope_v = vt_cache; p.rope_v_lo = vt_cache_lo;
     hipStream_t st = (hipStream_t)stream;
+    if (GEMM_BDA && (split || GEMM_BDA >= 2)) {
+        const int rc = launch_gemm_bda(p, LLARK_BF16, EPI_ROPE_QKV, st);
+        if (rc != -1000) return rc;
+    }
     return split ? launch_gemm_bd<bf16_t, true, EPI_ROPE_QKV, CfgBD0>(p, st) : launch_gemm_bd<bf16_t, false, EPI_ROPE_QKV, CfgBD0>(p, st);
 }
 

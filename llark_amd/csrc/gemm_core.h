@@ -339,6 +339,10 @@ int launch_gemm256n(const GemmParams& p, int dtype, int epi, hipStream_t s, int 
 int launch_gemm256x(const GemmParams& p, int dtype, int epi, hipStream_t s, int cus);
 // does launch_gemm256x take this split product (shape rules only; the LayerNorm-folding host path asks before it commits to it)
 bool gemm256x_takes(int m, int n, int kp);
+// gemm_bda.hip (round 5): the hi + lo form of the B-direct main loop (fragment-major weights, 128x256 tiles) with A staged by LDS-DMA,
+// a second set of A fragments read one sub-step ahead and hand-counted weight loads.  bf16; EPI_F32 / RESID / SPLIT16 / SWIGLU_SPLIT /
+// ROPE_QKV.  Bit-identical to gemm_bd_kernel<bf16, true, ...>.  Returns -1000 when the problem is not one it takes.
+int launch_gemm_bda(const GemmParams& p, int dtype, int epi, hipStream_t s);
 // gemm256_lo8n.hip: the 256x256 tile with an e4m3 low plane staged through LDS (p.W8), phases split over N, A fragments resident
 // across both (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of the stream's device (8 | cus).  Returns -1000
 // when the problem is not one it handles.

@@ -688,7 +688,8 @@ def gemm16_fragw(a_hi: torch.Tensor, a_lo: Optional[torch.Tensor], wfrag: torch.
                  out_hi: Optional[torch.Tensor] = None, out_lo: Optional[torch.Tensor] = None, m: Optional[int] = None,
                  variant: int = -1, stream_k: Optional[bool] = None) -> None:
     """Same product / epilogues as gemm16, weights given fragment-major (pack_weight16_frag).
-    variant: -1 library choice, 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogue).
+    variant: -1 library choice, 0 = 128x256 tiles, 1 = 128x128 tiles (no SwiGLU epilogue), 2 = 128x256 tiles with A by LDS-DMA
+    (csrc/gemm_bda.hip: hi + lo bf16 operands only; bit-identical to 0).
     stream_k: None = library choice (split operands and less than one round of tiles: Llama o_proj / down_proj at M = 2968),
     True = cut whenever the tile count is not a whole number of rounds (forces the 128x256 tiles), False = off."""
     dtype = a_hi.dtype

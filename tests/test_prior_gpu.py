@@ -374,6 +374,71 @@ def test_gemm16_ln_predicted_statistics_adversarial_rows():
         "expected round 4's unscaled planes to be several times further from float64 on the std 1e-3 rows (measured 8x)"
 
 
+@pytest.mark.parametrize("m,n,k", [(2968, 768, 4096), (371, 512, 192), (1000, 832, 1216), (130, 64, 256)])
+def test_gemm_bda_lds_dma_a_operand_bit_identical(m, n, k):
+    """csrc/gemm_bda.hip (round 5; llark_gemm16_fragw variant 2): the hi + lo B-direct product with A staged by LDS-DMA, a second
+    set of A fragments read one sub-step ahead and hand-counted weight loads -- BIT-identical to variant 0 (gemm_bd_kernel) for
+    every epilogue it takes: ragged M (row clamping in the DMA source addresses, masked stores: 2968 = 23 x 128 + 24), ragged N,
+    the shortest K it accepts (3 K-steps = the ring's prologue), and repeated launches (the hand-counted waits must not depend
+    on what is in flight from the previous launch).  Shapes outside its domain are refused, not mis-computed."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m + 2 * n + k)
+    a = torch.randn(m, k, generator=g)
+    wb = (torch.randn(n, k, generator=g) * 0.1).bfloat16()
+    b = torch.randn(n, generator=g).cuda()
+    r = torch.randn(m, n, generator=g).cuda()
+    hi, lo = ops.split16(a.cuda(), torch.bfloat16, kmult=64)
+    wt = ops.pack_weight16(wb.cuda(), False, torch.bfloat16, kmult=64)
+    wf = ops.pack_weight16_frag(wt, n)
+    kp = wt.shape[1]
+    for rep in range(3):
+        c0 = torch.full((m, n), float("nan"), device="cuda")
+        c1 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_F32, c=c0, variant=0, stream_k=False)
+        ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_F32, c=c1, variant=2)
+        assert torch.equal(c0, c1), f"F32 rep {rep}: {int((c0 != c1).sum())} elements differ, max {(c0 - c1).abs().nan_to_num(9e9).max().item():.3e}"
+    ref = (hi.double()[:, :k] + lo.double()[:, :k]) @ wt.double()[:n, :k].t() + b.double()
+    assert float((c1.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-4
+    c0, c1 = r.clone(), r.clone()
+    ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_RESID, c=c0, resid=c0, variant=0, stream_k=False)
+    ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_RESID, c=c1, resid=c1, variant=2)
+    assert torch.equal(c0, c1)
+    o0 = [torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    o1 = [torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_SPLIT16, out_hi=o0[0], out_lo=o0[1], variant=0, stream_k=False)
+    ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_SPLIT16, out_hi=o1[0], out_lo=o1[1], variant=2)
+    assert torch.equal(o0[0].view(torch.int16), o1[0].view(torch.int16)) and torch.equal(o0[1].view(torch.int16), o1[1].view(torch.int16))
+    if n % 64 == 0:                                                     # SwiGLU pairs
+        s0 = [torch.full((m, n // 2), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        s1 = [torch.full((m, n // 2), float("nan"), dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+        ops.gemm16_fragw(hi, lo, wf, None, n, kp, ops.EPI_SWIGLU_SPLIT, out_hi=s0[0], out_lo=s0[1], variant=0, stream_k=False)
+        ops.gemm16_fragw(hi, lo, wf, None, n, kp, ops.EPI_SWIGLU_SPLIT, out_hi=s1[0], out_lo=s1[1], variant=2)
+        assert torch.equal(s0[0].view(torch.int16), s1[0].view(torch.int16)) and torch.equal(s0[1].view(torch.int16), s1[1].view(torch.int16))
+    # plain bf16 operands (one plane, one MFMA per tile and sub-step, 4 DMA requests per K-step): the same loop, same bit-equality
+    c0 = torch.full((m, n), float("nan"), device="cuda")
+    c1 = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_F32, c=c0, variant=0, stream_k=False)
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_F32, c=c1, variant=2)
+    assert torch.equal(c0, c1), f"plain F32: {int((c0 != c1).sum())} elements differ"
+    c0, c1 = r.clone(), r.clone()
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_RESID, c=c0, resid=c0, variant=0, stream_k=False)
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_RESID, c=c1, resid=c1, variant=2)
+    assert torch.equal(c0, c1)
+    o0 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    o1 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_OUT16, out_hi=o0, variant=0, stream_k=False)
+    ops.gemm16_fragw(hi, None, wf, b, n, kp, ops.EPI_OUT16, out_hi=o1, variant=2)
+    assert torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+    if n % 64 == 0:
+        s0 = torch.full((m, n // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+        s1 = torch.full((m, n // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.gemm16_fragw(hi, None, wf, None, n, kp, ops.EPI_SWIGLU16, out_hi=s0, variant=0, stream_k=False)
+        ops.gemm16_fragw(hi, None, wf, None, n, kp, ops.EPI_SWIGLU16, out_hi=s1, variant=2)
+        assert torch.equal(s0.view(torch.int16), s1.view(torch.int16))
+    with pytest.raises(RuntimeError):                                   # an epilogue it does not have: refused, not mis-computed
+        ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_QGELU_SPLIT, out_hi=o0, out_lo=o1, variant=2)
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
