@@ -13,6 +13,6 @@ for c in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
   timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/p$i -o a -- python $R/bench.py --stages llama --steps 2 --warmup 1 --no-cpu-baseline > $O/p$i.log 2>&1; echo "pmc pass $i exit $?"
 done
 cd $R
-python scripts/pmc_summary.py $O gemm_bd_kernel attn_prefill rmsnorm > gpurun_out/r05/pmc_llama_bd_summary.txt 2>&1
+python scripts/pmc_summary.py $O gemm_bda_kernel gemm_bd_sk_kernel gemm_bd_kernel attn_prefill rmsnorm > gpurun_out/r05/pmc_llama_bd_summary.txt 2>&1
 rm -rf $O/*/
 head -c 6000 gpurun_out/r05/pmc_llama_bd_summary.txt
