@@ -439,6 +439,28 @@ def test_gemm_bda_lds_dma_a_operand_bit_identical(m, n, k):
         ops.gemm16_fragw(hi, lo, wf, b, n, kp, ops.EPI_QGELU_SPLIT, out_hi=o0, out_lo=o1, variant=2)
 
 
+def test_gemm_bda_declines_short_k_and_the_dispatcher_falls_back():
+    """K < 192 (fewer than three K-steps: the ring's prologue) is outside gemm_bda's domain: variant 2 is refused, and the library's
+    own routes (variant 0 / -1, which try the DMA loop first) fall back to gemm_bd_kernel -- same bits as the LDS-staged kernel."""
+    from llark_amd import ops
+    m, n, k = 300, 256, 128
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(m, k, generator=g)
+    wb = (torch.randn(n, k, generator=g) * 0.1).bfloat16()
+    hi, lo = ops.split16(a.cuda(), torch.bfloat16, kmult=64)
+    wt = ops.pack_weight16(wb.cuda(), False, torch.bfloat16, kmult=64)
+    wf = ops.pack_weight16_frag(wt, n)
+    for l in (lo, None):
+        c0 = torch.full((m, n), float("nan"), device="cuda")
+        ops.gemm16(hi, l, wt, None, n, ops.EPI_F32, c=c0, variant=12)
+        for v in (0, -1):
+            c1 = torch.full((m, n), float("nan"), device="cuda")
+            ops.gemm16_fragw(hi, l, wf, None, n, k, ops.EPI_F32, c=c1, variant=v, stream_k=False)
+            assert torch.equal(c0, c1)
+        with pytest.raises(RuntimeError):
+            ops.gemm16_fragw(hi, l, wf, None, n, k, ops.EPI_F32, c=c1, variant=2)
+
+
 @pytest.mark.parametrize("m,n,k", [(333, 450, 200), (1000, 768, 1216), (128, 64, 64), (700, 300, 4800)])
 def test_gemm_fragment_major_weights_bit_identical(m, n, k):
     """The B-direct kernel (fragment-major weights streamed L2 -> VGPR) accumulates every output element in the same
