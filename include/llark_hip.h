@@ -224,6 +224,15 @@ int llark_gemm16_ln_p(int dtype, int epilogue, const void* a_hi, const void* a_l
                       int n, int kp, float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo,
                       const float* ln_stat, const float* ln_vec, float* ln_part, const float* ln_pred, llark_workspace_t ws, llark_stream_t stream);
 int llark_ln_stats_finalize_p(const float* part, int rows, int nparts, int width, float eps, float* stat, float* pred, llark_stream_t stream);
+/* The producer role on 128x256 tiles, two workgroups to a CU, weights fragment-major (llark_pack_weight16_frag): one workgroup's epilogue
+ * (residual loads, fp32 + plane stores) runs under the other's K loop, which the persistent 256x256 tile (one workgroup per CU) cannot do.
+ * For the product with the short K loop -- upstream ResAttnBlock's attention-output Conv1D c_proj, K = n_state = 1200, reached from
+ * jukebox/main.py:108 -- where that serial epilogue was 40 % of the launch.  Same arithmetic as llark_gemm16_ln_p's producer role (ln_pred may be
+ * NULL); ln_part is [m][ceil(n / 64)][2] (64-column slices: pass nparts = ceil(n / 64) to llark_ln_stats_finalize[_p]).  kp % 64 == 0,
+ * kp >= 192, n % 4 == 0; LLARK_ERR_UNSUPPORTED otherwise, before anything is launched. */
+int llark_gemm16_lnp_fragw(int dtype, const void* a_hi, const void* a_lo, int lda, const void* wfrag, const float* bias, int m, int n, int kp,
+                           float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, const float* ln_vec,
+                           float* ln_part, const float* ln_pred, llark_stream_t stream);
 int llark_ln_row_pred(const float* x, int ldx, int rows, int width, float eps, float* pred, llark_stream_t stream);
 /* "lo8" form of the prior's split GEMM (csrc/gemm256_lo8n.hip; OPT-IN reduced precision, the default is the two-pass fp16
  * form behind llark_gemm16_ws): same call site, upstream Conv1D.forward reached from

@@ -77,6 +77,7 @@ _SIGS = {
     "llark_ln_stats_finalize": [_P, c_int, c_int, c_int, c_float, _P, _P],
     "llark_gemm16_fragw_whole_tiles": [c_int, c_int, c_int, c_int, c_int],
     "llark_gemm16_ln_p": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P],
+    "llark_gemm16_lnp_fragw": [c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, _P],
     "llark_ln_stats_finalize_p": [_P, c_int, c_int, c_int, c_float, _P, _P, _P],
     "llark_ln_row_pred": [_P, c_int, c_int, c_int, c_float, _P, _P],
     "llark_workspace_destroy": [_P],

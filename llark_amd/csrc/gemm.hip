@@ -1401,6 +1401,28 @@ extern "C" int llark_gemm16_ln_p(int dtype, int epilogue, const void* a_hi, cons
     return rc;
 }
 
+// The producer role with fragment-major weights on the DMA loop's 128x256 tiles, two workgroups to a CU (gemm_bda.hip,
+// gemm_bda_lnp_kernel): for the products whose K loop is too short to amortise the persistent tile's serial epilogue (the prior's
+// attention-output c_proj, K = 1216).  ln_part is [m][ceil(n / 64)][2]: 64-column slices.
+extern "C" int llark_gemm16_lnp_fragw(int dtype, const void* a_hi, const void* a_lo, int lda, const void* wfrag, const float* bias, int m, int n, int kp,
+                                      float* c, int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, const float* ln_vec,
+                                      float* ln_part, const float* ln_pred, llark_stream_t stream) {
+    LLARK_REQUIRE(a_hi && a_lo && wfrag && ln_vec && ln_part && c && resid && out_hi && out_lo && m > 0 && n > 0 && kp > 0,
+                  "gemm16_lnp_fragw: null pointer or empty problem");
+    LLARK_REQUIRE(kp % 64 == 0 && lda % 8 == 0 && lda >= kp && ldc >= n && ldr >= n && ldo >= n, "gemm16_lnp_fragw: kp must be a multiple of 64, lda >= kp a multiple of 8, ldc / ldr / ldo >= n");
+    LLARK_REQUIRE(((uintptr_t)a_hi & 15) == 0 && ((uintptr_t)a_lo & 15) == 0 && ((uintptr_t)wfrag & 15) == 0, "gemm16_lnp_fragw: operands must be 16-byte aligned");
+    GemmParams p = {};
+    p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.ldw = 0; p.bias = bias; p.M = m; p.N = n; p.Kp = kp;
+    p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.Ohi = out_hi; p.Olo = out_lo; p.ldo = ldo;
+    p.ln_vec = ln_vec; p.ln_part = ln_part; p.ln_pred = ln_pred;
+    const int rc = launch_gemm_bda_lnp(p, dtype, (hipStream_t)stream);
+    if (rc == -1000) {
+        set_error("gemm16_lnp_fragw: needs f16 / bf16 planes, kp >= 192, n %% 4 == 0, 16-byte aligned fp32 rows (ldc, ldr multiples of 4) and 8-byte aligned plane rows (ldo a multiple of 4)");
+        return LLARK_ERR_UNSUPPORTED;
+    }
+    return rc;
+}
+
 extern "C" llark_workspace_t llark_workspace_create(void) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {

@@ -95,19 +95,7 @@ struct Mfma16<bf16_t> {
 #define G256X_STAGGER_TICKS 0
 #endif
 
-// The value a hi / lo split starts from has to be ONE fp32 number.  hipcc (ROCm 7.2, even under -ffp-contract=off) selects
-// fp16(a * b) as v_fma_mixlo_f16 a, b, 0 -- the EXACT product rounded once to fp16 -- for the copy of the conversion that feeds the
-// subtraction, and v_cvt_pk_f16_f32 of the fp32 product for the copy that is stored: where the two roundings differ (3e-5 of the
-// elements, measured on gfx950 in round 4) hi + lo misses x by a whole fp16 ulp.  An empty asm on the register makes the product opaque.
-__device__ __forceinline__ float fp_pin(float x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
-// x - (float)h in one instruction: v_fma_mix_f32 takes the fp16 operand as it is (no v_cvt_f32_f16 back); h * -1 is exact, so the value is
-// bit for bit the (x - (float)h) of rounds 1-4.
-template <typename T>
-__device__ __forceinline__ float sub_hi(float x, T h) { return __builtin_fmaf((float)h, -1.0f, x); }
+// (fp_pin / sub_hi: gemm_core.h)
 // Consumer of a folded LayerNorm: rstd (acc - mu g) + b evaluated as acc rstd + (b - (mu rstd) g) -- two fused multiply-adds per element
 // instead of mul, sub, mul, add (the epilogue is VALU-bound: 7 us of issue per 256 x 256 tile, profiles/r05_gemm256x_tile_times.txt).
 __device__ __forceinline__ f32x4_t ln_apply(const f32x4_t a, const float mu_rstd, const float rstd, const f32x4_t g, const f32x4_t b) {

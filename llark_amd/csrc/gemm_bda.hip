@@ -24,15 +24,8 @@
 
 namespace llark {
 
-template <typename T, bool SPLIT, int EPI>
-__global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_kernel(const GemmParams p) {
-    typedef CfgBDA C;
-    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages x (hi | lo) x 16 KiB
-
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = 0, wn = w;
-
+// blockIdx -> tile: every XCD a contiguous band of the linear order, bands of 8 row tiles swept column by column (gemm_bd_kernel's order)
+__device__ __forceinline__ void bda_tile_of(const GemmParams& p, int& m0, int& n0) {
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {
@@ -44,9 +37,21 @@ __global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_kernel
     const int g = bid / gsz;
     const int first_m = g * GM;
     const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-    const int tile_m = first_m + (bid % gsz) % gm;
-    const int tile_n = (bid % gsz) / gm;
-    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    m0 = (first_m + (bid % gsz) % gm) * CfgBDA::BM;
+    n0 = ((bid % gsz) / gm) * CfgBDA::BN;
+}
+
+template <typename T, bool SPLIT, int EPI>
+__global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_kernel(const GemmParams p) {
+    typedef CfgBDA C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages x (hi | lo) x 16 KiB
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = 0, wn = w;
+
+    int m0, n0;
+    bda_tile_of(p, m0, n0);
 
     f32x16_t acc[C::TM][C::TN];
 #pragma unroll
@@ -58,6 +63,166 @@ __global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_kernel
     bda_kloop<T, SPLIT>(p, smem, m0, n0, w, lane, 0, p.Kp / C::BK, acc);
     if constexpr (EPI == EPI_ROPE_QKV) gemm_epilogue_rope_qkv<T, SPLIT, C>(p, acc, m0, n0, wn, lane, smem);
     else gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
+}
+
+// ---- the LayerNorm PRODUCER role of gemm256x.hip (llark_gemm16_ln_p with ln_part) on this loop (round 5) --------------------------------
+//   C = R + (A_hi + A_lo) . W^T + bias;  Ohi / Olo = hi / lo of ((C - shift_m) . scale_m) . ln_vec[n];
+//   ln_part[m][n / 64][0..1] = (sum, sum of squares) of (C - shift_m) over this wave's 64 columns      ((shift, scale) = ln_pred[m] or (0, 1))
+// For the prior's attention-output product (K = 1216: upstream Conv1D c_proj of the attention, jukebox/main.py:105-108 ->
+// transformer.py ResAttnBlock): on the persistent 256x256 tile its epilogue is 40 % of the launch (one workgroup per CU: 42 us of
+// stores and residual loads between two 64 us K loops, profiles/r05_gemm256x_tile_times.txt); here two workgroups share a CU and one's
+// epilogue runs under the other's K loop.  The product is computed TRANSPOSED (bda_kloop<.., TR = true>): a lane owns one output row
+// of each 32x32 tile and, per register quad, four consecutive columns -- 16-byte residual loads / stores straight from the accumulators,
+// row sums inside the lane (one cross-half add at the end), operand planes widened to 16 bytes by v_permlane32_swap.
+__device__ __forceinline__ void swap_halves32(unsigned& a, unsigned& b) {     // a's lanes 32..63 trade places with b's lanes 0..31
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+#ifndef BDA_LNP_DEBUG
+#define BDA_LNP_DEBUG 0   // timing experiments only: 1 = no planes / statistics (the transposed residual epilogue alone), 2 = no fp32 stream
+#endif
+template <typename T>
+__global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_lnp_kernel(const GemmParams p) {
+    typedef CfgBDA C;
+    typedef T out4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages x (hi | lo) x 16 KiB; after the loop: gamma | bias of every wave's columns
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int m0, n0;
+    bda_tile_of(p, m0, n0);
+
+    f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    bda_kloop<T, true, true>(p, smem, m0, n0, w, lane, 0, p.Kp / C::BK, acc);
+
+    const int ncw = n0 + w * 64;                                          // this wave's 64 columns
+    if (ncw >= p.N) return;                                               // (no barrier behind the loop's last one)
+    const int ml = lane & 31, h = lane >> 5;
+    // gamma | bias of the 64 columns through the LDS (wave-private 512 bytes: one element per lane each way, read back 16 bytes at a time)
+    float* park = (float*)(smem + w * 512);
+    {
+        const int nc = ncw + lane;
+        park[lane] = nc < p.N ? p.ln_vec[nc] : 0.0f;
+        park[64 + lane] = (p.bias != nullptr && nc < p.N) ? p.bias[nc] : 0.0f;
+    }
+    const bool full = (m0 + C::BM <= p.M) && (ncw + 64 <= p.N);
+    const bool wide = full && (p.ldo & 7) == 0 && (((uintptr_t)p.Ohi | (uintptr_t)p.Olo) & 15) == 0;
+    const int nparts = (p.N + 63) >> 6;
+    const int ncl = ncw + 4 * h;                                          // + 32 tn + 8 g: this lane's four columns of quad (tn, g)
+
+    auto load_res = [&](int tm, f32x4_t (&res)[8]) __attribute__((always_inline)) {
+        const int m = m0 + tm * 32 + ml;
+        const bool row_ok = full || m < p.M;
+        const float* rrow = p.R + (size_t)(row_ok ? m : 0) * p.ldr + ncl;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int co = (q >> 2) * 32 + (q & 3) * 8;
+            res[q] = (BDA_LNP_DEBUG != 2 && row_ok && (full || ncl + co < p.N)) ? *(const f32x4_t*)(rrow + co) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tm = [&](auto tmc, const f32x4_t (&res)[8]) __attribute__((always_inline)) {
+        constexpr int tm = decltype(tmc)::value;
+        const int m = m0 + tm * 32 + ml;
+        if (!full && m >= p.M) return;                                    // both lanes of a row leave together
+        const float2 st = p.ln_pred != nullptr ? *(const float2*)(p.ln_pred + 2 * (size_t)m) : make_float2(0.f, 1.f);
+        const float mu = st.x, rstd = st.y;
+        float sx = 0.f, sq = 0.f;
+        float* crow = p.C + (size_t)m * p.ldc + ncl;
+        uint2 ph[8], pl[8];
+        static_for<8>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value, tn = q >> 2, g = q & 3;
+            constexpr int co = tn * 32 + g * 8;
+            const bool ok = full || ncl + co < p.N;                        // N % 4 == 0: a quad is all in or all out
+            const f32x4_t gm = *(const f32x4_t*)(park + co + 4 * h);
+            const f32x4_t bs = *(const f32x4_t*)(park + 64 + co + 4 * h);
+            f32x4_t a4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a4[r] = acc[tm][tn][4 * g + r];
+            const f32x4_t out = res[q] + (a4 + bs);
+            if (ok && BDA_LNP_DEBUG != 2) *(f32x4_t*)(crow + co) = out;
+            out4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = out[r] - mu;
+                const float x = fp_pin((d * rstd) * gm[r]);
+                const T hh = (T)x;
+                hi[r] = hh;
+                lo[r] = (T)sub_hi<T>(x, hh);
+                if (ok) {
+                    sx += d;
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            ph[q] = __builtin_bit_cast(uint2, hi);
+            pl[q] = __builtin_bit_cast(uint2, lo);
+            if (!wide && ok && BDA_LNP_DEBUG != 1) {
+                const size_t o = (size_t)m * p.ldo + ncl + co;
+                *(uint2*)((T*)p.Ohi + o) = ph[q];
+                *(uint2*)((T*)p.Olo + o) = pl[q];
+            }
+        });
+        if (wide && BDA_LNP_DEBUG != 1) {                                                       // quads (g, g + 1): half 0 ends up with the 8 columns of g, half 1 with those of g + 1
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                swap_halves32(ph[q].x, ph[q + 1].x);
+                swap_halves32(ph[q].y, ph[q + 1].y);
+                swap_halves32(pl[q].x, pl[q + 1].x);
+                swap_halves32(pl[q].y, pl[q + 1].y);
+                const size_t o = (size_t)m * p.ldo + ncw + (q >> 2) * 32 + ((q & 3) + h) * 8;
+                *(uint4*)((T*)p.Ohi + o) = make_uint4(ph[q].x, ph[q].y, ph[q + 1].x, ph[q + 1].y);
+                *(uint4*)((T*)p.Olo + o) = make_uint4(pl[q].x, pl[q].y, pl[q + 1].x, pl[q + 1].y);
+            }
+        }
+        // the row's 64 columns of this wave: two lanes (halves) x 32 values, fixed order -> run-to-run bit-equal
+        sx += __shfl_xor(sx, 32);
+        sq += __shfl_xor(sq, 32);
+        if (h == 0 && BDA_LNP_DEBUG != 1) *(float2*)(p.ln_part + ((size_t)m * nparts + (ncw >> 6)) * 2) = make_float2(sx, sq);
+    };
+    // Residuals two row blocks ahead of their use: R may alias C, and vmcnt retires loads and stores in issue order -- the loads of row
+    // block t + 2 go out behind the stores of block t and are consumed after those of block t + 1 (as in gemm256x.hip's epilogue).
+    f32x4_t res0[8], res1[8];
+    load_res(0, res0);
+    load_res(1, res1);
+    store_tm(std::integral_constant<int, 0>{}, res0);
+    load_res(2, res0);
+    store_tm(std::integral_constant<int, 1>{}, res1);
+    load_res(3, res1);
+    store_tm(std::integral_constant<int, 2>{}, res0);
+    store_tm(std::integral_constant<int, 3>{}, res1);
+}
+
+template <typename T>
+static int launch_bda_lnp(GemmParams p, hipStream_t s) {
+    typedef CfgBDA C;
+    constexpr int LDS = 4 * C::A_BYTES;
+    auto kern = gemm_bda_lnp_kernel<T>;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1000;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    kern<<<dim3(p.tiles_m * p.tiles_n), C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm_bda_lnp");
+}
+
+// -1000: not a problem this kernel takes (hi + lo planes, fragment-major weights, Kp a multiple of 64 and >= 192, N % 4 == 0, 16-byte
+// aligned fp32 rows, 8-byte aligned plane rows).
+int launch_gemm_bda_lnp(const GemmParams& p, int dtype, hipStream_t s) {
+    if (!p.Alo || !p.ln_part || !p.ln_vec || !p.C || !p.R || !p.Ohi || !p.Olo) return -1000;
+    if (p.Kp % 64 != 0 || p.Kp < 192 || p.N % 4 != 0 || (long long)p.M * p.lda * 2 >= (1ll << 31)) return -1000;
+    if (p.ldc % 4 || p.ldr % 4 || p.ldo % 4 || (((uintptr_t)p.C | (uintptr_t)p.R) & 15) || (((uintptr_t)p.Ohi | (uintptr_t)p.Olo | (uintptr_t)p.ln_part | (uintptr_t)p.ln_pred) & 7))
+        return -1000;
+    if (dtype == LLARK_F16) return launch_bda_lnp<half_t>(p, s);
+    if (dtype == LLARK_BF16) return launch_bda_lnp<bf16_t>(p, s);
+    return -1000;
 }
 
 template <typename T, bool SPLIT, int EPI>

@@ -11,7 +11,10 @@ typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBDA;  // 128x256x64, 4 waves side by side, 
 
 // acc += (Ahi [+ Alo])[m0 .. m0 + 127][64 kt0 .. 64 kt1) . W[n0 + 64 wn .. + 63][same k]^T for this wave; smem = 2 stages x (hi [| lo]) x 16 KiB.
 // Leaves with every request retired and all waves past a barrier: the LDS is free for the caller's epilogue.
-template <typename T, bool SPLIT>
+// TR: the MFMA operands trade places -- the accumulators then hold the TRANSPOSED 32x32 tiles (lane l: output row m = l % 32 of the tile,
+// register r: column (r & 3) + 8 (r >> 2) + 4 (l >> 5)), four consecutive output columns per register quad: 16-byte epilogue accesses and
+// row sums that stay inside a lane (gemm_bda_lnp_kernel).  Same products, same order per accumulator.
+template <typename T, bool SPLIT, bool TR = false>
 __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const int m0, const int n0, const int w, const int lane, const int kt0,
                                           const int kt1, f32x16_t (&acc)[CfgBDA::TM][CfgBDA::TN]) {
     typedef CfgBDA C;
@@ -105,8 +108,13 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
             __builtin_amdgcn_sched_barrier(0);
             static_for<C::TM * C::TN>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value, tm = i / C::TN, tn = i % C::TN;
-                acc[tm][tn] = Mfma<T>::run(ah[cur][tm], __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
-                if constexpr (SPLIT) acc[tm][tn] = Mfma<T>::run(al[cur][tm], __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
+                if constexpr (TR) {
+                    acc[tm][tn] = Mfma<T>::run(__builtin_bit_cast(frag, ring[s][tn]), ah[cur][tm], acc[tm][tn]);
+                    if constexpr (SPLIT) acc[tm][tn] = Mfma<T>::run(__builtin_bit_cast(frag, ring[s][tn]), al[cur][tm], acc[tm][tn]);
+                } else {
+                    acc[tm][tn] = Mfma<T>::run(ah[cur][tm], __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
+                    if constexpr (SPLIT) acc[tm][tn] = Mfma<T>::run(al[cur][tm], __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (s < 3 && tn == 0) rdA(cur ^ 1, tm, sA, s + 1);      // next sub-step's fragments of row block tm: behind its first pair
                 __builtin_amdgcn_sched_barrier(0);

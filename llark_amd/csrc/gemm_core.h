@@ -185,6 +185,20 @@ __device__ __forceinline__ float quick_gelu(float x) { return fast_sigmoid_mul(x
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return fast_sigmoid_mul(x, 1.0f); }
 
+// The value a hi / lo split starts from has to be ONE fp32 number.  hipcc (ROCm 7.2, even under -ffp-contract=off) selects
+// fp16(a * b) as v_fma_mixlo_f16 a, b, 0 -- the EXACT product rounded once to fp16 -- for the copy of the conversion that feeds the
+// subtraction, and v_cvt_pk_f16_f32 of the fp32 product for the copy that is stored: where the two roundings differ (3e-5 of the
+// elements, measured on gfx950 in round 4) hi + lo misses x by a whole fp16 ulp.  An empty asm on the register makes the product opaque.
+__device__ __forceinline__ float fp_pin(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// x - (float)h in one instruction: v_fma_mix_f32 takes the fp16 operand as it is (no v_cvt_f32_f16 back); h * -1 is exact, so the value is
+// bit for bit the (x - (float)h) of rounds 1-4.
+template <typename T>
+__device__ __forceinline__ float sub_hi(float x, T h) { return __builtin_fmaf((float)h, -1.0f, x); }
+
 // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Shared by every main-loop variant.
 template <typename T, bool SPLIT, int EPI, typename C, bool SUMSQ = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[C::TM][C::TN], const int m0, const int n0,
@@ -343,6 +357,7 @@ bool gemm256x_takes(int m, int n, int kp);
 // a second set of A fragments read one sub-step ahead and hand-counted weight loads.  bf16; EPI_F32 / RESID / SPLIT16 / SWIGLU_SPLIT /
 // ROPE_QKV.  Bit-identical to gemm_bd_kernel<bf16, true, ...>.  Returns -1000 when the problem is not one it takes.
 int launch_gemm_bda(const GemmParams& p, int dtype, int epi, hipStream_t s);
+int launch_gemm_bda_lnp(const GemmParams& p, int dtype, hipStream_t s);   // gemm_bda.hip: the LayerNorm producer role on the DMA loop
 // gemm256_lo8n.hip: the 256x256 tile with an e4m3 low plane staged through LDS (p.W8), phases split over N, A fragments resident
 // across both (fp16 only; EPI_F32 / EPI_RESID / EPI_QGELU_SPLIT8).  `cus` = CUs of the stream's device (8 | cus).  Returns -1000
 // when the problem is not one it handles.

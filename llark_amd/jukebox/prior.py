@@ -49,6 +49,11 @@ DEFAULT_LN_FOLD = True
 # (2.7e-5 error per product instead of 2e-7, CPU simulation in tests/test_ln_fold_cpu.py), a row mean of 50 sigma costs 6 bits, |x| > 65504 /
 # gamma overflows.  LLARK_PRIOR_LN_PRED=0 = round 4's unscaled planes.
 DEFAULT_LN_PRED = True
+# Round 5 experiment, measured slower and left off: the attention-output product (K = 1216) as the LayerNorm producer on gemm_bda's
+# 128x256 tiles, two workgroups to a CU (llark_gemm16_lnp_fragw) instead of the persistent 256x256 tile -- 1.88 ms against 1.78 per
+# launch (profiles/r05_cproj_bda_lnp_ab.txt): the co-resident workgroup hides only part of the epilogue and the transposed 32x32
+# accumulators reach the fp32 stream in 32-byte row pieces.  LLARK_PRIOR_CPROJ_BDA=1 takes it (same results to rounding).
+DEFAULT_CPROJ_BDA = False
 
 
 class Labeller:
@@ -75,7 +80,7 @@ class Labeller:
 class _LayerWeights:
     __slots__ = ("ln0_g", "ln0_b", "ln1_g", "ln1_b", "w_attn", "b_attn", "w_proj", "b_proj", "w_fc", "b_fc", "w_proj2",
                  "b_proj2", "sw_attn", "sw_proj", "sw_fc", "sw_proj2", "w8_attn", "w8_proj", "w8_fc", "w8_proj2",
-                 "gw_attn", "bw_attn", "gw_fc", "bw_fc")
+                 "gw_attn", "bw_attn", "gw_fc", "bw_fc", "wf_proj")
 
 
 class PriorTransformer:
@@ -97,6 +102,7 @@ class PriorTransformer:
             ln_fold = os.environ.get("LLARK_PRIOR_LN_FOLD", "1" if DEFAULT_LN_FOLD else "0") != "0"
         self.ln_fold = bool(ln_fold) and precision == "f16x2"       # the lo8 tile has no folded epilogues
         self.ln_pred = self.ln_fold and os.environ.get("LLARK_PRIOR_LN_PRED", "1" if DEFAULT_LN_PRED else "0") != "0"
+        self.cproj_bda = self.ln_fold and os.environ.get("LLARK_PRIOR_CPROJ_BDA", "1" if DEFAULT_CPROJ_BDA else "0") != "0"
         self.width = hps.prior_width
         self.depth = hps.prior_depth if depth is None else depth
         dev = self.device
@@ -172,7 +178,7 @@ class PriorTransformer:
                                                         ((3 * S, Wp), (W, Sp), (Mw, Wp), (W, Mp))))
             if self._fold_rows:
                 self._ln_parts = 2 * ((W + 255) // 256)
-                ws["ln_part"] = torch.empty((rows, self._ln_parts, 2), dtype=torch.float32, device=dev)
+                ws["ln_part"] = torch.empty((rows, max(self._ln_parts, (W + 63) // 64 if self.cproj_bda else 0), 2), dtype=torch.float32, device=dev)
                 ws["ln_stat"] = torch.empty((rows, 2), dtype=torch.float32, device=dev)
                 ws["ln_pred"] = torch.empty((rows, 2), dtype=torch.float32, device=dev) if self.ln_pred else None
             self._ws, self._ws_rows = ws, rows
@@ -227,9 +233,16 @@ class PriorTransformer:
             ops.layernorm_split(h2, L.ln0_g, L.ln0_b, 1e-5, ws["ln_hi"], ws["ln_lo"])
             ops.gemm16(ws["ln_hi"], ws["ln_lo"], L.w_attn, L.b_attn, 3 * S, ops.EPI_F32, c=ws["qkv"])
         ops.prior_attn(ws["qkv"], n, hps.n_ctx, S, hps.heads, hps.blocks, [1, 2, 3][d % 3], ws["att_hi"], ws["att_lo"])
-        ops.gemm16_ln(ws["att_hi"], ws["att_lo"], L.w_proj, L.b_proj, W, ops.EPI_RESID, L.ln1_g, ln_part=part, c=h2, resid=h2,
-                      out_hi=ws["ln_hi"], out_lo=ws["ln_lo"], ln_pred=pred)
-        ops.ln_stats_finalize(part, rows, self._ln_parts, W, 1e-5, stat, pred)
+        if self.cproj_bda:
+            if getattr(L, "wf_proj", None) is None:
+                L.wf_proj = ops.pack_weight16_frag(L.w_proj, W)
+            np1 = ops.gemm16_lnp_fragw(ws["att_hi"], ws["att_lo"], L.wf_proj, L.b_proj, W, L.w_proj.shape[1], L.ln1_g, part, h2, h2,
+                                       ws["ln_hi"], ws["ln_lo"], ln_pred=pred)
+        else:
+            np1 = self._ln_parts
+            ops.gemm16_ln(ws["att_hi"], ws["att_lo"], L.w_proj, L.b_proj, W, ops.EPI_RESID, L.ln1_g, ln_part=part, c=h2, resid=h2,
+                          out_hi=ws["ln_hi"], out_lo=ws["ln_lo"], ln_pred=pred)
+        ops.ln_stats_finalize(part, rows, np1, W, 1e-5, stat, pred)
         ops.gemm16_ln(ws["ln_hi"], ws["ln_lo"], L.w_fc, L.bw_fc, Mw, ops.EPI_QGELU_SPLIT, L.gw_fc, ln_stat=stat,
                       out_hi=ws["g_hi"], out_lo=ws["g_lo"])
         if fold_out is None:

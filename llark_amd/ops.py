@@ -533,6 +533,31 @@ def gemm16_ln(a_hi: torch.Tensor, a_lo: torch.Tensor, wt: torch.Tensor, bias: Op
             _dev(ln_pred, "ln_pred", torch.float32) if ln_pred is not None else None, workspace(), _stream()), "gemm16_ln")
 
 
+def gemm16_lnp_fragw(a_hi: torch.Tensor, a_lo: torch.Tensor, wfrag: torch.Tensor, bias: Optional[torch.Tensor], n: int, kp: int,
+                     ln_vec: torch.Tensor, ln_part: torch.Tensor, c: torch.Tensor, resid: torch.Tensor, out_hi: torch.Tensor,
+                     out_lo: torch.Tensor, m: Optional[int] = None, ln_pred: Optional[torch.Tensor] = None) -> int:
+    """The producer role of :func:`gemm16_ln` with fragment-major weights on 128x256 tiles, two workgroups to a CU
+    (include/llark_hip.h, llark_gemm16_lnp_fragw).  Returns the number of 64-column slices ``ln_part`` [m][nparts][2] now holds:
+    pass it to :func:`ln_stats_finalize`."""
+    dtype = a_hi.dtype
+    assert dtype in (torch.float16, torch.bfloat16) and wfrag.dtype == dtype and a_hi.shape[1] >= kp
+    assert wfrag.numel() == round_up(n, 32) * kp and ln_vec.numel() >= n
+    m = a_hi.shape[0] if m is None else m
+    nparts = (n + 63) // 64
+    assert ln_part.numel() >= m * nparts * 2, "gemm16_lnp_fragw: ln_part is [m][ceil(n / 64)][2]"
+    if ln_pred is not None:
+        assert ln_pred.numel() >= 2 * m and ln_pred.is_contiguous()
+    name = "gemm_split_" + ("f16" if dtype == torch.float16 else "bf16")
+    with _timed(name, 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_lnp_fragw(
+            _DT[dtype], _dev(a_hi, "a_hi"), _dev(a_lo, "a_lo", dtype), a_hi.stride(0), _dev(wfrag, "wfrag"),
+            _dev(bias, "bias", torch.float32) if bias is not None else None, m, n, kp, _dev(c, "c", torch.float32), c.stride(0),
+            _dev(resid, "resid", torch.float32), resid.stride(0), _dev(out_hi, "out_hi", dtype), _dev(out_lo, "out_lo", dtype),
+            out_hi.stride(0), _dev(ln_vec, "ln_vec", torch.float32), _dev(ln_part, "ln_part", torch.float32),
+            _dev(ln_pred, "ln_pred", torch.float32) if ln_pred is not None else None, _stream()), "gemm16_lnp_fragw")
+    return nparts
+
+
 def ln_stats_finalize(part: torch.Tensor, rows: int, nparts: int, width: int, eps: float, stat: torch.Tensor,
                       pred: Optional[torch.Tensor] = None) -> None:
     """part [rows][nparts][2] (sum, sum of squares per column slice) -> stat [rows][2] (mean, rstd).  With ``pred`` [rows][2] (the

@@ -110,7 +110,9 @@ def test_gemm_bda_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
     spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)] + [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
     assert len(spills) >= 20 and not any(spills), f"spills / scratch: {spills}"
     assert all(int(v) <= 256 for v in re.findall(r"VGPRs: (\d+)", r.stderr))
-    assert audit_kernels(out.read_text().split("\n"), "_ZN5llark15gemm_bda_kernel", 10) == 10 * 16
+    txt = out.read_text().split("\n")
+    assert audit_kernels(txt, "_ZN5llark15gemm_bda_kernel", 10) == 10 * 16
+    assert audit_kernels(txt, "_ZN5llark19gemm_bda_lnp_kernel", 2) == 2 * 16      # the LayerNorm-producer role on the same loop (fp16, bf16)
 
 
 if __name__ == "__main__":      # python tests/test_gemm_bda_isa_cpu.py <file.s> <kernel symbol regex>: the same audit on any assembly file

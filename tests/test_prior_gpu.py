@@ -263,6 +263,71 @@ def test_gemm16_ln_folded_layernorm_roles(m, n, k):
         ops.gemm16_ln(ph0[:512], pl0[:512], wt2, bw, n2, ops.EPI_F32, gw, ln_stat=stat, c=out[:512])
 
 
+@pytest.mark.parametrize("m,n,k,dt", [(8232, 4800, 1216, torch.float16), (640, 1216, 256, torch.float16), (300, 4800, 192, torch.bfloat16)])
+def test_gemm16_lnp_fragw_producer_on_the_dma_loop(m, n, k, dt):
+    """llark_gemm16_lnp_fragw (round 5): the LayerNorm PRODUCER role on gemm_bda's 128x256 tiles (two workgroups to a CU, product
+    computed transposed, fragment-major weights) -- the prior's attention-output product.  Against float64 inside the split scheme's
+    bound and against the persistent tile's producer to rounding (the two MFMA shapes sum in different orders); the planes are
+    BIT-equal to split16(((c - shift) scale) gamma) of the stream the kernel itself wrote; the 64-column partial sums reduce to the
+    row's statistics; in place (resid aliases c); ragged last row tile, ragged last column tile (a whole wave beyond n), pad columns
+    untouched; run-to-run bit-equal; refused below three K-steps."""
+    from llark_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = (torch.randn(k, n, generator=g) * 0.1).half()
+    b = torch.randn(n, generator=g).cuda()
+    r = (torch.randn(m, n, generator=g) * 2.0 + 0.5).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(n, generator=g)).cuda()
+    hi, lo = ops.split16(a.cuda(), dt, kmult=64)
+    wt = ops.pack_weight16(w.cuda(), True, dt, kmult=64)
+    kp = wt.shape[1]
+    wf = ops.pack_weight16_frag(wt, n)
+    a16 = hi.float().cpu()[:, :k].double() + lo.float().cpu()[:, :k].double()
+    w16 = wt.float().cpu()[:n, :k].double()
+    ref = a16 @ w16.t() + b.cpu().double() + r.cpu().double()
+    bound = 2e-6 * (a16.abs() @ w16.abs().t()) + 2e-7 * ref.abs() + 1e-6
+    pred0 = torch.empty((m, 2), device="cuda")
+    ops.ln_row_pred(r, 1e-5, pred0)
+    for use_pred in (True, False):
+        first = None
+        for rep in range(2):
+            c1 = r.clone()
+            pred = pred0.clone() if use_pred else None
+            ph, pl = (torch.full((m, n + 8), float("nan"), dtype=dt, device="cuda") for _ in range(2))
+            part = torch.full((m, (n + 63) // 64, 2), float("nan"), device="cuda")
+            stat = torch.full((m, 2), float("nan"), device="cuda")
+            nparts = ops.gemm16_lnp_fragw(hi, lo, wf, b, n, kp, gamma, part, c1, c1, ph, pl, ln_pred=pred)
+            assert nparts == (n + 63) // 64
+            ops.ln_stats_finalize(part, m, nparts, n, 1e-5, stat, pred)
+            if first is None:
+                first = (c1.clone(), ph[:, :n].clone(), pl[:, :n].clone(), stat.clone())
+        assert all(torch.equal(x, y) for x, y in zip(first, (c1, ph[:, :n], pl[:, :n], stat))), "not run-to-run bit-equal"
+        err = (c1.cpu().double() - ref).abs()
+        assert bool((err <= bound).all()), f"stream vs float64: worst excess {float((err - bound).max()):.3e}"
+        assert bool(torch.isnan(ph[:, n:]).all() and torch.isnan(pl[:, n:]).all()), "planes written past column n"
+        assert bool(torch.isfinite(part).all()), "a partial sum was not written"
+        shift = pred0[:, 0:1] if use_pred else torch.zeros((m, 1), device="cuda")
+        scale = pred0[:, 1:2] if use_pred else torch.ones((m, 1), device="cuda")
+        xg = ((c1 - shift) * scale) * gamma
+        want_hi = xg.to(dt)
+        assert torch.equal(ph[:, :n], want_hi) and torch.equal(pl[:, :n], (xg - want_hi.float()).to(dt)), "planes are not split16(((c - shift) scale) gamma)"
+        c64 = c1.double()
+        mean64, var64 = c64.mean(1), c64.var(1, unbiased=False)
+        sd, rstd64 = torch.sqrt(var64 + 1e-5), 1.0 / torch.sqrt(var64 + 1e-5)
+        assert float(((stat[:, 0].double() / scale[:, 0].double() + shift[:, 0].double() - mean64).abs() / sd).max()) <= 1e-5
+        assert float((stat[:, 1].double() * scale[:, 0].double() / rstd64 - 1.0).abs().max()) <= 1e-5
+        if use_pred:
+            assert float(((pred[:, 0].double() - mean64).abs() / sd).max()) <= 1e-5, "pred was not replaced by the measured mean"
+    if dt == torch.float16 and ops.gemm16_ln_takes(m, n, kp):        # the persistent tile's producer: same values to rounding
+        c2 = r.clone()
+        ph2, pl2 = (torch.zeros((m, n + 8), dtype=dt, device="cuda") for _ in range(2))
+        part2 = torch.empty((m, 2 * ((n + 255) // 256), 2), device="cuda")
+        ops.gemm16_ln(hi, lo, wt, b, n, ops.EPI_RESID, gamma, ln_part=part2, c=c2, resid=c2, out_hi=ph2, out_lo=pl2)
+        assert float((c2 - c1).abs().max()) <= 4e-6 * float(ref.abs().max()) + 1e-6
+    with pytest.raises(RuntimeError):                                 # two K-steps: below the ring's prologue
+        ops.gemm16_lnp_fragw(hi[:, :128].contiguous(), lo[:, :128].contiguous(), wf[: ops.round_up(n, 32) * 128], b, n, 128, gamma, part, c1, c1, ph, pl)
+
+
 def test_gemm16_ln_predicted_statistics_adversarial_rows():
     """llark_gemm16_ln_p / llark_ln_stats_finalize_p / llark_ln_row_pred (round 5): the folded LayerNorm with planes
     pre-normalised by PREDICTED row statistics, on rows the unscaled planes lose bits on -- std 1e-3 (fp16 lo plane subnormal), std 1e3
