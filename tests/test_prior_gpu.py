@@ -848,6 +848,31 @@ def test_prior_folded_layernorm_matches_unfolded_and_oracle():
     assert e_fu <= 2e-5 * scale
 
 
+def test_prior_cproj_on_the_dma_loop_knob(monkeypatch):
+    """LLARK_PRIOR_CPROJ_BDA=1 (round 5, opt-in: measured slower): the attention-output product of every block as LayerNorm producer on
+    gemm_bda's tiles (llark_gemm16_lnp_fragw, 64-column partial sums) instead of the persistent tile -- same graph, another summation
+    order: equal to the default folded path to rounding, inside the oracle bar, clip 0 of a batch bit-equal to clip 0 alone."""
+    from llark_amd.jukebox.prior import TopPrior
+    from llark_amd.jukebox import extract as E
+    hps = hparams_5b_depth(3)
+    w = make_prior_weights(hps, 5, depth=3)
+    z = torch.randint(0, hps.l_bins, (2, hps.n_ctx), generator=torch.Generator().manual_seed(11))
+    tp_d = TopPrior(hps, w, "cuda", depth=3, ln_fold=True)
+    monkeypatch.setenv("LLARK_PRIOR_CPROJ_BDA", "1")
+    tp_b = TopPrior(hps, w, "cuda", depth=3, ln_fold=True)
+    assert tp_b.prior.cproj_bda and not tp_d.prior.cproj_bda
+    x_cond, y_cond = E.get_cond(hps, tp_d)
+    a_d = E.get_final_activations(z[:1].cuda(), x_cond, y_cond, tp_d)
+    a_b = E.get_final_activations(z[:1].cuda(), x_cond, y_cond, tp_b)
+    a_b2 = E.get_final_activations(z.cuda(), x_cond, y_cond, tp_b)
+    assert tp_b.prior._fold_rows and tp_b.prior.layers[0].wf_proj is not None, "the knob's path was not taken"
+    assert torch.equal(a_b2[0], a_b[0]), "clip 0 of a batch of 2 differs from clip 0 alone"
+    scale = float(a_d.abs().max())
+    e = float((a_b - a_d).abs().max())
+    print(f"\n[cproj-bda] 3 layers at 5b widths: knob vs default folded path {e:.2e}, max|h| {scale:.2f}")
+    assert e <= 2e-5 * scale
+
+
 def test_prior_rejects_unsupported():
     from llark_amd.jukebox.prior import TopPrior
     hps = hparams_tiny()
