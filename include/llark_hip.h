@@ -390,6 +390,12 @@ int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void
 int llark_gemm16_t_sumsq(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m, int n,
                          int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream);
 
+/* llark_gemm16_t / llark_gemm16_t_sumsq (sumsq nullable) with an explicit tile / pipeline variant, for benchmarks and A/B tests:
+ * -1 = library choice, 0 = one LDS stage per workgroup, 1 = 128x256x32 tiles with two stages, 2 = 128x256x64 two stages, 3 = 256x256x64
+ * two stages (8 waves).  Results are bit-identical across variants. */
+int llark_gemm16_t_ex(int variant, int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
+                      int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream);
+
 /* Training pair (csrc/llama.hip, csrc/attn_bwd.hip): what torch autograd does for LlamaAttention's eager path
  * (transformers==4.29.2 modeling_llama.py) under WrappedLlamav2ForCausalLM.forward + loss.backward()
  * (m2t/models/llamav2.py:259-337, m2t/train.py:53-277), without ever writing an S x S matrix.
@@ -532,6 +538,25 @@ int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, in
 int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm,
                      llark_stream_t stream);
+/* The two SwiGLU products of the training step with the element-wise pass in their epilogues (csrc/gemm_bda.hip; HF LlamaMLP.forward and
+ * its autograd under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:224-234,259-337, m2t/train.py:53-277).
+ * Plain bf16 operands, fragment-major weights (llark_pack_weight16_frag / llark_adamw_twins).  gu16 [m][ldg >= 2 I] = the gate | up
+ * pre-activations as bf16, interleaved like the fused gate/up weight rows ([32 gate | 32 up] per 64 columns).
+ *   mode 0: a = x [m][kp], wfrag = gate|up twin (n = 2 I): out = act [m][ldo >= I] = silu(gate) * up; gu16 is WRITTEN.
+ *   mode 1: a = d(h) [m][kp], wfrag = down_proj^T twin (n = I): out = d(gate | up) [m][ldo >= 2 I]; gu16 is READ.
+ * LLARK_ERR_UNSUPPORTED when the DMA loop does not take the shape (kp < 192, operand beyond 2 GiB). */
+int llark_gemm16_fragw_swiglu_train(int mode, const void* a, int lda, const void* wfrag, int m, int n, int kp, void* out, int ldo,
+                                    void* gu16, int ldg, llark_stream_t stream);
+/* The bf16 step of llark_adamw / llark_adamw_clip (grad_sumsq nullable = no clipping) on a weight MATRIX p [n][k] that also writes the
+ * fragment-major operand twins of the UPDATED weight (what the reference reaches through HF Trainer's optimizer.step(), m2t/train.py:255-260,
+ * followed by the next micro-batch's nn.Linear forward / backward, m2t/models/llamav2.py:259-337): wfrag (nullable) =
+ * llark_pack_weight16_frag(p), the B operand of the forward product -- rows below rope_rows (the q and k parts of a fused q|k|v weight)
+ * in llark_gemm16_fragw_rope_qkv's head-permuted order; wtfrag (nullable) = llark_pack_weight16_frag of p^T ([k][n]), the B operand
+ * of dX = dY . W.  n % 32 == 0, k % 128 == 0, wtfrag needs n % 64 == 0, rope_rows % 128 == 0, every pointer 16-byte aligned.
+ * Parameters and moments are bit-equal to llark_adamw / llark_adamw_clip. */
+int llark_adamw_twins(void* p, const float* g, float* m, float* v, int n, int k, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm, void* wfrag,
+                      int rope_rows, void* wtfrag, llark_stream_t stream);
 
 #ifdef __cplusplus
 }

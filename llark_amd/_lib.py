@@ -104,6 +104,7 @@ _SIGS = {
     "llark_gemv16_dma": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P],
     "llark_gemv16_dma_rmsnorm": [c_int, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P],
     "llark_gemm16_t": [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "llark_gemm16_t_ex": [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_gemm16_t_sumsq": [c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_attn_prefill_bf16_lse": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     "llark_attn_backward_bf16": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P],
@@ -147,6 +148,8 @@ _SIGS = {
     "llark_scatter_add_rows_f32": [_P, c_int, _P, c_int, c_int, _P, c_int, _P],
     "llark_adamw": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P],
     "llark_adamw_clip": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P],
+    "llark_gemm16_fragw_swiglu_train": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "llark_adamw_twins": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P, c_int, _P, _P],
 }
 
 

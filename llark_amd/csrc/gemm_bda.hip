@@ -261,8 +261,37 @@ int launch_gemm_bda(const GemmParams& p, int dtype, int epi, hipStream_t s) {
         case EPI_OUT16: return launch_bda<bf16_t, false, EPI_OUT16>(p, s);
         case EPI_SWIGLU16: return launch_bda<bf16_t, false, EPI_SWIGLU16>(p, s);
         case EPI_ROPE_QKV: return launch_bda<bf16_t, false, EPI_ROPE_QKV>(p, s);
+        case EPI_SWIGLU16_SAVE: return launch_bda<bf16_t, false, EPI_SWIGLU16_SAVE>(p, s);
+        case EPI_SWIGLU_BWD: return launch_bda<bf16_t, false, EPI_SWIGLU_BWD>(p, s);
     }
     return -1000;
 }
 
 }  // namespace llark
+
+using namespace llark;
+
+// The two SwiGLU products of the training step with the element-wise pass in their epilogues (round 6; the reference reaches them through
+// HF LlamaMLP.forward = down_proj(act_fn(gate_proj(x)) * up_proj(x)) and its autograd, m2t/models/llamav2.py:224-234 under
+// m2t/train.py:53-277; bf16 like `--bf16 True`, scripts/training/train_llark.sh:24).  Plain bf16 operands, fragment-major weights, the
+// DMA loop of this file (128x256 tiles).  gu16 [m][ldg >= 2 I]: gate | up pre-activations as bf16 in the interleaved order of the fused
+// gate/up weight rows ([32 gate | 32 up] per 64 columns) -- what nn.Linear leaves under bf16 autocast.
+//   mode 0 (forward):  a = x [m][kp], wfrag = gate|up weight twin (n = 2 I rows):  act [m][ldo >= I] = silu(gate) * up, gu16 = gate | up.
+//                      Replaces llark_gemm16 (fp32 gate|up) + llark_swiglu_fwd.
+//   mode 1 (backward): a = d(h) [m][kp], wfrag = down_proj^T twin (n = I rows):   d(act) = a . W stays in the accumulators;
+//                      dgu [m][ldo >= 2 I] = d(gate | up) from gu16.  Replaces llark_gemm16_t (fp32 d(act)) + llark_swiglu_bwd.
+// Returns LLARK_ERR_UNSUPPORTED for a shape the DMA loop does not take (kp < 192, operand beyond 2 GiB): callers keep the two-launch path.
+extern "C" int llark_gemm16_fragw_swiglu_train(int mode, const void* a, int lda, const void* wfrag, int m, int n, int kp, void* out, int ldo,
+                                               void* gu16, int ldg, llark_stream_t stream) {
+    LLARK_REQUIRE(mode == 0 || mode == 1, "gemm16_fragw_swiglu_train: mode must be 0 (forward) or 1 (backward)");
+    LLARK_REQUIRE(a && wfrag && out && gu16 && m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_fragw_swiglu_train: null pointer / empty problem / kp not a multiple of 64");
+    LLARK_REQUIRE(lda % 8 == 0 && lda >= kp && ((uintptr_t)a & 15) == 0 && ((uintptr_t)wfrag & 15) == 0, "gemm16_fragw_swiglu_train: a must be 16-byte aligned with lda >= kp, a multiple of 8");
+    const int inter = mode == 0 ? n / 2 : n;
+    LLARK_REQUIRE(mode == 0 ? (n % 64 == 0 && ldo >= inter) : (n % 32 == 0 && ldo >= 2 * inter), "gemm16_fragw_swiglu_train: bad n / ldo for this mode (n=%d ldo=%d)", n, ldo);
+    LLARK_REQUIRE(ldg >= 2 * inter, "gemm16_fragw_swiglu_train: ldg %d < 2 I = %d", ldg, 2 * inter);
+    GemmParams p = {};
+    p.Ahi = a; p.lda = lda; p.Wt = wfrag; p.M = m; p.N = n; p.Kp = kp; p.Ohi = out; p.ldo = ldo; p.G16 = gu16; p.ldg = ldg;
+    const int rc = launch_gemm_bda(p, LLARK_BF16, mode == 0 ? EPI_SWIGLU16_SAVE : EPI_SWIGLU_BWD, (hipStream_t)stream);
+    if (rc == -1000) { set_error("gemm16_fragw_swiglu_train: needs kp >= 192 and an A operand below 2 GiB"); return LLARK_ERR_UNSUPPORTED; }
+    return rc;
+}

@@ -131,12 +131,19 @@ struct GemmParams {
     void *rope_q, *rope_q_lo;      // bf16 [batch][nh][rope_s][128]
     void *rope_k, *rope_k_lo;      // bf16 [batch][nh][rope_smax][128]
     void *rope_v, *rope_v_lo;      // bf16 [batch][nh][128][rope_smax]  (V transposed)
+    // EPI_SWIGLU16_SAVE (output) / EPI_SWIGLU_BWD (input): the gate | up pre-activations, 16-bit, in the interleaved column order of the
+    // gate/up weight rows ([32 gate | 32 up] per 64 columns), pitch ldg
+    void* G16;
+    int ldg;
 };
 
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_QGELU_SPLIT = 2, EPI_OUT16 = 3, EPI_SWIGLU16 = 4, EPI_SPLIT16 = 5, EPI_SWIGLU_SPLIT = 6,
        EPI_QGELU_SPLIT8 = 7 /* lo8 mode: fp16 hi plane + e4m3 low plane (gemm256_lo8n.hip only) */,
-       EPI_ROPE_QKV = 8 /* internal (no public value): gemm_bd_kernel + gemm_epilogue_rope_qkv, llark_gemm16_fragw_rope_qkv */ };
-#define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT)
+       EPI_ROPE_QKV = 8 /* internal (no public value): gemm_bd_kernel + gemm_epilogue_rope_qkv, llark_gemm16_fragw_rope_qkv */,
+       // training step (round 6; internal, reached through llark_gemm16_fragw_swiglu_train; gemm_bda.hip, plain bf16 operands):
+       EPI_SWIGLU16_SAVE = 9 /* EPI_SWIGLU16 that also leaves the gate | up values as 16-bit [M][N] (G16) for the backward */,
+       EPI_SWIGLU_BWD = 10 /* acc = d(act) [M][N = I]: reads gate | up from G16 [M][2 N], writes d(gate | up) 16-bit to Ohi [M][2 N] */ };
+#define IS_SWIGLU(E) ((E) == EPI_SWIGLU16 || (E) == EPI_SWIGLU_SPLIT || (E) == EPI_SWIGLU16_SAVE)
 
 template <typename T>
 struct Mfma;
@@ -229,6 +236,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     }
     if (EPI == EPI_QGELU_SPLIT || EPI == EPI_SPLIT16 || EPI == EPI_SWIGLU_SPLIT)
         rL = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Olo + bz * p.sO + (size_t)mrow0 * p.ldo + ocol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t rG;
+    int vG = 0;
+    if (EPI == EPI_SWIGLU16_SAVE) {                                  // gate | up as the accumulators hold them: weight-row (column) space
+        rG = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.G16 + (size_t)mrow0 * p.ldg + ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vG = (lr * p.ldg + lc) * 2;
+    }
+    if (EPI == EPI_SWIGLU_BWD) {                                     // output column c of d(act) <-> columns 64 (c / 32) + c % 32 (gate), + 32 (up)
+        rG = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.G16 + (size_t)mrow0 * p.ldg + 2 * ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vG = (lr * p.ldg + lc) * 2;
+        rH = __builtin_amdgcn_make_buffer_rsrc((void*)((T*)p.Ohi + (size_t)mrow0 * p.ldo + 2 * ncol0), 0, 0x7FFFFFFF, RSRC_FLAGS);
+        vO = (lr * p.ldo + lc) * 2;
+    }
     int v8 = 0;
     float sa_mul = 1.0f;
     if (EPI == EPI_QGELU_SPLIT8) {     // e4m3 low plane: byte rows of ldo8, this wave's 128 columns = two 64-k blocks
@@ -262,6 +281,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                         res[tn][r] = (col_ok && (FULL || mrow0 + ml + lr < p.M))
                                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rR, vR, (ml * p.ldr + C::tile_col(tn)) * 4, 0))
                                          : 0.0f;
+                    }
+                }
+            }
+            unsigned short gq[EPI == EPI_SWIGLU_BWD ? C::TN : 1][16], uq[EPI == EPI_SWIGLU_BWD ? C::TN : 1][16];
+            if (EPI == EPI_SWIGLU_BWD) {                             // all of this tile row's gate / up loads in flight together
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) {
+                    const bool col_ok = FULL || (ocol0 + C::tile_col(tn) + lc < nlim);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);
+                        const bool ok = col_ok && (FULL || mrow0 + ml + lr < p.M);
+                        const int so = (ml * p.ldg + 2 * C::tile_col(tn)) * 2;
+                        gq[tn][r] = ok ? (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rG, vG, so, 0) : (unsigned short)0;
+                        uq[tn][r] = ok ? (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rG, vG, so + 64, 0) : (unsigned short)0;
                     }
                 }
             }
@@ -309,6 +343,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                         const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
                         __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
                                                               vO, (ml * p.ldo + ocl) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU16_SAVE) {
+                        constexpr int tu = (C::TN > 1) ? 1 : 0;
+                        const float gate = acc[tm][tn][r], up = acc[tm][(tn + tu) % C::TN][r];
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(silu(gate) * up)), rH,
+                                                              vO, (ml * p.ldo + ocl) * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(gate)), rG, vG,
+                                                              (ml * p.ldg + C::tile_col(tn)) * 2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(up)), rG, vG,
+                                                              (ml * p.ldg + C::tile_col((tn + tu) % C::TN)) * 2, 0);
+                    } else if (EPI == EPI_SWIGLU_BWD) {
+                        // act = silu(g) u:  d(gate) = d u sig (1 + g (1 - sig)),  d(up) = d g sig   (sig = sigmoid(g); hardware exp2 / rcp as silu())
+                        const float g = Mfma<T>::back(__builtin_bit_cast(T, gq[EPI == EPI_SWIGLU_BWD ? tn : 0][r]));
+                        const float u = Mfma<T>::back(__builtin_bit_cast(T, uq[EPI == EPI_SWIGLU_BWD ? tn : 0][r]));
+                        const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * g));
+                        const float dg = v * u * sig * (1.0f + g * (1.0f - sig));
+                        const float du = v * g * sig;
+                        const int so = (ml * p.ldo + 2 * C::tile_col(tn)) * 2;
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(dg)), rH, vO, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, Mfma<T>::cvt(du)), rH, vO, so + 64, 0);
                     } else if (EPI == EPI_SWIGLU_SPLIT) {
                         constexpr int tu = (C::TN > 1) ? 1 : 0;
                         const float a = silu(acc[tm][tn][r]) * acc[tm][(tn + tu) % C::TN][r];

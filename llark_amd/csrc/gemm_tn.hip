@@ -25,6 +25,13 @@ typedef Cfg<2, 2, 2, 2, 64, 3, 1> CfgT;            // 128x128x64, 4 waves (64x64
 typedef Cfg<2, 2, 2, 4, 64, 2, 1> CfgTW;           // 128x256x64, 4 waves (64x128 each), 48 KiB: 2 per CU -- 0.75 fragment reads per MFMA
                                                    // instead of 1: +8 % on the deep, many-tile products (K >= 4096, >= 512 tiles)
 
+// Round 6: the same tiles with TWO LDS stages per workgroup -- K-step kt + 1 is requested (LDS-DMA) right after the
+// barrier that opens K-step kt and has that step's whole MFMA time to land, instead of `request, wait, compute` with a co-resident
+// workgroup as the only cover (PMC round 3: matrix pipe 38-51 % busy, a third of the wave cycles parked).
+typedef Cfg<2, 2, 2, 4, 32, 2, 2> CfgT2H;          // 128x256x32, 4 waves, 2 x 24 KiB: still 2 workgroups per CU (half K-steps)
+typedef Cfg<2, 2, 2, 4, 64, 2, 2> CfgT2W;          // 128x256x64, 4 waves, 2 x 48 KiB: 1 workgroup per CU
+typedef Cfg<2, 4, 4, 2, 64, 2, 2> CfgT2Q;          // 256x256x64, 8 waves (128x64 each), 2 x 64 KiB: 1 workgroup per CU, 2 waves per SIMD
+
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef short v8s_t __attribute__((ext_vector_type(8)));
 
@@ -136,6 +143,109 @@ __global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_t_kernel(const GemmP
     gemm_epilogue<T, false, EPI, C, true>(p, acc, m0, n0, wm, wn, lane, 0);
 }
 
+// Two-stage form.  Order per accumulator (k ascending, one 32x32x16 MFMA per 16 k) is gemm_t_kernel's: bit-identical results for
+// equal tiles.  Protocol per K-step kt (stage kt & 1):  s_waitcnt vmcnt(0) [this wave's requests for stage kt, issued one K-step ago]
+// -> s_barrier [every wave's part of stage kt has landed AND every wave is done reading stage kt - 1, whose MFMAs consumed its ds_reads]
+// -> request stage kt + 1 into the other buffer -> fragment reads + MFMAs of stage kt.  Only LDS-DMA is outstanding at the wait, the
+// barrier is the raw one (a __syncthreads() would be the same here: nothing is in flight behind the wait).
+template <typename T, bool TA, bool TB, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::MINW) void gemm_t2_kernel(const GemmParams p) {
+    typedef typename Mfma<T>::frag frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = C::A_BYTES + C::B_BYTES;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w / C::WN, wn = w % C::WN;
+
+    int base, count;
+    xcd_band(p.tiles_m * p.tiles_n, blockIdx.x & 7, base, count);
+    const int bid = base + (blockIdx.x >> 3);
+    constexpr int GM = 8;
+    const int gsz = GM * p.tiles_n;
+    const int gi = bid / gsz;
+    const int first_m = gi * GM;
+    const int gm = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
+    const int m0 = (first_m + (bid % gsz) % gm) * C::BM, n0 = ((bid % gsz) / gm) * C::BN;
+
+    const T* A = (const T*)p.Ahi;
+    const T* W = (const T*)p.Wt;
+    constexpr int NIA = C::A_BYTES / 1024 / C::NW, NIB = C::B_BYTES / 1024 / C::NW;     // 1 KiB DMA instructions per wave and operand
+    static_assert(NIA >= 1 && NIB >= 1 && C::A_BYTES % (1024 * C::NW) == 0 && C::B_BYTES % (1024 * C::NW) == 0, "tile rows must deal evenly to the waves");
+    auto stage = [&](int kt, char* sA) __attribute__((always_inline)) {
+        char* sW = sA + C::A_BYTES;
+        const int k0 = kt * C::BK;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int j = w + i * C::NW;
+            if (TA) dma_rows_t<T, C::BM>(A, p.lda, k0 + j * (512 / C::BM), m0, p.M, sA + j * 1024, lane);
+            else dma_rows<T, C>(A, p.lda, m0 + j * C::RPI, p.M, k0, j * C::RPI, sA + j * 1024, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int j = w + i * C::NW;
+            if (TB) dma_rows_t<T, C::BN>(W, p.ldw, k0 + j * (512 / C::BN), n0, p.N, sW + j * 1024, lane);
+            else dma_rows<T, C>(W, p.ldw, n0 + j * C::RPI, p.N, k0, j * C::RPI, sW + j * 1024, lane);
+        }
+    };
+    const int q = lane >> 4, i16 = lane & 15;
+    const int trow = 8 * (q >> 1) + (i16 >> 2);
+    const int tcol = 16 * (q & 1) + 4 * (i16 & 3);
+    auto toff = [&](int f0, int s, int fw) __attribute__((always_inline)) {
+        const int col = f0 + tcol;
+        return (s * 16 + trow) * (fw * 2) + ((((col >> 3) ^ ((i16 >> 2) << 2)) << 4) | ((col & 7) << 1));
+    };
+
+    f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+    for (int a = 0; a < C::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < C::TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = p.Kp / C::BK;
+    stage(0, smem);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = smem + (kt & 1) * STAGE;
+        const char* sW = sA + C::A_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+#pragma unroll
+        for (int s = 0; s < C::BK / 16; ++s) {
+            const int c = s * 2 + (lane >> 5);
+            frag bf[C::TN], af[C::TM];
+#pragma unroll
+            for (int tn = 0; tn < C::TN; ++tn)
+                bf[tn] = TB ? read_frag_t<T, C::BN>(sW, toff((wn * C::TN + tn) * 32, s, C::BN))
+                            : *(const frag*)(sW + C::off((wn * C::TN + tn) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+                af[tm] = TA ? read_frag_t<T, C::BM>(sA, toff((wm * C::TM + tm) * 32, s, C::BM))
+                            : *(const frag*)(sA + C::off((wm * C::TM + tm) * 32 + (lane & 31), c));
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < C::TN; ++tn) acc[tm][tn] = Mfma<T>::run(af[tm], bf[tn], acc[tm][tn]);
+        }
+    }
+    gemm_epilogue<T, false, EPI, C, true>(p, acc, m0, n0, wm, wn, lane, 0);
+}
+
+template <typename T, bool TA, bool TB, int EPI, typename C>
+static int launch_t2(GemmParams p, hipStream_t s) {
+    constexpr int LDS = 2 * (C::A_BYTES + C::B_BYTES);
+    auto kern = gemm_t2_kernel<T, TA, TB, EPI, C>;
+    static PerDeviceOnce once;
+    if (once.first()) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1000;
+    }
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    kern<<<p.tiles_m * p.tiles_n, C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm16_t");
+}
+
 template <typename T, bool TA, bool TB, int EPI, typename C>
 static int launch_tc(GemmParams p, hipStream_t s) {
     constexpr int LDS = C::A_BYTES + C::B_BYTES;
@@ -147,17 +257,25 @@ static int launch_tc(GemmParams p, hipStream_t s) {
 
 // 128x256 tiles for the deep products with many tiles (the dX / dW products of a 4096-token micro-batch), 128x128 otherwise
 // (profiles/r03_gemm_train_variants_m{2048,4096}.txt: the same rule for the plain kernel's variants 11 / 12)
+#ifndef GEMM_T_DEFAULT
+#define GEMM_T_DEFAULT 0          // library choice for the deep many-tile products: 0 = one LDS stage (rounds 3-5), 1 / 2 / 3 = CfgT2H / CfgT2W / CfgT2Q
+#endif
 template <typename T, bool TA, bool TB, int EPI>
-static int launch_t(const GemmParams& p, hipStream_t s) {
+static int launch_t(const GemmParams& p, hipStream_t s, int variant) {
+    const bool deep = p.Kp >= 4096 && (long)cdiv(p.M, CfgTW::BM) * cdiv(p.N, CfgTW::BN) >= 512;
+    if (variant < 0) variant = deep ? GEMM_T_DEFAULT : 0;
+    if (variant == 1) return launch_t2<T, TA, TB, EPI, CfgT2H>(p, s);
+    if (variant == 2) return launch_t2<T, TA, TB, EPI, CfgT2W>(p, s);
+    if (variant == 3) return launch_t2<T, TA, TB, EPI, CfgT2Q>(p, s);
     if (p.Kp >= 4096 && (long)cdiv(p.M, CfgTW::BM) * cdiv(p.N, CfgTW::BN) >= 512) return launch_tc<T, TA, TB, EPI, CfgTW>(p, s);
     return launch_tc<T, TA, TB, EPI, CfgT>(p, s);
 }
 
 template <typename T, int EPI>
-static int dispatch_t(const GemmParams& p, bool ta, bool tb, hipStream_t s) {
-    if (ta && tb) return launch_t<T, true, true, EPI>(p, s);
-    if (tb) return launch_t<T, false, true, EPI>(p, s);
-    if (ta) return launch_t<T, true, false, EPI>(p, s);
+static int dispatch_t(const GemmParams& p, bool ta, bool tb, hipStream_t s, int variant) {
+    if (ta && tb) return launch_t<T, true, true, EPI>(p, s, variant);
+    if (tb) return launch_t<T, false, true, EPI>(p, s, variant);
+    if (ta) return launch_t<T, true, false, EPI>(p, s, variant);
     set_error("gemm16_t: neither operand is transposed -- use llark_gemm16");
     return LLARK_ERR_INVALID;
 }
@@ -171,8 +289,9 @@ using namespace llark;
 //   trans_b == 0: wt is [n][ldw] (k contiguous); trans_b != 0: wt is [kp][ldw] (row = k, column = n).
 //   kp % 64 == 0 (all kp contraction rows / columns are read: pad with zeros);  a transposed operand's free size (m or n) % 8 == 0.
 //   epilogue: LLARK_EPI_F32 (c = product) or LLARK_EPI_RESID (c = resid + product; resid may alias c).
-static int gemm16_t_impl(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
+static int gemm16_t_impl(int variant, int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
                          int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream) {
+    LLARK_REQUIRE(variant >= -1 && variant <= 3, "gemm16_t: unknown variant %d", variant);
     LLARK_REQUIRE(a && wt && c, "gemm16_t: null pointer");
     LLARK_REQUIRE(dtype == LLARK_F16 || dtype == LLARK_BF16, "gemm16_t: dtype must be LLARK_F16 or LLARK_BF16");
     LLARK_REQUIRE(m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_t: bad shape m=%d n=%d kp=%d (kp %% 64 == 0)", m, n, kp);
@@ -190,13 +309,21 @@ static int gemm16_t_impl(int dtype, int epilogue, int trans_a, int trans_b, cons
     hipStream_t s = (hipStream_t)stream;
     const bool ta = trans_a != 0, tb = trans_b != 0;
     if (dtype == LLARK_BF16)
-        return epilogue == EPI_F32 ? dispatch_t<bf16_t, EPI_F32>(p, ta, tb, s) : dispatch_t<bf16_t, EPI_RESID>(p, ta, tb, s);
-    return epilogue == EPI_F32 ? dispatch_t<half_t, EPI_F32>(p, ta, tb, s) : dispatch_t<half_t, EPI_RESID>(p, ta, tb, s);
+        return epilogue == EPI_F32 ? dispatch_t<bf16_t, EPI_F32>(p, ta, tb, s, variant) : dispatch_t<bf16_t, EPI_RESID>(p, ta, tb, s, variant);
+    return epilogue == EPI_F32 ? dispatch_t<half_t, EPI_F32>(p, ta, tb, s, variant) : dispatch_t<half_t, EPI_RESID>(p, ta, tb, s, variant);
 }
 
 extern "C" int llark_gemm16_t(int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw, int m,
                               int n, int kp, float* c, int ldc, const float* resid, int ldr, llark_stream_t stream) {
-    return gemm16_t_impl(dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, nullptr, stream);
+    return gemm16_t_impl(-1, dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, nullptr, stream);
+}
+
+// llark_gemm16_t with an explicit tile / pipeline variant (benchmarks and A/B tests): -1 = library choice, 0 = one LDS stage per
+// workgroup (128x128 or 128x256 by shape), 1 = 128x256x32 two stages (2 workgroups per CU), 2 = 128x256x64 two stages, 3 = 256x256x64
+// two stages (8 waves).  Same products in the same order per accumulator: results are bit-identical across variants.
+extern "C" int llark_gemm16_t_ex(int variant, int dtype, int epilogue, int trans_a, int trans_b, const void* a, int lda, const void* wt, int ldw,
+                                 int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq, llark_stream_t stream) {
+    return gemm16_t_impl(variant, dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, sumsq, stream);
 }
 
 // The same product; additionally *sumsq (a double in device memory) += the sum of squares of every value written to c: the dW product
@@ -206,5 +333,5 @@ extern "C" int llark_gemm16_t_sumsq(int dtype, int epilogue, int trans_a, int tr
                                     int m, int n, int kp, float* c, int ldc, const float* resid, int ldr, double* sumsq,
                                     llark_stream_t stream) {
     LLARK_REQUIRE(sumsq, "gemm16_t_sumsq: null sumsq");
-    return gemm16_t_impl(dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, sumsq, stream);
+    return gemm16_t_impl(-1, dtype, epilogue, trans_a, trans_b, a, lda, wt, ldw, m, n, kp, c, ldc, resid, ldr, sumsq, stream);
 }

@@ -438,6 +438,83 @@ __global__ void adamw_f32_kernel(float* __restrict__ p, const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// AdamW on a bf16 weight MATRIX W [N][K] that also writes the operand twins the NEXT step's products stream (round 6):
+//   wfrag  : W fragment-major (llark_pack_weight16_frag's layout: 1 KiB chunk (R = n / 32, q = k / 16) at (R * K / 16 + q), lane l of it =
+//            the 8 elements W[32 R + l % 32][16 q + 8 (l / 32) ..]) -- the B operand of the forward product  x . W^T  (gemm_bda.hip);
+//            rows below rope_rows (the q and k parts of a fused q|k|v weight) go to the head-permuted row block
+//            [0..31 | 64..95 | 32..63 | 96..127] that llark_gemm16_fragw_rope_qkv expects;
+//   wtfrag : W^T ([K][N]) fragment-major, chunk (R' = k / 32, q' = n / 16) at (R' * N / 16 + q'), lane l = W[16 q' + 8 (l / 32) ..][32 R' + l % 32]
+//            -- the B operand of  dX = dY . W  on the same kernel (no llark_gemm16_t, no per-step transpose16 + pack_frag: VERDICT r05).
+// The parameter, gradient and moment traffic (22 B per parameter) is what llark_adamw moves; the twins add 4 B of stores.
+// One workgroup per [32 n][128 k] tile: fp32 phase with 16-byte row-major accesses (512 B per row and tensor), the new bf16 values parked in
+// LDS, then both twins written as whole 1 KiB chunks (W: 8 consecutive chunks = 8 KiB contiguous; W^T: 4 x 2 chunks).
+// ------------------------------------------------------------------------------------------
+constexpr int AT_ROWS = 32, AT_COLS = 128, AT_LD = 136;      // LDS pitch 272 B: 16-byte aligned rows, 4 banks apart (b128 reads of 16 rows conflict free)
+__global__ __launch_bounds__(256) void adamw_twins_kernel(bf16_t* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, int N, int K, float lr, float b1, float b2, float eps,
+                                                          float wd, float bc1, float bc2, float gscale, const double* __restrict__ sumsq,
+                                                          float max_norm, uint4* __restrict__ wfrag, int rope_rows, uint4* __restrict__ wtfrag) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[AT_ROWS * AT_LD];
+    gscale = clipped_scale(gscale, sumsq, max_norm);
+    const int k0 = blockIdx.x * AT_COLS, nt = blockIdx.y, n0 = nt * AT_ROWS;
+    const int t = threadIdx.x, c4 = t & 31, r = t >> 5;
+    const float decay = 1.0f - lr * wd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = r + 8 * i;
+        const size_t idx = (size_t)(n0 + row) * K + k0 + 4 * c4;
+        const float4 gv = *(const float4*)(g + idx);
+        float4 mv = *(const float4*)(m + idx), vv = *(const float4*)(v + idx);
+        const uint2 pw = *(const uint2*)(p + idx);
+        const unsigned short pe[4] = {(unsigned short)(pw.x & 0xffffu), (unsigned short)(pw.x >> 16), (unsigned short)(pw.y & 0xffffu), (unsigned short)(pw.y >> 16)};
+        const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+        float me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+        unsigned short out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                       // the arithmetic of adamw_bf16_kernel, expression for expression (bit-equal parameters)
+            const float gi = ge[e] * gscale;
+            const float mi = b1 * me[e] + (1.0f - b1) * gi;
+            const float vi = b2 * ve[e] + (1.0f - b2) * gi * gi;
+            me[e] = mi;
+            ve[e] = vi;
+            float pi = (float)__builtin_bit_cast(bf16_t, pe[e]);
+            pi = pi * decay - lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+            out[e] = __builtin_bit_cast(unsigned short, (bf16_t)pi);
+        }
+        *(float4*)(m + idx) = make_float4(me[0], me[1], me[2], me[3]);
+        *(float4*)(v + idx) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+        const uint2 po = make_uint2((unsigned)out[0] | ((unsigned)out[1] << 16), (unsigned)out[2] | ((unsigned)out[3] << 16));
+        *(uint2*)(p + idx) = po;
+        *(uint2*)(tile + row * AT_LD + 4 * c4) = po;
+    }
+    __syncthreads();
+    if (wfrag != nullptr) {
+        int R = nt;
+        if (n0 < rope_rows) R = (nt & ~3) | ((nt & 1) << 1) | ((nt >> 1) & 1);     // row blocks 1 and 2 of a 128-row head trade places
+        const size_t base = ((size_t)R * (K >> 4) + (k0 >> 4)) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = t + 256 * i, q = j >> 6, l = j & 63;
+            wfrag[base + j] = *(const uint4*)(tile + (l & 31) * AT_LD + q * 16 + (l >> 5) * 8);
+        }
+    }
+    if (wtfrag != nullptr) {
+        const int nn16 = N >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = t + 256 * i, ch = j >> 6, l = j & 63;
+            const int kk = ch >> 1, nn = ch & 1;
+            const unsigned short* src = tile + (nn * 16 + (l >> 5) * 8) * AT_LD + kk * 32 + (l & 31);
+            unsigned e[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) e[x] = src[x * AT_LD];
+            wtfrag[((size_t)((k0 >> 5) + kk) * nn16 + (n0 >> 4) + nn) * 64 + l] =
+                make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+        }
+    }
+}
+
 static inline int grid_for(size_t total) {
     size_t g = (total + 255) / 256;
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
@@ -611,4 +688,28 @@ extern "C" int llark_adamw_clip(int param_dtype, void* p, const float* g, float*
                                 float max_grad_norm, llark_stream_t stream) {
     LLARK_REQUIRE(grad_sumsq && max_grad_norm > 0.0f, "adamw_clip: grad_sumsq and a positive max_grad_norm are required");
     return adamw_impl(param_dtype, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, grad_sumsq, max_grad_norm, stream);
+}
+
+// AdamW (llark_adamw / llark_adamw_clip on bf16 parameters) on a weight MATRIX p [n][k] that also writes the fragment-major operand
+// twins of the updated weight: wfrag (nullable) = llark_pack_weight16_frag(p) -- with the q / k rows of every 128-row head below
+// rope_rows in llark_gemm16_fragw_rope_qkv's order -- and wtfrag (nullable) = llark_pack_weight16_frag of p^T ([k][n]).  Replaces the
+// per-optimizer-step llark_transpose16 + llark_pack_weight16_frag of the trainer's derived operands (m2t/train.py:53-277 -> HF Trainer's
+// optimizer.step(); scripts/training/train_llark.sh:20-45).  n % 32 == 0, k % 128 == 0; wtfrag needs n % 64 == 0 (the twin's K padding);
+// rope_rows % 128 == 0.  grad_sumsq nullable (no clipping).  Parameters, moments: bit-equal to llark_adamw / llark_adamw_clip.
+extern "C" int llark_adamw_twins(void* p, const float* g, float* m, float* v, int n, int k, float lr, float beta1, float beta2, float eps,
+                                 float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm, void* wfrag,
+                                 int rope_rows, void* wtfrag, llark_stream_t stream) {
+    LLARK_REQUIRE(p && g && m && v && n > 0 && k > 0 && step >= 1, "adamw_twins: bad arguments");
+    LLARK_REQUIRE(n % AT_ROWS == 0 && k % AT_COLS == 0, "adamw_twins: n %% 32 == 0 and k %% 128 == 0 required (n=%d k=%d)", n, k);
+    LLARK_REQUIRE(!wtfrag || n % 64 == 0, "adamw_twins: the W^T twin needs n %% 64 == 0 (n=%d)", n);
+    LLARK_REQUIRE(rope_rows >= 0 && rope_rows <= n && rope_rows % 128 == 0, "adamw_twins: rope_rows %d must be a multiple of 128 within n", rope_rows);
+    LLARK_REQUIRE(!grad_sumsq || max_grad_norm > 0.0f, "adamw_twins: grad_sumsq needs a positive max_grad_norm");
+    LLARK_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)wfrag | (uintptr_t)wtfrag) & 15) == 0,
+                  "adamw_twins: every pointer must be 16-byte aligned");
+    LLARK_REQUIRE(n / AT_ROWS <= 65535, "adamw_twins: n too large");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    adamw_twins_kernel<<<dim3(k / AT_COLS, n / AT_ROWS), 256, 0, (hipStream_t)stream>>>(
+        (bf16_t*)p, g, m, v, n, k, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_sumsq, max_grad_norm, (uint4*)wfrag,
+        rope_rows, (uint4*)wtfrag);
+    return check_launch("adamw_twins");
 }

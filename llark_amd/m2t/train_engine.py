@@ -59,6 +59,7 @@ class HipLlamaTrainer:
         self.params += [("norm", engine.norm), ("embed", engine.embed)]
         if engine.proj_w is not None:
             self.params += [("proj_w", engine.proj_w), ("proj_b", engine.proj_b)]
+        self._pname = {p.data_ptr(): n for n, p in self.params}
         total = sum(p.numel() for _, p in self.params)
         self.flat_grad = torch.zeros((total,), dtype=torch.float32, device=dev)
         # AdamW moments (2 x 27 GB at 7B): not allocated on the autograd-bridge path, where a torch optimizer owns the state
@@ -90,6 +91,19 @@ class HipLlamaTrainer:
         # 3 % of the B-direct kernel on these shapes, and the twins cost a transpose + a pack of all 13.5 GB of weights per step
         # (25 ms and 24 GB of HBM at 7B: 896 -> 868 ms for 4 micro-batches of 2 x 2048); they would pay from ~16 micro-batches.
         self.dx_direct_uses = int(os.environ.get("LLARK_TRAIN_DX_DIRECT_USES", str(1 << 30)))
+        # Round 6: the optimizer itself keeps the operand twins current.  Every Llama weight matrix the twin kernel
+        # takes carries TWO persistent fragment-major copies -- W (forward: the B-direct DMA loop from the FIRST micro-batch on) and W^T
+        # (dX = dY . W on the same kernel instead of llark_gemm16_t) -- built once here and rewritten by llark_adamw_twins inside the
+        # AdamW pass that already reads and writes every parameter (+ 4 B of stores on 22 B per parameter; no transpose16 / pack_frag in
+        # the step).  +2 x 13.5 GB at 7B.  The q|k|v twin is stored in the fused-RoPE row order: the training forward takes
+        # llark_gemm16_fragw_rope_qkv (RoPE, head split and both cache writes in the epilogue) wherever the shape qualifies.
+        self.twins: Dict[str, Tuple[torch.Tensor, torch.Tensor, int]] = {}
+        self._frozen_wT: Dict[int, torch.Tensor] = {}
+        self.use_twins = bool(optimizer_state) and os.environ.get("LLARK_TRAIN_TWINS", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
+        self.swiglu_fused = self.use_twins and os.environ.get("LLARK_TRAIN_SWIGLU_FUSED", "1") != "0"
+        self.rope_fused = self.use_twins and d.head_dim == 128 and d.num_attention_heads % 2 == 0 and os.environ.get("LLARK_TRAIN_ROPE_FUSED", "1") != "0"
+        if self.use_twins:
+            self._build_twins()
         # gradient-norm bookkeeping (HF Trainer max_grad_norm): sum of squares collected by the dW epilogues of a step's last
         # micro-batch, the flat-gradient spans it already covers, and the total of the last clipped step
         self._norm_collect = False
@@ -109,6 +123,41 @@ class HipLlamaTrainer:
                 self.grads[name].zero_()
         self._fresh = set(self._matrix_grads)
         self.micro_batches = 0
+
+    def _build_twins(self) -> None:
+        """Initial construction of the operand twins (afterwards llark_adamw_twins rewrites them with every optimizer step)."""
+        eng, d = self.eng, self.eng.dims
+        H = d.hidden_size
+        order = None
+        for i, L in enumerate(eng.layers):
+            for nm in ("wqkv", "wo", "wgu", "wdown"):
+                w = getattr(L, nm)
+                n, k = w.shape
+                if not ops.adamw_twins_takes(n, k) or not w.is_contiguous():
+                    continue
+                rope_rows = 2 * H if (nm == "wqkv" and self.rope_fused) else 0
+                if rope_rows:
+                    if order is None:
+                        order = ops.rope_qkv_row_order(d.num_attention_heads, d.head_dim).to(w.device)
+                    wfrag = ops.pack_weight16_frag(w.index_select(0, order), n)
+                else:
+                    wfrag = ops.pack_weight16_frag(w, n)
+                    w._llark_frag = (wfrag, n, k)                 # ops.gemm16 takes the B-direct kernel for >= FRAG_MIN_ROWS rows
+                wT = ops.transposed16(w)                          # [k][n] (n % 64 == 0: no padding)
+                wtfrag = ops.pack_weight16_frag(wT, k)
+                del wT
+                self.twins[f"layers.{i}.{nm}"] = (wfrag, wtfrag, rope_rows)
+        # lm_head is frozen (m2t/models/llamav2.py:412-415): its twins are built once and never go stale
+        lm = eng.lm_head
+        if lm is not None and lm.shape[1] % 64 == 0:
+            ops.attach_frag(lm, lm.shape[0])
+            wT = ops.transposed16(lm)                             # [H][V padded to 64]
+            ops.attach_frag(wT, wT.shape[0])
+            self._frozen_wT[lm.data_ptr()] = wT
+
+    def _twin_of(self, w: torch.Tensor):
+        name = self._pname.get(w.data_ptr())
+        return self.twins.get(name) if name is not None else None
 
     def _dw(self, dy16: torch.Tensor, x16: torch.Tensor, grad: torch.Tensor, name: str) -> None:
         """grad[N][K] (+)= dY^T . X   (dy16 [rows][N], x16 [rows][K] bf16); plain write on the first micro-batch.
@@ -150,6 +199,8 @@ class HipLlamaTrainer:
     def _fwd_weight(self, w: torch.Tensor) -> torch.Tensor:
         """A weight about to be multiplied in a forward product: from its second use since the last optimizer step it carries a
         fragment-major twin (ops.gemm16 then takes the B-direct kernel)."""
+        if self.twins and self._twin_of(w) is not None:
+            return w
         if self.derived_operands:
             ent = self._fwd_uses.get(w.data_ptr())
             if ent is None or ent[0] != self._wver:
@@ -164,8 +215,8 @@ class HipLlamaTrainer:
         """After an optimizer step: every derived operand is stale."""
         self._wver += 1
         if self.derived_operands:
-            for _, p in self.params:
-                if p.dim() == 2:
+            for n, p in self.params:
+                if p.dim() == 2 and n not in self.twins:
                     ops.detach_frag(p)
 
     def _dx(self, dy16: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
@@ -174,6 +225,16 @@ class HipLlamaTrainer:
         step -- by default all of them; past that the K-contiguous transpose + fragment-major twin are built once and the B-direct
         kernel (~3 % faster per product) amortises them over the remaining micro-batches."""
         n, k = w.shape
+        rows = dy16.shape[0]
+        if rows >= ops.FRAG_MIN_ROWS and dy16.stride(0) % 8 == 0:
+            tw = self._twin_of(w)
+            if tw is not None and dy16.shape[1] >= n:                # W^T fragment-major, kept current by llark_adamw_twins
+                ops.gemm16_fragw(dy16, None, tw[1], None, k, n, ops.EPI_F32, c=out)
+                return
+            wT = self._frozen_wT.get(w.data_ptr())
+            if wT is not None and dy16.shape[1] >= wT.shape[1]:
+                ops.gemm16(dy16, None, wT, None, k, ops.EPI_F32, c=out)
+                return
         if self.derived_operands:
             ent = self._dx_uses.get(w.data_ptr())
             if ent is None or ent[0] != self._wver:
@@ -239,17 +300,23 @@ class HipLlamaTrainer:
             ops.gemm16(a16, None, eng.proj_w, eng.proj_b, H, ops.EPI_F32, c=h[r0: r0 + F])
             seg_rows.append(torch.arange(r0, r0 + F, device=dev))
             seg_a16.append(a16[:, : d.mm_hidden_size])
+        fused_rows = rows >= ops.FRAG_MIN_ROWS                          # the fragment-major (B-direct) kernels take the products
         # ---------------- forward, saving what the backward needs ----------------
         def layer_forward(i, L, h):
             """One decoder layer on the residual stream ``h`` (updated in place); returns everything its backward reads."""
             st = {"h_in": h.clone()}
             x1 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x1)
-            qkv = torch.empty((rows, 3 * H), **f32)
-            ops.gemm16(x1, None, self._fwd_weight(L.wqkv), None, 3 * H, ops.EPI_F32, c=qkv)
             q = torch.empty((B, nh, S, hd), **bf)
             kc, vc = eng.k_cache[i, :B], eng.vt_cache[i, :B]
-            ops.rope_split_heads(qkv, B, S, nh, hd, 0, eng.cos, eng.sin, q, kc, vc)
+            tw = self.twins.get(f"layers.{i}.wqkv")
+            if tw is not None and tw[2] and S >= 32 and fused_rows:     # RoPE / head split / K and V^T writes in the product's epilogue
+                ops.gemm16_fragw_rope_qkv(x1, None, tw[0], H, B, S, nh, 0, eng.cos, eng.sin, q, kc, vc)
+            else:
+                qkv = torch.empty((rows, 3 * H), **f32)
+                ops.gemm16(x1, None, self._fwd_weight(L.wqkv), None, 3 * H, ops.EPI_F32, c=qkv)
+                ops.rope_split_heads(qkv, B, S, nh, hd, 0, eng.cos, eng.sin, q, kc, vc)
+                del qkv
             att = torch.empty((rows, H), **bf)
             lse = torch.empty((B * nh, S), **f32)                         # per-query log-sum-exp: the backward recomputes P from it
             ops.attn_prefill_lse(q, kc, vc, B, S, nh, hd, att, lse)
@@ -257,10 +324,17 @@ class HipLlamaTrainer:
             st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h.clone())
             x2 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
-            gu = torch.empty((rows, 2 * I), **f32)
-            ops.gemm16(x2, None, self._fwd_weight(L.wgu), None, 2 * I, ops.EPI_F32, c=gu)
             act = torch.empty((rows, I), **bf)
-            ops.swiglu_fwd(gu, act)
+            tw = self.twins.get(f"layers.{i}.wgu")
+            gu = None
+            if tw is not None and fused_rows and self.swiglu_fused and self.twins.get(f"layers.{i}.wdown") is not None:
+                gu = torch.empty((rows, 2 * I), **bf)                    # SwiGLU in the epilogue; gate | up kept as bf16 for the backward
+                if not ops.gemm16_fragw_swiglu_train(0, x2, tw[0], 2 * I, H, act, gu):
+                    gu = None
+            if gu is None:
+                gu = torch.empty((rows, 2 * I), **f32)
+                ops.gemm16(x2, None, self._fwd_weight(L.wgu), None, 2 * I, ops.EPI_F32, c=gu)
+                ops.swiglu_fwd(gu, act)
             ops.gemm16(act, None, self._fwd_weight(L.wdown), None, H, ops.EPI_RESID, c=h, resid=h)
             st.update(x2=x2, gu=gu, act=act)
             return st
@@ -300,12 +374,17 @@ class HipLlamaTrainer:
             # ---- MLP ----
             dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
             dh16 = dh16[:, :H]
-            dact = torch.empty((rows, I), **f32)
-            self._dx(dh16, L.wdown, dact)
-            self._dw(dh16, st["act"], g[pre + "wdown"], pre + "wdown")
             dgu = torch.empty((rows, 2 * I), **bf)
-            ops.swiglu_bwd(st["gu"], dact, dgu)
-            del dact
+            tw = self.twins.get(pre + "wdown")
+            if not (st["gu"].dtype == _BF and tw is not None and
+                    ops.gemm16_fragw_swiglu_train(1, dh16, tw[1], I, H, dgu, st["gu"])):   # d(act) never leaves the accumulators
+                dact = torch.empty((rows, I), **f32)
+                self._dx(dh16, L.wdown, dact)
+                if st["gu"].dtype == _BF:
+                    raise RuntimeError("train_engine: bf16 gate|up was saved but the fused SwiGLU backward declined the shape")
+                ops.swiglu_bwd(st["gu"], dact, dgu)
+                del dact
+            self._dw(dh16, st["act"], g[pre + "wdown"], pre + "wdown")
             self._dx(dgu, L.wgu, dtmp)
             self._dw(dgu, st["x2"], g[pre + "wgu"], pre + "wgu")
             del dgu
@@ -495,6 +574,12 @@ class HipLlamaTrainer:
         b1, b2 = self.betas
         for name, p in self.params:
             off, n = self._slices[name]
+            tw = self.twins.get(name)
+            if tw is not None:
+                ops.adamw_twins(p, self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n], self.lr, b1, b2,
+                                self.eps, self.wd, self.step_count, 1.0 / world, grad_sumsq=sumsq,
+                                max_grad_norm=float(max_grad_norm) if clip else 0.0, wfrag=tw[0], rope_rows=tw[2], wtfrag=tw[1])
+                continue
             ops.adamw(p.view(-1), self.flat_grad[off: off + n], self.flat_m[off: off + n], self.flat_v[off: off + n],
                       self.lr, b1, b2, self.eps, 0.0 if p.dim() == 1 else self.wd, self.step_count, 1.0 / world,
                       grad_sumsq=sumsq, max_grad_norm=float(max_grad_norm) if clip else 0.0)

@@ -583,7 +583,7 @@ def ln_row_pred(x: torch.Tensor, eps: float, pred: torch.Tensor) -> None:
 
 
 def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a: bool, trans_b: bool, c: torch.Tensor,
-             accumulate: bool = False, sumsq: Optional[torch.Tensor] = None) -> None:
+             accumulate: bool = False, sumsq: Optional[torch.Tensor] = None, variant: int = -1) -> None:
     """c[m][n] (= | +=) sum_k A(m, k) W(n, k) with operands that may be stored contraction-major (csrc/gemm_tn.hip;
     include/llark_hip.h: llark_gemm16_t): ``trans_a`` -> a is [kp][>= m], ``trans_b`` -> wt is [kp][>= n].
     ``sumsq`` (device double): += the sum of squares of every value written to c (llark_gemm16_t_sumsq)."""
@@ -593,7 +593,10 @@ def gemm16_t(a: torch.Tensor, wt: torch.Tensor, m: int, n: int, kp: int, trans_a
             _dev(wt, "wt", contiguous=False), wt.stride(0), m, n, kp, _dev(c, "c", torch.float32, contiguous=False), c.stride(0),
             _dev(c, "c", torch.float32, contiguous=False) if accumulate else None, c.stride(0))
     with _timed("gemm_f16" if dtype == torch.float16 else "gemm_bf16", 2.0 * m * n * kp):
-        if sumsq is None:
+        if variant >= 0:                                   # explicit tile / pipeline variant (llark_gemm16_t_ex): benchmarks, A/B tests
+            check(_lib.lib().llark_gemm16_t_ex(int(variant), *args, _dev(sumsq, "sumsq", torch.float64) if sumsq is not None else None,
+                                               _stream()), "gemm16_t_ex")
+        elif sumsq is None:
             check(_lib.lib().llark_gemm16_t(*args, _stream()), "gemm16_t")
         else:
             check(_lib.lib().llark_gemm16_t_sumsq(*args, _dev(sumsq, "sumsq", torch.float64), _stream()), "gemm16_t_sumsq")
@@ -1219,3 +1222,45 @@ def split16_into(x: torch.Tensor, hi: torch.Tensor, lo: Optional[torch.Tensor]) 
     rows, width = x.shape
     check(_lib.lib().llark_split16(_DT[hi.dtype], _dev(x, "x", torch.float32), x.stride(0), rows, width, _dev(hi, "hi"),
                                    _opt(lo, "lo", hi.dtype), hi.stride(0), _stream()), "split16")
+
+
+def adamw_twins(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float, eps: float,
+                weight_decay: float, step: int, grad_scale: float = 1.0, grad_sumsq: Optional[torch.Tensor] = None,
+                max_grad_norm: float = 0.0, wfrag: Optional[torch.Tensor] = None, rope_rows: int = 0,
+                wtfrag: Optional[torch.Tensor] = None) -> None:
+    """:func:`adamw` on a bf16 weight matrix ``p`` [n][k] that also writes the fragment-major twins of the updated weight
+    (include/llark_hip.h: llark_adamw_twins): ``wfrag`` = pack_weight16_frag(p) (rows < ``rope_rows`` in :func:`rope_qkv_row_order`),
+    ``wtfrag`` = pack_weight16_frag(p^T)."""
+    n, k = p.shape
+    bf = torch.bfloat16
+    assert p.dtype == bf and p.is_contiguous() and g.numel() == m.numel() == v.numel() == n * k
+    for t in (wfrag, wtfrag):
+        assert t is None or (t.dtype == bf and t.numel() == n * k)
+    check(_lib.lib().llark_adamw_twins(
+        _dev(p, "p"), _dev(g, "g", torch.float32), _dev(m, "m", torch.float32), _dev(v, "v", torch.float32), n, k, float(lr), float(beta1),
+        float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+        _dev(grad_sumsq, "grad_sumsq", torch.float64) if grad_sumsq is not None else None, float(max_grad_norm),
+        _opt(wfrag, "wfrag", bf), int(rope_rows), _opt(wtfrag, "wtfrag", bf), _stream()), "adamw_twins")
+
+
+def adamw_twins_takes(n: int, k: int) -> bool:
+    """Shapes llark_adamw_twins takes with both twins."""
+    return n % 64 == 0 and k % 128 == 0 and n // 32 <= 65535
+
+
+def gemm16_fragw_swiglu_train(mode: int, a: torch.Tensor, wfrag: torch.Tensor, n: int, kp: int, out: torch.Tensor, gu16: torch.Tensor) -> bool:
+    """The SwiGLU products of the training step with the element-wise pass in the epilogue (include/llark_hip.h:
+    llark_gemm16_fragw_swiglu_train).  mode 0: out = act [m][I], gu16 [m][2 I] written; mode 1: out = d(gate | up) [m][2 I], gu16 read.
+    Returns False (nothing launched) when the kernel does not take the shape: the caller keeps the two-launch path."""
+    bf = torch.bfloat16
+    m = a.shape[0]
+    assert a.dtype == bf and wfrag.dtype == bf and out.dtype == bf and gu16.dtype == bf and a.shape[1] >= kp
+    assert wfrag.numel() == round_up(n, 32) * kp
+    if kp < 192 or m * a.stride(0) * 2 >= (1 << 31):
+        return False
+    name = "gemm_bf16"
+    with _timed(name, 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_fragw_swiglu_train(int(mode), _dev(a, "a", contiguous=False), a.stride(0), _dev(wfrag, "wfrag"), m, n, kp,
+                                                         _dev(out, "out", contiguous=False), out.stride(0),
+                                                         _dev(gu16, "gu16", contiguous=False), gu16.stride(0), _stream()), "gemm16_fragw_swiglu_train")
+    return True

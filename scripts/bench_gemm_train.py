@@ -5,7 +5,8 @@ layer at M = tokens per micro-step.
     python scripts/bench_gemm_train.py 11,13 [M]        # variants of llark_gemm16_ex; prints ms and TFLOP/s per product
 Variants >= 100 are the B-direct kernel on fragment-major weights (100, 101 = its two tiles, 102 = its own choice); -1 = ops.gemm16's
 default (what the trainer gets for an operand without a fragment-major twin); 200 = llark_gemm16_t on the operands as the training
-step has them (dX: W contraction-major; dW: both operands contraction-major) -- the time of the transposes it replaces is printed too.
+step has them (dX: W contraction-major; dW: both operands contraction-major) -- the time of the transposes it replaces is printed too;
+210 .. 213 = llark_gemm16_t_ex variants 0 .. 3 (0 = one LDS stage, 1 = 128x256x32 two stages, 2 = 128x256x64 two stages, 3 = 256x256x64).
 """
 import os
 import sys
@@ -49,21 +50,22 @@ def main():
         c = torch.zeros(rows, n, device=dev)
         frag = ops.pack_weight16_frag(wt, n) if any(100 <= v < 200 for v in VARIANTS) else None
         is_dw, is_dx = name.startswith("dW"), name.startswith("dX")
-        if 200 in VARIANTS and (is_dw or is_dx):
+        if any(v >= 200 for v in VARIANTS) and (is_dw or is_dx):
             wkn = wt.t().contiguous()                                   # [k][n]: how the forward stores W (dX) / X (dW)
             akm = a.t().contiguous() if is_dw else None                 # [k][rows]: dY as the backward has it (dW)
             ms_t = timeit(lambda: (ops.transposed16(wkn), ops.transposed16(akm) if is_dw else None))
             print(f"M={M} {name:18s} transposes the old path needs: {ms_t:7.3f} ms")
         for v in VARIANTS:
-            if v == 200 and not (is_dw or is_dx):
+            if v >= 200 and not (is_dw or is_dx):
                 continue
             def fn():
                 kw = dict(c=c, resid=c) if epi == ops.EPI_RESID else dict(c=c)
-                if v == 200:
+                if v >= 200:
+                    tv = -1 if v == 200 else v - 210
                     if is_dw:
-                        ops.gemm16_t(akm, wkn, rows, n, k, True, True, c, accumulate=epi == ops.EPI_RESID)
+                        ops.gemm16_t(akm, wkn, rows, n, k, True, True, c, accumulate=epi == ops.EPI_RESID, variant=tv)
                     else:
-                        ops.gemm16_t(a, wkn, rows, n, k, False, True, c)
+                        ops.gemm16_t(a, wkn, rows, n, k, False, True, c, variant=tv)
                 elif v >= 100:
                     ops.gemm16_fragw(a, None, frag, None, n, k, epi, variant={100: 0, 101: 1, 102: -1}[v], **kw)
                 else:
@@ -76,7 +78,7 @@ def main():
                 ref[name] = out
             same = bool((out == ref[name]).all())
             ms = timeit(fn)
-            total[v] += ms if not (v == 200 and not (is_dw or is_dx)) else 0.0
+            total[v] += ms
             print(f"M={M} {name:18s} [{rows} x {n} x {k}] variant {v}: {ms:7.3f} ms {2.0 * rows * n * k / ms / 1e9:7.1f} TFLOP/s  "
                   f"{'= first variant' if same else 'DIFFERS from first variant: max ' + format((out - ref[name]).abs().max().item(), '.3e')}", flush=True)
     for v in VARIANTS:

@@ -90,3 +90,32 @@ def test_split16_vector_and_scalar_forms(rows, width, dtype, kmult):
     assert torch.equal(hi[:, :width], ref_hi) and torch.equal(lo[:, :width], ref_lo)
     if hi.shape[1] > width:
         assert hi[:, width:].abs().max().item() == 0 and lo[:, width:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("form", ["dw", "dx"])
+def test_two_stage_variants_bit_identical_to_the_single_stage_kernel(variant, form):
+    """Round 6: the double-buffered LDS-DMA forms (128x256x32 / 128x256x64 / 256x256x64 tiles, llark_gemm16_t_ex) accumulate every output
+    element in the same order (k ascending, one 32x32x16 MFMA per 16 k) as the single-stage kernel: equal bits, on whole and ragged
+    tiles, with and without accumulation into c, and with the gradient-norm side output."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(31 + variant)
+    for (m, n, kp, accumulate) in [(4096, 1024, 4096, True), (1000, 520, 448, False), (264, 8, 64, True), (12288, 4096, 4096, False)]:
+        if form == "dw":
+            a = torch.randn(kp, m, generator=g, device="cuda").bfloat16()
+            ta = True
+        else:
+            a = torch.randn(m, kp, generator=g, device="cuda").bfloat16()
+            ta = False
+        w = (torch.randn(kp, n, generator=g, device="cuda") * 0.1).bfloat16()
+        init = torch.randn(m, n, generator=g, device="cuda")
+        outs, sums = [], []
+        for v in (0, variant):
+            c = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+            ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+            ops.gemm16_t(a, w, m, n, kp, ta, True, c, accumulate=accumulate, sumsq=ss, variant=v)
+            outs.append(c)
+            sums.append(ss.item())
+        assert torch.equal(outs[0], outs[1]), (variant, form, m, n, kp, (outs[0] - outs[1]).abs().max().item())
+        _check(outs[1], a.float().t() if ta else a.float(), w.float().t(), init if accumulate else None)
+        assert abs(sums[0] - sums[1]) <= 1e-6 * abs(sums[0])            # (per-wave partials meet in a double atomic: order varies)

@@ -573,3 +573,152 @@ def test_grad_norm_bookkeeping_invalidated_by_accumulation_and_exchange(monkeypa
     full = tr.flat_grad.double().norm().item() / 2
     tr.step(world=2, max_grad_norm=1e9)
     assert abs(tr.last_grad_norm - full) <= 1e-6 * full, (tr.last_grad_norm, full)
+
+
+def test_adamw_twins_equals_adamw_plus_packed_twins():
+    """llark_adamw_twins (round 6): parameters and moments bit-equal to llark_adamw_clip; wfrag = llark_pack_weight16_frag of the updated
+    weight with the q / k head rows in the fused-RoPE order; wtfrag = llark_pack_weight16_frag of its transpose."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n, k, rope_rows = 384, 256, 256
+    p0 = (torch.randn(n, k, generator=g, device="cuda") * 0.05).bfloat16()
+    grad = torch.randn(n * k, generator=g, device="cuda") * 1e-2
+    m0 = torch.randn(n * k, generator=g, device="cuda") * 1e-3
+    v0 = torch.rand(n * k, generator=g, device="cuda") * 1e-5
+    sumsq = (grad.double() ** 2).sum().reshape(1)
+    for clip in (False, True):
+        pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+        pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+        kw = dict(grad_sumsq=sumsq, max_grad_norm=0.5) if clip else {}
+        ops.adamw(pa.view(-1), grad, ma, va, 1e-3, 0.9, 0.999, 1e-8, 0.01, 3, 0.25, **kw)
+        wfrag = torch.full((n * k,), 7.0, dtype=torch.bfloat16, device="cuda")
+        wtfrag = torch.full((n * k,), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.adamw_twins(pb, grad, mb, vb, 1e-3, 0.9, 0.999, 1e-8, 0.01, 3, 0.25, wfrag=wfrag, rope_rows=rope_rows, wtfrag=wtfrag, **kw)
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+        assert not torch.equal(pa, p0)
+        order = ops.rope_qkv_row_order(1, 128).cuda()                     # 384 rows: q and k "heads" permuted, the last 128 rows natural
+        assert torch.equal(wfrag, ops.pack_weight16_frag(pb.index_select(0, order), n))
+        assert torch.equal(wtfrag, ops.pack_weight16_frag(ops.transposed16(pb), k))
+    # only one twin requested; plain row order
+    pc, mc, vc = p0.clone(), m0.clone(), v0.clone()
+    wf = torch.zeros(n * k, dtype=torch.bfloat16, device="cuda")
+    ops.adamw_twins(pc, grad, mc, vc, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, wfrag=wf)
+    assert torch.equal(wf, ops.pack_weight16_frag(pc, n))
+
+
+def test_swiglu_train_epilogues_match_the_two_launch_path():
+    """llark_gemm16_fragw_swiglu_train: mode 0 = gate|up product + SwiGLU (act from the fp32 accumulators like llark_swiglu_fwd; gate | up
+    left as bf16); mode 1 = d(act) product + SwiGLU backward on those bf16 values.  Compared with the separate kernels run on the same
+    bf16-rounded gate | up: only the hardware exp2 / rcp of the epilogue (<= 1e-6 relative) and one bf16 rounding differ."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(8)
+    m, H, I = 300, 256, 384
+    x = torch.randn(m, H, generator=g, device="cuda").bfloat16()
+    wgu = (torch.randn(2 * I, H, generator=g, device="cuda") * 0.08).bfloat16()
+    wdown = (torch.randn(H, I, generator=g, device="cuda") * 0.08).bfloat16()
+    act = torch.empty(m, I, dtype=torch.bfloat16, device="cuda")
+    gu16 = torch.empty(m, 2 * I, dtype=torch.bfloat16, device="cuda")
+    assert ops.gemm16_fragw_swiglu_train(0, x, ops.pack_weight16_frag(wgu, 2 * I), 2 * I, H, act, gu16)
+    gu = torch.empty(m, 2 * I, device="cuda")
+    ops.gemm16(x, None, wgu, None, 2 * I, ops.EPI_F32, c=gu)
+    act_ref = torch.empty_like(act)
+    ops.swiglu_fwd(gu, act_ref)
+    assert torch.equal(gu16, gu.bfloat16())
+    assert (act.float() - act_ref.float()).abs().max().item() <= 2 ** -7 * act_ref.float().abs().max().item()
+    dh = torch.randn(m, H, generator=g, device="cuda").bfloat16()
+    dgu = torch.empty(m, 2 * I, dtype=torch.bfloat16, device="cuda")
+    wdT = ops.transposed16(wdown)                                       # [I][H]
+    assert ops.gemm16_fragw_swiglu_train(1, dh, ops.pack_weight16_frag(wdT, I), I, H, dgu, gu16)
+    dact = torch.empty(m, I, device="cuda")
+    ops.gemm16_t(dh, wdown, m, I, H, False, True, dact)
+    dgu_ref = torch.empty_like(dgu)
+    ops.swiglu_bwd(gu16.float(), dact, dgu_ref)
+    err = (dgu.float() - dgu_ref.float()).abs().max().item()
+    assert err <= 2 ** -6 * dgu_ref.float().abs().max().item(), err
+    assert dgu_ref.float().abs().max().item() > 0
+
+
+def _setup_long(S=72, B=2, layers=2):
+    """Like _setup with sequences long enough for the fragment-major paths (>= 129 rows) and the fused-RoPE epilogue (S >= 32)."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from oracle import llama_ref as LR
+    V = 128
+    spec = LR.LlamaSpec(hidden_size=256, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=2, vocab_size=V,
+                        mm_hidden_size=96, audio_start_token=V - 2, audio_end_token=V - 1, audio_patch_token=V - 3)
+    w = {k: _bf(v) for k, v in LR.make_weights(spec, seed=0, std=0.08).items()}
+    g = torch.Generator().manual_seed(6)
+    F = 5
+    ids = torch.stack([torch.tensor([1] + torch.randint(3, V - 3, (2 + b,), generator=g).tolist() + [V - 2] + [V - 3] * F + [V - 1]
+                                    + torch.randint(3, V - 3, (S - F - 5 - b,), generator=g).tolist()) for b in range(B)])
+    assert ids.shape == (B, S)
+    aud = torch.randn(B, F, 96, generator=g)
+    labels = ids.clone()
+    labels[:, :10] = -100
+    dims = LlamaDims(hidden_size=256, intermediate_size=512, num_hidden_layers=layers, num_attention_heads=2, vocab_size=V, mm_hidden_size=96)
+    eng = HipLlamaEngine(dims, "cuda", B, 128, precision="bf16")
+    eng.load_state_dict(w)
+    segs = [(b, int((ids[b] == V - 2).nonzero()[0, 0]), aud[b].cuda()) for b in range(B)]
+    return spec, w, ids, aud, labels, eng, segs
+
+
+def test_twin_paths_gradients_match_autograd_and_survive_an_optimizer_step():
+    """Round 6: with >= 129 rows and S >= 32 every product of the step runs on the optimizer-maintained twins -- forward on W fragment-major
+    (q|k|v with RoPE in the epilogue, gate|up with SwiGLU in the epilogue), dX on W^T fragment-major (down_proj's with the SwiGLU backward
+    in the epilogue).  (1) gradients vs torch autograd of the oracle, same bars as the small-shape test; (2) after one AdamW step the twins
+    ARE the packed updated weights, and the next micro-batch's gradients equal those of a fresh trainer built on the updated weights."""
+    from llark_amd import ops
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup_long()
+    toks = (spec.audio_start_token, spec.audio_end_token)
+    tr = HipLlamaTrainer(eng, lr=1e-2, weight_decay=0.0, embed_grad_tokens=toks)
+    assert tr.twins and tr.rope_fused and tr.swiglu_fused and len(tr.twins) == 4 * spec.num_hidden_layers
+    loss = tr.forward_backward(ids.cuda(), segs, labels.cuda()).item()
+    ref_loss, ref = _oracle_grads(spec, w, ids, aud, labels)
+    assert abs(loss - ref_loss) <= 5e-3 * max(1.0, abs(ref_loss)), (loss, ref_loss)
+    for name, gh in tr.export_grads_hf().items():
+        r = ref[name]
+        gh = gh.float().cpu()
+        if name == "model.embed_tokens.weight":
+            rows = [spec.audio_start_token, spec.audio_end_token]
+            gh, r = gh[rows], r[rows]
+        rel = ((gh - r).norm() / (r.norm() + 1e-30)).item()
+        cos = torch.nn.functional.cosine_similarity(gh.flatten(), r.flatten(), dim=0).item()
+        assert np.isfinite(rel) and rel <= 3e-2 and cos >= 0.999, f"{name}: rel {rel:.3e} cos {cos:.5f}"
+    tr.step(max_grad_norm=1.0)
+    H = spec.hidden_size
+    order = ops.rope_qkv_row_order(spec.num_attention_heads, 128).cuda()
+    for name, (wfrag, wtfrag, rope_rows) in tr.twins.items():
+        p = dict(tr.params)[name]
+        n, k = p.shape
+        src = p.index_select(0, order) if rope_rows else p
+        assert rope_rows == (2 * H if name.endswith("wqkv") else 0)
+        assert torch.equal(wfrag, ops.pack_weight16_frag(src, n)), name
+        assert torch.equal(wtfrag, ops.pack_weight16_frag(ops.transposed16(p), k)), name
+    tr.forward_backward(ids.cuda(), segs, labels.cuda())
+    g_next = tr.flat_grad.clone()
+    tr2 = HipLlamaTrainer(eng, lr=1e-2, weight_decay=0.0, embed_grad_tokens=toks)       # twins packed from the updated weights
+    tr2.forward_backward(ids.cuda(), segs, labels.cuda())
+    for name, prm in tr.params:
+        if prm.dim() == 2:
+            assert torch.equal(tr.grads[name], tr2.grads[name]), name
+
+
+def test_twin_paths_agree_with_the_untwinned_trainer(monkeypatch):
+    """The same micro-batch through the round-5 paths (LLARK_TRAIN_TWINS=0: generic forward kernels, llark_gemm16_t for dX, separate RoPE /
+    SwiGLU launches with fp32 gate | up) and through the twins: gradients agree to bf16-flow noise."""
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup_long()
+    toks = (spec.audio_start_token, spec.audio_end_token)
+    tr = HipLlamaTrainer(eng, embed_grad_tokens=toks)
+    tr.forward_backward(ids.cuda(), segs, labels.cuda())
+    monkeypatch.setenv("LLARK_TRAIN_TWINS", "0")
+    tr0 = HipLlamaTrainer(eng, embed_grad_tokens=toks)
+    assert not tr0.twins
+    tr0.forward_backward(ids.cuda(), segs, labels.cuda())
+    for name, prm in tr.params:
+        a, b = tr.grads[name].float(), tr0.grads[name].float()
+        if b.norm().item() == 0.0:
+            assert a.norm().item() == 0.0, name
+            continue
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel <= 2e-2, f"{name}: {rel:.3e}"
