@@ -538,6 +538,16 @@ int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, in
 int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm,
                      llark_stream_t stream);
+/* dW = dY^T . X without transposed copies of dY (csrc/gemm_bda.hip, round 6; torch autograd of nn.Linear: grad_weight = grad_output^T .
+ * input, under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
+ *   llark_pack_frag_t16: src [kp][ld] 16-bit (row = contraction index: the token; column = feature) -> dst = the fragment-major copy of
+ *     src^T ([n][kp]; the layout of llark_pack_weight16_frag), kp % 64 == 0, n % 8 == 0; dst holds round_up(n, 32) * kp elements;
+ *   llark_gemm16_ta_fragw: c[m][n] (= | +=) sum_k a[k][m] . B(n, k) with a [kp][lda] bf16 contraction-major (dY as it stands) and wfrag =
+ *     B fragment-major (llark_pack_frag_t16 of X).  epilogue LLARK_EPI_F32 / LLARK_EPI_RESID (resid may alias c); sumsq (nullable) += sum of
+ *     squares of every stored value (as llark_gemm16_t_sumsq).  m % 8 == 0, kp >= 192; LLARK_ERR_UNSUPPORTED otherwise. */
+int llark_pack_frag_t16(const void* src, int ld, int kp, int n, void* dst, llark_stream_t stream);
+int llark_gemm16_ta_fragw(int epilogue, const void* a, int lda, const void* wfrag, int m, int n, int kp, float* c, int ldc,
+                          const float* resid, int ldr, double* sumsq, llark_stream_t stream);
 /* The two SwiGLU products of the training step with the element-wise pass in their epilogues (csrc/gemm_bda.hip; HF LlamaMLP.forward and
  * its autograd under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:224-234,259-337, m2t/train.py:53-277).
  * Plain bf16 operands, fragment-major weights (llark_pack_weight16_frag / llark_adamw_twins).  gu16 [m][ldg >= 2 I] = the gate | up

@@ -149,6 +149,8 @@ _SIGS = {
     "llark_adamw": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P],
     "llark_adamw_clip": [c_int, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P],
     "llark_gemm16_fragw_swiglu_train": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
+    "llark_pack_frag_t16": [_P, c_int, c_int, c_int, _P, _P],
+    "llark_gemm16_ta_fragw": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_adamw_twins": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P, c_int, _P, _P],
 }
 

@@ -65,6 +65,72 @@ __global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_kernel
     else gemm_epilogue<T, SPLIT, EPI, C>(p, acc, m0, n0, wm, wn, lane, 0);
 }
 
+// dW = dY^T . X on the DMA loop (round 6): C[m][n] (+)= sum_k A[k][m] B[k][n] with A = dY stored as the backward leaves it ([tokens][features]:
+// contraction-major, staged as it lies and read through the transposing LDS read, bda_kloop<.., TA = true>) and B = X^T fragment-major
+// (llark_pack_frag_t16).  The llark_gemm16_t kernels it replaces stage BOTH operands through one LDS stage per workgroup
+// (request, wait, compute: matrix pipe 38-51 % busy, profiles/r03_pmc_gemm_tn.txt); here the B fragments stream L2 -> VGPR and A is
+// double-buffered with its fragments read one sub-step ahead.  EPI_F32 / EPI_RESID, optional sum of squares of the stored values.
+template <typename T, int EPI>
+__global__ __launch_bounds__(CfgBDA::THREADS, CfgBDA::MINW) void gemm_bda_ta_kernel(const GemmParams p) {
+    typedef CfgBDA C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages x 16 KiB
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int m0, n0;
+    bda_tile_of(p, m0, n0);
+    f32x16_t acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    bda_kloop<T, false, false, true>(p, smem, m0, n0, w, lane, 0, p.Kp / C::BK, acc);
+    gemm_epilogue<T, false, EPI, C, true>(p, acc, m0, n0, 0, w, lane, 0);
+}
+
+template <typename T, int EPI>
+static int launch_bda_ta(GemmParams p, hipStream_t s) {
+    typedef CfgBDA C;
+    constexpr int LDS = 2 * C::A_BYTES;
+    p.tiles_m = cdiv(p.M, C::BM);
+    p.tiles_n = cdiv(p.N, C::BN);
+    gemm_bda_ta_kernel<T, EPI><<<dim3(p.tiles_m * p.tiles_n), C::THREADS, LDS, s>>>(p);
+    return check_launch("gemm_bda_ta");
+}
+
+// [kp][ld] 16-bit, row = contraction index (token), column = feature  ->  fragment-major copy of its TRANSPOSE ([n features][kp]): chunk
+// (R = feature / 32, q = row / 16) at (R * kp / 16 + q) KiB, lane l = the 8 rows 16 q + 8 (l / 32) .. of feature 32 R + l % 32; features >= n
+// are zero.  64 rows x 128 features per workgroup through LDS: 16-byte row-major loads, whole 1 KiB chunks out (4 consecutive per R).
+__global__ __launch_bounds__(256) void pack_frag_t_kernel(const unsigned short* __restrict__ src, int ld, int n, int kp, uint4* __restrict__ dst) {
+    constexpr int LD = 136;                                               // LDS pitch (elements): 16-byte aligned rows, 4 banks apart
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * LD];
+    const int r0 = blockIdx.x * 64, f0 = blockIdx.y * 128;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 4) + 16 * i, c8 = (t & 15) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (f0 + c8 + 8 <= n) v = *(const uint4*)(src + (size_t)(r0 + row) * ld + f0 + c8);
+        else if (f0 + c8 < n) {                                          // ragged right edge (n % 8 != 0 is rejected by the launcher: never partial)
+        }
+        *(uint4*)(tile + row * LD + c8) = v;
+    }
+    __syncthreads();
+    const int nk16 = kp >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = t + 256 * i, ch = j >> 6, l = j & 63;                // chunk (Rl = ch / 4, ql = ch % 4) of this tile
+        const int Rl = ch >> 2, ql = ch & 3;
+        if (f0 + Rl * 32 >= ((n + 31) & ~31)) continue;                   // row blocks beyond the padded feature count do not exist in dst
+        const unsigned short* sp = tile + (ql * 16 + (l >> 5) * 8) * LD + Rl * 32 + (l & 31);
+        unsigned e[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) e[x] = sp[x * LD];
+        dst[((size_t)((f0 >> 5) + Rl) * nk16 + (r0 >> 4) + ql) * 64 + l] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    }
+}
+
 // ---- the LayerNorm PRODUCER role of gemm256x.hip (llark_gemm16_ln_p with ln_part) on this loop (round 5) --------------------------------
 //   C = R + (A_hi + A_lo) . W^T + bias;  Ohi / Olo = hi / lo of ((C - shift_m) . scale_m) . ln_vec[n];
 //   ln_part[m][n / 64][0..1] = (sum, sum of squares) of (C - shift_m) over this wave's 64 columns      ((shift, scale) = ln_pred[m] or (0, 1))
@@ -294,4 +360,33 @@ extern "C" int llark_gemm16_fragw_swiglu_train(int mode, const void* a, int lda,
     const int rc = launch_gemm_bda(p, LLARK_BF16, mode == 0 ? EPI_SWIGLU16_SAVE : EPI_SWIGLU_BWD, (hipStream_t)stream);
     if (rc == -1000) { set_error("gemm16_fragw_swiglu_train: needs kp >= 192 and an A operand below 2 GiB"); return LLARK_ERR_UNSUPPORTED; }
     return rc;
+}
+
+// Transposed fragment-major pack: src [kp][ld] (row = contraction index, e.g. the token; column = feature) -> dst = llark_pack_weight16_frag
+// of src^T ([n][kp]) without the intermediate transpose: the B operand of llark_gemm16_ta_fragw.  kp % 64 == 0, n % 8 == 0, ld >= n, ld % 8 == 0;
+// dst holds round_up(n, 32) * kp elements.
+extern "C" int llark_pack_frag_t16(const void* src, int ld, int kp, int n, void* dst, llark_stream_t stream) {
+    LLARK_REQUIRE(src && dst && kp > 0 && n > 0 && kp % 64 == 0 && n % 8 == 0 && ld >= n && ld % 8 == 0, "pack_frag_t16: bad arguments (kp %% 64, n %% 8, ld >= n, ld %% 8)");
+    LLARK_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "pack_frag_t16: pointers must be 16-byte aligned");
+    LLARK_REQUIRE(cdiv(n, 128) <= 65535, "pack_frag_t16: n too large");
+    pack_frag_t_kernel<<<dim3(kp / 64, cdiv(n, 128)), 256, 0, (hipStream_t)stream>>>((const unsigned short*)src, ld, n, kp, (uint4*)dst);
+    return check_launch("pack_frag_t16");
+}
+
+// dW-form product on the DMA loop:  c[m][n] (= | +=) sum_k a[k][m] . B(n, k),  a [kp][lda] bf16 CONTRACTION-major (dY as the backward leaves
+// it), wfrag = fragment-major B ([n][kp]; llark_pack_frag_t16 of X [kp][n]).  The reference reaches it through torch autograd of nn.Linear
+// (grad_weight = grad_output^T . input) under WrappedLlamav2ForCausalLM.forward + loss.backward() (m2t/models/llamav2.py:259-337,
+// m2t/train.py:53-277).  epilogue LLARK_EPI_F32 or LLARK_EPI_RESID (resid may alias c); sumsq (nullable) += sum of squares of the stored
+// values (llark_gemm16_t_sumsq's side output).  m % 8 == 0, lda >= m, lda % 8 == 0, kp % 64 == 0, kp >= 192.  LLARK_ERR_UNSUPPORTED when
+// the loop does not take the shape.
+extern "C" int llark_gemm16_ta_fragw(int epilogue, const void* a, int lda, const void* wfrag, int m, int n, int kp, float* c, int ldc,
+                                     const float* resid, int ldr, double* sumsq, llark_stream_t stream) {
+    LLARK_REQUIRE(a && wfrag && c && m > 0 && n > 0 && kp > 0 && kp % 64 == 0, "gemm16_ta_fragw: null pointer / empty problem / kp not a multiple of 64");
+    LLARK_REQUIRE(m % 8 == 0 && lda >= m && lda % 8 == 0 && ldc >= n, "gemm16_ta_fragw: m %% 8 == 0, lda >= m (a multiple of 8), ldc >= n required (m=%d lda=%d)", m, lda);
+    LLARK_REQUIRE(epilogue == EPI_F32 || (epilogue == EPI_RESID && resid && ldr >= n), "gemm16_ta_fragw: epilogue must be F32 or RESID (with resid)");
+    LLARK_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)wfrag & 15) == 0, "gemm16_ta_fragw: operands must be 16-byte aligned");
+    if (kp < 192 || (long long)kp * lda * 2 >= (1ll << 31)) { set_error("gemm16_ta_fragw: needs kp >= 192 and an A operand below 2 GiB"); return LLARK_ERR_UNSUPPORTED; }
+    GemmParams p = {};
+    p.Ahi = a; p.lda = lda; p.Wt = wfrag; p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr; p.sumsq = sumsq;
+    return epilogue == EPI_F32 ? launch_bda_ta<bf16_t, EPI_F32>(p, (hipStream_t)stream) : launch_bda_ta<bf16_t, EPI_RESID>(p, (hipStream_t)stream);
 }

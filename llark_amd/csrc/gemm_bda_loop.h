@@ -14,7 +14,12 @@ typedef Cfg<1, 4, 4, 2, 64, 2, 2> CfgBDA;  // 128x256x64, 4 waves side by side, 
 // TR: the MFMA operands trade places -- the accumulators then hold the TRANSPOSED 32x32 tiles (lane l: output row m = l % 32 of the tile,
 // register r: column (r & 3) + 8 (r >> 2) + 4 (l >> 5)), four consecutive output columns per register quad: 16-byte epilogue accesses and
 // row sums that stay inside a lane (gemm_bda_lnp_kernel).  Same products, same order per accumulator.
-template <typename T, bool SPLIT, bool TR = false>
+// TA (round 6, plain operands only): the A operand is stored CONTRACTION-major -- a [Kp][lda] array whose row is k and whose column is the
+// output row m (dY [tokens][features] for dW = dY^T X) -- and is staged exactly as it lies in memory, [64 k][128 m] per K-step with the
+// 16-byte chunks of row r at chunk ^ 4 (r & 3) (swizzle on the DMA's source address), its MFMA fragments fetched with the transposing LDS
+// read (two ds_read_b64_tr_b16 per fragment: gemm_tn.hip's image and offsets).  Same request counts per K-step and wave, so the
+// hand-counted waits are unchanged.
+template <typename T, bool SPLIT, bool TR = false, bool TA = false>
 __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const int m0, const int n0, const int w, const int lane, const int kt0,
                                           const int kt1, f32x16_t (&acc)[CfgBDA::TM][CfgBDA::TN]) {
     typedef CfgBDA C;
@@ -27,7 +32,8 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
     // num_records = the operand's extent: the request for the K-step BEHIND the last one (issued unconditionally, so that the loop has
     // no special last iteration and the wait counts stay exact) reads 64 columns further right -- the next row's first columns, or,
     // in the last row of a tightly packed operand, beyond the extent, where a buffer load returns zeros instead of faulting
-    const int a_bytes = ((p.M - 1) * p.lda + p.Kp) * 2;
+    static_assert(!TA || !SPLIT, "the contraction-major A operand exists for plain operands only");
+    const int a_bytes = TA ? ((p.Kp - 1) * p.lda + p.M) * 2 : ((p.M - 1) * p.lda + p.Kp) * 2;
     const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc((void*)p.Ahi, 0, a_bytes, RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc((void*)(SPLIT ? p.Alo : p.Ahi), 0, a_bytes, RSRC_FLAGS);
     constexpr int APW = (C::BM / C::RPI) / C::NW;                         // 4
@@ -35,17 +41,25 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
     unsigned voA[APW];
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
-        const int trow = (w + i * C::NW) * C::RPI + a_rl;                // row inside the tile
-        int r = m0 + trow;
-        r = r < p.M ? r : p.M - 1;
-        voA[i] = (unsigned)r * (unsigned)(p.lda * 2) + (unsigned)((a_slot ^ C::swz(trow)) << 4);
+        if constexpr (TA) {                                             // one instruction = 4 k rows x 256 B (128 m); lane -> (row lane / 16, slot lane % 16)
+            const int krow = (w + i * C::NW) * 4 + (lane >> 4);          // k row inside the K-step (krow & 3 == lane >> 4)
+            int col = m0 + (((lane & 15) ^ ((lane >> 4) << 2)) << 3);
+            col = col + 8 <= p.M ? col : p.M - 8;                        // edge tile: any valid 8 columns (stores are masked); M % 8 == 0
+            voA[i] = (unsigned)krow * (unsigned)(p.lda * 2) + (unsigned)(col * 2);
+        } else {
+            const int trow = (w + i * C::NW) * C::RPI + a_rl;            // row inside the tile
+            int r = m0 + trow;
+            r = r < p.M ? r : p.M - 1;
+            voA[i] = (unsigned)r * (unsigned)(p.lda * 2) + (unsigned)((a_slot ^ C::swz(trow)) << 4);
+        }
     }
+    const int kstep_bytes = TA ? p.lda * 128 : 128;                       // source bytes one K-step (64 k) advances the A operand by
     auto dmaA = [&](int kt, int stage) __attribute__((always_inline)) {
         char* base = smem + stage * ASTAGE;
 #pragma unroll
         for (int i = 0; i < APW; ++i) {
             char* dst = base + (w + i * C::NW) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, (__attribute__((address_space(3))) void*)dst, 16, voA[i], kt << 7, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, (__attribute__((address_space(3))) void*)dst, 16, voA[i], kt * kstep_bytes, 0, 0);
             if constexpr (SPLIT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, (__attribute__((address_space(3))) void*)(dst + OFF_L), 16, voA[i], kt << 7, 0, 0);
         }
     };
@@ -88,15 +102,50 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
     __builtin_amdgcn_s_barrier();
 
     frag ah[2][C::TM], al[SPLIT ? 2 : 1][SPLIT ? C::TM : 1];
+    // transposing read (TA): lane (q = lane / 16, i = lane % 16) is the SOURCE lane of k row 8 (q / 2) + i / 4 of the k16 sub-step and the
+    // 4 columns 16 (q % 2) + 4 (i % 4) .. of the 32-column block; the second read takes the rows 4 further down (gemm_tn.hip: read_frag_t).
+    // INLINE ASM: hipcc orders the ds_read_tr16_b64 builtin behind every LDS-DMA it believes pending -- it does not see the hand-counted
+    // waits that retired them -- with an s_waitcnt vmcnt(0) in front of the first read of every K-step, which drains the weight ring and the
+    // next K-step's requests (seen in the ISA, caught by tests/test_gemm_bda_isa_cpu.py).  As asm the reads are invisible to that pass and
+    // their completion is counted by hand (TA_WAITA): LDS operations return in order, the loop issues no scalar loads (audited).  When
+    // (sub-step s, row block tm) is waited for, the LDS operations issued behind its two reads are the reads of (s, tm + 1 .. 3) and of
+    // (s + 1, 0 .. tm - 1): 6 in every sub-step but the last, which reads nothing ahead: 2 (3 - tm).
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    unsigned ta_base[TA ? C::TM : 1];
+    u32x2_ ta_lo[2][TA ? C::TM : 1], ta_hi[2][TA ? C::TM : 1];
+    if constexpr (TA) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const int t_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * 256 + (tcol & 7) * 2;
+        const int t_swz = ((lane & 15) >> 2) << 2;
+#pragma unroll
+        for (int tm = 0; tm < C::TM; ++tm) ta_base[tm] = lds0 + (unsigned)(t_off + (((tm * 4 + (tcol >> 3)) ^ t_swz) << 4));
+    }
+#define TA_READA(SET, TM_, STAGEOFF, S_)                                                                                             \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                                       \
+                 : "=&v"(ta_lo[SET][TM_]), "=&v"(ta_hi[SET][TM_])                                                                    \
+                 : "v"(ta_base[TM_] + (unsigned)(STAGEOFF)), "i"((S_) * 4096), "i"((S_) * 4096 + 1024)                               \
+                 : "memory")
+#define TA_WAITA(N, SET, TM_) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(ta_lo[SET][TM_]), "+v"(ta_hi[SET][TM_])::"memory")
     auto rdA = [&](int set, int tm, const char* sA, int s) __attribute__((always_inline)) {
         ah[set][tm] = *(const frag*)(sA + C::off(tm * 32 + l31, s * 2 + lhi));
         if constexpr (SPLIT) al[set][tm] = *(const frag*)(sA + OFF_L + C::off(tm * 32 + l31, s * 2 + lhi));
     };
     for (int kt = kt0; kt < kt1; ++kt) {
         const char* sA = smem + ((kt - kt0) & 1) * ASTAGE;
+        const unsigned sAoff = (unsigned)(((kt - kt0) & 1) * ASTAGE);
         dmaA(kt + 1, (kt + 1 - kt0) & 1);                                       // unconditional (behind the last K-step: harmless, see rAh): the counts below stay exact
+        if constexpr (TA) {
+            static_assert(!TA || C::TM == 4, "four row blocks, written out (an asm operand inside a fresh generic lambda trips clang's capture analysis)");
+            TA_READA(0, 0, sAoff, 0);
+            TA_READA(0, 1, sAoff, 0);
+            TA_READA(0, 2, sAoff, 0);
+            TA_READA(0, 3, sAoff, 0);
+        } else {
 #pragma unroll
-        for (int tm = 0; tm < C::TM; ++tm) rdA(0, tm, sA, 0);             // sub-step 0 follows the barrier: exposed
+            for (int tm = 0; tm < C::TM; ++tm) rdA(0, tm, sA, 0);         // sub-step 0 follows the barrier: exposed
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<4>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value, cur = s & 1;
@@ -108,7 +157,17 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
             __builtin_amdgcn_sched_barrier(0);
             static_for<C::TM * C::TN>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value, tm = i / C::TN, tn = i % C::TN;
-                if constexpr (TR) {
+                if constexpr (TA) {
+                    if constexpr (tn == 0) {                              // this row block's two reads have landed (count: see TA_WAITA above)
+                        if constexpr (s < 3 || tm == 0) TA_WAITA(6, cur, tm);
+                        else if constexpr (tm == 1) TA_WAITA(4, cur, tm);
+                        else if constexpr (tm == 2) TA_WAITA(2, cur, tm);
+                        else TA_WAITA(0, cur, tm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const u32x4_ av = {ta_lo[cur][tm][0], ta_lo[cur][tm][1], ta_hi[cur][tm][0], ta_hi[cur][tm][1]};
+                    acc[tm][tn] = Mfma<T>::run(__builtin_bit_cast(frag, av), __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
+                } else if constexpr (TR) {
                     acc[tm][tn] = Mfma<T>::run(__builtin_bit_cast(frag, ring[s][tn]), ah[cur][tm], acc[tm][tn]);
                     if constexpr (SPLIT) acc[tm][tn] = Mfma<T>::run(__builtin_bit_cast(frag, ring[s][tn]), al[cur][tm], acc[tm][tn]);
                 } else {
@@ -116,7 +175,10 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
                     if constexpr (SPLIT) acc[tm][tn] = Mfma<T>::run(al[cur][tm], __builtin_bit_cast(frag, ring[s][tn]), acc[tm][tn]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (s < 3 && tn == 0) rdA(cur ^ 1, tm, sA, s + 1);      // next sub-step's fragments of row block tm: behind its first pair
+                if constexpr (s < 3 && tn == 0) {                                  // next sub-step's fragments of row block tm: behind its first pair
+                    if constexpr (TA) TA_READA(cur ^ 1, tm, sAoff, s + 1);
+                    else rdA(cur ^ 1, tm, sA, s + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -135,5 +197,7 @@ __device__ __forceinline__ void bda_kloop(const GemmParams& p, char* smem, const
 }
 #undef BDA_LOADB
 #undef BDA_WAITB
+#undef TA_READA
+#undef TA_WAITA
 
 }  // namespace llark

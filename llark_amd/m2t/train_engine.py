@@ -100,6 +100,7 @@ class HipLlamaTrainer:
         self.twins: Dict[str, Tuple[torch.Tensor, torch.Tensor, int]] = {}
         self._frozen_wT: Dict[int, torch.Tensor] = {}
         self.use_twins = bool(optimizer_state) and os.environ.get("LLARK_TRAIN_TWINS", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
+        self.dw_fragw = os.environ.get("LLARK_TRAIN_DW_FRAGW", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
         self.swiglu_fused = self.use_twins and os.environ.get("LLARK_TRAIN_SWIGLU_FUSED", "1") != "0"
         self.rope_fused = self.use_twins and d.head_dim == 128 and d.num_attention_heads % 2 == 0 and os.environ.get("LLARK_TRAIN_ROPE_FUSED", "1") != "0"
         if self.use_twins:
@@ -169,6 +170,17 @@ class HipLlamaTrainer:
         n, k = dy16.shape[1], x16.shape[1]
         fresh = name in self._fresh
         self._fresh.discard(name)
+        toks = dy16.shape[0]
+        if (self.dw_fragw and toks >= ops.FRAG_MIN_ROWS and x16.shape[0] == toks and k % 8 == 0 and x16.stride(0) % 8 == 0
+                and ops.gemm16_ta_fragw_takes(n, toks, dy16.stride(0))):
+            # round 6: dY as it stands through the DMA loop's transposing LDS read, X^T fragment-major (one transposing pack of X: 2 x its
+            # bytes) -- the B operand streams L2 -> VGPR and never waits on a barrier (csrc/gemm_bda.hip: gemm_bda_ta_kernel)
+            xt = ops.pack_frag_t16(x16, k)
+            ops.gemm16_ta_fragw(dy16, xt, n, k, toks, grad, accumulate=not fresh, sumsq=sumsq)
+            if sumsq is not None:
+                off, cnt = self._slices[name]
+                self._norm_spans.append((off, off + cnt))
+            return
         if dy16.shape[0] % 64 == 0 and n % 8 == 0 and k % 8 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
             ops.gemm16_t(dy16, x16, n, k, dy16.shape[0], True, True, grad, accumulate=not fresh, sumsq=sumsq)
             if sumsq is not None:                          # this gradient's share of the squared norm is in the accumulator already
@@ -304,7 +316,7 @@ class HipLlamaTrainer:
         # ---------------- forward, saving what the backward needs ----------------
         def layer_forward(i, L, h):
             """One decoder layer on the residual stream ``h`` (updated in place); returns everything its backward reads."""
-            st = {"h_in": h.clone()}
+            st = {"h_in": h}                                       # the stream is never updated in place: each residual product writes a new buffer
             x1 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln1, d.rms_norm_eps, x1)
             q = torch.empty((B, nh, S, hd), **bf)
@@ -320,8 +332,10 @@ class HipLlamaTrainer:
             att = torch.empty((rows, H), **bf)
             lse = torch.empty((B * nh, S), **f32)                         # per-query log-sum-exp: the backward recomputes P from it
             ops.attn_prefill_lse(q, kc, vc, B, S, nh, hd, att, lse)
-            ops.gemm16(att, None, self._fwd_weight(L.wo), None, H, ops.EPI_RESID, c=h, resid=h)
-            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h.clone())
+            h_mid = torch.empty_like(h)
+            ops.gemm16(att, None, self._fwd_weight(L.wo), None, H, ops.EPI_RESID, c=h_mid, resid=h)
+            h = h_mid
+            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h_mid)
             x2 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
             act = torch.empty((rows, I), **bf)
@@ -335,13 +349,15 @@ class HipLlamaTrainer:
                 gu = torch.empty((rows, 2 * I), **f32)
                 ops.gemm16(x2, None, self._fwd_weight(L.wgu), None, 2 * I, ops.EPI_F32, c=gu)
                 ops.swiglu_fwd(gu, act)
-            ops.gemm16(act, None, self._fwd_weight(L.wdown), None, H, ops.EPI_RESID, c=h, resid=h)
-            st.update(x2=x2, gu=gu, act=act)
+            h_out = torch.empty_like(h)
+            ops.gemm16(act, None, self._fwd_weight(L.wdown), None, H, ops.EPI_RESID, c=h_out, resid=h)
+            st.update(x2=x2, gu=gu, act=act, h_out=h_out)
             return st
 
         saved = []
         for i, L in enumerate(eng.layers):
             st = layer_forward(i, L, h)
+            h = st.pop("h_out")
             saved.append({"h_in": st["h_in"]} if self.gradient_checkpointing else st)
             del st
         xf = torch.empty((rows, H), **bf)
@@ -368,7 +384,8 @@ class HipLlamaTrainer:
         for i in reversed(range(len(eng.layers))):
             L, st = eng.layers[i], saved[i]
             if self.gradient_checkpointing:          # recompute this layer's forward from its saved input (K / V caches included)
-                st = layer_forward(i, L, st["h_in"].clone())
+                st = layer_forward(i, L, st["h_in"])
+                st.pop("h_out")
                 saved[i] = None
             pre = f"layers.{i}."
             # ---- MLP ----

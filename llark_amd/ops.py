@@ -1264,3 +1264,31 @@ def gemm16_fragw_swiglu_train(mode: int, a: torch.Tensor, wfrag: torch.Tensor, n
                                                          _dev(out, "out", contiguous=False), out.stride(0),
                                                          _dev(gu16, "gu16", contiguous=False), gu16.stride(0), _stream()), "gemm16_fragw_swiglu_train")
     return True
+
+
+def pack_frag_t16(x: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+    """x [kp][>= n] 16-bit, row = contraction index (token) -> the fragment-major copy of x^T ([n][kp]): the B operand of
+    :func:`gemm16_ta_fragw` (include/llark_hip.h: llark_pack_frag_t16)."""
+    kp = x.shape[0]
+    n = x.shape[1] if n is None else n
+    assert x.stride(1) == 1 and kp % 64 == 0 and n % 8 == 0
+    out = torch.empty((round_up(n, 32) * kp,), dtype=x.dtype, device=x.device)
+    check(_lib.lib().llark_pack_frag_t16(_dev(x, "x", contiguous=False), x.stride(0), kp, n, _dev(out, "out"), _stream()), "pack_frag_t16")
+    return out
+
+
+def gemm16_ta_fragw_takes(m: int, kp: int, lda: int) -> bool:
+    return m % 8 == 0 and kp % 64 == 0 and kp >= 192 and lda % 8 == 0 and kp * lda * 2 < (1 << 31)
+
+
+def gemm16_ta_fragw(a: torch.Tensor, wfrag: torch.Tensor, m: int, n: int, kp: int, c: torch.Tensor, accumulate: bool = False,
+                    sumsq: Optional[torch.Tensor] = None) -> None:
+    """c[m][n] (= | +=) sum_k a[k][m] B(n, k): ``a`` [kp][>= m] bf16 contraction-major (dY as the backward leaves it), ``wfrag`` =
+    :func:`pack_frag_t16` of X [kp][n] (include/llark_hip.h: llark_gemm16_ta_fragw)."""
+    bf = torch.bfloat16
+    assert a.dtype == bf and wfrag.dtype == bf and a.stride(1) == 1 and wfrag.numel() == round_up(n, 32) * kp
+    with _timed("gemm_bf16", 2.0 * m * n * kp):
+        check(_lib.lib().llark_gemm16_ta_fragw(
+            EPI_RESID if accumulate else EPI_F32, _dev(a, "a", contiguous=False), a.stride(0), _dev(wfrag, "wfrag"), m, n, kp,
+            _dev(c, "c", torch.float32, contiguous=False), c.stride(0), _dev(c, "c", torch.float32, contiguous=False) if accumulate else None,
+            c.stride(0), _dev(sumsq, "sumsq", torch.float64) if sumsq is not None else None, _stream()), "gemm16_ta_fragw")

@@ -6,7 +6,9 @@ layer at M = tokens per micro-step.
 Variants >= 100 are the B-direct kernel on fragment-major weights (100, 101 = its two tiles, 102 = its own choice); -1 = ops.gemm16's
 default (what the trainer gets for an operand without a fragment-major twin); 200 = llark_gemm16_t on the operands as the training
 step has them (dX: W contraction-major; dW: both operands contraction-major) -- the time of the transposes it replaces is printed too;
-210 .. 213 = llark_gemm16_t_ex variants 0 .. 3 (0 = one LDS stage, 1 = 128x256x32 two stages, 2 = 128x256x64 two stages, 3 = 256x256x64).
+210 .. 213 = llark_gemm16_t_ex variants 0 .. 3 (0 = one LDS stage, 1 = 128x256x32 two stages, 2 = 128x256x64 two stages, 3 = 256x256x64);
+220 (dW only) = llark_gemm16_ta_fragw: dY as it stands + X^T fragment-major, the time of llark_pack_frag_t16(X) is printed next to it and
+counted in the sum.
 """
 import os
 import sys
@@ -58,9 +60,18 @@ def main():
         for v in VARIANTS:
             if v >= 200 and not (is_dw or is_dx):
                 continue
+            if v == 220 and not is_dw:
+                continue
+            if v == 220:
+                ms_p = timeit(lambda: ops.pack_frag_t16(wkn, n))
+                xt = ops.pack_frag_t16(wkn, n)
+                total[v] += ms_p
+                print(f"M={M} {name:18s} llark_pack_frag_t16(X [{k} x {n}]): {ms_p:7.3f} ms")
             def fn():
                 kw = dict(c=c, resid=c) if epi == ops.EPI_RESID else dict(c=c)
-                if v >= 200:
+                if v == 220:
+                    ops.gemm16_ta_fragw(akm, xt, rows, n, k, c, accumulate=epi == ops.EPI_RESID)
+                elif v >= 200:
                     tv = -1 if v == 200 else v - 210
                     if is_dw:
                         ops.gemm16_t(akm, wkn, rows, n, k, True, True, c, accumulate=epi == ops.EPI_RESID, variant=tv)

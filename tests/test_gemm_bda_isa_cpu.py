@@ -71,6 +71,12 @@ def audit_kernels(txt, name_regex, min_kernels):
             assert not any(x.startswith("v_mov") or x.startswith("v_accvgpr") for x in ins), f"{name} {b}: register copies inside the K loop"
             assert not any(x.startswith("scratch_") for x in ins), f"{name} {b}: scratch access inside the K loop"
             assert not any(re.match(r"s_waitcnt.*vmcnt\(0\)", x) for x in ins), f"{name} {b}: a vmcnt(0) drain inside the K loop"
+            if any(x.startswith("ds_read_b64_tr_b16") for x in ins):
+                # the dW form (round 6): its transposing LDS reads are inline asm retired by hand-counted s_waitcnt lgkmcnt(N) -- exact only
+                # while nothing else shares that counter inside the loop (scalar loads return out of order; other LDS operations shift the count)
+                assert not any(x.startswith(("s_load", "s_buffer_load")) for x in ins), f"{name} {b}: a scalar load inside the K loop"
+                assert all(x.startswith("ds_read_b64_tr_b16") for x in ins if x.startswith("ds_")), f"{name} {b}: an LDS operation the counts do not know"
+                assert sum(x.startswith("ds_read_b64_tr_b16") for x in ins) == 32, f"{name} {b}: expected 4 sub-steps x 4 row blocks x 2 reads"
         # the instruction stream a wave sees: loop body twice (back edge), then the peeled iteration (or the loop once more), then whatever follows
         tail_blocks = [b for b in hot if b != loop] or [loop]
         nxt = order.index(tail_blocks[-1]) + 1
@@ -112,6 +118,7 @@ def test_gemm_bda_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
     assert all(int(v) <= 256 for v in re.findall(r"VGPRs: (\d+)", r.stderr))
     txt = out.read_text().split("\n")
     assert audit_kernels(txt, "_ZN5llark15gemm_bda_kernel", 12) == 12 * 16       # 5 hi + lo and 7 plain epilogues (round 6: + the two training SwiGLU forms)
+    assert audit_kernels(txt, "_ZN5llark18gemm_bda_ta_kernel", 2) == 2 * 16       # the dW form: contraction-major A through the transposing LDS read
     assert audit_kernels(txt, "_ZN5llark19gemm_bda_lnp_kernel", 2) == 2 * 16      # the LayerNorm-producer role on the same loop (fp16, bf16)
 
 

@@ -119,3 +119,39 @@ def test_two_stage_variants_bit_identical_to_the_single_stage_kernel(variant, fo
         assert torch.equal(outs[0], outs[1]), (variant, form, m, n, kp, (outs[0] - outs[1]).abs().max().item())
         _check(outs[1], a.float().t() if ta else a.float(), w.float().t(), init if accumulate else None)
         assert abs(sums[0] - sums[1]) <= 1e-6 * abs(sums[0])            # (per-wave partials meet in a double atomic: order varies)
+
+
+@pytest.mark.parametrize("kp,n", [(64, 8), (128, 200), (4096, 4096), (192, 11008), (448, 72)])
+def test_pack_frag_t16_equals_transpose_then_pack(kp, n):
+    """llark_pack_frag_t16 (round 6) = llark_pack_weight16_frag of the transposed operand, without the intermediate transpose; also from a
+    column slice of a wider buffer."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(kp + n)
+    buf = torch.randn(kp, n + 24, generator=g, device="cuda").bfloat16()
+    x = buf[:, :n]
+    got = ops.pack_frag_t16(x, n)
+    xt = torch.zeros(ops.round_up(n, 32), kp, dtype=torch.bfloat16, device="cuda")
+    xt[:n] = x.t()
+    assert torch.equal(got, ops.pack_weight16_frag(xt, ops.round_up(n, 32)))
+
+
+@pytest.mark.parametrize("m,n,kp,accumulate", [(128, 256, 192, False), (136, 200, 256, True), (4096, 11008, 1024, True), (72, 1000, 448, False),
+                                               (12288, 4096, 4096, True), (4104, 4360, 4096, False), (22016, 4096, 4096, True)])
+def test_dw_form_on_the_dma_loop(m, n, kp, accumulate):
+    """llark_gemm16_ta_fragw (round 6): dW[m][n] (+)= sum_k dY[k][m] X[k][n] with dY contraction-major through the transposing LDS read of the
+    DMA loop and X^T fragment-major; same bound as the llark_gemm16_t tests, and EQUAL BITS to llark_gemm16_t (same MFMA, k ascending per
+    accumulator); sum-of-squares side output against the stored values."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m * 3 + n)
+    a = torch.randn(kp, m, generator=g, device="cuda").bfloat16()
+    x = (torch.randn(kp, n, generator=g, device="cuda") * 0.1).bfloat16()
+    init = torch.randn(m, n, generator=g, device="cuda") if accumulate else None
+    c = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+    ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ops.gemm16_ta_fragw(a, ops.pack_frag_t16(x, n), m, n, kp, c, accumulate=accumulate, sumsq=ss)
+    _check(c, a.float().t(), x.float().t(), init)
+    c2 = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_t(a, x, m, n, kp, True, True, c2, accumulate=accumulate)
+    assert torch.equal(c, c2)
+    ref_ss = (c.double() ** 2).sum().item()
+    assert abs(ss.item() - ref_ss) <= 1e-5 * ref_ss
