@@ -538,6 +538,19 @@ int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, in
 int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm,
                      llark_stream_t stream);
+/* Layout glue of the Llama training step folded into the kernels around it (round 6; torch autograd of LlamaAttention.forward under
+ * WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
+ *   llark_gemm16_fragw_rope_qkv_train: llark_gemm16_fragw_rope_qkv in the plain bf16 mode that ALSO writes V row-major,
+ *     v_rm [batch][nh][s][128] (the attention backward's operand; no llark_transpose16 of the V^T cache);
+ *   llark_attn_backward_bf16_fused: llark_attn_backward_bf16 that reads dO TOKEN-major ([batch*s][ld_do], head h at column 128 h: what the
+ *     o_proj dX product leaves; no llark_split_heads16) and writes d(q | k | v) of the fused projection as bf16 dqkv [batch*s][3 nh 128] with
+ *     the RoPE backward applied to the q and k parts (bit-equal to llark_rope_merge_bwd over the fp32 outputs of llark_attn_backward_bf16). */
+int llark_gemm16_fragw_rope_qkv_train(const void* a, int lda, const void* wfrag, int kp, int batch, int s, int nh, int hd, int pos0,
+                                      const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache, int smax,
+                                      void* v_rm, llark_stream_t stream);
+int llark_attn_backward_bf16_fused(const void* q, const void* k_cache, const void* v_rm, const void* dO, int ld_do, const void* o,
+                                   const float* lse, float* dsum, int batch, int s, int nh, int hd, int smax, const float* cos_t,
+                                   const float* sin_t, int pos0, int max_pos, void* dqkv, llark_stream_t stream);
 /* dW = dY^T . X without transposed copies of dY (csrc/gemm_bda.hip, round 6; torch autograd of nn.Linear: grad_weight = grad_output^T .
  * input, under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
  *   llark_pack_frag_t16: src [kp][ld] 16-bit (row = contraction index: the token; column = feature) -> dst = the fragment-major copy of

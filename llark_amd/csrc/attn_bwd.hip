@@ -56,12 +56,12 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ base, size
 // The same tile streamed global -> LDS by LDS-DMA (no registers; the tile must lie completely inside the tensor): the DMA image is
 // lane-linear, so lane i of the instruction covering rows 4j..4j+3 FETCHES the chunk that belongs in its slot -- the XOR swizzle of
 // bk_off applied to the source address.  Each wave issues 4 of the 16 x 1 KiB.
-__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0, char* dst, int wv, int lane) {
+__device__ __forceinline__ void dma_rows(const bf16_t* __restrict__ base, int r0, char* dst, int wv, int lane, size_t ld = 128) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int j = wv * 4 + i;
         const int row = 4 * j + (lane >> 4);
-        const bf16_t* src = base + (size_t)(r0 + row) * 128 + (((lane & 15) ^ swz(row)) << 3);
+        const bf16_t* src = base + (size_t)(r0 + row) * ld + (((lane & 15) ^ swz(row)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
     }
@@ -88,19 +88,63 @@ __device__ __forceinline__ bf16x8_t tr_frag(const char* tile, int row0, int col0
 }  // namespace
 
 // D[bh][s] = sum_d dO[bh][s][d] * O[(b*S + s)][h*128 + d]; one wave per row
+// ld_do: 128 = dO head-major [bh][s][128]; otherwise dO token-major [(b*S + s)][ld_do] with head h at column 128 h (like o)
 __global__ __launch_bounds__(256) void attn_bwd_rowdot_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ o,
-                                                              float* __restrict__ dsum, int S, int nh, long rows) {
+                                                              float* __restrict__ dsum, int S, int nh, long rows, int ld_do) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);                // = bh * S + s
     if (row >= rows) return;
     const long bh = row / S;
     const int s = (int)(row - bh * S);
     const int b = (int)(bh / nh), h = (int)(bh - (long)b * nh);
-    const bf16_t* a = dO + row * 128 + lane * 2;
+    const bf16_t* a = ld_do == 128 ? dO + row * 128 + lane * 2 : dO + ((size_t)b * S + s) * (size_t)ld_do + h * 128 + lane * 2;
     const bf16_t* c = o + ((size_t)b * S + s) * (size_t)(nh * 128) + h * 128 + lane * 2;
     float v = (float)a[0] * (float)c[0] + (float)a[1] * (float)c[1];
     v = wave_sum(v);
     if (lane == 0) dsum[row] = v;
+}
+
+// Round 6: the backward's layout glue folded into these kernels.  ld_do: see attn_bwd_rowdot_kernel.  dqkv != nullptr: instead of fp32
+// dq / dk / dv [bh][s][128] the epilogues write d(q | k | v) of the FUSED projection as bf16 [(b*S + s)][3 nh 128] with the RoPE backward
+// applied to the q and k parts (what llark_rope_merge_bwd did in a separate pass over 3 fp32 tensors: dx1 = dy1 c + dy2 s,
+// dx2 = dy2 c - dy1 s for the pair (d, d + 64), which a lane holds in accumulators dt and dt + 4) -- same expressions, same rounding.
+struct AttnBwdFused {
+    int ld_do;
+    bf16_t* dqkv;
+    const float* cos_t;      // [max_pos][64]
+    const float* sin_t;
+    int pos0;
+};
+
+// one row (query / key `pos_s` of sequence b, head h) of region 0 (q) / 1 (k) / 2 (v): acc[dt] = d = 16 dt + 4 g + r
+__device__ __forceinline__ void store_dqkv_row(const AttnBwdFused& f, const f32x4_t (&acc)[8], int region, int b, int h, int nh, int S, int pos_s, int g) {
+    typedef bf16_t bf4_t __attribute__((ext_vector_type(4)));
+    bf16_t* out = f.dqkv + ((size_t)b * S + pos_s) * (size_t)(3 * nh * 128) + (size_t)region * nh * 128 + h * 128 + 4 * g;
+    if (region == 2) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            bf4_t v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[dt][r];
+            *(bf4_t*)(out + dt * 16) = v;
+        }
+        return;
+    }
+    const float* ct = f.cos_t + (size_t)(f.pos0 + pos_s) * 64 + 4 * g;
+    const float* st = f.sin_t + (size_t)(f.pos0 + pos_s) * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const f32x4_t c = *(const f32x4_t*)(ct + dt * 16), sn = *(const f32x4_t*)(st + dt * 16);
+        bf4_t lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float y1 = acc[dt][r], y2 = acc[dt + 4][r];
+            lo[r] = (bf16_t)(y1 * c[r] + y2 * sn[r]);
+            hi[r] = (bf16_t)(y2 * c[r] - y1 * sn[r]);
+        }
+        *(bf4_t*)(out + dt * 16) = lo;
+        *(bf4_t*)(out + 64 + dt * 16) = hi;
+    }
 }
 
 // Blocks -> (tile, batch*head): the 8 XCDs each take whole heads (one L2 sees one head's operands)
@@ -137,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                            const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            float* __restrict__ dk, float* __restrict__ dv, int S, int smax,
-                                                           int nbh, int nh, float scale, const float* __restrict__ alibi) {
+                                                           int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two LDS stages of DKV_STAGE bytes: Q [64 q][128 d] | dO [64][128] | log-sum-exp [64] | rowsum(dO * O) [64].  Tile qt+1 streams in
     // by LDS-DMA while tile qt is computed: one barrier per tile.  The products that contract over the queries (dV^T = dO^T P,
@@ -152,7 +196,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t bh = (size_t)bhid;
     const int kb0 = tile * 64 * NK;
     const bf16_t* qb = q + bh * S * 128;
-    const bf16_t* dob = dO + bh * S * 128;
+    const size_t ldo_ = (size_t)f.ld_do;                                 // 128: head-major dO; else token-major [(b*S + s)][ld_do], head at column 128 h
+    const bf16_t* dob = f.ld_do == 128 ? dO + bh * S * 128 : dO + (size_t)(bhid / nh) * S * ldo_ + (size_t)(bhid % nh) * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
     const float* lb = lse + bh * S;
@@ -185,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         char* base = smem + ((qt - qt0) & 1) * DKV_STAGE;
         if (q0 + 64 <= S) {
             dma_rows(qb, q0, base, wv, lane);
-            dma_rows(dob, q0, base + 16384, wv, lane);
+            dma_rows(dob, q0, base + 16384, wv, lane, ldo_);
             if (wv == 0) {                                          // the 64 log-sum-exps and row sums: 4 B per lane
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb + q0 + lane),
                                                  (__attribute__((address_space(3))) void*)(base + 32768), 4, 0, 0);
@@ -194,7 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         } else {                                                    // the ragged last tile: through registers, zero-filled
             stage_rows(qb, 128, q0, S, base);
-            stage_rows(dob, 128, q0, S, base + 16384);
+            stage_rows(dob, ldo_, q0, S, base + 16384);
             if (threadIdx.x < 64) {
                 const int qi = q0 + threadIdx.x;
                 float* sl = (float*)(base + 32768);
@@ -309,6 +354,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < NK; ++u) {
         const int key = wk0 + u * 16 + c;
         if (key >= S) continue;
+        if (f.dqkv != nullptr) {
+            store_dqkv_row(f, dka[u], 1, bhid / nh, bhid % nh, nh, S, key, g);
+            store_dqkv_row(f, dva[u], 2, bhid / nh, bhid % nh, nh, S, key, g);
+            continue;
+        }
         float* ko = dk + (bh * S + key) * 128 + 4 * g;
         float* vo = dv + (bh * S + key) * 128 + 4 * g;
 #pragma unroll
@@ -327,7 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                           const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           const float* __restrict__ dsum, float* __restrict__ dq, int S,
-                                                          int smax, int nbh, int nh, float scale, const float* __restrict__ alibi) {
+                                                          int smax, int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two LDS stages of 32 KiB: K [64 keys][128 d] | V [64][128]; tile kt+1 streams in by LDS-DMA while tile kt is computed.
     // dQ^T = K^T dS^T reads its A operand (row = d, contraction over the keys) from the row-major K tile through tr_frag.
@@ -342,7 +392,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t bh = (size_t)bhid;
     const int q0 = tile * 64 * NQ;
     const bf16_t* qb = q + bh * S * 128;
-    const bf16_t* dob = dO + bh * S * 128;
+    const size_t ldo_ = (size_t)f.ld_do;                                 // 128: head-major dO; else token-major [(b*S + s)][ld_do], head at column 128 h
+    const bf16_t* dob = f.ld_do == 128 ? dO + bh * S * 128 : dO + (size_t)(bhid / nh) * S * ldo_ + (size_t)(bhid % nh) * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
     const int wq0 = q0 + wv * 16 * NQ;
@@ -358,7 +409,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
-            df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * 128 + ks * 32 + g * 8);
+            df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * ldo_ + ks * 32 + g * 8);
         }
         l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
         dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
@@ -467,6 +518,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < NQ; ++u) {
         const int qi = wq0 + u * 16 + c;
         if (qi >= S) continue;
+        if (f.dqkv != nullptr) {
+            store_dqkv_row(f, dqa[u], 0, bhid / nh, bhid % nh, nh, S, qi, g);
+            continue;
+        }
         float* o = dq + (bh * S + qi) * 128 + 4 * g;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) *(f32x4_t*)(o + dt * 16) = dqa[u][dt];
@@ -482,16 +537,13 @@ using namespace llark;
 //   o [B*s][nh*128] bf16 (the forward's output); lse [B*nh][s] fp32 from llark_attn_prefill_bf16_lse;
 //   dsum [B*nh][s] fp32 scratch; dq, dk, dv [B*nh][s][128] fp32 outputs (dk, dv before the RoPE / head merge).
 //   alibi_slopes: nullptr (Llama) or fp32 [nh] (MPT, m2t/llava/model/mpt/attention.py:build_alibi_bias), as given to the forward.
-extern "C" int llark_attn_backward_bf16(const void* q, const void* k_cache, const void* v_rm, const void* dO, const void* o,
-                                        const float* lse, float* dsum, int batch, int s, int nh, int hd, int smax, float* dq, float* dk,
-                                        float* dv, const float* alibi_slopes, llark_stream_t stream) {
-    LLARK_REQUIRE(q && k_cache && v_rm && dO && o && lse && dsum && dq && dk && dv, "attn_backward: null pointer");
-    LLARK_REQUIRE(hd == 128, "attn_backward: head_dim must be 128 (Llama-2), got %d", hd);
-    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax, "attn_backward: bad shape");
+static int attn_backward_impl(const void* q, const void* k_cache, const void* v_rm, const void* dO, const void* o, const float* lse, float* dsum,
+                              int batch, int s, int nh, int hd, int smax, float* dq, float* dk, float* dv, const float* alibi_slopes,
+                              const AttnBwdFused& f, llark_stream_t stream) {
     const float scale = (float)(1.0 / sqrt((double)hd));
     hipStream_t st = (hipStream_t)stream;
     const long rows = (long)batch * nh * s;
-    attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows);
+    attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows, f.ld_do);
     const int nbh = batch * nh;
     const int grid = cdiv(s, 64 * DQ_NQ) * nbh;
     const int lds_kv = 2 * (32768 + 512), lds_q = 2 * 32768;
@@ -499,8 +551,35 @@ extern "C" int llark_attn_backward_bf16(const void* q, const void* k_cache, cons
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
     attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
                                                                                (const bf16_t*)dO, lse, dsum, dk, dv, s, smax, nbh, nh, scale,
-                                                                               alibi_slopes);
+                                                                               alibi_slopes, f);
     attn_bwd_dq_kernel<DQ_NQ><<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
-                                                 dq, s, smax, nbh, nh, scale, alibi_slopes);
+                                                 dq, s, smax, nbh, nh, scale, alibi_slopes, f);
     return check_launch("attn_backward");
+}
+
+extern "C" int llark_attn_backward_bf16(const void* q, const void* k_cache, const void* v_rm, const void* dO, const void* o,
+                                        const float* lse, float* dsum, int batch, int s, int nh, int hd, int smax, float* dq, float* dk,
+                                        float* dv, const float* alibi_slopes, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && v_rm && dO && o && lse && dsum && dq && dk && dv, "attn_backward: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_backward: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax, "attn_backward: bad shape");
+    AttnBwdFused f = {};
+    f.ld_do = 128;
+    return attn_backward_impl(q, k_cache, v_rm, dO, o, lse, dsum, batch, s, nh, hd, smax, dq, dk, dv, alibi_slopes, f, stream);
+}
+
+// The same backward with the layout glue of the Llama training step folded in (round 6): dO is read TOKEN-major ([batch*s][ld_do], head h at
+// column 128 h: the d(attention output) a Linear's dX product leaves, no llark_split_heads16 pass), and instead of fp32 dq / dk / dv the
+// epilogues write d(q | k | v) of the fused projection as bf16 dqkv [batch*s][3 nh 128] with the RoPE backward applied to the q and k parts
+// (bit-equal to llark_rope_merge_bwd on the fp32 outputs of llark_attn_backward_bf16).  cos_t / sin_t [max_pos][64], pos0 + s <= max_pos.
+extern "C" int llark_attn_backward_bf16_fused(const void* q, const void* k_cache, const void* v_rm, const void* dO, int ld_do, const void* o,
+                                              const float* lse, float* dsum, int batch, int s, int nh, int hd, int smax, const float* cos_t,
+                                              const float* sin_t, int pos0, int max_pos, void* dqkv, llark_stream_t stream) {
+    LLARK_REQUIRE(q && k_cache && v_rm && dO && o && lse && dsum && cos_t && sin_t && dqkv, "attn_backward_fused: null pointer");
+    LLARK_REQUIRE(hd == 128, "attn_backward_fused: head_dim must be 128 (Llama-2), got %d", hd);
+    LLARK_REQUIRE(batch > 0 && s > 0 && nh > 0 && s <= smax && pos0 >= 0 && pos0 + s <= max_pos, "attn_backward_fused: bad shape");
+    LLARK_REQUIRE(ld_do >= nh * 128 && ld_do % 8 == 0 && ((uintptr_t)dO & 15) == 0 && ((uintptr_t)dqkv & 7) == 0, "attn_backward_fused: dO must be [batch*s][ld_do >= nh*128], ld_do %% 8 == 0, 16-byte aligned");
+    AttnBwdFused f = {};
+    f.ld_do = ld_do; f.dqkv = (bf16_t*)dqkv; f.cos_t = cos_t; f.sin_t = sin_t; f.pos0 = pos0;
+    return attn_backward_impl(q, k_cache, v_rm, dO, o, lse, dsum, batch, s, nh, hd, smax, nullptr, nullptr, nullptr, nullptr, f, stream);
 }

@@ -1637,9 +1637,9 @@ extern "C" int llark_gemm16_fragw_sk(int variant, int dtype, int split, int epil
 // wfrag: llark_pack_weight16_frag of the [3 * nh * 128][kp] q|k|v weight whose q and k rows are permuted per head to
 // [0..31 | 64..95 | 32..63 | 96..127] (v rows in natural order).  Always whole 128x256 tiles (no K cut): callers that want results
 // bit-equal to the two-launch path use it where that path runs whole tiles too (m >= 2 rounds of tiles, see gemm16_fragw_impl).
-extern "C" int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, int lda, const void* wfrag, int kp, int batch, int s, int nh,
-                                           int hd, int pos0, const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache,
-                                           void* vt_cache, void* q_lo, void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream) {
+static int gemm16_fragw_rope_qkv_impl(const void* a_hi, const void* a_lo, int lda, const void* wfrag, int kp, int batch, int s, int nh,
+                                      int hd, int pos0, const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache,
+                                      void* vt_cache, void* q_lo, void* k_cache_lo, void* vt_cache_lo, int smax, void* v_rm, llark_stream_t stream) {
     LLARK_REQUIRE(a_hi && wfrag && cos_t && sin_t && q && k_cache && vt_cache, "gemm16_fragw_rope_qkv: null pointer");
     LLARK_REQUIRE(hd == 128, "gemm16_fragw_rope_qkv: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE(nh > 0 && nh % 2 == 0, "gemm16_fragw_rope_qkv: a 256-column tile holds two heads: nh must be even, got %d", nh);
@@ -1658,12 +1658,31 @@ extern "C" int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, i
     p.Ahi = a_hi; p.Alo = a_lo; p.lda = lda; p.Wt = wfrag; p.M = batch * s; p.N = 3 * nh * 128; p.Kp = kp;
     p.rope_cos = cos_t; p.rope_sin = sin_t; p.rope_s = s; p.rope_nh = nh; p.rope_pos0 = pos0; p.rope_smax = smax;
     p.rope_q = q; p.rope_q_lo = q_lo; p.rope_k = k_cache; p.rope_k_lo = k_cache_lo; p.rope_v = vt_cache; p.rope_v_lo = vt_cache_lo;
+    LLARK_REQUIRE(!v_rm || (!split && (long long)batch * nh * s * 256 < (1ll << 31)), "gemm16_fragw_rope_qkv: the row-major V output exists in the plain bf16 mode only");
+    p.rope_v_rm = v_rm;
     hipStream_t st = (hipStream_t)stream;
     if (GEMM_BDA && (split || GEMM_BDA >= 2)) {
         const int rc = launch_gemm_bda(p, LLARK_BF16, EPI_ROPE_QKV, st);
         if (rc != -1000) return rc;
     }
     return split ? launch_gemm_bd<bf16_t, true, EPI_ROPE_QKV, CfgBD0>(p, st) : launch_gemm_bd<bf16_t, false, EPI_ROPE_QKV, CfgBD0>(p, st);
+}
+
+extern "C" int llark_gemm16_fragw_rope_qkv(const void* a_hi, const void* a_lo, int lda, const void* wfrag, int kp, int batch, int s, int nh,
+                                           int hd, int pos0, const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache,
+                                           void* vt_cache, void* q_lo, void* k_cache_lo, void* vt_cache_lo, int smax, llark_stream_t stream) {
+    return gemm16_fragw_rope_qkv_impl(a_hi, a_lo, lda, wfrag, kp, batch, s, nh, hd, pos0, cos_t, sin_t, max_pos, q, k_cache, vt_cache, q_lo,
+                                      k_cache_lo, vt_cache_lo, smax, nullptr, stream);
+}
+
+// Training form (plain bf16 operands): llark_gemm16_fragw_rope_qkv that ALSO writes V row-major, v_rm [batch][nh][s][128] -- the operand
+// the attention backward (llark_attn_backward_bf16*) reads, otherwise rebuilt from the V^T cache by a llark_transpose16 per layer and step.
+extern "C" int llark_gemm16_fragw_rope_qkv_train(const void* a, int lda, const void* wfrag, int kp, int batch, int s, int nh, int hd, int pos0,
+                                                 const float* cos_t, const float* sin_t, int max_pos, void* q, void* k_cache, void* vt_cache,
+                                                 int smax, void* v_rm, llark_stream_t stream) {
+    LLARK_REQUIRE(v_rm, "gemm16_fragw_rope_qkv_train: null v_rm");
+    return gemm16_fragw_rope_qkv_impl(a, nullptr, lda, wfrag, kp, batch, s, nh, hd, pos0, cos_t, sin_t, max_pos, q, k_cache, vt_cache, nullptr,
+                                      nullptr, nullptr, smax, v_rm, stream);
 }
 
 // Decode-step form of `h += x . W^T` followed by RMSNorm(h) -> bf16 planes, in ONE launch (m <= 16 rows): the skinny

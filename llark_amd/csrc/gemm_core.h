@@ -131,6 +131,7 @@ struct GemmParams {
     void *rope_q, *rope_q_lo;      // bf16 [batch][nh][rope_s][128]
     void *rope_k, *rope_k_lo;      // bf16 [batch][nh][rope_smax][128]
     void *rope_v, *rope_v_lo;      // bf16 [batch][nh][128][rope_smax]  (V transposed)
+    void* rope_v_rm;               // plain bf16 mode, nullable: V additionally row-major [batch][nh][rope_s][128] (training: the attention backward's operand)
     // EPI_SWIGLU16_SAVE (output) / EPI_SWIGLU_BWD (input): the gate | up pre-activations, 16-bit, in the interleaved column order of the
     // gate/up weight rows ([32 gate | 32 up] per 64 columns), pitch ldg
     void* G16;

@@ -103,6 +103,29 @@ __device__ __forceinline__ void gemm_epilogue_rope_qkv_impl(const GemmParams& p,
         const unsigned head_bytes = 128u * (unsigned)smax * 2u, batch_bytes = (unsigned)p.rope_nh * head_bytes;
         __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(p.rope_v, 0, 0x7FFFFFFF, RSRC_FLAGS);
         __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? p.rope_v_lo : nullptr, 0, 0x7FFFFFFF, RSRC_FLAGS);
+        if (!SPLIT && p.rope_v_rm != nullptr) {
+            // training (round 6): V also ROW-major [b][nh][S][128] for the attention backward -- straight from the accumulators (a lane holds
+            // column d = 64 (wn % 2) + 32 tn + lane % 32 of 16 rows), which saves the llark_transpose16 of the V^T cache per layer and step
+            __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(p.rope_v_rm, 0, 0x7FFFFFFF, RSRC_FLAGS);
+            const unsigned hb = (unsigned)S * 256u, bb = (unsigned)p.rope_nh * hb;
+            const unsigned ol = (unsigned)head * hb + (64u * (wn & 1) + (unsigned)lc) * 2u;
+#pragma unroll
+            for (int tm = 0; tm < C::TM; ++tm) {
+                const int mt = mlane + C::tile_row(tm);
+                const int bt = mt / S, st = mt - bt * S;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = C::tile_row(tm) + (r & 3) + 8 * (r >> 2);
+                    if (!FULL && mlane + ml >= p.M) continue;
+                    const int sr = st + (r & 3) + 8 * (r >> 2);
+                    const bool wrap = sr >= S;
+                    const unsigned o = ol + (unsigned)bt * bb + (unsigned)(wrap ? sr - S : sr) * 256u + (wrap ? bb : 0u);
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16_t)acc[tm][tn][r]), rV, o, tn * 64, 0);
+                }
+            }
+        }
         float* patch = (float*)smem + (threadIdx.x >> 6) * (32 * 33);
         const int rrow = lane & 31, rcol = lane >> 5;            // read-back role: row of the 32-row block, first of this lane's columns
         const unsigned col_bytes = (unsigned)smax * 2u;

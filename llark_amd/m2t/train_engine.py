@@ -101,6 +101,7 @@ class HipLlamaTrainer:
         self._frozen_wT: Dict[int, torch.Tensor] = {}
         self.use_twins = bool(optimizer_state) and os.environ.get("LLARK_TRAIN_TWINS", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
         self.dw_fragw = os.environ.get("LLARK_TRAIN_DW_FRAGW", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
+        self.attn_glue_fused = os.environ.get("LLARK_TRAIN_ATTN_GLUE_FUSED", "1") != "0"
         self.swiglu_fused = self.use_twins and os.environ.get("LLARK_TRAIN_SWIGLU_FUSED", "1") != "0"
         self.rope_fused = self.use_twins and d.head_dim == 128 and d.num_attention_heads % 2 == 0 and os.environ.get("LLARK_TRAIN_ROPE_FUSED", "1") != "0"
         if self.use_twins:
@@ -322,8 +323,13 @@ class HipLlamaTrainer:
             q = torch.empty((B, nh, S, hd), **bf)
             kc, vc = eng.k_cache[i, :B], eng.vt_cache[i, :B]
             tw = self.twins.get(f"layers.{i}.wqkv")
+            v_rm = None
             if tw is not None and tw[2] and S >= 32 and fused_rows:     # RoPE / head split / K and V^T writes in the product's epilogue
-                ops.gemm16_fragw_rope_qkv(x1, None, tw[0], H, B, S, nh, 0, eng.cos, eng.sin, q, kc, vc)
+                if self.attn_glue_fused:                                 # ... and V row-major for the backward (no transpose16 of the V^T cache)
+                    v_rm = torch.empty((B * nh, S, hd), **bf)
+                    ops.gemm16_fragw_rope_qkv_train(x1, tw[0], H, B, S, nh, 0, eng.cos, eng.sin, q, kc, vc, v_rm)
+                else:
+                    ops.gemm16_fragw_rope_qkv(x1, None, tw[0], H, B, S, nh, 0, eng.cos, eng.sin, q, kc, vc)
             else:
                 qkv = torch.empty((rows, 3 * H), **f32)
                 ops.gemm16(x1, None, self._fwd_weight(L.wqkv), None, 3 * H, ops.EPI_F32, c=qkv)
@@ -335,7 +341,7 @@ class HipLlamaTrainer:
             h_mid = torch.empty_like(h)
             ops.gemm16(att, None, self._fwd_weight(L.wo), None, H, ops.EPI_RESID, c=h_mid, resid=h)
             h = h_mid
-            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h_mid)
+            st.update(x1=x1, q=q, att=att, lse=lse, h_mid=h_mid, v_rm=v_rm)
             x2 = torch.empty((rows, H), **bf)
             ops.rmsnorm_bf16(h, L.ln2, d.rms_norm_eps, x2)
             act = torch.empty((rows, I), **bf)
@@ -409,25 +415,37 @@ class HipLlamaTrainer:
             # ---- attention ----
             dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
             dh16 = dh16[:, :H]
-            self._dx(dh16, L.wo, dtmp)                                  # d(att)
-            self._dw(dh16, st["att"], g[pre + "wo"], pre + "wo")
-            datt16, _ = ops.split16(dtmp, _BF, want_lo=False, kmult=64)
-            dO = torch.empty((BH, S, hd), **bf)
-            ops.split_heads16(datt16[:, :H].contiguous() if datt16.shape[1] != H else datt16, B, S, nh, hd, dO)
             q = st["q"].view(BH, S, hd)
             kc = eng.k_cache[i, :B]                                      # [B][nh][smax][hd]
             vtc = eng.vt_cache[i, :B]                                    # [B][nh][hd][smax]
             # flash-style backward (csrc/attn_bwd.hip): P is recomputed per tile from the forward's log-sum-exp, no S x S matrix
-            # exists and no operand is transposed; the only layout work is V back to row-major from the transposed cache
-            v_rm = torch.empty((BH, S, hd), **bf)
-            ops.transpose16(vtc, smax, hd, S, v_rm, hd, BH, hd * smax, S * hd)
-            dq = torch.empty((BH, S, hd), **f32)
-            dk = torch.empty((BH, S, hd), **f32)
-            dv = torch.empty((BH, S, hd), **f32)
+            # exists and no operand is transposed
+            v_rm = st.get("v_rm")
+            if v_rm is None:                                             # (V back to row-major from the transposed cache)
+                v_rm = torch.empty((BH, S, hd), **bf)
+                ops.transpose16(vtc, smax, hd, S, v_rm, hd, BH, hd * smax, S * hd)
             dsum = torch.empty((BH, S), **f32)
-            ops.attn_backward(q, kc, v_rm, dO, st["att"], st["lse"], dsum, B, S, nh, hd, dq, dk, dv)
             dqkv = torch.empty((rows, 3 * H), **bf)
-            ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
+            tw = self.twins.get(pre + "wo")
+            if self.attn_glue_fused and tw is not None and fused_rows and hd == 128:
+                # round 6: d(att) leaves the o_proj dX product as bf16, token-major, and is read like that by the attention backward, whose
+                # epilogues write d(q | k | v) with the RoPE backward applied: no fp32 d(att), split16, split_heads16, fp32 dq / dk / dv
+                # or rope_merge_bwd passes
+                datt16 = torch.empty((rows, H), **bf)
+                ops.gemm16_fragw(dh16, None, tw[1], None, H, H, ops.EPI_OUT16, out_hi=datt16)
+                self._dw(dh16, st["att"], g[pre + "wo"], pre + "wo")
+                ops.attn_backward_fused(q, kc, v_rm, datt16, st["att"], st["lse"], dsum, B, S, nh, hd, eng.cos, eng.sin, 0, dqkv)
+            else:
+                self._dx(dh16, L.wo, dtmp)                                  # d(att)
+                self._dw(dh16, st["att"], g[pre + "wo"], pre + "wo")
+                datt16, _ = ops.split16(dtmp, _BF, want_lo=False, kmult=64)
+                dO = torch.empty((BH, S, hd), **bf)
+                ops.split_heads16(datt16[:, :H].contiguous() if datt16.shape[1] != H else datt16, B, S, nh, hd, dO)
+                dq = torch.empty((BH, S, hd), **f32)
+                dk = torch.empty((BH, S, hd), **f32)
+                dv = torch.empty((BH, S, hd), **f32)
+                ops.attn_backward(q, kc, v_rm, dO, st["att"], st["lse"], dsum, B, S, nh, hd, dq, dk, dv)
+                ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
             self._dx(dqkv, L.wqkv, dtmp)
             self._dw(dqkv, st["x1"], g[pre + "wqkv"], pre + "wqkv")
             ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"])

@@ -1292,3 +1292,34 @@ def gemm16_ta_fragw(a: torch.Tensor, wfrag: torch.Tensor, m: int, n: int, kp: in
             EPI_RESID if accumulate else EPI_F32, _dev(a, "a", contiguous=False), a.stride(0), _dev(wfrag, "wfrag"), m, n, kp,
             _dev(c, "c", torch.float32, contiguous=False), c.stride(0), _dev(c, "c", torch.float32, contiguous=False) if accumulate else None,
             c.stride(0), _dev(sumsq, "sumsq", torch.float64) if sumsq is not None else None, _stream()), "gemm16_ta_fragw")
+
+
+def gemm16_fragw_rope_qkv_train(a: torch.Tensor, wfrag: torch.Tensor, kp: int, batch: int, s: int, nh: int, pos0: int, cos_t: torch.Tensor,
+                                sin_t: torch.Tensor, q: torch.Tensor, k_cache: torch.Tensor, vt_cache: torch.Tensor, v_rm: torch.Tensor) -> None:
+    """:func:`gemm16_fragw_rope_qkv` (plain bf16 operands) that also writes V row-major, ``v_rm`` [batch][nh][s][128]: the attention
+    backward's operand (include/llark_hip.h: llark_gemm16_fragw_rope_qkv_train)."""
+    bf = torch.bfloat16
+    hd = 128
+    smax = k_cache.shape[-2]
+    n = 3 * nh * hd
+    assert a.dtype == bf and wfrag.dtype == bf and wfrag.numel() == n * kp and a.shape[0] >= batch * s and a.shape[1] >= kp
+    assert k_cache.shape[-1] == hd and vt_cache.shape[-1] == smax and q.numel() >= batch * nh * s * hd and v_rm.numel() >= batch * nh * s * hd
+    with _timed("gemm_bf16", 2.0 * batch * s * n * kp):
+        check(_lib.lib().llark_gemm16_fragw_rope_qkv_train(
+            _dev(a, "a", bf), a.stride(0), _dev(wfrag, "wfrag", bf), kp, batch, s, nh, hd, pos0, _dev(cos_t, "cos", torch.float32),
+            _dev(sin_t, "sin", torch.float32), cos_t.shape[0], _dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf),
+            smax, _dev(v_rm, "v_rm", bf), _stream()), "gemm16_fragw_rope_qkv_train")
+
+
+def attn_backward_fused(q, k_cache, v_rm, dO: torch.Tensor, o, lse, dsum, batch: int, s: int, nh: int, hd: int, cos_t: torch.Tensor,
+                        sin_t: torch.Tensor, pos0: int, dqkv: torch.Tensor) -> None:
+    """:func:`attn_backward` with the layout glue folded in (include/llark_hip.h: llark_attn_backward_bf16_fused): ``dO`` token-major
+    [batch*s][>= nh*hd] (any row pitch), output ``dqkv`` bf16 [batch*s][3*nh*hd] = d(q | k | v) with the RoPE backward applied."""
+    smax = k_cache.shape[-2]
+    bf, f32 = torch.bfloat16, torch.float32
+    assert dO.dtype == bf and dO.stride(1) == 1 and dO.shape[0] >= batch * s and dO.shape[1] >= nh * hd
+    assert dqkv.dtype == bf and dqkv.is_contiguous() and dqkv.shape == (batch * s, 3 * nh * hd)
+    check(_lib.lib().llark_attn_backward_bf16_fused(
+        _dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(v_rm, "v_rm", bf), _dev(dO, "dO", bf, contiguous=False), dO.stride(0),
+        _dev(o, "o", bf), _dev(lse, "lse", f32), _dev(dsum, "dsum", f32), batch, s, nh, hd, smax, _dev(cos_t, "cos", f32),
+        _dev(sin_t, "sin", f32), pos0, cos_t.shape[0], _dev(dqkv, "dqkv", bf), _stream()), "attn_backward_fused")

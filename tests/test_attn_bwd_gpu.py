@@ -110,3 +110,44 @@ def test_attention_backward_matches_materialised_path():
     for name, got, ref in (("dq", dq, mdq), ("dk", dk, mdk), ("dv", dv, mdv)):
         rel = ((got.view(BH, S, HD) - ref).norm() / ref.norm()).item()
         assert rel <= 5e-3, (name, rel)
+
+
+def test_fused_glue_equals_the_separate_passes():
+    """llark_attn_backward_bf16_fused (round 6): dO read token-major + d(q | k | v) written as bf16 with the RoPE backward in the epilogues
+    == llark_split_heads16 + llark_attn_backward_bf16 + llark_rope_merge_bwd, bit for bit (same accumulators, same expressions)."""
+    import torch
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(12)
+    B, S, nh, hd, smax = 2, 200, 2, 128, 256
+    H = nh * hd
+    bf, f32 = torch.bfloat16, torch.float32
+    q = (torch.randn(B * nh, S, hd, generator=g, device="cuda") * 0.5).to(bf)
+    kc = torch.zeros(B, nh, smax, hd, dtype=bf, device="cuda")
+    kc[:, :, :S] = (torch.randn(B, nh, S, hd, generator=g, device="cuda") * 0.5).to(bf)
+    v_rm = (torch.randn(B * nh, S, hd, generator=g, device="cuda") * 0.5).to(bf)
+    vt = torch.zeros(B, nh, hd, smax, dtype=bf, device="cuda")
+    vt[:, :, :, :S] = v_rm.view(B, nh, S, hd).transpose(2, 3)
+    att = torch.empty(B * S, H, dtype=bf, device="cuda")
+    lse = torch.empty(B * nh, S, dtype=f32, device="cuda")
+    ops.attn_prefill_lse(q.view(B, nh, S, hd), kc, vt, B, S, nh, hd, att, lse)
+    dbuf = (torch.randn(B * S, H + 64, generator=g, device="cuda") * 0.1).to(bf)      # token-major with a wider pitch
+    datt = dbuf[:, :H]
+    half = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, device="cuda", dtype=f32) / half))
+    ang = torch.arange(0, 512, device="cuda", dtype=f32)[:, None] * inv[None, :]
+    cos_t, sin_t = ang.cos().contiguous(), ang.sin().contiguous()
+    # separate passes
+    dO = torch.empty(B * nh, S, hd, dtype=bf, device="cuda")
+    ops.split_heads16(datt.contiguous(), B, S, nh, hd, dO)
+    dq, dk, dv = (torch.empty(B * nh, S, hd, dtype=f32, device="cuda") for _ in range(3))
+    dsum = torch.empty(B * nh, S, dtype=f32, device="cuda")
+    ops.attn_backward(q, kc, v_rm, dO, att, lse, dsum, B, S, nh, hd, dq, dk, dv)
+    ref = torch.empty(B * S, 3 * H, dtype=bf, device="cuda")
+    ops.rope_merge_bwd(dq, dk, dv, cos_t, sin_t, B, S, nh, hd, 0, ref)
+    # fused
+    got = torch.full((B * S, 3 * H), 7.0, dtype=bf, device="cuda")
+    dsum2 = torch.empty_like(dsum)
+    ops.attn_backward_fused(q, kc, v_rm, datt, att, lse, dsum2, B, S, nh, hd, cos_t, sin_t, 0, got)
+    assert torch.equal(dsum, dsum2)
+    assert torch.equal(got, ref), (got.float() - ref.float()).abs().max().item()
+    assert ref.float().abs().max().item() > 0

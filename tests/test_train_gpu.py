@@ -722,3 +722,35 @@ def test_twin_paths_agree_with_the_untwinned_trainer(monkeypatch):
             continue
         rel = ((a - b).norm() / b.norm()).item()
         assert rel <= 2e-2, f"{name}: {rel:.3e}"
+
+
+def test_rope_qkv_train_epilogue_writes_v_row_major():
+    """llark_gemm16_fragw_rope_qkv_train: q, the K cache and the V^T cache exactly as llark_gemm16_fragw_rope_qkv, plus V row-major
+    [b][nh][s][128] == the transpose of what went into the V^T cache."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B, S, nh, hd, smax, H = 2, 72, 2, 128, 128, 256
+    bf = torch.bfloat16
+    x = torch.randn(B * S, H, generator=g, device="cuda").to(bf)
+    w = (torch.randn(3 * H, H, generator=g, device="cuda") * 0.06).to(bf)
+    wfrag = ops.pack_weight16_frag(w.index_select(0, ops.rope_qkv_row_order(nh, hd).cuda()), 3 * H)
+    half = hd // 2
+    inv = 1.0 / (10000.0 ** (torch.arange(0, half, device="cuda", dtype=torch.float32) / half))
+    ang = torch.arange(0, 256, device="cuda", dtype=torch.float32)[:, None] * inv[None, :]
+    cos_t, sin_t = ang.cos().contiguous(), ang.sin().contiguous()
+    outs = []
+    for train in (False, True):
+        q = torch.zeros(B, nh, S, hd, dtype=bf, device="cuda")
+        kc = torch.zeros(B, nh, smax, hd, dtype=bf, device="cuda")
+        vt = torch.zeros(B, nh, hd, smax, dtype=bf, device="cuda")
+        v_rm = torch.full((B * nh, S, hd), 9.0, dtype=bf, device="cuda")
+        if train:
+            ops.gemm16_fragw_rope_qkv_train(x, wfrag, H, B, S, nh, 0, cos_t, sin_t, q, kc, vt, v_rm)
+        else:
+            ops.gemm16_fragw_rope_qkv(x, None, wfrag, H, B, S, nh, 0, cos_t, sin_t, q, kc, vt)
+        outs.append((q, kc, vt, v_rm))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    vt, v_rm = outs[1][2], outs[1][3]
+    assert torch.equal(v_rm.view(B, nh, S, hd), vt[:, :, :, :S].transpose(2, 3))
+    assert v_rm.float().abs().max().item() > 0
