@@ -77,6 +77,11 @@ struct Mfma16<bf16_t> {
 // A/B knobs (same arithmetic): G256X_R0 = MFMAs that go out back to back at the start of a phase before the first gap carries a
 // fragment read; G256X_PRIO = 1: s_setprio 1 for the later-dispatched half of the workgroup (waves 4..7).  Measured:
 // profiles/r04_gemm256x_knobs.txt.
+#ifndef G256X_GM
+#define G256X_GM 4                // tile rows per M-group of the tile order: a chunk of 32 resident workgroups per XCD covers G256X_GM x (32 / G256X_GM) tiles.
+                                  // Unique operand bytes per chunk (two A planes): 4.9 MB x GM + 2.46 MB x 32 / GM at K = 4800 -- 49 / 39 / 49 / 83 MB for
+                                  // GM = 2 / 4 / 8 / 16; measured in round 6 (profiles/r06_gemm256x_chunk_shape.txt)
+#endif
 #ifndef G256X_R0
 #define G256X_R0 0
 #endif
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(Cfg256X::THREADS, Cfg256X::MINW) void gemm256x_kern
 
     auto tile_of = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) {
         // M-grouped tile order: 4 tile rows, N-major inside a group (a chunk of 32 tiles = 4 x 8 tiles)
-        constexpr int GM = 4;
+        constexpr int GM = G256X_GM;
         const int gsz = GM * p.tiles_n;
         const int g = bid / gsz;
         const int first_m = g * GM;

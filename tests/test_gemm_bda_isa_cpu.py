@@ -122,7 +122,24 @@ def test_gemm_bda_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
     assert audit_kernels(txt, "_ZN5llark19gemm_bda_lnp_kernel", 2) == 2 * 16      # the LayerNorm-producer role on the same loop (fp16, bf16)
 
 
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_gemm_bd_sk_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
+    """The same audit on the K-cut / stream-K kernels (csrc/gemm_bd_sk.hip), which inline the same hand-counted loop and are the default for
+    the Llama o_proj / down_proj products (until round 6 they sat inside gemm.hip, a five-minute compile, and were audited by
+    hand only).  Twelve bf16 instantiations (hi + lo and plain x six epilogues) carry the DMA loop; the fp16 ones keep the register-staged
+    loop and are skipped by the audit."""
+    out = tmp_path / "sk.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(ROOT, "llark_amd", "csrc", "gemm_bd_sk.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)] + [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(spills) >= 24 and not any(spills), f"spills / scratch: {spills}"
+    txt = out.read_text().split("\n")
+    assert audit_kernels(txt, "_ZN5llark17gemm_bd_sk_kernel", 24) == 12 * 16
+
+
 if __name__ == "__main__":      # python tests/test_gemm_bda_isa_cpu.py <file.s> <kernel symbol regex>: the same audit on any assembly file
-    import sys                  # (gemm.hip's K-cut kernel inlines the same loop: hipcc ... -S gemm.hip takes ~4 min, so it is run by hand after edits)
+    import sys
 
     print("loads followed to their retiring wait:", audit_kernels(open(sys.argv[1]).read().split("\n"), sys.argv[2], 1))
