@@ -324,7 +324,8 @@ def prior_roofline(timers, hps, args, precision):
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_note = None, "no PMC record committed for this kernel version"
     pmc = os.path.join(ROOT, "profiles", pmc_name)
-    if os.path.exists(pmc):
+    # the record is of ONE launch shape (M = 8 clips x 8192 rows, 5b widths): attached to that workload only
+    if os.path.exists(pmc) and args.batch == 8 and hps.n_ctx == 8192 and hps.prior_width == 4800:
         d = json.load(open(pmc))
         traffic = d["traffic_bytes_per_launch"]
         traffic_note = ("NOT measured in this run: memory-side bytes of ONE launch of %s from the committed rocprofv3 --pmc passes in "
@@ -332,6 +333,7 @@ def prior_roofline(timers, hps, args, precision):
                         % (d["kernel"], pmc_name, d["algorithmic_bytes_per_launch"] / 1e9))
     return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_F16_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "traffic_source": ("profiles/" + pmc_name) if traffic is not None else None,
             "launches": launches, "avg_launch_ms": round(ms / launches, 4), "mfma_passes": passes,
             "frac_of_issued_mfma": round(passes * achieved / PEAK_F16_MFMA_TFLOPS, 4),
             "layernorm_folded": folded,

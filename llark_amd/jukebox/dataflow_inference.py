@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import extract as E
+from .audio_decode import UnsupportedContainerError
 
 # apache_beam.ml.inference.base.PredictionResult is a (example, inference) named tuple
 PredictionResult = namedtuple("PredictionResult", ["example", "inference"])
@@ -64,6 +65,11 @@ class JukeboxModelWrapper:
                                                       meanpool=True, pool_frames_per_second=10)
                 return representation
             except E.EmptyFileError:
+                return None
+            except UnsupportedContainerError as e:
+                # mp3 / ogg are legitimate inputs of the reference (librosa -> audioread) that this decoder does not read: one such file
+                # must not abort the whole extraction run -- skipped with its own message, like an empty file
+                logging.warning(f"{input_path}: unsupported container, no representation written ({e})")
                 return None
 
 

@@ -169,10 +169,26 @@ class HipLlamaEngine:
         """The q|k|v weight in the fused epilogue's row order, fragment-major: + 3 H^2 x 2 bytes per layer (3.2 GB at 7B), so it is
         built LAZILY -- engines that only decode, prefill short prompts or train never pay for it."""
         if L.wqkv_rope is None and self._rope_capable(L):
-            if self._rope_rows is None:
-                self._rope_rows = ops.rope_qkv_row_order(self.dims.num_attention_heads, self.dims.head_dim).to(self.device)
-            L.wqkv_rope = ops.pack_weight16_frag(L.wqkv.index_select(0, self._rope_rows).contiguous(), L.wqkv.shape[0])
+            try:
+                if self._rope_rows is None:
+                    self._rope_rows = ops.rope_qkv_row_order(self.dims.num_attention_heads, self.dims.head_dim).to(self.device)
+                L.wqkv_rope = ops.pack_weight16_frag(L.wqkv.index_select(0, self._rope_rows).contiguous(), L.wqkv.shape[0])
+            except torch.cuda.OutOfMemoryError:
+                # built inside the first qualifying prefill, i.e. after the KV cache and the activations were allocated: running out of
+                # memory here must not fail the forward (ADVICE r05) -- this engine keeps the two-launch path from now on
+                self.fuse_prefill_rope = "0"
+                for M in self.layers:
+                    if M is not None:
+                        M.wqkv_rope = None
+                torch.cuda.empty_cache()
+                return None
         return L.wqkv_rope
+
+    def prepare_prefill(self) -> bool:
+        """Build the fused-RoPE q|k|v twins of every layer NOW (+ 3 H^2 x 2 bytes per layer, 3.2 GB at 7B) instead of inside the first
+        qualifying prefill: callers that time their first forward, or want an out-of-memory condition at load time rather than in the
+        middle of inference, call this after loading the weights.  Returns False when this engine does not take the fused epilogue."""
+        return all(L is not None and self._rope_weight(L) is not None for L in self.layers)
 
     def set_globals(self, embed, norm, lm_head, proj_w=None, proj_b=None) -> None:
         self._dec.clear()
@@ -384,7 +400,10 @@ class HipLlamaEngine:
         ops.gemm16(act, actl, L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
 
     def _prefill_two_streams(self, ws, batch: int, s: int, pos0: int, n_layers: int) -> None:
-        """The layer stack of a prefill as two half-batches, each on its own stream, enqueued layer by layer in alternation."""
+        """The layer stack of a prefill as two half-batches, each on its own stream, enqueued layer by layer in alternation.
+        The side streams work on row slices of `ws`, tensors allocated on the CALLER's stream: safe only because the workspace is
+        persistent (owned by the engine, never returned to the caching allocator while a forward is in flight) and both side streams
+        are joined into the caller's stream before this returns."""
         if self._side_streams is None:
             self._side_streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
         cur = torch.cuda.current_stream()

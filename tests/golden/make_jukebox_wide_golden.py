@@ -122,9 +122,16 @@ def stage_case(name, w, hps):
         f"{name}_min_gap": np.float64(gap.min()), f"{name}_agree_f64": np.float64((arg64 == c[0]).mean()),
         f"{name}_probe_rows": np.array(rows), f"{name}_probe_layers": np.array(sorted(probes)),
         f"{name}_probes": np.stack([probes[l] for l in sorted(probes)]), f"{name}_maxabs": np.array([maxabs[l] for l in sorted(probes)]),
-        f"{name}_emb_f10": f10.numpy().astype(np.float32), f"{name}_emb_f0": f0.numpy().astype(np.float32),
+        f"{name}_emb_f0": f0.numpy().astype(np.float32),
         f"{name}_acts_maxabs": np.float64(acts.abs().max()),
     })
+    # round 6: every 4th pooled frame + the last one is kept (18 MB -> 7 MB in git; each frame is a mean over 34 tokens x all channels)
+    keep = list(range(0, f10.shape[0], 4))
+    if keep[-1] != f10.shape[0] - 1:
+        keep.append(f10.shape[0] - 1)
+    keep = np.array(keep, dtype=np.int64)
+    OUT.update({f"{name}_emb_f10": f10.numpy().astype(np.float32)[keep], f"{name}_emb_f10_rows": keep, f"{name}_emb_f10_frames": np.int64(f10.shape[0]),
+                f"{name}_emb_f10_maxabs": np.float64(f10.abs().max())})
     print(f"[{name}] emb_f10 {tuple(f10.shape)} max|emb| {float(f10.abs().max()):.3f} max|acts| {float(acts.abs().max()):.3f}", flush=True)
     return c[0], latent_len, f10
 
@@ -134,7 +141,8 @@ def stage_head64(name, w, hps, codes, latent_len, f10_fp32):
     acts, rows, probes, _ = run_layers(w, hps, codes, torch.float64, tokens=FD.HEAD_TOKENS, tag=name + "/f64")
     n = min(FD.HEAD_TOKENS, latent_len)
     f10 = R.windowed_average(acts[:n], frame_len(hps))[0]
-    OUT.update({f"head64_{name}_f10": f10.numpy().astype(np.float64), f"head64_{name}_rows": np.array(rows),
+    keep = np.array(sorted({0, 7, 15, 22, f10.shape[0] - 1}), dtype=np.int64)       # five of the first frames (round 6: fixture size)
+    OUT.update({f"head64_{name}_f10": f10.numpy().astype(np.float64)[keep], f"head64_{name}_f10_frames": keep, f"head64_{name}_rows": np.array(rows),
                 f"head64_{name}_probes36": probes[36].astype(np.float64)})
     if f10_fp32 is not None:
         e = float((f10_fp32[: f10.shape[0]].double() - f10).abs().max())

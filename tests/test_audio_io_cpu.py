@@ -285,3 +285,18 @@ def test_id3_tagged_files_are_sniffed_behind_the_tag(tmp_path):
     sr0, a0 = decode_audio(io.BytesIO(bare))
     sr1, a1 = decode_audio(io.BytesIO(id3(77) + bare))
     assert sr0 == sr1 == 44100 and np.array_equal(a0, a1)
+
+
+def test_dataflow_wrapper_skips_an_unsupported_container(tmp_path, caplog):
+    """an mp3 in the input directory must not abort the extraction run -- JukeboxModelWrapper.__call__ logs it and returns None
+    like it does for an empty file (the reference decodes mp3 through librosa / audioread: jukebox/dataflow_inference.py:73-115)."""
+    import logging
+    from llark_amd.jukebox.dataflow_inference import JukeboxModelWrapper
+    mp3 = tmp_path / "song.wav"                                      # (the pipeline lists *.wav; the content decides)
+    mp3.write_bytes(b"ID3\x03\x00\x00\x00\x00\x00\x0a" + b"\x00" * 10 + b"\xff\xfb\x90\x64" + b"\x00" * 400)
+    w = object.__new__(JukeboxModelWrapper)                         # no model needed: decoding fails before anything touches the GPU
+    w.hps = w.vqvae = w.top_prior = None
+    w.device = "cpu"
+    with caplog.at_level(logging.WARNING):
+        assert w(str(mp3)) is None
+    assert "unsupported container" in caplog.text
