@@ -512,6 +512,10 @@ int llark_rope_merge_bwd(const float* dq, const float* dk, const float* dv, cons
 /* LlamaRMSNorm backward: dx (=|+=) ..., dw += ... (fp32 atomics) */
 int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx, int accumulate,
                       float* dw, llark_stream_t stream);
+/* ... that also writes the final dx as bf16 [rows][ld16] (ld16 >= width, a multiple of 4): the A operand of the products that follow in the
+ * training step, without a llark_split16 pass over the fp32 tensor (same rounding as its hi plane). */
+int llark_rmsnorm_bwd_out16(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx, int accumulate,
+                            float* dw, void* dx16, int ld16, llark_stream_t stream);
 /* SwiGLU on the interleaved [32 gate | 32 up] layout: gu fp32 [rows][2*inter] */
 int llark_swiglu_fwd(const float* gu, int rows, int inter, void* act, llark_stream_t stream);
 int llark_swiglu_bwd(const float* gu, const float* dact, int rows, int inter, void* dgu, llark_stream_t stream);

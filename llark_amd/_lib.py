@@ -140,6 +140,7 @@ _SIGS = {
     "llark_attn_ds": [_P, _P, c_int, c_int, c_float, _P, c_int, _P],
     "llark_rope_merge_bwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "llark_rmsnorm_bwd": [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P],
+    "llark_rmsnorm_bwd_out16": [_P, _P, _P, c_int, c_int, c_float, _P, c_int, _P, _P, c_int, _P],
     "llark_swiglu_fwd": [_P, c_int, c_int, _P, _P],
     "llark_swiglu_bwd": [_P, _P, c_int, c_int, _P, _P],
     "llark_cross_entropy_bwd": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, c_int, _P],

@@ -120,10 +120,20 @@ __global__ void rope_merge_bwd_kernel(const float* __restrict__ dq, const float*
 // in LDS once, and only then added to global memory: width atomics per workgroup instead of per 4 rows (the first version spent
 // 3.5x the time the row traffic needs on 4 M global atomics per call).
 // ------------------------------------------------------------------------------------------
+// round 6: the bf16 copy of the final dx the next product's A operand needs, written by the kernel that has the value in a register
+// (llark_split16 used to re-read the fp32 tensor for it); same rounding as llark_split16's hi plane (RNE)
+__device__ __forceinline__ void store_bf16x4(bf16_t* dst, const float4 v) {
+    typedef bf16_t bf4_ __attribute__((ext_vector_type(4)));
+    bf4_ o;
+    o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+    *(bf4_*)dst = o;
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ dy, int rows, int width, float eps,
-                                                          float* __restrict__ dx, float* __restrict__ dw, int accumulate) {
+                                                          float* __restrict__ dx, float* __restrict__ dw, int accumulate,
+                                                          bf16_t* __restrict__ dx16, int ld16) {
     extern __shared__ float sdw[];                      // [width] per-block partial dw
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int w4 = width >> 2;                          // width % 4 == 0 (checked by the launcher)
@@ -171,6 +181,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 dxr[c] = v;
+                if (dx16 != nullptr) store_bf16x4(dx16 + (size_t)row * ld16 + 4 * c, v);
             }
         }
     }
@@ -197,7 +208,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* __restric
 template <int WPR, int NWV>
 __global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ dy, int rows, int width, float eps,
-                                                           float* __restrict__ dx, float* __restrict__ dw, int accumulate) {
+                                                           float* __restrict__ dx, float* __restrict__ dw, int accumulate,
+                                                           bf16_t* __restrict__ dx16, int ld16) {
     constexpr int NV = 16 / WPR;                         // float4 per lane: 64 lanes x NV x 4 columns per wave
     constexpr int RPB = NWV / WPR;                       // rows per workgroup and iteration
     extern __shared__ float sdw[];                      // [width] per-block partial dw
@@ -267,6 +279,7 @@ __global__ __launch_bounds__(NWV * 64) void rmsnorm_bwd2_kernel(const float* __r
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 dxr[c] = v;
+                if (dx16 != nullptr) store_bf16x4(dx16 + (size_t)row * ld16 + 4 * c, v);
             }
         }
     }
@@ -564,15 +577,16 @@ extern "C" int llark_rope_merge_bwd(const float* dq, const float* dk, const floa
     return check_launch("rope_merge_bwd");
 }
 
-extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx,
-                                 int accumulate, float* dw, llark_stream_t stream) {
+static int rmsnorm_bwd_impl(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx,
+                            int accumulate, float* dw, bf16_t* dx16, int ld16, llark_stream_t stream) {
     LLARK_REQUIRE(x && w && dy && dx && dw && rows > 0 && width > 0, "rmsnorm_bwd: bad arguments");
+    LLARK_REQUIRE(!dx16 || (ld16 >= width && ld16 % 4 == 0 && ((uintptr_t)dx16 & 7) == 0), "rmsnorm_bwd: the bf16 copy needs ld16 >= width, a multiple of 4, 8-byte aligned");
     LLARK_REQUIRE(width % 4 == 0, "rmsnorm_bwd: width %d must be a multiple of 4", width);
     const int nblk = cdiv(rows, 4) < 512 ? cdiv(rows, 4) : 512;    // 2 workgroups per CU walk the rows; dw leaves each one once
     dim3 grid(nblk);
     const size_t lds = (size_t)width * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-#define RB(NV) rmsnorm_bwd_kernel<NV><<<grid, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate)
+#define RB(NV) rmsnorm_bwd_kernel<NV><<<grid, 256, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate, dx16, ld16)
     if (width <= 256) RB(1);
     else if (width <= 1024) RB(4);
     else if (width > 2048 && width <= 4096) {
@@ -585,7 +599,7 @@ extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy
         constexpr int WPR = RMSNORM_BWD_WPR, NWV = RMSNORM_BWD_NWV, RPB = NWV / WPR;
         const int cap = 4096 / NWV;                                              // workgroups: 16 waves per CU
         const int nb2 = cdiv(rows, RPB) < cap ? cdiv(rows, RPB) : cap;
-        rmsnorm_bwd2_kernel<WPR, NWV><<<nb2, NWV * 64, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate);
+        rmsnorm_bwd2_kernel<WPR, NWV><<<nb2, NWV * 64, lds, s>>>(x, w, dy, rows, width, eps, dx, dw, accumulate, dx16, ld16);
     } else if (width <= 4096) RB(16);
     else if (width <= 8192) RB(32);                                 // (wider than Llama-2-7B: works, spills part of the row)
     else {
@@ -594,6 +608,19 @@ extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy
     }
 #undef RB
     return check_launch("rmsnorm_bwd");
+}
+
+extern "C" int llark_rmsnorm_bwd(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx,
+                                 int accumulate, float* dw, llark_stream_t stream) {
+    return rmsnorm_bwd_impl(x, w, dy, rows, width, eps, dx, accumulate, dw, nullptr, 0, stream);
+}
+
+// llark_rmsnorm_bwd that also writes the final dx (after the accumulation) as bf16 [rows][ld16]: the A operand of the dX / dW products that
+// follow it in the training step (saves the llark_split16 pass over the fp32 tensor; same round-to-nearest-even as its hi plane).
+extern "C" int llark_rmsnorm_bwd_out16(const float* x, const float* w, const float* dy, int rows, int width, float eps, float* dx,
+                                       int accumulate, float* dw, void* dx16, int ld16, llark_stream_t stream) {
+    LLARK_REQUIRE(dx16, "rmsnorm_bwd_out16: null dx16");
+    return rmsnorm_bwd_impl(x, w, dy, rows, width, eps, dx, accumulate, dw, (bf16_t*)dx16, ld16, stream);
 }
 
 extern "C" int llark_swiglu_fwd(const float* gu, int rows, int inter, void* act, llark_stream_t stream) {

@@ -381,7 +381,10 @@ class HipLlamaTrainer:
         dtmp = torch.empty((rows, H), **f32)
         self._dx(dlogits, eng.lm_head, dtmp)                           # d(norm output); lm_head itself is frozen
         dh = torch.empty((rows, H), **f32)
-        ops.rmsnorm_bwd(h, eng.norm, dtmp, d.rms_norm_eps, dh, False, g["norm"])
+        # round 6: every RMSNorm backward also leaves the bf16 copy of its dx (the next products' A operand): no split16 pass over dh
+        fuse16 = H % 64 == 0 and os.environ.get("LLARK_TRAIN_NORM_BWD_OUT16", "1") != "0"
+        dh16 = torch.empty((rows, H), **bf) if fuse16 else None
+        ops.rmsnorm_bwd(h, eng.norm, dtmp, d.rms_norm_eps, dh, False, g["norm"], dx16=dh16)
         del dlogits
         Sp = ops.round_up(S, 64)
         BH = B * nh
@@ -395,8 +398,9 @@ class HipLlamaTrainer:
                 saved[i] = None
             pre = f"layers.{i}."
             # ---- MLP ----
-            dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
-            dh16 = dh16[:, :H]
+            if not fuse16:
+                dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
+                dh16 = dh16[:, :H]
             dgu = torch.empty((rows, 2 * I), **bf)
             tw = self.twins.get(pre + "wdown")
             if not (st["gu"].dtype == _BF and tw is not None and
@@ -411,10 +415,11 @@ class HipLlamaTrainer:
             self._dx(dgu, L.wgu, dtmp)
             self._dw(dgu, st["x2"], g[pre + "wgu"], pre + "wgu")
             del dgu
-            ops.rmsnorm_bwd(st["h_mid"], L.ln2, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln2"])
+            ops.rmsnorm_bwd(st["h_mid"], L.ln2, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln2"], dx16=dh16)
             # ---- attention ----
-            dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
-            dh16 = dh16[:, :H]
+            if not fuse16:
+                dh16, _ = ops.split16(dh, _BF, want_lo=False, kmult=64)
+                dh16 = dh16[:, :H]
             q = st["q"].view(BH, S, hd)
             kc = eng.k_cache[i, :B]                                      # [B][nh][smax][hd]
             vtc = eng.vt_cache[i, :B]                                    # [B][nh][hd][smax]
@@ -448,7 +453,7 @@ class HipLlamaTrainer:
                 ops.rope_merge_bwd(dq, dk, dv, eng.cos, eng.sin, B, S, nh, hd, 0, dqkv)
             self._dx(dqkv, L.wqkv, dtmp)
             self._dw(dqkv, st["x1"], g[pre + "wqkv"], pre + "wqkv")
-            ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"])
+            ops.rmsnorm_bwd(st["h_in"], L.ln1, dtmp, d.rms_norm_eps, dh, True, g[pre + "ln1"], dx16=dh16)
             saved[i] = None
             if overlap_allreduce_world > 1:
                 self._start_layer_allreduce(i)

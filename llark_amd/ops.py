@@ -1023,9 +1023,17 @@ def rope_merge_bwd(dq, dk, dv, cos_t, sin_t, batch: int, s: int, nh: int, hd: in
                                           _stream()), "rope_merge_bwd")
 
 
-def rmsnorm_bwd(x, w, dy, eps: float, dx, accumulate: bool, dw) -> None:
+def rmsnorm_bwd(x, w, dy, eps: float, dx, accumulate: bool, dw, dx16: Optional[torch.Tensor] = None) -> None:
+    """RMSNorm backward (include/llark_hip.h: llark_rmsnorm_bwd); ``dx16`` (bf16 [rows][>= width]) also receives the final dx rounded
+    to bf16 -- the next products' A operand, without a split16 pass (llark_rmsnorm_bwd_out16)."""
     rows, width = x.shape
     f = torch.float32
+    if dx16 is not None:
+        assert dx16.dtype == torch.bfloat16 and dx16.shape[0] >= rows and dx16.stride(1) == 1
+        check(_lib.lib().llark_rmsnorm_bwd_out16(_dev(x, "x", f), _dev(w, "w", f), _dev(dy, "dy", f), rows, width, float(eps),
+                                                 _dev(dx, "dx", f), int(accumulate), _dev(dw, "dw", f),
+                                                 _dev(dx16, "dx16", torch.bfloat16, contiguous=False), dx16.stride(0), _stream()), "rmsnorm_bwd_out16")
+        return
     check(_lib.lib().llark_rmsnorm_bwd(_dev(x, "x", f), _dev(w, "w", f), _dev(dy, "dy", f), rows, width, float(eps),
                                        _dev(dx, "dx", f), int(accumulate), _dev(dw, "dw", f), _stream()), "rmsnorm_bwd")
 

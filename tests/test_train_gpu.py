@@ -754,3 +754,24 @@ def test_rope_qkv_train_epilogue_writes_v_row_major():
     vt, v_rm = outs[1][2], outs[1][3]
     assert torch.equal(v_rm.view(B, nh, S, hd), vt[:, :, :, :S].transpose(2, 3))
     assert v_rm.float().abs().max().item() > 0
+
+
+@pytest.mark.parametrize("rows,width,accumulate", [(300, 4096, True), (64, 256, False), (130, 1024, True)])
+def test_rmsnorm_bwd_bf16_copy_equals_split16_of_its_dx(rows, width, accumulate):
+    """llark_rmsnorm_bwd_out16 (round 6): dx and the gain gradient exactly as llark_rmsnorm_bwd, plus bf16(dx) == llark_split16's hi plane."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(rows + width)
+    x = torch.randn(rows, width, generator=g, device="cuda")
+    w = 1 + 0.1 * torch.randn(width, generator=g, device="cuda")
+    dy = torch.randn(rows, width, generator=g, device="cuda") * 0.3
+    dx0 = torch.randn(rows, width, generator=g, device="cuda")
+    outs = []
+    for fused in (False, True):
+        dx, dw = dx0.clone(), torch.zeros(width, device="cuda")
+        d16 = torch.full((rows, width + 64), 5.0, dtype=torch.bfloat16, device="cuda")[:, :width] if fused else None
+        ops.rmsnorm_bwd(x, w, dy, 1e-5, dx, accumulate, dw, dx16=d16)
+        outs.append((dx, dw, d16))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)          # fp32 atomics: order varies
+    hi, _ = ops.split16(outs[1][0], torch.bfloat16, want_lo=False, kmult=64)
+    assert torch.equal(outs[1][2], hi[:, :width])
