@@ -772,6 +772,6 @@ def test_rmsnorm_bwd_bf16_copy_equals_split16_of_its_dx(rows, width, accumulate)
         ops.rmsnorm_bwd(x, w, dy, 1e-5, dx, accumulate, dw, dx16=d16)
         outs.append((dx, dw, d16))
     assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-6)          # fp32 atomics: order varies
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)          # per-workgroup partials meet in fp32 atomics: order varies run to run
     hi, _ = ops.split16(outs[1][0], torch.bfloat16, want_lo=False, kmult=64)
     assert torch.equal(outs[1][2], hi[:, :width])
