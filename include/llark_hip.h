@@ -542,6 +542,22 @@ int llark_adamw(int param_dtype, void* p, const float* g, float* m, float* v, in
 int llark_adamw_clip(int param_dtype, void* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, float grad_scale, const double* grad_sumsq, float max_grad_norm,
                      llark_stream_t stream);
+/* Decode-step launches that overlap across their boundaries (round 6; model.generate -> LlamaModel.forward with ONE new token,
+ * m2t/infer.py:146, m2t/models/llamav2.py:339-365): a chained consumer is launched on ANOTHER stream while its producer still runs; it fills
+ * its LDS ring with weights (64 KiB per workgroup: it fits a CU next to the producer's workgroup), waits until the producer's monotonic
+ * arrival counter *wait has reached wait_target before it reads activations / the residual, and adds 1 per workgroup to *signal when its own
+ * outputs are written and released.  Counters are caller-owned device words (zeroed once); a producer launch advances its counter by its
+ * grid size: llark_gemv16_dma_blocks(epilogue, n) for the Linears, nh * batch for the attention.  The spin is bounded (a lost producer gives
+ * wrong data, never a hung GPU).  Results equal the unchained entry points (llark_gemv16_dma, llark_gemv16_dma_rmsnorm,
+ * llark_attn_decode_rope_bf16).  llark_gemv16_dma_chain: x != NULL selects the RMSNorm-fused form; m == 1, kp <= 4096. */
+int llark_gemv16_dma_blocks(int epilogue, int n);
+int llark_gemv16_dma_chain(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const float* x, int ldx, const float* norm_w,
+                           float eps, const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c, int ldc, const float* resid,
+                           int ldr, void* out_hi, void* out_lo, int ldo, const unsigned* wait, unsigned wait_target, unsigned* signal,
+                           llark_stream_t stream);
+int llark_attn_decode_rope_bf16_chain(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                      const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo, void* vt_cache_lo,
+                                      int smax, void* out, void* out_lo, const float* alibi_slopes, unsigned* done, llark_stream_t stream);
 /* Layout glue of the Llama training step folded into the kernels around it (round 6; torch autograd of LlamaAttention.forward under
  * WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:259-337, m2t/train.py:53-277):
  *   llark_gemm16_fragw_rope_qkv_train: llark_gemm16_fragw_rope_qkv in the plain bf16 mode that ALSO writes V row-major,

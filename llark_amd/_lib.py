@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLARK_HIP_LIB") or os.path.join(_HERE, "libllark_hip.so")   # override: profiling builds only
@@ -154,6 +154,9 @@ _SIGS = {
     "llark_gemm16_ta_fragw": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_gemm16_fragw_rope_qkv_train": [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P],
     "llark_attn_backward_bf16_fused": [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P],
+    "llark_gemv16_dma_blocks": [c_int, c_int],
+    "llark_gemv16_dma_chain": [c_int, c_int, _P, _P, c_int, _P, c_int, _P, c_float, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P, c_int, _P, c_uint, _P, _P],
+    "llark_attn_decode_rope_bf16_chain": [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P],
     "llark_adamw_twins": [_P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P, c_float, _P, c_int, _P, _P],
 }
 

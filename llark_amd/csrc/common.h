@@ -52,6 +52,40 @@ struct PerDeviceOnce {
         }                                        \
     } while (0)
 
+// ---- in-launch hand-off between kernels that overlap across a launch boundary (round 6: decode; MI355X guide, Guideline 16) ---------
+// A consumer kernel may be resident (and already streaming the operands that do not depend on its producer) while the producer still runs on
+// another stream; it spins on the producer's arrival counter before touching what the producer writes.  Producer: every workgroup, after its
+// last global store -- all waves drain their stores, barrier, ONE lane: agent-scope release (writes the XCD's L2 back), drain, relaxed
+// agent-scope add on the counter.  Consumer: ONE lane polls the counter relaxed (s_sleep between polls, BOUNDED: a lost producer gives wrong
+// data, never a hung GPU), ONE agent-scope acquire (drops this CU's L1), barrier, plain loads.  Counters are monotonic: the host passes the
+// value the counter reaches when the producer launch it waits for has completed.
+struct ChainSync {
+    const unsigned* wait;      // nullptr = no wait
+    unsigned target;
+    unsigned* signal;          // nullptr = no signal
+};
+typedef __attribute__((address_space(1))) unsigned chain_word_t;
+__device__ __forceinline__ void chain_wait(const ChainSync& cs) {      // called by ALL threads of the workgroup (contains a barrier)
+    if (cs.wait == nullptr) return;
+    if (threadIdx.x == 0) {
+        const chain_word_t* w = (const chain_word_t*)cs.wait;
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - cs.target) < 0 && ++spins < (1u << 21)) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __builtin_amdgcn_s_barrier();                                       // raw: LDS-DMA requests of the caller stay in flight across it
+}
+__device__ __forceinline__ void chain_signal(const ChainSync& cs) {    // called by ALL threads after their last global store
+    if (cs.signal == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (hipcc may drop the wait behind buffer_wbl2: restated where it cannot)
+        __hip_atomic_fetch_add((chain_word_t*)cs.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

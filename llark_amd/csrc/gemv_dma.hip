@@ -58,6 +58,7 @@ struct GemvParams {
     const float* xg;
     int ldxn;
     float xeps;
+    ChainSync chain;     // round 6: overlap with the producer / consumer launches (common.h); all-null = plain launch
 };
 
 __device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float acc) {
@@ -72,12 +73,16 @@ __device__ __forceinline__ float dot8(const bf16x8_t w, const bf16x8_t x, float 
 }  // namespace
 
 // XREG: K <= 4096 and MM <= 2 -- the lane's activation fragments (8 pieces x hi / lo x MM) live in registers.
-template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM, int NPCM = 8>
+// NSLOT_T (round 6): 0 = the default ring (16 x 1 KiB per wave in the register form, 12 in the LDS form: one workgroup per CU); 8 = a
+// 64 KiB ring, so that TWO workgroups fit a CU -- the chained launches (p.chain), where this kernel fills its ring while its producer still
+// runs and spins on the producer's arrival counter before it touches the activations.
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM, int NPCM = 8, int NSLOT_T = 0>
 __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;                      // weight rows per output column
     constexpr int NP = SPLIT ? 2 : 1;                                // activation planes
-    constexpr int GV_NSLOT = XREG ? 16 : 12;                         // 1 KiB pieces per wave ring (the LDS form keeps 48 KiB for x)
+    constexpr int GV_NSLOT = NSLOT_T ? NSLOT_T : (XREG ? 16 : 12);   // 1 KiB pieces per wave ring (the LDS form keeps 48 KiB for x)
+    static_assert(GV_NSLOT == 16 || GV_NSLOT == 12 || GV_NSLOT == 8, "the counted waits below are written for rings of 16, 12 and 8 slots");
     constexpr int GV_RING = GV_NSLOT * 1024;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
     };
     const int pro = total < GV_NSLOT - 1 ? total : GV_NSLOT - 1;
     for (int t = 0; t < pro; ++t) issue();             // the weight stream starts before anything else: it does not depend on x
+    chain_wait(p.chain);                                // chained launch: the producer of x (and of the residual) has arrived
 
 
     // ---- activations ----
@@ -192,8 +198,9 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
         if (t + GV_NSLOT - 1 < total) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot being refilled was read one step ago: its data has arrived
             issue();
-            if (XREG) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // GV_NSLOT - 1 newer requests may be outstanding: piece t has landed
-            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            if constexpr (GV_NSLOT == 16) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // GV_NSLOT - 1 newer requests may be outstanding: piece t has landed
+            else if constexpr (GV_NSLOT == 12) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tail (a counted wait per remaining piece measured nothing)
         }
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(GV_WAVES * 64) void gemv_dma_kernel(const GemvParam
             if (EPI == EPI_SWIGLU_SPLIT) p.olo[(size_t)m * p.ldo + n] = (bf16_t)(a - (float)hi);
         }
     }
+    chain_signal(p.chain);
 }
 
 
@@ -272,16 +280,16 @@ static bool gemv_shape_ok(int split, int m, int kp) {
     return xbytes <= GV_XLDS_MAX;
 }
 
-template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM = false, int NPCM = 8>
+template <bool SPLIT, int EPI, int MM, bool XREG, bool NORM = false, int NPCM = 8, int NSLOT_T = 0>
 static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
     constexpr int RPC = IS_SWIGLU(EPI) ? 2 : 1;
     p.ncols = IS_SWIGLU(EPI) ? p.N / 2 : p.N;
     p.cols_per_block = cdiv(p.ncols, cus);
     const int blocks = cdiv(p.ncols, p.cols_per_block);
     p.xbytes = XREG ? 0 : MM * (SPLIT ? 2 : 1) * ((p.Kp + GV_CHUNK - 1) / GV_CHUNK) * GV_CHUNK * 2;
-    const int lds = GV_WAVES * (XREG ? 16 : 12) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
+    const int lds = GV_WAVES * (NSLOT_T ? NSLOT_T : (XREG ? 16 : 12)) * 1024 + p.xbytes + p.cols_per_block * RPC * MM * (int)sizeof(float);
     if (lds > 160 * 1024) return -1000;
-    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM, NPCM>;
+    auto kern = gemv_dma_kernel<SPLIT, EPI, MM, XREG, NORM, NPCM, NSLOT_T>;
     static PerDeviceOnce once;                           // the whole 160 KiB once per (instantiation, device), not per launch
     if (once.first()) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     kern<<<blocks, GV_WAVES * 64, lds, s>>>(p);
@@ -291,6 +299,10 @@ static int launch_gemv(GemvParams p, hipStream_t s, int cus) {
 template <bool SPLIT, int EPI>
 static int dispatch_gemv_m(const GemvParams& p, hipStream_t s, int cus) {
     const bool xreg = p.Kp <= GV_CHUNK && p.M <= 2;
+    if (p.chain.wait != nullptr || p.chain.signal != nullptr) {      // chained launch: one row, K <= 4096 (checked by the caller): the 8-slot ring
+        if (p.xn != nullptr) return launch_gemv<SPLIT, EPI, 1, true, true, 8, 8>(p, s, cus);
+        return launch_gemv<SPLIT, EPI, 1, true, false, 8, 8>(p, s, cus);
+    }
     if (p.xn != nullptr) return launch_gemv<SPLIT, EPI, 1, true, true>(p, s, cus);       // fused RMSNorm: m == 1, kp <= 4096 (checked by the caller)
     if (p.M == 1 && p.Kp > GV_CHUNK) return launch_gemv<SPLIT, EPI, 1, true, false, 24>(p, s, cus);     // one row of up to 12288: 24 pieces in registers
     if (p.M == 1) return xreg ? launch_gemv<SPLIT, EPI, 1, true>(p, s, cus) : launch_gemv<SPLIT, EPI, 1, false>(p, s, cus);
@@ -394,5 +406,43 @@ extern "C" int llark_gemv16_dma_rmsnorm(int split, int epilogue, const float* x,
     p.wt = (const bf16_t*)wt; p.ldw = ldw; p.bias = bias; p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc;
     p.ohi = (bf16_t*)out_hi; p.olo = (bf16_t*)out_lo; p.ldo = ldo;
     p.xn = x; p.xg = norm_w; p.ldxn = ldx; p.xeps = eps;
+    return gemv_run(p, split, epilogue, stream);
+}
+
+// Grid size of a llark_gemv16_dma* launch with these n / epilogue on the current device: the value a CONSUMER's wait target advances by per
+// launch of this producer (llark_gemv16_dma_chain).
+extern "C" int llark_gemv16_dma_blocks(int epilogue, int n) {
+    const int cus = gemv_device_cus();
+    const int ncols = IS_SWIGLU(epilogue) ? n / 2 : n;
+    if (ncols <= 0) return 0;
+    return cdiv(ncols, cdiv(ncols, cus));
+}
+
+// llark_gemv16_dma / llark_gemv16_dma_rmsnorm as links of a CHAIN of launches that overlap across their boundaries (round 6; the decode
+// step of model.generate, m2t/infer.py:146 -> LlamaDecoderLayer with one new token): launched on another stream than its producer, the
+// kernel fills its LDS ring with weights (64 KiB per workgroup, so that it fits next to the producer's workgroup on a CU), then waits until
+// *wait has reached wait_target (nullable: no wait) before it reads its activations / residual, and adds 1 per workgroup to *signal when its
+// outputs are written (nullable).  Counters are monotonic device words the caller owns; a producer launch advances its counter by its grid
+// size (llark_gemv16_dma_blocks; nh * batch for llark_attn_decode_rope_bf16_chain).  m == 1, kp <= 4096.  x != NULL: the RMSNorm-fused form
+// (a_hi / a_lo unused), else a_hi (+ a_lo when split).  Results are those of the unchained entry points.
+extern "C" int llark_gemv16_dma_chain(int split, int epilogue, const void* a_hi, const void* a_lo, int lda, const float* x, int ldx,
+                                      const float* norm_w, float eps, const void* wt, int ldw, const float* bias, int m, int n, int kp, float* c,
+                                      int ldc, const float* resid, int ldr, void* out_hi, void* out_lo, int ldo, const unsigned* wait,
+                                      unsigned wait_target, unsigned* signal, llark_stream_t stream) {
+    LLARK_REQUIRE(wt && (x || a_hi) && m == 1 && n > 0 && kp > 0 && kp <= GV_CHUNK && kp % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)wt & 15) == 0,
+                  "gemv16_dma_chain: one row, kp <= 4096 (a multiple of 8), 16-byte aligned weight rows");
+    LLARK_REQUIRE(wait || signal, "gemv16_dma_chain: neither wait nor signal given -- use llark_gemv16_dma");
+    GemvParams p = {};
+    p.wt = (const bf16_t*)wt; p.ldw = ldw; p.bias = bias; p.M = m; p.N = n; p.Kp = kp; p.C = c; p.ldc = ldc; p.R = resid; p.ldr = ldr;
+    p.ohi = (bf16_t*)out_hi; p.olo = (bf16_t*)out_lo; p.ldo = ldo;
+    if (x) {
+        LLARK_REQUIRE(norm_w && ldx % 4 == 0 && ldx >= kp && ((uintptr_t)x & 15) == 0 && ((uintptr_t)norm_w & 15) == 0 && epilogue != EPI_RESID,
+                      "gemv16_dma_chain: RMSNorm form needs norm_w, 16-byte aligned fp32 rows and an F32 / SwiGLU epilogue");
+        p.xn = x; p.xg = norm_w; p.ldxn = ldx; p.xeps = eps;
+    } else {
+        LLARK_REQUIRE((!split || a_lo) && lda % 8 == 0 && ((uintptr_t)a_hi & 15) == 0 && (!split || ((uintptr_t)a_lo & 15) == 0), "gemv16_dma_chain: activation planes missing / misaligned");
+        p.ahi = (const bf16_t*)a_hi; p.alo = (const bf16_t*)a_lo; p.lda = lda;
+    }
+    p.chain.wait = wait; p.chain.target = wait_target; p.chain.signal = signal;
     return gemv_run(p, split, epilogue, stream);
 }

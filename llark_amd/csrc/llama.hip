@@ -462,13 +462,13 @@ static void launch_attn_prefill(hipStream_t st, const bf16_t* q, const bf16_t* k
 //   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vtc,
+__global__ __launch_bounds__(NW * 64, NW >= 16 ? 7 : 1) void attn_decode_kernel(const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vtc,
                                                               const bf16_t* __restrict__ q_lo, bf16_t* kc_lo, bf16_t* vtc_lo,
                                                               bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                               int nh, int total, int smax, float scale,
                                                               const int* __restrict__ pos_dev, const float* __restrict__ alibi,
                                                               const float* __restrict__ qkv, const float* __restrict__ cos_t,
-                                                              const float* __restrict__ sin_t) {
+                                                              const float* __restrict__ sin_t, unsigned* chain_done) {
     // NW waves per (batch, head).  A single sequence has only nh blocks (32 of 256 CUs busy): there the block is 16 waves
     // wide so that the whole K pass and the whole V pass are each ONE round of loads in flight (the kernel is a chain of
     // memory latencies, not bandwidth); batched decode keeps 4 waves per block.
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(const bf16_t* __re
 #pragma unroll
     for (int o = 1; o < PARTS; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (part == 0) store_split(out, out_lo, (size_t)b * (nh * 128) + h * 128 + d, acc * inv);
+    chain_signal(ChainSync{nullptr, 0u, chain_done});                 // round 6: a chained consumer (o_proj) may be waiting for this head
 }
 
 // 16 waves per block while the grid is smaller than the chip, 4 otherwise
@@ -821,7 +822,7 @@ extern "C" int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, 
     launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh,
                        total, smax, scale, (const int*)nullptr, alibi_slopes, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr);
+                       (const float*)nullptr, (unsigned*)nullptr);
     return check_launch("attn_decode");
 }
 
@@ -848,17 +849,17 @@ extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, c
     }
     launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, 1,
-                       smax, scale, pos_dev, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       smax, scale, pos_dev, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
     return check_launch("attn_decode_dpos");
 }
 
 // Decode step: RoPE of the new token + KV-cache append + attention over the cache in ONE launch per layer (replaces
 // llark_rope_split_heads[_dpos] followed by llark_attn_decode_bf16[_alibi|_dpos]; m2t/models/llamav2.py:339-365 decode loop).
 // qkv fp32 [batch][3 * nh * 128] of the new token; position = pos (host int) or *pos_dev when pos_dev != NULL.
-extern "C" int llark_attn_decode_rope_bf16(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
-                                           const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo,
-                                           void* vt_cache_lo, int smax, void* out, void* out_lo, const float* alibi_slopes,
-                                           llark_stream_t stream) {
+static int attn_decode_rope_impl(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                 const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo,
+                                 void* vt_cache_lo, int smax, void* out, void* out_lo, const float* alibi_slopes, unsigned* chain_done,
+                                 llark_stream_t stream) {
     LLARK_REQUIRE(qkv && cos_t && sin_t && k_cache && vt_cache && out, "attn_decode_rope: null pointer");
     LLARK_REQUIRE(hd == 128, "attn_decode_rope: head_dim must be 128 (Llama-2), got %d", hd);
     LLARK_REQUIRE((k_cache_lo == nullptr) == (vt_cache_lo == nullptr) && (k_cache_lo == nullptr) == (out_lo == nullptr),
@@ -876,6 +877,26 @@ extern "C" int llark_attn_decode_rope_bf16(const float* qkv, int batch, int nh, 
     }
     launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)nullptr, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)nullptr, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax,
-                       scale, pos_dev, alibi_slopes, qkv, cos_t, sin_t);
+                       scale, pos_dev, alibi_slopes, qkv, cos_t, sin_t, chain_done);
     return check_launch("attn_decode_rope");
+}
+
+extern "C" int llark_attn_decode_rope_bf16(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                           const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo,
+                                           void* vt_cache_lo, int smax, void* out, void* out_lo, const float* alibi_slopes,
+                                           llark_stream_t stream) {
+    return attn_decode_rope_impl(qkv, batch, nh, hd, pos, pos_dev, cos_t, sin_t, max_pos, k_cache, vt_cache, k_cache_lo, vt_cache_lo, smax, out,
+                                 out_lo, alibi_slopes, nullptr, stream);
+}
+
+// ... as the PRODUCER of a chained launch (llark_gemv16_dma_chain): every (batch, head) workgroup adds 1 to *done once its slice of `out` is
+// written and released at agent scope -- the o_proj launch that waits on it (target advanced by nh * batch per call) runs on another stream
+// and fills its weight ring while this kernel walks the cache.
+extern "C" int llark_attn_decode_rope_bf16_chain(const float* qkv, int batch, int nh, int hd, int pos, const int* pos_dev, const float* cos_t,
+                                                 const float* sin_t, int max_pos, void* k_cache, void* vt_cache, void* k_cache_lo,
+                                                 void* vt_cache_lo, int smax, void* out, void* out_lo, const float* alibi_slopes,
+                                                 unsigned* done, llark_stream_t stream) {
+    LLARK_REQUIRE(done, "attn_decode_rope_chain: null counter");
+    return attn_decode_rope_impl(qkv, batch, nh, hd, pos, pos_dev, cos_t, sin_t, max_pos, k_cache, vt_cache, k_cache_lo, vt_cache_lo, smax, out,
+                                 out_lo, alibi_slopes, done, stream);
 }

@@ -111,6 +111,10 @@ class HipLlamaEngine:
         self.decode_replay = os.environ.get("LLARK_DECODE_REPLAY", "0") == "1"
         # decode: RoPE + KV-cache append inside the attention launch (one launch per layer fewer); LLARK_DECODE_FUSE_ROPE=0 = two launches
         self.fuse_decode_rope = os.environ.get("LLARK_DECODE_FUSE_ROPE", "1") != "0"
+        # round 6: batch-1 decode with o_proj launched on a side stream while the attention still runs (it fills its weight ring and spins on
+        # the attention's arrival counter) and gate/up filling its ring while o_proj runs (llark_gemv16_dma_chain); opt-in until measured
+        self.decode_chain = os.environ.get("LLARK_DECODE_CHAIN", "0") == "1"
+        self._chain = None
         # prefill: RoPE + head split + K / V^T cache writes inside the q|k|v GEMM's epilogue (llark_gemm16_fragw_rope_qkv: no fp32 qkv
         # tensor, no rope_split_kernel launch).  "auto" (default) = fused wherever the two-launch path runs the same whole-tile kernel,
         # so q / K / V^T and the logits stay BIT-equal (tests/test_llama_gpu.py); "1" = fused for every prefill of >= 32 positions;
@@ -322,6 +326,10 @@ class HipLlamaEngine:
                 and hidden_sink is None and not torch.cuda.is_current_stream_capturing()):
             self._prefill_two_streams(ws, batch, s, pos0, n_layers)
             return False
+        if (self.decode_chain and s == 1 and batch == 1 and norm_a and self.fuse_decode_rope and pos_dev is None and hidden_sink is None
+                and not fused and H <= 4096 and not torch.cuda.is_current_stream_capturing()):
+            self._decode_layers_chained(ws, pos0, n_layers)
+            return False
         for i in range(n_layers):
             L = self.layers[i]
             if hidden_sink is not None:                       # HF output_hidden_states: the stream as it ENTERS every layer
@@ -375,6 +383,45 @@ class HipLlamaEngine:
             else:
                 ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
         return fused
+
+    def _decode_layers_chained(self, ws, pos0: int, n_layers: int) -> None:
+        """The decoder layers of a batch-1 decode step with two launches per layer overlapping their producers (round 6):
+
+            main stream:  q|k|v (RMSNorm fused) -> attention [signals A_i] ------------> gate/up [fills its ring, waits O_i] -> down_proj
+            side stream:            (after q|k|v)  o_proj [fills its ring, waits A_i, signals O_i]
+
+        o_proj's 33.5 MB of weights start streaming into LDS while the attention launch -- a chain of memory latencies on 32 of 256 CUs, no
+        weight traffic -- is running, and gate/up's while o_proj streams.  Both chained kernels use a 64 KiB ring so that two workgroups share a
+        CU (98 / 144 registers: the only pairs of the layer that fit 4 waves per SIMD: DESIGN.md 7(d)).  Counters are monotonic device words.
+        Same kernels, same arithmetic: results equal the unchained path."""
+        d = self.dims
+        H, I, nh, hd = d.hidden_size, d.intermediate_size, d.num_attention_heads, d.head_dim
+        sp = self.split
+        if self._chain is None or self._chain["layers"] != n_layers:
+            self._chain = {"layers": n_layers, "cnt": torch.zeros((2 * n_layers,), dtype=torch.int32, device=self.device), "epoch": 0,
+                           "side": torch.cuda.Stream(device=self.device), "ev": torch.cuda.Event(), "blocks_o": ops.gemv16_dma_blocks(ops.EPI_RESID, H)}
+        ch = self._chain
+        ch["epoch"] += 1
+        ep, cnt, side, ev = ch["epoch"], ch["cnt"], ch["side"], ch["ev"]
+        main = torch.cuda.current_stream()
+        h = ws["h"]
+        for i in range(n_layers):
+            L = self.layers[i]
+            kc, vc = self.k_cache[i, :1], self.vt_cache[i, :1]
+            kcl = self.k_cache_lo[i, :1] if sp else None
+            vcl = self.vt_cache_lo[i, :1] if sp else None
+            a_done, o_done = cnt[2 * i: 2 * i + 1], cnt[2 * i + 1: 2 * i + 2]
+            ops.gemm16_rmsnorm_a(h, L.ln1, d.rms_norm_eps, L.wqkv, 3 * H, ops.EPI_F32, sp, c=ws["qkv"])
+            ev.record(main)
+            side.wait_event(ev)                                  # o_proj becomes resident when q|k|v has finished, i.e. while the attention runs
+            ops.attn_decode_rope_chain(ws["qkv"], 1, nh, hd, pos0, self.cos, self.sin, kc, vc, ws["att"], kcl, vcl, ws["att_lo"], a_done)
+            with torch.cuda.stream(side):
+                ops.gemv16_dma_chain(L.wo, H, ops.EPI_RESID, sp, a_hi=ws["att"], a_lo=ws["att_lo"], c=h, resid=h,
+                                     wait=a_done, wait_target=ep * nh, signal=o_done)
+            ops.gemv16_dma_chain(L.wgu, 2 * I, ops.EPI_SWIGLU_SPLIT if sp else ops.EPI_SWIGLU16, sp, x=h, norm_w=L.ln2, eps=d.rms_norm_eps,
+                                 out_hi=ws["act"], out_lo=ws["act_lo"], wait=o_done, wait_target=ep * ch["blocks_o"])
+            ops.gemm16(ws["act"], ws["act_lo"], L.wdown, None, H, ops.EPI_RESID, c=h, resid=h)
+        main.wait_stream(side)                                   # (the data dependency is already met through O_i: this is for the allocator's sake)
 
     def _prefill_layer_rows(self, ws, L, i: int, b0: int, b1: int, s: int, pos0: int) -> None:
         """One decoder layer of a PREFILL on batch rows b0 .. b1 - 1 (the fused-RoPE path of _layers_forward on row slices)."""

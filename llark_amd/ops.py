@@ -1331,3 +1331,40 @@ def attn_backward_fused(q, k_cache, v_rm, dO: torch.Tensor, o, lse, dsum, batch:
         _dev(q, "q", bf), _dev(k_cache, "k_cache", bf), _dev(v_rm, "v_rm", bf), _dev(dO, "dO", bf, contiguous=False), dO.stride(0),
         _dev(o, "o", bf), _dev(lse, "lse", f32), _dev(dsum, "dsum", f32), batch, s, nh, hd, smax, _dev(cos_t, "cos", f32),
         _dev(sin_t, "sin", f32), pos0, cos_t.shape[0], _dev(dqkv, "dqkv", bf), _stream()), "attn_backward_fused")
+
+
+# ---- decode-step launches chained across their boundaries (include/llark_hip.h: llark_gemv16_dma_chain) -----------------------------------
+def gemv16_dma_blocks(epilogue: int, n: int) -> int:
+    """Grid size of a streaming-Linear launch: what its arrival counter advances by per launch."""
+    return int(_lib.lib().llark_gemv16_dma_blocks(int(epilogue), int(n)))
+
+
+def gemv16_dma_chain(wt: torch.Tensor, n: int, epilogue: int, split: bool, a_hi=None, a_lo=None, x=None, norm_w=None, eps: float = 0.0,
+                     c=None, resid=None, out_hi=None, out_lo=None, wait: Optional[torch.Tensor] = None, wait_target: int = 0,
+                     signal: Optional[torch.Tensor] = None) -> None:
+    """One-row streaming Linear as a link of a chain of overlapping launches: ``wait`` / ``signal`` are one-element int32 views of the
+    caller's counter tensor.  ``x`` (fp32 row) + ``norm_w`` = the RMSNorm-fused form, else ``a_hi`` (+ ``a_lo``)."""
+    bf, f32 = torch.bfloat16, torch.float32
+    kp = wt.shape[1]
+    name = ("gemm_split_" if split else "gemm_") + "bf16_skinny"
+    with _timed(name, 2.0 * n * kp):
+        check(_lib.lib().llark_gemv16_dma_chain(
+            int(split), int(epilogue), _opt(a_hi, "a_hi", bf), _opt(a_lo, "a_lo", bf), a_hi.stride(0) if a_hi is not None else 0,
+            _opt(x, "x", f32), x.stride(0) if x is not None else 0, _opt(norm_w, "norm_w", f32), float(eps), _dev(wt, "wt", bf), wt.stride(0),
+            None, 1, n, kp, _opt(c, "c", f32), c.stride(0) if c is not None else 0, _opt(resid, "resid", f32),
+            resid.stride(0) if resid is not None else 0, _opt(out_hi, "out_hi", bf), _opt(out_lo, "out_lo", bf),
+            out_hi.stride(0) if out_hi is not None else 0, wait.data_ptr() if wait is not None else None, int(wait_target) & 0xFFFFFFFF,
+            signal.data_ptr() if signal is not None else None, _stream()), "gemv16_dma_chain")
+
+
+def attn_decode_rope_chain(qkv: torch.Tensor, batch: int, nh: int, hd: int, pos: int, cos_t, sin_t, k_cache, vt_cache, out,
+                           k_cache_lo, vt_cache_lo, out_lo, done: torch.Tensor) -> None:
+    """:func:`attn_decode_rope` (host position) whose workgroups add 1 to ``done`` when their heads are written (chained o_proj)."""
+    smax = k_cache.shape[-2]
+    bf = torch.bfloat16
+    assert qkv.shape == (batch, 3 * nh * hd)
+    check(_lib.lib().llark_attn_decode_rope_bf16_chain(
+        _dev(qkv, "qkv", torch.float32), batch, nh, hd, int(pos), None, _dev(cos_t, "cos", torch.float32), _dev(sin_t, "sin", torch.float32),
+        cos_t.shape[0], _dev(k_cache, "k_cache", bf), _dev(vt_cache, "vt_cache", bf), _opt(k_cache_lo, "k_cache_lo", bf),
+        _opt(vt_cache_lo, "vt_cache_lo", bf), smax, _dev(out, "out", bf), _opt(out_lo, "out_lo", bf), None, done.data_ptr(), _stream()),
+        "attn_decode_rope_chain")

@@ -611,3 +611,44 @@ def test_prefill_two_streams_matches_one_stream(precision):
     assert torch.equal(l2[0], l2[3]) and torch.equal(l2[0], l2[7]), "equal prompts in the two halves must give bit-equal logits"
     report_close("K cache", k2.float().cpu(), k1.float().cpu(), 2e-2 * float(k1.float().abs().max()))
     assert float(k2[:, 4:].float().abs().max()) > 0 and float(v2[:, 4:].float().abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+def test_decode_chained_launches_bit_identical(precision):
+    """Round 6: batch-1 decode with o_proj launched on a side stream while the attention runs (it fills its weight ring
+    and spins on the attention's arrival counter) and gate/up filling its ring while o_proj runs (llark_gemv16_dma_chain, 64 KiB rings, two
+    workgroups per CU).  Same kernels, same arithmetic per output: logits bit-equal to the unchained path, over layers, steps and repeats
+    (a lost hand-off would show as stale activations in some step)."""
+    from llark_amd import ops
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    dims = LlamaDims(num_hidden_layers=3, vocab_size=32004)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H, I, V = dims.hidden_size, dims.intermediate_size, dims.vocab_size
+    assert ops.gemv_dma_rmsnorm_takes(1, 3 * H, H)
+
+    def n(*shape):
+        return (torch.randn(*shape, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+
+    layers = [[n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I)] for _ in range(3)]
+    norm = (1.0 + 0.1 * torch.randn(H, generator=g, device="cuda"))
+    glob = (n(V, H), norm.clone(), n(V, H), n(H, dims.mm_hidden_size), torch.zeros(H, device="cuda"))
+    ids = torch.randint(3, 32000, (1, 40), generator=torch.Generator().manual_seed(2)).cuda()
+    toks = torch.randint(3, 32000, (8, 1, 1), generator=torch.Generator().manual_seed(3)).cuda()
+    res = []
+    for chain in (False, True, True):
+        eng = HipLlamaEngine(dims, "cuda", 1, 64, precision=precision)
+        for i, ws in enumerate(layers):
+            eng.set_layer(i, *ws, norm.clone(), norm.clone())
+        eng.set_globals(*glob)
+        eng.decode_chain = chain
+        eng.forward_tokens(ids)
+        outs = [eng.forward_tokens(toks[i], (), pos0=eng.cur_len).clone() for i in range(8)]
+        torch.cuda.synchronize()
+        if chain:
+            assert eng._chain is not None and eng._chain["epoch"] == 8          # the chained path really ran
+            cnt = eng._chain["cnt"].cpu().tolist()
+            assert cnt[0::2] == [8 * dims.num_attention_heads] * 3 and cnt[1::2] == [8 * eng._chain["blocks_o"]] * 3
+        res.append(torch.stack(outs))
+        del eng
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
