@@ -618,8 +618,8 @@ def test_prefill_two_streams_matches_one_stream(precision):
 def test_decode_chained_launches_bit_identical(precision):
     """Round 6: batch-1 decode with o_proj launched on a side stream while the attention runs (it fills its weight ring
     and spins on the attention's arrival counter) and gate/up filling its ring while o_proj runs (llark_gemv16_dma_chain, 64 KiB rings, two
-    workgroups per CU).  Same kernels, same arithmetic per output: logits bit-equal to the unchained path, over layers, steps and repeats
-    (a lost hand-off would show as stale activations in some step)."""
+    workgroups per CU).  Logits equal the unchained path to fp32 round-off (one product changes kernel), the chain is bit-reproducible over
+    repeats, and the arrival counters end where the protocol says (a lost hand-off would show as stale activations in some step)."""
     from llark_amd import ops
     from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
     dims = LlamaDims(num_hidden_layers=3, vocab_size=32004)
@@ -651,4 +651,8 @@ def test_decode_chained_launches_bit_identical(precision):
             assert cnt[0::2] == [8 * dims.num_attention_heads] * 3 and cnt[1::2] == [8 * eng._chain["blocks_o"]] * 3
         res.append(torch.stack(outs))
         del eng
-    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    # the chained o_proj is the STREAMING kernel (v_dot2c chains), the unchained one the MFMA skinny kernel (33.5 MB is under the streaming
+    # threshold): another fp32 summation order for that one product -- agreement to fp32 round-off, and run-to-run EQUAL bits of the chain
+    assert torch.equal(res[1], res[2])
+    err = (res[0] - res[1]).abs().max().item()
+    assert err <= 2e-5 * res[0].abs().max().item() + 1e-6, err
