@@ -461,8 +461,12 @@ static void launch_attn_prefill(hipStream_t st, const bf16_t* q, const bf16_t* k
 // Decode attention (one new token per sequence): one block per (batch, head).
 //   q [B][nh][1][128] bf16, caches as above, `total` keys visible. fp32 math, HBM-bound on the cache.
 // ------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW >= 16 ? 7 : 1) void attn_decode_kernel(const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vtc,
+// UBT = loads in flight per lane and pass.  16 waves x 4 keys x UBT cover 256 (UBT = 4) or 512 (UBT = 8) keys per round of the K pass, 8 threads
+// x 8 keys x UBT the same per round of the V pass: with the 25 s prompt (371 + up to 64 keys) UBT = 8 walks each pass in ONE round of memory
+// latency instead of two (round 6).  UBT = 4 at 16 waves is capped at 72 registers so that the workgroup fits a CU next to a chained o_proj
+// workgroup (llark_attn_decode_rope_bf16_chain: 4 x 72 + 2 x 104 of 512 registers per SIMD lane).
+template <int NW, int UBT>
+__global__ __launch_bounds__(NW * 64, (NW >= 16 && UBT == 4) ? 7 : 1) void attn_decode_kernel(const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vtc,
                                                               const bf16_t* __restrict__ q_lo, bf16_t* kc_lo, bf16_t* vtc_lo,
                                                               bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                               int nh, int total, int smax, float scale,
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 16 ? 7 : 1) void attn_decode_kernel(
     // wide so that the whole K pass and the whole V pass are each ONE round of loads in flight (the kernel is a chain of
     // memory latencies, not bandwidth); batched decode keeps 4 waves per block.
     constexpr int NT = NW * 64;
-    constexpr int UB = NW >= 16 ? 4 : 8;          // loads in flight per lane
+    constexpr int UB = UBT;                       // loads in flight per lane
     constexpr int PARTS = NT / 128;               // threads sharing one output dim in the PV pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (pos_dev) total = *pos_dev + 1;            // graph-captured decode: keys 0..pos are visible
@@ -614,16 +618,23 @@ __global__ __launch_bounds__(NW * 64, NW >= 16 ? 7 : 1) void attn_decode_kernel(
 }
 
 // 16 waves per block while the grid is smaller than the chip, 4 otherwise
+#ifndef ATTN_DECODE_WIDE
+#define ATTN_DECODE_WIDE 0        // 1: 8 loads in flight per lane at 16 waves beyond 256 keys -- measured in round 6 (profiles/r06_decode_attn_ub_ab.txt): no gain (302.9 vs 302.1 ms per clip), off
+#endif
+// `keys`: how many keys the walk may see (the host position + 1, or smax when the position lives in device memory)
 template <typename... Args>
-static void launch_attn_decode(int nh, int batch, size_t lds, hipStream_t s, Args... args) {
+static void launch_attn_decode(int nh, int batch, size_t lds, hipStream_t s, int keys, bool chained, Args... args) {
     dim3 grid(nh, batch);
-    if ((long)nh * batch < 256) attn_decode_kernel<16><<<grid, 1024, lds, s>>>(args...);
-    else attn_decode_kernel<4><<<grid, 256, lds, s>>>(args...);
+    if ((long)nh * batch < 256) {
+        if (ATTN_DECODE_WIDE && keys > 256 && !chained) attn_decode_kernel<16, 8><<<grid, 1024, lds, s>>>(args...);
+        else attn_decode_kernel<16, 4><<<grid, 1024, lds, s>>>(args...);
+    } else attn_decode_kernel<4, 8><<<grid, 256, lds, s>>>(args...);
 }
 
 static void attn_decode_lds_limit(int lds) {
-    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attn_decode_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 
@@ -819,7 +830,7 @@ extern "C" int llark_attn_decode_bf16_alibi(const void* q, const void* k_cache, 
     const size_t lds = (size_t)((total + 7) & ~7) * sizeof(float);
     LLARK_REQUIRE(lds <= 128 * 1024, "attn_decode: context %d too long for the LDS score buffer", total);
     if (lds > 48 * 1024) attn_decode_lds_limit((int)lds);
-    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, total, false, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh,
                        total, smax, scale, (const int*)nullptr, alibi_slopes, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (unsigned*)nullptr);
@@ -847,7 +858,7 @@ extern "C" int llark_attn_decode_bf16_dpos(const void* q, const void* k_cache, c
         attn_decode_lds_limit((int)lds);
         attr_lds = (int)lds;
     }
-    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, smax, false, (const bf16_t*)q, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)q_lo, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, 1,
                        smax, scale, pos_dev, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (unsigned*)nullptr);
     return check_launch("attn_decode_dpos");
@@ -875,7 +886,7 @@ static int attn_decode_rope_impl(const float* qkv, int batch, int nh, int hd, in
         attn_decode_lds_limit((int)lds);
         attr_lds = (int)lds;
     }
-    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, (const bf16_t*)nullptr, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+    launch_attn_decode(nh, batch, lds, (hipStream_t)stream, pos_dev ? smax : total, chain_done != nullptr, (const bf16_t*)nullptr, (bf16_t*)k_cache, (bf16_t*)vt_cache,
                        (const bf16_t*)nullptr, (bf16_t*)k_cache_lo, (bf16_t*)vt_cache_lo, (bf16_t*)out, (bf16_t*)out_lo, nh, total, smax,
                        scale, pos_dev, alibi_slopes, qkv, cos_t, sin_t, chain_done);
     return check_launch("attn_decode_rope");

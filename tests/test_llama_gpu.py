@@ -655,4 +655,6 @@ def test_decode_chained_launches_bit_identical(precision):
     # threshold): another fp32 summation order for that one product -- agreement to fp32 round-off, and run-to-run EQUAL bits of the chain
     assert torch.equal(res[1], res[2])
     err = (res[0] - res[1]).abs().max().item()
-    assert err <= 2e-5 * res[0].abs().max().item() + 1e-6, err
+    # (in the bf16 flow an fp32-round-off difference flips single bf16 roundings of the following Linear inputs: bf16-ulp-sized logit changes)
+    bar = 2e-5 if precision == "split" else 2e-2
+    assert err <= bar * res[0].abs().max().item() + 1e-6, err
