@@ -104,7 +104,9 @@ def _grad_worker(rank, world, port, q):
     assert tr._flat_stage is stage and torch.equal(tr.flat_grad, want)
     tr.grad_comm = torch.float32
     tr.flat_grad = first.clone()
-    q.put((rank, tr.flat_grad.clone()))
+    # by VALUE (numpy pickles its bytes): a torch tensor travels through a multiprocessing queue as a shared-memory handle, and this worker
+    # may exit -- unlinking the segment -- before the parent has mapped it (seen once in round 6 as a FileNotFoundError in the parent)
+    q.put((rank, tr.flat_grad.clone().numpy()))
     D.shutdown(world)
 
 
@@ -123,7 +125,7 @@ def test_gradient_allreduce_two_ranks():
         assert p.exitcode == 0
     expect = torch.arange(1000, dtype=torch.float32) * 3          # (1 + 2) x
     for _, gsum in res:
-        assert torch.equal(gsum, expect)
+        assert torch.equal(torch.from_numpy(gsum), expect)
 
 
 def test_bench_self_launches_its_ranks():
