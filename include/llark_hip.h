@@ -581,6 +581,14 @@ int llark_attn_backward_bf16_fused(const void* q, const void* k_cache, const voi
 int llark_pack_frag_t16(const void* src, int ld, int kp, int n, void* dst, llark_stream_t stream);
 int llark_gemm16_ta_fragw(int epilogue, const void* a, int lda, const void* wfrag, int m, int n, int kp, float* c, int ldc,
                           const float* resid, int ldr, double* sumsq, llark_stream_t stream);
+/* The same product on the 16x16x32 MFMA shape (csrc/gemm_bda16.hip, round 6): per joule that instruction does more, and the training
+ * GEMMs run against the power limit.  llark_pack_frag_t16x16 = llark_pack_frag_t16 in 16-row chunks (chunk (feature / 16, token / 32), lane
+ * l = the 8 tokens 32 q + 8 (l / 16) .. of feature 16 R + l % 16; same extent); llark_gemm16_ta_fragw16 = llark_gemm16_ta_fragw over it.
+ * Additionally kp % 128 == 0, kp >= 256, n / ldc / ldr multiples of 4, c / resid 16-byte aligned: LLARK_ERR_UNSUPPORTED otherwise (the
+ * caller keeps llark_gemm16_ta_fragw).  32 products per MFMA: agrees with llark_gemm16_ta_fragw to fp32 rounding, not bit for bit. */
+int llark_pack_frag_t16x16(const void* src, int ld, int kp, int n, void* dst, llark_stream_t stream);
+int llark_gemm16_ta_fragw16(int epilogue, const void* a, int lda, const void* wfrag, int m, int n, int kp, float* c, int ldc,
+                            const float* resid, int ldr, double* sumsq, llark_stream_t stream);
 /* The two SwiGLU products of the training step with the element-wise pass in their epilogues (csrc/gemm_bda.hip; HF LlamaMLP.forward and
  * its autograd under WrappedLlamav2ForCausalLM.forward + loss.backward(), m2t/models/llamav2.py:224-234,259-337, m2t/train.py:53-277).
  * Plain bf16 operands, fragment-major weights (llark_pack_weight16_frag / llark_adamw_twins).  gu16 [m][ldg >= 2 I] = the gate | up

@@ -152,6 +152,8 @@ _SIGS = {
     "llark_gemm16_fragw_swiglu_train": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P],
     "llark_pack_frag_t16": [_P, c_int, c_int, c_int, _P, _P],
     "llark_gemm16_ta_fragw": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
+    "llark_pack_frag_t16x16": [_P, c_int, c_int, c_int, _P, _P],
+    "llark_gemm16_ta_fragw16": [c_int, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, _P],
     "llark_gemm16_fragw_rope_qkv_train": [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, c_int, _P, _P],
     "llark_attn_backward_bf16_fused": [_P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P],
     "llark_gemv16_dma_blocks": [c_int, c_int],

@@ -101,6 +101,8 @@ class HipLlamaTrainer:
         self._frozen_wT: Dict[int, torch.Tensor] = {}
         self.use_twins = bool(optimizer_state) and os.environ.get("LLARK_TRAIN_TWINS", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
         self.dw_fragw = os.environ.get("LLARK_TRAIN_DW_FRAGW", "1") != "0" and os.environ.get("LLARK_FRAG", "1") != "0"
+        # the dW product on the 16x16x32 MFMA shape (csrc/gemm_bda16.hip): more flops per joule under the power limit
+        self.dw_mfma16 = self.dw_fragw and os.environ.get("LLARK_TRAIN_DW_MFMA16", "0") != "0"
         self.attn_glue_fused = os.environ.get("LLARK_TRAIN_ATTN_GLUE_FUSED", "1") != "0"
         self.swiglu_fused = self.use_twins and os.environ.get("LLARK_TRAIN_SWIGLU_FUSED", "1") != "0"
         self.rope_fused = self.use_twins and d.head_dim == 128 and d.num_attention_heads % 2 == 0 and os.environ.get("LLARK_TRAIN_ROPE_FUSED", "1") != "0"
@@ -176,8 +178,9 @@ class HipLlamaTrainer:
                 and ops.gemm16_ta_fragw_takes(n, toks, dy16.stride(0))):
             # round 6: dY as it stands through the DMA loop's transposing LDS read, X^T fragment-major (one transposing pack of X: 2 x its
             # bytes) -- the B operand streams L2 -> VGPR and never waits on a barrier (csrc/gemm_bda.hip: gemm_bda_ta_kernel)
-            xt = ops.pack_frag_t16(x16, k)
-            ops.gemm16_ta_fragw(dy16, xt, n, k, toks, grad, accumulate=not fresh, sumsq=sumsq)
+            c16 = self.dw_mfma16 and ops.gemm16_ta_fragw16_takes(n, k, toks, dy16.stride(0), grad)
+            xt = ops.pack_frag_t16(x16, k, chunk16=c16)
+            ops.gemm16_ta_fragw(dy16, xt, n, k, toks, grad, accumulate=not fresh, sumsq=sumsq, chunk16=c16)
             if sumsq is not None:
                 off, cnt = self._slices[name]
                 self._norm_spans.append((off, off + cnt))

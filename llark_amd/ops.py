@@ -1274,14 +1274,16 @@ def gemm16_fragw_swiglu_train(mode: int, a: torch.Tensor, wfrag: torch.Tensor, n
     return True
 
 
-def pack_frag_t16(x: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+def pack_frag_t16(x: torch.Tensor, n: Optional[int] = None, chunk16: bool = False) -> torch.Tensor:
     """x [kp][>= n] 16-bit, row = contraction index (token) -> the fragment-major copy of x^T ([n][kp]): the B operand of
-    :func:`gemm16_ta_fragw` (include/llark_hip.h: llark_pack_frag_t16)."""
+    :func:`gemm16_ta_fragw` (include/llark_hip.h: llark_pack_frag_t16; ``chunk16``: llark_pack_frag_t16x16, the 16-row chunks of the
+    16x16x32 MFMA shape)."""
     kp = x.shape[0]
     n = x.shape[1] if n is None else n
     assert x.stride(1) == 1 and kp % 64 == 0 and n % 8 == 0
     out = torch.empty((round_up(n, 32) * kp,), dtype=x.dtype, device=x.device)
-    check(_lib.lib().llark_pack_frag_t16(_dev(x, "x", contiguous=False), x.stride(0), kp, n, _dev(out, "out"), _stream()), "pack_frag_t16")
+    fn = _lib.lib().llark_pack_frag_t16x16 if chunk16 else _lib.lib().llark_pack_frag_t16
+    check(fn(_dev(x, "x", contiguous=False), x.stride(0), kp, n, _dev(out, "out"), _stream()), "pack_frag_t16")
     return out
 
 
@@ -1289,14 +1291,22 @@ def gemm16_ta_fragw_takes(m: int, kp: int, lda: int) -> bool:
     return m % 8 == 0 and kp % 64 == 0 and kp >= 192 and lda % 8 == 0 and kp * lda * 2 < (1 << 31)
 
 
+def gemm16_ta_fragw16_takes(m: int, n: int, kp: int, lda: int, c: torch.Tensor) -> bool:
+    """Whether llark_gemm16_ta_fragw16 (the 16x16x32 MFMA shape) takes the product into ``c`` (include/llark_hip.h)."""
+    return (gemm16_ta_fragw_takes(m, kp, lda) and kp % 128 == 0 and kp >= 256 and n % 4 == 0 and c.stride(0) % 4 == 0
+            and c.data_ptr() % 16 == 0)
+
+
 def gemm16_ta_fragw(a: torch.Tensor, wfrag: torch.Tensor, m: int, n: int, kp: int, c: torch.Tensor, accumulate: bool = False,
-                    sumsq: Optional[torch.Tensor] = None) -> None:
+                    sumsq: Optional[torch.Tensor] = None, chunk16: bool = False) -> None:
     """c[m][n] (= | +=) sum_k a[k][m] B(n, k): ``a`` [kp][>= m] bf16 contraction-major (dY as the backward leaves it), ``wfrag`` =
-    :func:`pack_frag_t16` of X [kp][n] (include/llark_hip.h: llark_gemm16_ta_fragw)."""
+    :func:`pack_frag_t16` of X [kp][n] (include/llark_hip.h: llark_gemm16_ta_fragw; ``chunk16``: llark_gemm16_ta_fragw16 over
+    ``pack_frag_t16(.., chunk16=True)``)."""
     bf = torch.bfloat16
     assert a.dtype == bf and wfrag.dtype == bf and a.stride(1) == 1 and wfrag.numel() == round_up(n, 32) * kp
+    fn = _lib.lib().llark_gemm16_ta_fragw16 if chunk16 else _lib.lib().llark_gemm16_ta_fragw
     with _timed("gemm_bf16", 2.0 * m * n * kp):
-        check(_lib.lib().llark_gemm16_ta_fragw(
+        check(fn(
             EPI_RESID if accumulate else EPI_F32, _dev(a, "a", contiguous=False), a.stride(0), _dev(wfrag, "wfrag"), m, n, kp,
             _dev(c, "c", torch.float32, contiguous=False), c.stride(0), _dev(c, "c", torch.float32, contiguous=False) if accumulate else None,
             c.stride(0), _dev(sumsq, "sumsq", torch.float64) if sumsq is not None else None, _stream()), "gemm16_ta_fragw")

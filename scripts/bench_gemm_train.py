@@ -8,7 +8,7 @@ default (what the trainer gets for an operand without a fragment-major twin); 20
 step has them (dX: W contraction-major; dW: both operands contraction-major) -- the time of the transposes it replaces is printed too;
 210 .. 213 = llark_gemm16_t_ex variants 0 .. 3 (0 = one LDS stage, 1 = 128x256x32 two stages, 2 = 128x256x64 two stages, 3 = 256x256x64);
 220 (dW only) = llark_gemm16_ta_fragw: dY as it stands + X^T fragment-major, the time of llark_pack_frag_t16(X) is printed next to it and
-counted in the sum.
+counted in the sum; 221 = the same on the 16x16x32 MFMA shape (llark_gemm16_ta_fragw16 over llark_pack_frag_t16x16).
 """
 import os
 import sys
@@ -60,17 +60,17 @@ def main():
         for v in VARIANTS:
             if v >= 200 and not (is_dw or is_dx):
                 continue
-            if v == 220 and not is_dw:
+            if v in (220, 221) and not is_dw:
                 continue
-            if v == 220:
-                ms_p = timeit(lambda: ops.pack_frag_t16(wkn, n))
-                xt = ops.pack_frag_t16(wkn, n)
+            if v in (220, 221):
+                ms_p = timeit(lambda: ops.pack_frag_t16(wkn, n, chunk16=v == 221))
+                xt = ops.pack_frag_t16(wkn, n, chunk16=v == 221)
                 total[v] += ms_p
-                print(f"M={M} {name:18s} llark_pack_frag_t16(X [{k} x {n}]): {ms_p:7.3f} ms")
+                print(f"M={M} {name:18s} llark_pack_frag_t16{'x16' if v == 221 else ''}(X [{k} x {n}]): {ms_p:7.3f} ms")
             def fn():
                 kw = dict(c=c, resid=c) if epi == ops.EPI_RESID else dict(c=c)
-                if v == 220:
-                    ops.gemm16_ta_fragw(akm, xt, rows, n, k, c, accumulate=epi == ops.EPI_RESID)
+                if v in (220, 221):
+                    ops.gemm16_ta_fragw(akm, xt, rows, n, k, c, accumulate=epi == ops.EPI_RESID, chunk16=v == 221)
                 elif v >= 200:
                     tv = -1 if v == 200 else v - 210
                     if is_dw:

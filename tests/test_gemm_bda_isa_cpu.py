@@ -50,9 +50,10 @@ def _blocks(lines):
     return blocks, order
 
 
-def audit_kernels(txt, name_regex, min_kernels):
+def audit_kernels(txt, name_regex, min_kernels, shapes=((64, 8), (32, 4)), loads=8, tr_reads=32):
     """txt: lines of an AMDGPU assembly file; checks every kernel whose symbol matches name_regex (see the module docstring).
-    Returns the number of (kernel, load) pairs followed to their retiring wait."""
+    shapes: (MFMAs, LDS-DMA requests) one K-step of the loop may hold; loads: its global_load_dwordx4 count; tr_reads: its transposing LDS
+    reads when it has any.  Returns the number of (kernel, load) pairs followed to their retiring wait."""
     names = [l.split(":")[0] for l in txt if re.match(r"^" + name_regex + r"\S*:", l)]
     assert len(names) >= min_kernels, f"{len(names)} kernels match {name_regex}"
     total = 0
@@ -60,8 +61,8 @@ def audit_kernels(txt, name_regex, min_kernels):
         start = next(i for i, l in enumerate(txt) if l.startswith(name + ":"))
         end = next(i for i in range(start, len(txt)) if txt[i].strip().startswith(".Lfunc_end"))
         blocks, order = _blocks(txt[start:end])
-        hot = [b for b in order if (sum("v_mfma" in x for x in blocks[b]), sum(" lds" in x for x in blocks[b])) in ((64, 8), (32, 4))
-               and sum("global_load_dwordx4" in x for x in blocks[b]) == 8]          # hi + lo form: 64 MFMAs + 8 DMA requests per K-step; plain: 32 + 4
+        hot = [b for b in order if (sum("v_mfma" in x for x in blocks[b]), sum(" lds" in x for x in blocks[b])) in shapes
+               and sum("global_load_dwordx4" in x for x in blocks[b]) == loads]          # hi + lo form: 64 MFMAs + 8 DMA requests per K-step; plain: 32 + 4
         if not hot:
             continue                                                  # a kernel of the file that does not contain the DMA loop
         assert len(hot) in (1, 2), f"{name}: expected the K loop (+ a peeled last iteration), found {hot}"
@@ -76,7 +77,7 @@ def audit_kernels(txt, name_regex, min_kernels):
                 # while nothing else shares that counter inside the loop (scalar loads return out of order; other LDS operations shift the count)
                 assert not any(x.startswith(("s_load", "s_buffer_load")) for x in ins), f"{name} {b}: a scalar load inside the K loop"
                 assert all(x.startswith("ds_read_b64_tr_b16") for x in ins if x.startswith("ds_")), f"{name} {b}: an LDS operation the counts do not know"
-                assert sum(x.startswith("ds_read_b64_tr_b16") for x in ins) == 32, f"{name} {b}: expected 4 sub-steps x 4 row blocks x 2 reads"
+                assert sum(x.startswith("ds_read_b64_tr_b16") for x in ins) == tr_reads, f"{name} {b}: expected {tr_reads} transposing reads"
         # the instruction stream a wave sees: loop body twice (back edge), then the peeled iteration (or the loop once more), then whatever follows
         tail_blocks = [b for b in hot if b != loop] or [loop]
         nxt = order.index(tail_blocks[-1]) + 1
@@ -101,7 +102,7 @@ def audit_kernels(txt, name_regex, min_kernels):
                 assert not (touched & dest), f"{name}: `{y}` touches v{sorted(touched & dest)} while `{x}` (stream position {i}) is in flight"
             assert retired is not None, f"{name}: load at stream position {i} is never retired"
             checked += 1
-        assert checked == 16
+        assert checked == 2 * loads
         total += checked
     return total
 
@@ -120,6 +121,22 @@ def test_gemm_bda_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
     assert audit_kernels(txt, "_ZN5llark15gemm_bda_kernel", 12) == 12 * 16       # 5 hi + lo and 7 plain epilogues (round 6: + the two training SwiGLU forms)
     assert audit_kernels(txt, "_ZN5llark18gemm_bda_ta_kernel", 2) == 2 * 16       # the dW form: contraction-major A through the transposing LDS read
     assert audit_kernels(txt, "_ZN5llark19gemm_bda_lnp_kernel", 2) == 2 * 16      # the LayerNorm-producer role on the same loop (fp16, bf16)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_gemm_bda16_generated_code_keeps_the_inflight_ring_untouched(tmp_path):
+    """The dW product on the 16x16x32 MFMA shape (csrc/gemm_bda16.hip): the same hand-counted protocol with 128 MFMAs, 8 DMA requests,
+    16 chunk loads and 64 transposing reads per K-step of 128 tokens."""
+    out = tmp_path / "bda16.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                        "-Rpass-analysis=kernel-resource-usage", "-o", str(out), os.path.join(ROOT, "llark_amd", "csrc", "gemm_bda16.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    spills = [int(v) for v in re.findall(r"VGPRs Spill: (\d+)", r.stderr)] + [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    assert len(spills) >= 6 and not any(spills), f"spills / scratch: {spills}"
+    assert all(int(v) <= 256 for v in re.findall(r"VGPRs: (\d+)", r.stderr))
+    txt = out.read_text().split("\n")
+    assert audit_kernels(txt, r"_ZN5llark12_GLOBAL__N_120gemm_bda16_ta_kernel", 2, shapes=((128, 8),), loads=16, tr_reads=64) == 2 * 32
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -155,3 +155,43 @@ def test_dw_form_on_the_dma_loop(m, n, kp, accumulate):
     assert torch.equal(c, c2)
     ref_ss = (c.double() ** 2).sum().item()
     assert abs(ss.item() - ref_ss) <= 1e-5 * ref_ss
+
+
+@pytest.mark.parametrize("m,n,kp,accumulate", [(128, 256, 256, False), (136, 200, 384, True), (4096, 11008, 1024, True), (72, 1000, 512, False),
+                                               (12288, 4096, 4096, True), (4104, 4360, 4096, False), (22016, 4096, 4096, True)])
+def test_dw_form_on_the_16x16x32_mfma_shape(m, n, kp, accumulate):
+    """llark_gemm16_ta_fragw16 over llark_pack_frag_t16x16 (csrc/gemm_bda16.hip): the dW product with 32 products per MFMA.  Same bound
+    against the fp64 product as every kernel of this file; against llark_gemm16_ta_fragw a few fp32 ulps of the absolute-value product
+    (different grouping of the same products); sum-of-squares side output against the stored values; reproducible bit for bit."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(m * 3 + n)
+    a = torch.randn(kp, m, generator=g, device="cuda").bfloat16()
+    x = (torch.randn(kp, n, generator=g, device="cuda") * 0.1).bfloat16()
+    init = torch.randn(m, n, generator=g, device="cuda") if accumulate else None
+    assert ops.gemm16_ta_fragw16_takes(m, n, kp, a.stride(0), init if accumulate else torch.empty(m, n, device="cuda"))
+    outs = []
+    for _ in range(2):
+        c = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+        ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ops.gemm16_ta_fragw(a, ops.pack_frag_t16(x, n, chunk16=True), m, n, kp, c, accumulate=accumulate, sumsq=ss, chunk16=True)
+        outs.append(c)
+    c = outs[0]
+    assert torch.equal(outs[0], outs[1])
+    _check(c, a.float().t(), x.float().t(), init)
+    ref_ss = (c.double() ** 2).sum().item()
+    assert abs(ss.item() - ref_ss) <= 1e-5 * ref_ss
+    c2 = init.clone() if accumulate else torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm16_ta_fragw(a, ops.pack_frag_t16(x, n), m, n, kp, c2, accumulate=accumulate)
+    bound = a.float().t().abs() @ x.float().abs() + (init.abs() if accumulate else 0)
+    assert ((c - c2).abs() <= 4e-6 * bound + 1e-30).all()
+
+
+def test_dw_16x16x32_rejects_what_it_cannot_take():
+    from llark_amd import ops
+    from llark_amd._lib import LlarkHipError
+    a = torch.zeros(192, 128, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(192, 256, dtype=torch.bfloat16, device="cuda")
+    c = torch.zeros(128, 256, device="cuda")
+    assert not ops.gemm16_ta_fragw16_takes(128, 256, 192, 128, c)
+    with pytest.raises(LlarkHipError):
+        ops.gemm16_ta_fragw(a, ops.pack_frag_t16(x, 256, chunk16=True), 128, 256, 192, c, chunk16=True)      # kp % 128 != 0
