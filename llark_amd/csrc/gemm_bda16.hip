@@ -51,6 +51,13 @@ typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 
 #define B16_VMCNT(N) "s_waitcnt vmcnt(" #N ")"
 
+#ifndef B16_EPI_DEPTH
+#define B16_EPI_DEPTH 5   // residual rows (of 8) whose loads are in flight ahead of the stores
+#endif
+#ifndef B16_DEBUG
+#define B16_DEBUG 0   // timing experiments only (results are garbage): 1 = no epilogue stores, 2 = no X^T loads inside the loop, 4 = no LDS reads
+#endif                //   inside the loop, 8 = no DMA inside the loop, 16 = no barrier inside the loop
+
 template <int EPI>
 __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages x 32 KiB
@@ -135,6 +142,14 @@ __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const Gem
     }
     u32x2_ ta_lo[2][4], ta_hi[2][4];
     unsigned tb[4];                                                        // ta_base + this K-step's stage
+    if constexpr (B16_DEBUG & 6) {                                         // knocked-out operands: defined once, outside the loop
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ring[3][j] = ring[2][j];
+            ta_lo[0][j] = ta_lo[1][j] = u32x2_{lane16, 0x3c003c00u};
+            ta_hi[0][j] = ta_hi[1][j] = u32x2_{0x3c003c00u, lane16};
+        }
+    }
 #define T16_READA(SET, ROW, MT_, S_)                                                                                                 \
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"                                       \
                  : "=&v"(ta_lo[SET][ROW]), "=&v"(ta_hi[SET][ROW])                                                                    \
@@ -144,18 +159,21 @@ __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const Gem
 
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned sAoff = (unsigned)((kt & 1) * B16_STAGE);
-        dmaA(kt + 1, (kt + 1) & 1);                                       // unconditional (behind the last K-step: zeros): the counts below stay exact
+        if constexpr (!(B16_DEBUG & 8)) dmaA(kt + 1, (kt + 1) & 1);        // unconditional (behind the last K-step: zeros): the counts below stay exact
 #pragma unroll
         for (int j = 0; j < 4; ++j) tb[j] = ta_base[j] + sAoff;
-        T16_READA(0, 0, 0, 0);
-        T16_READA(0, 1, 1, 0);
-        T16_READA(0, 2, 2, 0);
-        T16_READA(0, 3, 3, 0);
+        if constexpr (!(B16_DEBUG & 4) ) {
+            T16_READA(0, 0, 0, 0);
+            T16_READA(0, 1, 1, 0);
+            T16_READA(0, 2, 2, 0);
+            T16_READA(0, 3, 3, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         static_for<4>([&](auto sc) __attribute__((always_inline)) {
             constexpr int s = decltype(sc)::value;
-            B16_LOADB((s + 3) & 3, kt * 4 + s + 3);
-            if constexpr (s == 3) B16_WAITB(s, 12);
+            if constexpr (!(B16_DEBUG & 2)) B16_LOADB((s + 3) & 3, kt * 4 + s + 3);
+            if constexpr (B16_DEBUG & 10) { if constexpr (s == 3) B16_WAITB(s, 0); }
+            else if constexpr (s == 3) B16_WAITB(s, 12);
             else B16_WAITB(s, 20);
             __builtin_amdgcn_sched_barrier(0);
             static_for<2>([&](auto hc) __attribute__((always_inline)) {
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const Gem
                     const u32x4_ bv = {ta_lo[mh][row][0], ta_lo[mh][row][1], ta_hi[mh][row][0], ta_hi[mh][row][1]};
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ring[s][nt]), __builtin_bit_cast(bf16x8_t, bv), acc[mt][nt], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (nt == 0 && !last) {                     // the next half's fragments of this row: behind its first MFMA
+                    if constexpr (nt == 0 && !last && !(B16_DEBUG & 4)) {  // the next half's fragments of this row: behind its first MFMA
                         if constexpr (mh == 0) T16_READA(1, row, 4 + row, s);
                         else T16_READA(0, row, row, s + 1);
                     }
@@ -182,7 +200,7 @@ __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const Gem
             });
         });
         // sub-step 3's wait retired this K-step's DMA: every wave's part of A(kt + 1) has landed
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(B16_DEBUG & 16)) __builtin_amdgcn_s_barrier();
     }
     // the tail re-loads name every ring register (an unused asm load is dead to hipcc the moment it is issued: gemm_bda_loop.h)
     asm volatile(B16_VMCNT(0)
@@ -198,31 +216,49 @@ __global__ __launch_bounds__(B16_THREADS, 2) void gemm_bda16_ta_kernel(const Gem
     const int ncw = n0 + w * 64 + 4 * (lane >> 4);
     float ssq = 0.0f;
     auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_c)::value;                    // interior tile: no bounds checks, loads of a row batched ahead of its stores
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        constexpr bool FULL = decltype(full_c)::value;                    // interior tile: no bounds checks
+        // Residual form: R may alias C, so hipcc never moves a load above a store -- written naively (row: 4 loads, add, 4 stores) the tile
+        // is eight serial memory round trips.  The loads run B16_EPI_DEPTH rows ahead of the stores, in program order: the registers of
+        // the weight ring and the fragments are dead here and hold them.
+        constexpr int D = EPI == EPI_RESID ? B16_EPI_DEPTH : 0;
+        f32x4_t rv[D > 0 ? D : 1][4];
+        auto load_row = [&](int mt, f32x4_t (&dst)[4]) __attribute__((always_inline)) {
             const int m = m0 + 16 * mt + (lane & 15);
-            const bool mok = FULL || m < p.M;
-            f32x4_t rv[4];
-            if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int n = ncw + 16 * nt;
-                    rv[nt] = (mok && (FULL || n < p.N)) ? *(const f32x4_t*)(p.R + (size_t)m * p.ldr + n) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-                }
-            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n = ncw + 16 * nt;
-                if (mok && (FULL || n < p.N)) {
+                dst[nt] = (FULL || (m < p.M && n < p.N)) ? *(const f32x4_t*)(p.R + (size_t)m * p.ldr + n) : f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        };
+        if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+            for (int mt = 0; mt < D; ++mt) load_row(mt, rv[mt]);
+        }
+        static_for<8>([&](auto mc) __attribute__((always_inline)) {
+            constexpr int mt = decltype(mc)::value;
+            const int m = m0 + 16 * mt + (lane & 15);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = ncw + 16 * nt;
+                if (FULL || (m < p.M && n < p.N)) {
                     f32x4_t v = acc[mt][nt];
-                    if constexpr (EPI == EPI_RESID) v += rv[nt];
+                    if constexpr (EPI == EPI_RESID) v += rv[mt % (D > 0 ? D : 1)][nt];
                     ssq += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
                     *(f32x4_t*)(p.C + (size_t)m * p.ldc + n) = v;
                 }
             }
-        }
+            if constexpr (EPI == EPI_RESID && mt + D < 8) load_row(mt + D, rv[mt % (D > 0 ? D : 1)]);
+        });
     };
+    if constexpr (B16_DEBUG & 1) {                                         // keep the accumulators alive, store (almost) nothing
+        float t = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) t += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (t == 12345.678f) p.C[lane] = t;
+        return;
+    }
     if (m0 + B16_BM <= p.M && n0 + B16_BN <= p.N) epilogue(std::true_type{});
     else epilogue(std::false_type{});
     if (p.sumsq != nullptr) {
