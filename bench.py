@@ -486,6 +486,26 @@ def extra_train(args, device, steps: int = 2):
         out["cpu_baseline"] = cpu_baseline_train(a, layers=1)
     del wl
     torch.cuda.empty_cache()
+    # The same optimizer step with the accumulation FUSED: the 4 micro-batches as one pass of 8 clips, the loss normalised per micro-batch
+    # (HipLlamaTrainer.forward_backward(loss_groups=4): the same gradient up to the order of fp32 sums, tests/test_train_gpu.py) -- every dW
+    # product writes its fp32 gradient once instead of read-modify-writing it per micro-batch; activations of 8 clips instead of 2 in HBM.
+    a.micro_batch, a.loss_groups = 8, 4
+    torch.cuda.reset_peak_memory_stats()
+    wl = bench_support.TrainWorkload(a, device, 1)
+    with torch.no_grad():
+        wl.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            wl.step()
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / steps
+    out["fused_accumulation"] = {"what": "the same 8 clips x 2048 tokens as ONE pass, loss normalised per recipe micro-batch (loss_groups=4): same optimizer step",
+                                 "ms_per_step": round(dtf * 1e3, 2), "value": round(a.batch / dtf, 4), "unit": "clips/s",
+                                 "mfu": round(wl.model_flops_per_step() / dtf / (PEAK_F16_MFMA_TFLOPS * 1e12), 4),
+                                 "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    del wl
+    torch.cuda.empty_cache()
     return out
 
 
@@ -545,6 +565,7 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only for --stages dist-check on CPU)")
     ap.add_argument("--new-tokens", type=int, default=64, help="generate: answer tokens per clip (BASELINE configs[2]: 64)")
     ap.add_argument("--micro-batch", type=int, default=4, help="train: clips per micro-step (train_llark.sh uses per_device_train_batch_size 2 x accumulation; 4 x 1 is the same optimizer step, measured 24 %% faster)")
+    ap.add_argument("--loss-groups", type=int, default=1, help="train: recipe micro-batches fused into one pass of --micro-batch clips (loss normalised per group: the same optimizer step)")
     ap.add_argument("--grad-checkpoint", action="store_true", help="train: per-layer recompute in the backward (train_llark.sh:25 --gradient_checkpointing True)")
     ap.add_argument("--train-seq", type=int, default=512, help="train: tokens per clip (371 prompt+audio positions + answer)")
     ap.add_argument("--grad-comm", dest="grad_comm", default="bf16", choices=["fp32", "bf16"],

@@ -147,6 +147,8 @@ class TrainWorkload:
             dims.num_hidden_layers = layers
         self.dims, self.device, self.world = dims, device, world
         self.micro, self.accum, self.seq = args.micro_batch, max(1, args.batch // args.micro_batch), args.train_seq
+        # fused accumulation: ``micro`` holds ``loss_groups`` of the recipe's micro-batches in one pass, the loss normalised per group
+        self.loss_groups = max(1, int(getattr(args, "loss_groups", 1)))
         eng = HipLlamaEngine(dims, device, max_batch=self.micro, max_seq=ops.round_up(self.seq, 64), precision="bf16")
         g = torch.Generator(device=device).manual_seed(0)
         H, I = dims.hidden_size, dims.intermediate_size
@@ -179,9 +181,9 @@ class TrainWorkload:
         loss = None
         for k, (ids, labels, emb) in enumerate(self.batches):
             segs = [(b, 1, emb[b]) for b in range(self.micro)]
-            loss = tr.forward_backward(ids, segs, labels, 1.0 / self.accum,
+            loss = tr.forward_backward(ids, segs, labels, 1.0 / (self.accum * self.loss_groups),
                                        overlap_allreduce_world=self.world if k == len(self.batches) - 1 else 1,
-                                       last_micro_batch=k == len(self.batches) - 1)
+                                       last_micro_batch=k == len(self.batches) - 1, loss_groups=self.loss_groups)
         tr.allreduce_grads(self.world)
         tr.step(self.world, max_grad_norm=1.0)       # HF Trainer's default clip_grad_norm_: one reduction over the 27 GB of gradients
         return loss

@@ -33,6 +33,8 @@ class TrainConfig:
     lr_scheduler_type: str = "cosine"           # :35
     gradient_checkpointing: bool = False        # train_llark.sh:25 (per-layer recompute in the backward; same gradients, less HBM)
     max_grad_norm: float = 1.0                  # transformers TrainingArguments default (clip_grad_norm_ in Trainer's step); not set by train_llark.sh
+    fuse_accumulation: bool = False             # run the accumulation micro-batches of a step as ONE pass when they share a shape and the engine
+                                                # holds them (loss normalised per micro-batch: the same gradient; 8 x 2048: 714 -> 685 ms, +60 GB)
     grad_comm: str = "bf16"                     # the reference's DDP buckets are bf16 (m2t/train.py:94-103 casts the model): 13.5 GB/step; "fp32" = 27 GB
 
 
@@ -69,6 +71,14 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
     if max_optimizer_steps and tr.step_count >= max_optimizer_steps:
         return []
     losses, acc, micro = [], 0.0, 0
+    accum = cfg.gradient_accumulation_steps
+    pending = []                                            # fuse_accumulation: the step's micro-batches until the last one arrives
+
+    def run_micro(ids, segs, labels, last):
+        loss = tr.forward_backward(ids, segs, labels, 1.0 / accum, overlap_allreduce_world=world if last else 1,
+                                   last_micro_batch=last and cfg.max_grad_norm > 0)
+        return float(loss.item()) / accum
+
     for batch in batches:
         ids = batch["input_ids"].to(engine.device)
         feats = batch.get("audio_encodings")
@@ -76,12 +86,25 @@ def train(engine, batches: Iterable[Dict], audio_cfg, cfg: TrainConfig = TrainCo
             feats = [f.to(engine.device, torch.float32) for f in feats] if isinstance(feats, (list, tuple)) \
                 else feats.to(engine.device, torch.float32)
         segs = plan_audio_splice(ids, feats, audio_cfg, False)
-        last = (micro + 1) % cfg.gradient_accumulation_steps == 0          # DDP no_sync boundary: exchange only on the last micro-step
-        loss = tr.forward_backward(ids, segs, batch["labels"].to(engine.device), 1.0 / cfg.gradient_accumulation_steps,
-                                   overlap_allreduce_world=world if last else 1, last_micro_batch=last and cfg.max_grad_norm > 0)
-        acc += float(loss.item()) / cfg.gradient_accumulation_steps
+        labels = batch["labels"].to(engine.device)
+        last = (micro + 1) % accum == 0                     # DDP no_sync boundary: exchange only on the last micro-step
+        if cfg.fuse_accumulation and accum > 1:
+            pending.append((ids, segs, labels))
+            if last:
+                B = ids.shape[0]
+                if len({tuple(p[0].shape) for p in pending}) == 1 and B * accum <= engine.max_batch:
+                    all_segs = [(b + k * B, st, fr) for k, p in enumerate(pending) for (b, st, fr) in p[1]]
+                    loss = tr.forward_backward(torch.cat([p[0] for p in pending]), all_segs, torch.cat([p[2] for p in pending]), 1.0 / accum,
+                                               overlap_allreduce_world=world, last_micro_batch=cfg.max_grad_norm > 0, loss_groups=accum)
+                    acc = float(loss.item())
+                else:                                       # ragged step (the collator pads each micro-batch to its own longest sequence)
+                    for k, p in enumerate(pending):
+                        acc += run_micro(*p, k == accum - 1)
+                pending = []
+        else:
+            acc += run_micro(ids, segs, labels, last)
         micro += 1
-        if micro % cfg.gradient_accumulation_steps == 0:
+        if micro % accum == 0:
             tr.allreduce_grads(world)                       # the one exchange step of the path
             tr.lr = lr_at(tr.step_count, cfg)
             tr.step(world, max_grad_norm=cfg.max_grad_norm)
@@ -156,6 +179,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--grad_comm", default="bf16", choices=["fp32", "bf16"], help="transport dtype of the gradient all-reduce (reference: bf16)")
     ap.add_argument("--allow_pickle", type=boolean, default=False, help=".pyd shard members are pickles: enable only for trusted data")
+    ap.add_argument("--fuse_accumulation", type=boolean, default=False,
+                    help="not a reference flag: run the accumulation micro-batches of a step as one pass when they share a shape (same gradient; more HBM)")
     ap.add_argument("--gradient_checkpointing", type=boolean, default=False, help="train_llark.sh:25: recompute each decoder layer in the backward")
     ap.add_argument("--apply_task_sample_probs", type=boolean, default=False, help="m2t/arguments.py:68: weight shards by the task in their name")
     ap.add_argument("--task_sample_probs", default=None, help='JSON dict task -> probability (default: m2t/arguments.py:61-67)')
@@ -186,7 +211,8 @@ def main(argv=None):
     dims = LlamaDims(hidden_size=c.hidden_size, intermediate_size=c.intermediate_size, num_hidden_layers=c.num_hidden_layers,
                      num_attention_heads=c.num_attention_heads, vocab_size=len(tok), rms_norm_eps=c.rms_norm_eps,
                      rope_theta=getattr(c, "rope_theta", 10000.0), mm_hidden_size=args.mm_hidden_size)
-    eng = HipLlamaEngine(dims, dev, max_batch=args.per_device_train_batch_size, max_seq=args.model_max_length, precision="bf16", frag_weights=False)
+    eng = HipLlamaEngine(dims, dev, max_batch=args.per_device_train_batch_size * (args.gradient_accumulation_steps if args.fuse_accumulation else 1),
+                         max_seq=args.model_max_length, precision="bf16", frag_weights=False)
     eng.load_state_dict(model.state_dict())
     audio_cfg = model.get_model().audio_encoder_config
     hf_config = model.config                                              # written into every checkpoint-N (with the tokenizer)
@@ -198,7 +224,8 @@ def main(argv=None):
     mm_cfg = dict(is_multimodal=True, sep_audio_conv_front=False, use_audio_start_end=args.mm_use_audio_start_end)
     cfg = TrainConfig(learning_rate=args.learning_rate, weight_decay=args.weight_decay, warmup_ratio=args.warmup_ratio,
                       max_steps=args.max_steps, gradient_accumulation_steps=args.gradient_accumulation_steps, grad_comm=args.grad_comm,
-                      gradient_checkpointing=args.gradient_checkpointing, max_grad_norm=args.max_grad_norm)
+                      gradient_checkpointing=args.gradient_checkpointing, max_grad_norm=args.max_grad_norm,
+                      fuse_accumulation=args.fuse_accumulation)
     task_probs = None
     if args.apply_task_sample_probs:
         import json as _json

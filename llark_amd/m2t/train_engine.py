@@ -272,9 +272,14 @@ class HipLlamaTrainer:
 
     # ------------------------------------------------------------------------------------------
     def forward_backward(self, input_ids: torch.Tensor, audio_segments, labels: torch.Tensor, loss_scale: float = 1.0,
-                         overlap_allreduce_world: int = 1, last_micro_batch: bool = False) -> torch.Tensor:
+                         overlap_allreduce_world: int = 1, last_micro_batch: bool = False, loss_groups: int = 1) -> torch.Tensor:
         """One micro-batch: returns the (unscaled) loss as a device scalar and ACCUMULATES gradients.
         ``loss_scale`` = 1 / gradient_accumulation_steps like HF Trainer.
+        ``loss_groups`` > 1: the batch holds that many of the recipe's micro-batches (consecutive, equal-sized groups of sequences) run
+        as ONE pass -- the accumulation of train_llark.sh:26-27 (per_device_train_batch_size 2 x gradient_accumulation_steps 4) fused:
+        the loss is normalised per group (each group's mean over ITS label tokens, times ``loss_scale``), so the gradient is the sum the
+        separate micro-batches would accumulate; every dW product then writes its gradient once instead of read-modify-writing 27 GB of
+        fp32 per micro-batch.  Returns the mean of the group losses.
         ``last_micro_batch``: this call completes the gradients of an optimizer step: every dW product then also adds the sum of
         squares of the gradient it writes to a device scalar (epilogue of ``llark_gemm16_t_sumsq``) -- ``step(max_grad_norm=...)``
         only reduces what is left (norm gains, embedding rows) instead of re-reading all 27 GB of gradients.  (Single rank only: with
@@ -375,7 +380,17 @@ class HipLlamaTrainer:
         ops.gemm16(xf, None, eng.lm_head, None, V, ops.EPI_F32, c=logits)
         Vp = ops.round_up(V, 64)
         dlogits = torch.empty((rows, Vp), **bf)
-        loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale)
+        if loss_groups > 1:
+            assert B % loss_groups == 0, "loss_groups must divide the batch"
+            gb, lab = B // loss_groups, labels.to(dev)
+            lg = logits.view(B, S, V)
+            loss = None
+            for gi in range(loss_groups):
+                li = ops.cross_entropy_fwd_bwd(lg[gi * gb: (gi + 1) * gb], lab[gi * gb: (gi + 1) * gb], dlogits[gi * gb * S: (gi + 1) * gb * S], loss_scale)
+                loss = li if loss is None else loss + li
+            loss = loss / loss_groups
+        else:
+            loss = ops.cross_entropy_fwd_bwd(logits.view(B, S, V), labels.to(dev), dlogits, loss_scale)
         del logits
         # ---------------- backward ----------------
         if ev is not None:

@@ -219,6 +219,31 @@ def test_train_loop_schedule():
     assert losses[-1] < losses[1]
 
 
+def test_train_loop_fused_accumulation_follows_the_separate_micro_batches():
+    """TrainConfig.fuse_accumulation: the loop runs a step's micro-batches as one pass (engine sized for them) -- the logged losses track
+    the unfused loop's to the fp32-order differences a few optimizer steps amplify; an engine too small for the fused batch falls back to
+    separate passes (identical losses)."""
+    from llark_amd.m2t import AudioEncoderConfig
+    from llark_amd.m2t.engine import HipLlamaEngine
+    from llark_amd.m2t.train import TrainConfig, train
+    spec, w, ids, aud, labels, eng, segs = _setup(B=2)
+    ac = AudioEncoderConfig()
+    ac.audio_start_token, ac.audio_end_token, ac.audio_patch_token = spec.audio_start_token, spec.audio_end_token, spec.audio_patch_token
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids, dtype=torch.bool), audio_encodings=aud)
+    batch2 = dict(batch, input_ids=ids.flip(0), labels=labels.flip(0), audio_encodings=aud.flip(0))
+    stream = [batch, batch2] * 4
+
+    def run(fuse, max_batch):
+        e = HipLlamaEngine(eng.dims, "cuda", max_batch, eng.smax, precision="bf16")
+        e.load_state_dict(w)
+        return train(e, stream, ac, TrainConfig(learning_rate=2e-3, max_steps=20, gradient_accumulation_steps=2, fuse_accumulation=fuse), world=1)
+
+    base, fused, small = run(False, 2), run(True, 4), run(True, 2)
+    assert len(base) == len(fused) == 4 and small == base
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(base, fused)), (base, fused)
+    assert fused[-1] < fused[1]
+
+
 def test_checkpoint_resume_and_adapter_sidefile(tmp_path):
     """Save after 2 optimizer steps, resume in a NEW engine + trainer, take a 3rd step == 3 uninterrupted steps; the
     on-disk names are the reference's (full model + mm_projector side-file), old checkpoints are pruned."""
@@ -775,3 +800,32 @@ def test_rmsnorm_bwd_bf16_copy_equals_split16_of_its_dx(rows, width, accumulate)
     assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)          # per-workgroup partials meet in fp32 atomics: order varies run to run
     hi, _ = ops.split16(outs[1][0], torch.bfloat16, want_lo=False, kmult=64)
     assert torch.equal(outs[1][2], hi[:, :width])
+
+
+def test_fused_accumulation_equals_separate_micro_batches():
+    """``forward_backward(..., loss_groups=G)``: G of the recipe's micro-batches (train_llark.sh:26-27: per_device_train_batch_size 2 x
+    gradient_accumulation_steps 4) in ONE pass with the loss normalised per group = the gradients G separate calls accumulate (same
+    products, fp32 sums in a different order: 2e-3 relative per tensor against ~3e-2 for either against autograd), the same mean loss;
+    label counts differ between the groups, so a global token mean would NOT pass."""
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    spec, w, ids, aud, labels, eng, segs = _setup_long(S=72, B=4)
+    labels[2:, :40] = -100                                   # the second group has fewer label tokens than the first
+    toks = (spec.audio_start_token, spec.audio_end_token)
+    tr = HipLlamaTrainer(eng, lr=1e-2, weight_decay=0.0, embed_grad_tokens=toks)
+    losses = []
+    for gi in range(2):
+        sl = slice(2 * gi, 2 * gi + 2)
+        sg = [(b - 2 * gi, st, a) for (b, st, a) in segs[2 * gi: 2 * gi + 2]]
+        losses.append(tr.forward_backward(ids[sl].cuda(), sg, labels[sl].cuda(), 0.5).item())
+    sep = {k: v.float().clone() for k, v in tr.export_grads_hf().items()}
+    tr.zero_grad()
+    loss = tr.forward_backward(ids.cuda(), segs, labels.cuda(), 0.5, loss_groups=2).item()
+    assert abs(loss - 0.5 * (losses[0] + losses[1])) <= 1e-5 * abs(loss)
+    for name, gf in tr.export_grads_hf().items():
+        r = sep[name]
+        rel = ((gf.float() - r).norm() / (r.norm() + 1e-30)).item()
+        assert np.isfinite(rel) and rel <= 2e-3, f"{name}: rel {rel:.3e}"
+    tr.zero_grad()
+    glob = tr.forward_backward(ids.cuda(), segs, labels.cuda(), 1.0)          # one global token mean: a different gradient
+    rel = max(((gf.float() - sep[name]).norm() / (sep[name].norm() + 1e-30)).item() for name, gf in tr.export_grads_hf().items())
+    assert rel > 1e-2
