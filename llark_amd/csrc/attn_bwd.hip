@@ -147,15 +147,18 @@ __device__ __forceinline__ void store_dqkv_row(const AttnBwdFused& f, const f32x
     }
 }
 
-// Blocks -> (tile, batch*head): the 8 XCDs each take whole heads (one L2 sees one head's operands)
-__device__ __forceinline__ void block_to_tile(int nt, int nbh, int& tile, int& bhid) {
+// Blocks -> (pair index, batch*head): the 8 XCDs each take whole heads (one L2 sees one head's operands).  `paired`: a workgroup takes
+// TWO tiles of its head -- the p-th longest and the p-th shortest of the causal triangle: constant work per workgroup (one tile per
+// workgroup leaves the last-launched heads' long tiles running alone: 21 % over the balanced time at 64 heads x 32 tiles, 5 % at 256 heads,
+// scripts/sim_attn_order.py) -- else np = nt and the workgroup's only tile is the p-th longest.
+__device__ __forceinline__ void block_to_pair(int np, int nbh, int& pidx, int& bhid) {
     const int L = blockIdx.x;
     if ((nbh & 7) == 0) {
-        bhid = (L & 7) + 8 * (L / (8 * nt));
-        tile = (L >> 3) % nt;
+        bhid = (L & 7) + 8 * (L / (8 * np));
+        pidx = (L >> 3) % np;
     } else {
-        bhid = L / nt;
-        tile = L - bhid * nt;
+        bhid = L / np;
+        pidx = L - bhid * np;
     }
 }
 
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                            const bf16_t* __restrict__ dO,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            float* __restrict__ dk, float* __restrict__ dv, int S, int smax,
-                                                           int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f) {
+                                                           int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f, int paired) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two LDS stages of DKV_STAGE bytes: Q [64 q][128 d] | dO [64][128] | log-sum-exp [64] | rowsum(dO * O) [64].  Tile qt+1 streams in
     // by LDS-DMA while tile qt is computed: one barrier per tile.  The products that contract over the queries (dV^T = dO^T P,
@@ -191,10 +194,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
-    int tile, bhid;
-    block_to_tile((S + 64 * NK - 1) / (64 * NK), nbh, tile, bhid);               // key tile 0 has the most query tiles: dispatched first
+    const int nt = (S + 64 * NK - 1) / (64 * NK);
+    int pidx, bhid;
+    block_to_pair(paired ? (nt + 1) >> 1 : nt, nbh, pidx, bhid);                  // key tile 0 has the most query tiles: dispatched first
     const size_t bh = (size_t)bhid;
-    const int kb0 = tile * 64 * NK;
     const bf16_t* qb = q + bh * S * 128;
     const size_t ldo_ = (size_t)f.ld_do;                                 // 128: head-major dO; else token-major [(b*S + s)][ld_do], head at column 128 h
     const bf16_t* dob = f.ld_do == 128 ? dO + bh * S * 128 : dO + (size_t)(bhid / nh) * S * ldo_ + (size_t)(bhid % nh) * 128;
@@ -202,169 +205,176 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* vb = v_rm + bh * S * 128;
     const float* lb = lse + bh * S;
     const float* db = dsum + bh * S;
-    const int wk0 = kb0 + wv * 16 * NK;                                  // the wave's first key
     const float scale2 = scale * kLog2e;
     // ALiBi (MPT): the forward added slope_h * (key - (S - 1)) to the scaled scores; it has no gradient of its own
     const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
 
-    bf16x8_t kf[NK][4], vf[NK][4];       // B operands: column = key c of set u, d = ks*32 + g*8 .. +8
-#pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        int kr = wk0 + u * 16 + c;
-        kr = kr < S ? kr : S - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[u][ks] = *(const bf16x8_t*)(kb + (size_t)kr * 128 + ks * 32 + g * 8);
-            vf[u][ks] = *(const bf16x8_t*)(vb + (size_t)kr * 128 + ks * 32 + g * 8);
-        }
-    }
-    f32x4_t dka[NK][8], dva[NK][8];      // dK^T, dV^T: d = dt*16 + 4g + r, key c of set u
-#pragma unroll
-    for (int u = 0; u < NK; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) dka[u][dt] = dva[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int nqt = (S + 63) / 64;
-    const int qt0 = kb0 / 64;
-    auto stage = [&](int qt) __attribute__((always_inline)) {
-        const int q0 = qt * 64;
-        char* base = smem + ((qt - qt0) & 1) * DKV_STAGE;
-        if (q0 + 64 <= S) {
-            dma_rows(qb, q0, base, wv, lane);
-            dma_rows(dob, q0, base + 16384, wv, lane, ldo_);
-            if (wv == 0) {                                          // the 64 log-sum-exps and row sums: 4 B per lane
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb + q0 + lane),
-                                                 (__attribute__((address_space(3))) void*)(base + 32768), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + q0 + lane),
-                                                 (__attribute__((address_space(3))) void*)(base + 32768 + 256), 4, 0, 0);
-            }
-        } else {                                                    // the ragged last tile: through registers, zero-filled
-            stage_rows(qb, 128, q0, S, base);
-            stage_rows(dob, ldo_, q0, S, base + 16384);
-            if (threadIdx.x < 64) {
-                const int qi = q0 + threadIdx.x;
-                float* sl = (float*)(base + 32768);
-                sl[threadIdx.x] = qi < S ? lb[qi] : 0.0f;
-                sl[64 + threadIdx.x] = qi < S ? db[qi] : 0.0f;
-            }
-        }
-    };
-    if (qt0 < nqt) stage(qt0);
-    for (int qt = qt0; qt < nqt; ++qt) {
-        const int q0 = qt * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile qt has landed
-        __syncthreads();                                            // ... everybody's has, and tile qt-1 is fully consumed
-        if (qt + 1 < nqt) stage(qt + 1);
-        const char* sQ = smem + ((qt - qt0) & 1) * DKV_STAGE;
-        const char* sdO = sQ + 16384;
-        const float* sL = (const float*)(sQ + 32768);
-        const float* sD = sL + 64;
-        if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
-        const bool need_mask = q0 < wk0 + 16 * NK || q0 + 63 >= S;  // else every (query, key) pair of the tile is visible
-        // Software pipeline, pinned with scheduling barriers: the LDS fragment reads of a GROUP of MFMAs (8 b128 reads for the S and
-        // dP of one sub-tile, 8 transposing reads for 2 d tiles of dV^T and dK^T) are issued one group ahead, behind the MFMAs or
-        // the softmax arithmetic of the group before, so that an MFMA never waits for a read issued just in front of it.  (Left to
-        // itself the scheduler put every read directly before its MFMA to save registers: read, wait a full LDS round trip,
-        // multiply -- the matrix pipe was busy 25 % of the time, profiles/r03_pmc_attn_swz.txt.)  A masked score becomes -inf
-        // BEFORE the exponential: one select on the argument, no branch around v_exp_f32, one basic block per tile.
-        auto load_s = [&](int sub, bf16x8_t* qfr, bf16x8_t* dfr) __attribute__((always_inline)) {
-#pragma unroll
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int tile = pass == 0 ? pidx : nt - 1 - pidx;
+        if (pass == 1 && (!paired || tile == pidx)) break;            // odd tile count: the middle tile stands alone
+        if (pass == 1) __syncthreads();                                 // every wave is done with the first tile's last stage
+        const int kb0 = tile * 64 * NK;
+        const int wk0 = kb0 + wv * 16 * NK;                                  // the wave's first key
+        bf16x8_t kf[NK][4], vf[NK][4];       // B operands: column = key c of set u, d = ks*32 + g*8 .. +8
+    #pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            int kr = wk0 + u * 16 + c;
+            kr = kr < S ? kr : S - 1;
+    #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                qfr[ks] = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
-                dfr[ks] = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
-            }
-        };
-        auto mma_s = [&](const bf16x8_t* qfr, const bf16x8_t* dfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int u = 0; u < NK; ++u) {
-                    sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[ks], kf[u][ks], sa[u], 0, 0, 0);
-                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[ks], vf[u][ks], dp[u], 0, 0, 0);
-                }
-            }
-        };
-        auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* pf, bf16x8_t* sf) __attribute__((always_inline)) {
-            const int ql = 32 * p + 8 * g + 4 * hb;                  // this lane's 4 query rows: ql .. ql + 3
-            const float4 l4 = *(const float4*)(sL + ql);
-            const float4 d4 = *(const float4*)(sD + ql);
-            const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-            for (int u = 0; u < NK; ++u) {
-                const int key = wk0 + u * 16 + c;
-                const float bias2 = slope2 * (float)(key - (S - 1));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int qa = q0 + ql + r;
-                    const bool ok = !need_mask || (qa < S && key <= qa);
-                    const float x = sa[u][r] * scale2 + bias2 - lr[r];
-                    const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
-                    pf[u][hb * 4 + r] = pb;
-                    sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
-                }
-            }
-        };
-        auto load_t = [&](int p, int h, bf16x8_t* dof, bf16x8_t* qtf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                dof[j] = tr_frag(sdO, 32 * p, (2 * h + j) * 16, g, c);     // dO^T rows d = dt*16 + c, queries 32p + 8g ..
-                qtf[j] = tr_frag(sQ, 32 * p, (2 * h + j) * 16, g, c);      // Q^T
-            }
-        };
-        auto mma_t = [&](int h, const bf16x8_t* dof, const bf16x8_t* qtf, const bf16x8_t* pf, const bf16x8_t* sf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int u = 0; u < NK; ++u) {
-                    dva[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[j], pf[u], dva[u][2 * h + j], 0, 0, 0);
-                    dka[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[j], sf[u], dka[u][2 * h + j], 0, 0, 0);
-                }
-            }
-        };
-        bf16x8_t qA[4], dA[4], qB[4], dB[4];
-        load_s(0, qA, dA);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            bf16x8_t pf[NK], sf[NK];
-            f32x4_t sa0[NK], dp0[NK], sa1[NK], dp1[NK];
-            bf16x8_t tdo[2][2], tq[2][2];
-            mma_s(qA, dA, sa0, dp0);
-            load_s(2 * p + 1, qB, dB);
-            __builtin_amdgcn_sched_barrier(0);
-            softmax(p, 0, sa0, dp0, pf, sf);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_s(qB, dB, sa1, dp1);
-            load_t(p, 0, tdo[0], tq[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            softmax(p, 1, sa1, dp1, pf, sf);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (h < 3) load_t(p, h + 1, tdo[(h + 1) & 1], tq[(h + 1) & 1]);
-                else if (p == 0) load_s(2, qA, dA);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_t(h, tdo[h & 1], tq[h & 1], pf, sf);
-                __builtin_amdgcn_sched_barrier(0);
+                kf[u][ks] = *(const bf16x8_t*)(kb + (size_t)kr * 128 + ks * 32 + g * 8);
+                vf[u][ks] = *(const bf16x8_t*)(vb + (size_t)kr * 128 + ks * 32 + g * 8);
             }
         }
-    }
-#pragma unroll
-    for (int u = 0; u < NK; ++u) {
-        const int key = wk0 + u * 16 + c;
-        if (key >= S) continue;
-        if (f.dqkv != nullptr) {
-            store_dqkv_row(f, dka[u], 1, bhid / nh, bhid % nh, nh, S, key, g);
-            store_dqkv_row(f, dva[u], 2, bhid / nh, bhid % nh, nh, S, key, g);
-            continue;
+        f32x4_t dka[NK][8], dva[NK][8];      // dK^T, dV^T: d = dt*16 + 4g + r, key c of set u
+    #pragma unroll
+        for (int u = 0; u < NK; ++u)
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) dka[u][dt] = dva[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int nqt = (S + 63) / 64;
+        const int qt0 = kb0 / 64;
+        auto stage = [&](int qt) __attribute__((always_inline)) {
+            const int q0 = qt * 64;
+            char* base = smem + ((qt - qt0) & 1) * DKV_STAGE;
+            if (q0 + 64 <= S) {
+                dma_rows(qb, q0, base, wv, lane);
+                dma_rows(dob, q0, base + 16384, wv, lane, ldo_);
+                if (wv == 0) {                                          // the 64 log-sum-exps and row sums: 4 B per lane
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(lb + q0 + lane),
+                                                     (__attribute__((address_space(3))) void*)(base + 32768), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + q0 + lane),
+                                                     (__attribute__((address_space(3))) void*)(base + 32768 + 256), 4, 0, 0);
+                }
+            } else {                                                    // the ragged last tile: through registers, zero-filled
+                stage_rows(qb, 128, q0, S, base);
+                stage_rows(dob, ldo_, q0, S, base + 16384);
+                if (threadIdx.x < 64) {
+                    const int qi = q0 + threadIdx.x;
+                    float* sl = (float*)(base + 32768);
+                    sl[threadIdx.x] = qi < S ? lb[qi] : 0.0f;
+                    sl[64 + threadIdx.x] = qi < S ? db[qi] : 0.0f;
+                }
+            }
+        };
+        if (qt0 < nqt) stage(qt0);
+        for (int qt = qt0; qt < nqt; ++qt) {
+            const int q0 = qt * 64;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of tile qt has landed
+            __syncthreads();                                            // ... everybody's has, and tile qt-1 is fully consumed
+            if (qt + 1 < nqt) stage(qt + 1);
+            const char* sQ = smem + ((qt - qt0) & 1) * DKV_STAGE;
+            const char* sdO = sQ + 16384;
+            const float* sL = (const float*)(sQ + 32768);
+            const float* sD = sL + 64;
+            if (wk0 > q0 + 63) continue;                                // every query of the tile precedes the wave's keys
+            const bool need_mask = q0 < wk0 + 16 * NK || q0 + 63 >= S;  // else every (query, key) pair of the tile is visible
+            // Software pipeline, pinned with scheduling barriers: the LDS fragment reads of a GROUP of MFMAs (8 b128 reads for the S and
+            // dP of one sub-tile, 8 transposing reads for 2 d tiles of dV^T and dK^T) are issued one group ahead, behind the MFMAs or
+            // the softmax arithmetic of the group before, so that an MFMA never waits for a read issued just in front of it.  (Left to
+            // itself the scheduler put every read directly before its MFMA to save registers: read, wait a full LDS round trip,
+            // multiply -- the matrix pipe was busy 25 % of the time, profiles/r03_pmc_attn_swz.txt.)  A masked score becomes -inf
+            // BEFORE the exponential: one select on the argument, no branch around v_exp_f32, one basic block per tile.
+            auto load_s = [&](int sub, bf16x8_t* qfr, bf16x8_t* dfr) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    qfr[ks] = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
+                    dfr[ks] = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
+                }
+            };
+            auto mma_s = [&](const bf16x8_t* qfr, const bf16x8_t* dfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+    #pragma unroll
+                    for (int u = 0; u < NK; ++u) {
+                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[ks], kf[u][ks], sa[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[ks], vf[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+            };
+            auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* pf, bf16x8_t* sf) __attribute__((always_inline)) {
+                const int ql = 32 * p + 8 * g + 4 * hb;                  // this lane's 4 query rows: ql .. ql + 3
+                const float4 l4 = *(const float4*)(sL + ql);
+                const float4 d4 = *(const float4*)(sD + ql);
+                const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+    #pragma unroll
+                for (int u = 0; u < NK; ++u) {
+                    const int key = wk0 + u * 16 + c;
+                    const float bias2 = slope2 * (float)(key - (S - 1));
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qa = q0 + ql + r;
+                        const bool ok = !need_mask || (qa < S && key <= qa);
+                        const float x = sa[u][r] * scale2 + bias2 - lr[r];
+                        const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
+                        pf[u][hb * 4 + r] = pb;
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
+                    }
+                }
+            };
+            auto load_t = [&](int p, int h, bf16x8_t* dof, bf16x8_t* qtf) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    dof[j] = tr_frag(sdO, 32 * p, (2 * h + j) * 16, g, c);     // dO^T rows d = dt*16 + c, queries 32p + 8g ..
+                    qtf[j] = tr_frag(sQ, 32 * p, (2 * h + j) * 16, g, c);      // Q^T
+                }
+            };
+            auto mma_t = [&](int h, const bf16x8_t* dof, const bf16x8_t* qtf, const bf16x8_t* pf, const bf16x8_t* sf) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int j = 0; j < 2; ++j) {
+    #pragma unroll
+                    for (int u = 0; u < NK; ++u) {
+                        dva[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[j], pf[u], dva[u][2 * h + j], 0, 0, 0);
+                        dka[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[j], sf[u], dka[u][2 * h + j], 0, 0, 0);
+                    }
+                }
+            };
+            bf16x8_t qA[4], dA[4], qB[4], dB[4];
+            load_s(0, qA, dA);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                bf16x8_t pf[NK], sf[NK];
+                f32x4_t sa0[NK], dp0[NK], sa1[NK], dp1[NK];
+                bf16x8_t tdo[2][2], tq[2][2];
+                mma_s(qA, dA, sa0, dp0);
+                load_s(2 * p + 1, qB, dB);
+                __builtin_amdgcn_sched_barrier(0);
+                softmax(p, 0, sa0, dp0, pf, sf);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_s(qB, dB, sa1, dp1);
+                load_t(p, 0, tdo[0], tq[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                softmax(p, 1, sa1, dp1, pf, sf);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    if (h < 3) load_t(p, h + 1, tdo[(h + 1) & 1], tq[(h + 1) & 1]);
+                    else if (p == 0) load_s(2, qA, dA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_t(h, tdo[h & 1], tq[h & 1], pf, sf);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-        float* ko = dk + (bh * S + key) * 128 + 4 * g;
-        float* vo = dv + (bh * S + key) * 128 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            *(f32x4_t*)(ko + dt * 16) = dka[u][dt];
-            *(f32x4_t*)(vo + dt * 16) = dva[u][dt];
+    #pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int key = wk0 + u * 16 + c;
+            if (key >= S) continue;
+            if (f.dqkv != nullptr) {
+                store_dqkv_row(f, dka[u], 1, bhid / nh, bhid % nh, nh, S, key, g);
+                store_dqkv_row(f, dva[u], 2, bhid / nh, bhid % nh, nh, S, key, g);
+                continue;
+            }
+            float* ko = dk + (bh * S + key) * 128 + 4 * g;
+            float* vo = dv + (bh * S + key) * 128 + 4 * g;
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                *(f32x4_t*)(ko + dt * 16) = dka[u][dt];
+                *(f32x4_t*)(vo + dt * 16) = dva[u][dt];
+            }
         }
     }
 }
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                           const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
                                                           const float* __restrict__ dsum, float* __restrict__ dq, int S,
-                                                          int smax, int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f) {
+                                                          int smax, int nbh, int nh, float scale, const float* __restrict__ alibi, const AttnBwdFused f, int paired) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // two LDS stages of 32 KiB: K [64 keys][128 d] | V [64][128]; tile kt+1 streams in by LDS-DMA while tile kt is computed.
     // dQ^T = K^T dS^T reads its A operand (row = d, contraction over the keys) from the row-major K tile through tr_frag.
@@ -386,145 +396,150 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int nt = (S + 64 * NQ - 1) / (64 * NQ);
-    int tile, bhid;
-    block_to_tile(nt, nbh, tile, bhid);
-    tile = nt - 1 - tile;                                           // the query tiles with the most keys first
+    int pidx, bhid;
+    block_to_pair(paired ? (nt + 1) >> 1 : nt, nbh, pidx, bhid);
     const size_t bh = (size_t)bhid;
-    const int q0 = tile * 64 * NQ;
     const bf16_t* qb = q + bh * S * 128;
     const size_t ldo_ = (size_t)f.ld_do;                                 // 128: head-major dO; else token-major [(b*S + s)][ld_do], head at column 128 h
     const bf16_t* dob = f.ld_do == 128 ? dO + bh * S * 128 : dO + (size_t)(bhid / nh) * S * ldo_ + (size_t)(bhid % nh) * 128;
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
-    const int wq0 = q0 + wv * 16 * NQ;
     const float scale2 = scale * kLog2e;
     const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
 
-    bf16x8_t qf[NQ][4], df[NQ][4];       // B operands: column = query c of set u
-    float l2[NQ], dd[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int qi = wq0 + u * 16 + c;
-        const int qr = qi < S ? qi : S - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
-            df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * ldo_ + ks * 32 + g * 8);
-        }
-        l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
-        dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
-    }
-    f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
-#pragma unroll
-    for (int u = 0; u < NQ; ++u)
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) dqa[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    int last_key = q0 + 64 * NQ - 1;
-    if (last_key > S - 1) last_key = S - 1;
-    const int nkt = last_key / 64 + 1;
-    auto stage = [&](int kt) __attribute__((always_inline)) {
-        const int key0 = kt * 64;
-        char* base = smem + (kt & 1) * DQ_STAGE;
-        if (key0 + 64 <= S) {
-            dma_rows(kb, key0, base, wv, lane);
-            dma_rows(vb, key0, base + 16384, wv, lane);
-        } else {
-            stage_rows(kb, 128, key0, S, base);
-            stage_rows(vb, 128, key0, S, base + 16384);
-        }
-    };
-    stage(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int key0 = kt * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nkt) stage(kt + 1);
-        const char* sK = smem + (kt & 1) * DQ_STAGE;
-        const char* sV = sK + 16384;
-        if (key0 > wq0 + 16 * NQ - 1) continue;                              // every key of the tile is beyond the wave's queries
-        const bool need_mask = key0 + 63 > wq0 || wq0 + 16 * NQ - 1 >= S;    // else every (query, key) pair of the tile is visible
-        // the same software pipeline as the dK / dV kernel: fragment reads one group of MFMAs ahead, pinned with scheduling barriers
-        auto load_s = [&](int sub, bf16x8_t* kfr, bf16x8_t* vfr) __attribute__((always_inline)) {
-#pragma unroll
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int tile = pass == 0 ? nt - 1 - pidx : pidx;            // the query tiles with the most keys first
+        if (pass == 1 && (!paired || tile == nt - 1 - pidx)) break;   // odd tile count: the middle tile stands alone
+        if (pass == 1) __syncthreads();
+        const int q0 = tile * 64 * NQ;
+        const int wq0 = q0 + wv * 16 * NQ;
+        bf16x8_t qf[NQ][4], df[NQ][4];       // B operands: column = query c of set u
+        float l2[NQ], dd[NQ];
+    #pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int qi = wq0 + u * 16 + c;
+            const int qr = qi < S ? qi : S - 1;
+    #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                kfr[ks] = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
-                vfr[ks] = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
+                qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+                df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * ldo_ + ks * 32 + g * 8);
+            }
+            l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
+            dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
+        }
+        f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
+    #pragma unroll
+        for (int u = 0; u < NQ; ++u)
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) dqa[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int last_key = q0 + 64 * NQ - 1;
+        if (last_key > S - 1) last_key = S - 1;
+        const int nkt = last_key / 64 + 1;
+        auto stage = [&](int kt) __attribute__((always_inline)) {
+            const int key0 = kt * 64;
+            char* base = smem + (kt & 1) * DQ_STAGE;
+            if (key0 + 64 <= S) {
+                dma_rows(kb, key0, base, wv, lane);
+                dma_rows(vb, key0, base + 16384, wv, lane);
+            } else {
+                stage_rows(kb, 128, key0, S, base);
+                stage_rows(vb, 128, key0, S, base + 16384);
             }
         };
-        auto mma_s = [&](const bf16x8_t* kfr, const bf16x8_t* vfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
+        stage(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int key0 = kt * 64;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nkt) stage(kt + 1);
+            const char* sK = smem + (kt & 1) * DQ_STAGE;
+            const char* sV = sK + 16384;
+            if (key0 > wq0 + 16 * NQ - 1) continue;                              // every key of the tile is beyond the wave's queries
+            const bool need_mask = key0 + 63 > wq0 || wq0 + 16 * NQ - 1 >= S;    // else every (query, key) pair of the tile is visible
+            // the same software pipeline as the dK / dV kernel: fragment reads one group of MFMAs ahead, pinned with scheduling barriers
+            auto load_s = [&](int sub, bf16x8_t* kfr, bf16x8_t* vfr) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    kfr[ks] = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
+                    vfr[ks] = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
+                }
+            };
+            auto mma_s = [&](const bf16x8_t* kfr, const bf16x8_t* vfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+    #pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks], qf[u][ks], sa[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks], df[u][ks], dp[u], 0, 0, 0);
+                    }
+                }
+            };
+            auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* sf) __attribute__((always_inline)) {
+                const int kl = key0 + 32 * p + 8 * g + 4 * hb;               // this lane's 4 key rows: kl .. kl + 3
+    #pragma unroll
                 for (int u = 0; u < NQ; ++u) {
-                    sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks], qf[u][ks], sa[u], 0, 0, 0);
-                    dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks], df[u][ks], dp[u], 0, 0, 0);
+                    const int qa = wq0 + u * 16 + c;
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = !need_mask || (qa < S && kl + r <= qa);
+                        const float x = sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u];
+                        const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
+                    }
                 }
-            }
-        };
-        auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* sf) __attribute__((always_inline)) {
-            const int kl = key0 + 32 * p + 8 * g + 4 * hb;               // this lane's 4 key rows: kl .. kl + 3
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) {
-                const int qa = wq0 + u * 16 + c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = !need_mask || (qa < S && kl + r <= qa);
-                    const float x = sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u];
-                    const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
-                    sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
+            };
+            auto load_t = [&](int p, int h, bf16x8_t* ktf) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
+            };
+            auto mma_t = [&](int h, const bf16x8_t* ktf, const bf16x8_t* sf) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                    for (int u = 0; u < NQ; ++u) dqa[u][4 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[j], sf[u], dqa[u][4 * h + j], 0, 0, 0);
                 }
+            };
+            bf16x8_t kA[4], vA[4], kB[4], vB[4];
+            load_s(0, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                bf16x8_t sf[NQ];
+                f32x4_t sa0[NQ], dp0[NQ], sa1[NQ], dp1[NQ];
+                bf16x8_t t0[4], t1[4];
+                mma_s(kA, vA, sa0, dp0);
+                load_s(2 * p + 1, kB, vB);
+                __builtin_amdgcn_sched_barrier(0);
+                softmax(p, 0, sa0, dp0, sf);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_s(kB, vB, sa1, dp1);
+                load_t(p, 0, t0);
+                __builtin_amdgcn_sched_barrier(0);
+                softmax(p, 1, sa1, dp1, sf);
+                load_t(p, 1, t1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_t(0, t0, sf);
+                if (p == 0) load_s(2, kA, vA);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_t(1, t1, sf);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        };
-        auto load_t = [&](int p, int h, bf16x8_t* ktf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
-        };
-        auto mma_t = [&](int h, const bf16x8_t* ktf, const bf16x8_t* sf) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) dqa[u][4 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[j], sf[u], dqa[u][4 * h + j], 0, 0, 0);
+        }
+    #pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int qi = wq0 + u * 16 + c;
+            if (qi >= S) continue;
+            if (f.dqkv != nullptr) {
+                store_dqkv_row(f, dqa[u], 0, bhid / nh, bhid % nh, nh, S, qi, g);
+                continue;
             }
-        };
-        bf16x8_t kA[4], vA[4], kB[4], vB[4];
-        load_s(0, kA, vA);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            bf16x8_t sf[NQ];
-            f32x4_t sa0[NQ], dp0[NQ], sa1[NQ], dp1[NQ];
-            bf16x8_t t0[4], t1[4];
-            mma_s(kA, vA, sa0, dp0);
-            load_s(2 * p + 1, kB, vB);
-            __builtin_amdgcn_sched_barrier(0);
-            softmax(p, 0, sa0, dp0, sf);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_s(kB, vB, sa1, dp1);
-            load_t(p, 0, t0);
-            __builtin_amdgcn_sched_barrier(0);
-            softmax(p, 1, sa1, dp1, sf);
-            load_t(p, 1, t1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_t(0, t0, sf);
-            if (p == 0) load_s(2, kA, vA);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_t(1, t1, sf);
-            __builtin_amdgcn_sched_barrier(0);
+            float* o = dq + (bh * S + qi) * 128 + 4 * g;
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) *(f32x4_t*)(o + dt * 16) = dqa[u][dt];
         }
-    }
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int qi = wq0 + u * 16 + c;
-        if (qi >= S) continue;
-        if (f.dqkv != nullptr) {
-            store_dqkv_row(f, dqa[u], 0, bhid / nh, bhid % nh, nh, S, qi, g);
-            continue;
-        }
-        float* o = dq + (bh * S + qi) * 128 + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) *(f32x4_t*)(o + dt * 16) = dqa[u][dt];
     }
 }
 
@@ -545,15 +560,22 @@ static int attn_backward_impl(const void* q, const void* k_cache, const void* v_
     const long rows = (long)batch * nh * s;
     attn_bwd_rowdot_kernel<<<cdiv(rows, 4), 256, 0, st>>>((const bf16_t*)dO, (const bf16_t*)o, dsum, s, nh, rows, f.ld_do);
     const int nbh = batch * nh;
-    const int grid = cdiv(s, 64 * DQ_NQ) * nbh;
+    // tiles in pairs (block_to_pair) when the halved grid still fills the 512 workgroup slots of the chip evenly: at least four rounds, or
+    // exactly one or two
+    auto grid_of = [&](int nt, int& paired) {
+        const long wgs = (long)((nt + 1) / 2) * nbh;
+        paired = nt >= 2 && (wgs >= 2048 || wgs == 512 || wgs == 1024);
+        return (paired ? (nt + 1) / 2 : nt) * nbh;
+    };
+    int pkv = 0, pq = 0;
+    const int grid_kv = grid_of(cdiv(s, 64 * DKV_NK), pkv), grid_q = grid_of(cdiv(s, 64 * DQ_NQ), pq);
     const int lds_kv = 2 * (32768 + 512), lds_q = 2 * 32768;
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attn_bwd_dkv_kernel<DKV_NK><<<cdiv(s, 64 * DKV_NK) * nbh, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm,
-                                                                               (const bf16_t*)dO, lse, dsum, dk, dv, s, smax, nbh, nh, scale,
-                                                                               alibi_slopes, f);
-    attn_bwd_dq_kernel<DQ_NQ><<<grid, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
-                                                 dq, s, smax, nbh, nh, scale, alibi_slopes, f);
+    attn_bwd_dkv_kernel<DKV_NK><<<grid_kv, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
+                                                           dk, dv, s, smax, nbh, nh, scale, alibi_slopes, f, pkv);
+    attn_bwd_dq_kernel<DQ_NQ><<<grid_q, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
+                                                       dq, s, smax, nbh, nh, scale, alibi_slopes, f, pq);
     return check_launch("attn_backward");
 }
 

@@ -174,14 +174,21 @@ __device__ __forceinline__ int sub_row(int sub, int i) { return ((sub >> 1) << 5
 // P2 = p enters the second product as bf16 hi+lo planes (16 significant bits: finer than the reference's bf16 probabilities);
 // !P2 (the training forward) = p rounded to bf16 once, the reference's bf16 flow (modeling_llama.py: softmax(fp32).to(query
 // dtype)) and the same p the backward recomputes.
-template <bool SPLIT, int NQ, bool P2>
+#ifndef ATTN_PREFILL_SM2
+#define ATTN_PREFILL_SM2 1        // the training forward's softmax in fewer instructions (see SM2 in the kernel)
+#endif
+#ifndef ATTN_PREFILL_PF
+#define ATTN_PREFILL_PF 3         // plain bf16 operands: K / V^T fragments requested ahead of their products (see PF in the kernel)
+#endif
+template <bool SPLIT, int NQ, bool P2, bool ALIBI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 && !SPLIT) ? 3 : 2, (NQ == 1 && !SPLIT) ? 3 : 2))) void attn_prefill_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                            const bf16_t* __restrict__ vtc, const bf16_t* __restrict__ q_lo,
                                                            const bf16_t* __restrict__ kc_lo, const bf16_t* __restrict__ vtc_lo,
                                                            bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo,
                                                            int S, int nh, int nbh, int past, int smax, float scale,
-                                                           const float* __restrict__ alibi, float* __restrict__ lse) {
+                                                           const float* __restrict__ alibi_arg, float* __restrict__ lse, int paired) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* alibi = ALIBI ? alibi_arg : nullptr;               // compile-time: the Llama instantiations carry no ALiBi code
     // LDS: per stage K [64][128] 16 KiB + V^T [128][64] 16 KiB; !SPLIT two stages, SPLIT one stage + the lo planes
     char* sKl = smem + 32768;        // SPLIT only: lo planes of K and V^T
     char* sVl = smem + 49152;
@@ -191,20 +198,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int nt = (S + BQ - 1) / BQ;
-    int tile, bhid;
+    // A workgroup takes TWO query blocks of one (batch, head): block nt - 1 - pidx (many keys) and then block pidx (few): every workgroup
+    // does the same 2 nt + 2 key tiles of work -- with one causal block per workgroup the last-launched heads' long blocks ran alone
+    // (53 % over the balanced time at 64 heads x 16 blocks, 13 % at 256 heads: scripts/sim_attn_order.py) -- and both blocks read the
+    // same head's K / V (one L2 sees one head).
+    const int np = paired ? (nt + 1) >> 1 : nt;                     // (launcher: pairs only when they still fill the chip evenly)
+    int pidx, bhid;
     {
         const int L = blockIdx.x;
         if ((nbh & 7) == 0) {
-            bhid = (L & 7) + 8 * (L / (8 * nt));
-            tile = (L >> 3) % nt;
+            bhid = (L & 7) + 8 * (L / (8 * np));
+            pidx = (L >> 3) % np;
         } else {
-            bhid = L / nt;
-            tile = L - bhid * nt;
+            bhid = L / np;
+            pidx = L - bhid * np;
         }
-        tile = nt - 1 - tile;
     }
     const int b = bhid / nh, h = bhid - b * nh;
-    const int q0 = tile * BQ;
     const int total = past + S;                                     // keys available
     // ALiBi (MPT, m2t/llava/model/mpt/attention.py build_alibi_bias): additive bias slope_h * (key - (total - 1))
     const float slope2 = alibi ? alibi[h] * LOG2E : 0.0f;
@@ -215,33 +225,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
     const bf16_t* vb = vtc + bh * (size_t)128 * smax;
     const bf16_t* kbl = SPLIT ? kc_lo + bh * (size_t)smax * 128 : nullptr;
     const bf16_t* vbl = SPLIT ? vtc_lo + bh * (size_t)128 * smax : nullptr;
-    const int wq0 = q0 + wv * 16 * NQ;                              // the wave's first query
-
-    // Q fragments (B operand): column = query c of set u, d = ks*32 + g*8 .. +8
-    bf16x8_t qf[NQ][4], ql[SPLIT ? NQ : 1][4];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        int qr = wq0 + u * 16 + c;
-        qr = qr < S ? qr : S - 1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
-            if (SPLIT) ql[u][ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
-        }
-    }
-    f32x4_t o[NQ][8];                                               // O^T: d = dt*16 + 4g + r, query c
-    float m_run[NQ], l_run[NQ];
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) o[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        m_run[u] = -INFINITY;
-        l_run[u] = 0.0f;
-    }
-
-    int last_key = past + q0 + BQ - 1;                              // last key any query of this block may see
-    if (last_key > total - 1) last_key = total - 1;
-    const int ntiles = last_key / 64 + 1;
 
     // ---- staging.  !SPLIT: two LDS stages; tile kt+1 streams global -> LDS (LDS-DMA, no registers) while tile kt is computed,
     //      one barrier per tile.  The DMA image is lane-linear, so lane i of the instruction that covers rows 4j..4j+3 of K
@@ -250,10 +233,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
     //      SPLIT (64 KiB of planes per tile): one stage, registers, two barriers -- two workgroups per CU cover each other.
     constexpr int NST = SPLIT ? 1 : 2;
     constexpr int STAGE_BYTES = 32768;
+    // (both staging forms rebuild their per-lane addresses from a laundered thread index every tile: ~30 VALU instructions, against the
+    //  20-odd registers the hoisted addresses otherwise hold across the whole kernel -- spills, with two query blocks per workgroup)
     auto stage_regs = [&](const bf16_t* kbase, const bf16_t* vbase, char* dK, char* dV, int key0) __attribute__((always_inline)) {
+        int tid_ = threadIdx.x;
+        if constexpr (!SPLIT) asm volatile("" : "+v"(tid_));          // (the hi + lo kernels have the registers: 142 of 256)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int idx = threadIdx.x + i * 256;                  // 1024 16-B chunks each
+            const int idx = tid_ + i * 256;                         // 1024 16-B chunks each
             {
                 const int key = idx >> 4, ch = idx & 15;
                 uint4 val = make_uint4(0, 0, 0, 0);
@@ -278,6 +265,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
         }
     };
     auto stage_dma = [&](char* dK, char* dV, int key0) __attribute__((always_inline)) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = wv * 4 + i;                                // this wave's 1 KiB pieces of each 16 KiB tile
@@ -304,136 +293,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             }
         }
     };
-    if (NST == 2) stage(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * 64;
-        if (NST == 2) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile kt has landed
-            __syncthreads();                                        // ... everybody's has, and tile kt-1 is fully consumed
-            if (kt + 1 < ntiles) stage(kt + 1);
-        } else {
-            __syncthreads();                                        // previous tile fully consumed
-            stage(kt);
-            __syncthreads();
-        }
-        const char* sK = smem + (NST == 2 ? (kt & 1) * STAGE_BYTES : 0);
-        const char* sV = sK + 16384;
-        if (key0 > past + wq0 + 16 * NQ - 1) continue;              // every key of the tile is beyond the wave's queries
-        // ---- S^T = K Q^T : 4 key sub-tiles x 4 k-steps, for each query set ----
-        f32x4_t st[NQ][4];
-#pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-#pragma unroll
-            for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), ks * 4 + g));
-                bf16x8_t kfl;
-                if (SPLIT) kfl = *(const bf16x8_t*)(sKl + k_off(sub_row(sub, c), ks * 4 + g));
-#pragma unroll
-                for (int u = 0; u < NQ; ++u) {
-                    st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][sub], 0, 0, 0);
-                    if (SPLIT) {
-                        st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[u][ks], st[u][sub], 0, 0, 0);
-                        st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[u][ks], st[u][sub], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        // ---- mask + online softmax: this lane owns query c of each set; rows are keys sub_row(sub, 4g + r) ----
-        // tiles entirely below the diagonal of every query of the wave (and inside `total`) need no mask: wave-uniform test
-        const bool need_mask = key0 + 63 > past + wq0 || key0 + 63 >= total;
-        bf16x8_t ph[NQ][2], pl[P2 ? NQ : 1][2];
-#pragma unroll
+#pragma nounroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int tile = pass == 0 ? nt - 1 - pidx : pidx;
+        if (pass == 1 && (!paired || tile == nt - 1 - pidx)) break; // odd block count: the middle block stands alone
+        if (pass == 1) __syncthreads();                               // every wave is done with the first block's last K / V tile
+        const int q0 = tile * BQ;
+        const int wq0 = q0 + wv * 16 * NQ;                          // the wave's first query
+        // Q fragments (B operand): column = query c of set u, d = ks*32 + g*8 .. +8
+        bf16x8_t qf[NQ][4], ql[SPLIT ? NQ : 1][4];
+    #pragma unroll
         for (int u = 0; u < NQ; ++u) {
-            const int lim = past + wq0 + u * 16 + c;                 // last visible key of this lane's query
-            float mloc = -INFINITY;
-            if (need_mask || alibi) {
-#pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = key0 + sub_row(sub, 4 * g + r);
-                        float sv = st[u][sub][r] * scale2;
-                        if (alibi) sv += slope2 * (float)(key - (total - 1));
-                        if (key > lim || key >= total) sv = -INFINITY;
-                        st[u][sub][r] = sv;
-                        mloc = fmaxf(mloc, sv);
-                    }
+            int qr = wq0 + u * 16 + c;
+            qr = qr < S ? qr : S - 1;
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
+                if (SPLIT) ql[u][ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
+            }
+        }
+        f32x4_t o[NQ][8];                                               // O^T: d = dt*16 + 4g + r, query c
+        float m_run[NQ], l_run[NQ];
+    #pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) o[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            m_run[u] = -INFINITY;
+            l_run[u] = 0.0f;
+        }
+
+        int last_key = past + q0 + BQ - 1;                              // last key any query of this block may see
+        if (last_key > total - 1) last_key = total - 1;
+        const int ntiles = last_key / 64 + 1;
+
+        if (NST == 2) stage(0);
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int key0 = kt * 64;
+            if (NST == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of tile kt has landed
+                __syncthreads();                                        // ... everybody's has, and tile kt-1 is fully consumed
+                if (kt + 1 < ntiles) stage(kt + 1);
             } else {
-#pragma unroll
-                for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        st[u][sub][r] *= scale2;
-                        mloc = fmaxf(mloc, st[u][sub][r]);
+                __syncthreads();                                        // previous tile fully consumed
+                stage(kt);
+                __syncthreads();
+            }
+            const char* sK = smem + (NST == 2 ? (kt & 1) * STAGE_BYTES : 0);
+            const char* sV = sK + 16384;
+            if (key0 > past + wq0 + 16 * NQ - 1) continue;              // every key of the tile is beyond the wave's queries
+            // ---- S^T = K Q^T : 4 key sub-tiles x 4 k-steps, for each query set ----
+            f32x4_t st[NQ][4];
+            // PF (plain bf16 operands): all 16 K fragments are requested before the first MFMA -- one exposed LDS latency per tile instead of one
+            // per k-step (the compiler's order: read, wait, two MFMAs, 16 times: 8 s_waitcnt per product in the ISA) -- and the 16 V^T fragments
+            // of the second product are requested BEFORE the softmax, whose ~260 VALU instructions cover their latency.  Same arithmetic.
+            constexpr bool PF = !SPLIT && !ALIBI && (ATTN_PREFILL_PF & 1), PFV = !SPLIT && !ALIBI && NQ == 2 && (ATTN_PREFILL_PF & 2);   // (one query set: 168 registers at three waves per SIMD)
+            bf16x8_t vfa[PFV ? 8 : 1];
+            if constexpr (PF) {
+                // k-step outermost: the 4 x NQ accumulators of a k-step are independent (the sub-tile-outermost order chains dependent MFMAs two
+                // apart and hipcc schedules three of them back to back), and the next k-step's four fragments are read under this one's MFMAs
+                bf16x8_t kfa[2][4];
+    #pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    kfa[0][sub] = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), g));
+    #pragma unroll
+                    for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ks < 3) {
+    #pragma unroll
+                        for (int sub = 0; sub < 4; ++sub) kfa[(ks + 1) & 1][sub] = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), (ks + 1) * 4 + g));
                     }
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float mn = fmaxf(m_run[u], mloc);
-            const bool dead = mn == -INFINITY;
-            const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
-            float rs = 0.0f;
-#pragma unroll
-            for (int sub = 0; sub < 4; ++sub)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(st[u][sub][r] - mn);
-                    rs += pv;
-                    const bf16_t pb = (bf16_t)pv;
-                    ph[u][sub >> 1][(sub & 1) * 4 + r] = pb;
-                    if (P2) pl[u][sub >> 1][(sub & 1) * 4 + r] = (bf16_t)(pv - (float)pb);
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                        for (int u = 0; u < NQ; ++u) st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfa[ks & 1][sub], qf[u][ks], st[u][sub], 0, 0, 0);
                 }
-            rs += __shfl_xor(rs, 16, 64);
-            rs += __shfl_xor(rs, 32, 64);
-            l_run[u] = l_run[u] * alpha + rs;
-            m_run[u] = mn;
-            // once the running maxima have settled (after the first tiles of a row) no lane rescales: skip the 32 multiplies
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-                for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
+            } else {
+    #pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+    #pragma unroll
+                for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), ks * 4 + g));
+                    bf16x8_t kfl;
+                    if (SPLIT) kfl = *(const bf16x8_t*)(sKl + k_off(sub_row(sub, c), ks * 4 + g));
+    #pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][sub], 0, 0, 0);
+                        if (SPLIT) {
+                            st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfl, qf[u][ks], st[u][sub], 0, 0, 0);
+                            st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[u][ks], st[u][sub], 0, 0, 0);
+                        }
+                    }
+                }
             }
-        }
-        // ---- O^T += V^T P^T : 2 k-steps (32 keys) x 8 d-tiles ----
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                const bf16x8_t vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, p * 4 + g));
-                bf16x8_t vfl;
-                if (SPLIT) vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, p * 4 + g));
-#pragma unroll
+            }
+            if constexpr (PFV) {                                         // the first 32 keys' V^T fragments: in flight during the softmax
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int dt = 0; dt < 8; ++dt) vfa[dt] = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, g));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- mask + online softmax: this lane owns query c of each set; rows are keys sub_row(sub, 4g + r) ----
+            // tiles entirely below the diagonal of every query of the wave (and inside `total`) need no mask: wave-uniform test
+            const bool need_mask = key0 + 63 > past + wq0 || key0 + 63 >= total;
+            bf16x8_t ph[NQ][2], pl[P2 ? NQ : 1][2];
+            // SM2 (the training forward: one bf16 probability plane, no ALiBi): the same online softmax in fewer instructions -- the running
+            // maximum is taken over the RAW scores (max commutes with the positive scale), scale and subtraction are one fma, the two
+            // cross-group reductions of the maximum are register swaps (v_permlane16_swap / v_permlane32_swap, no LDS round trip), and the
+            // row sum stays PER LANE (alpha is common to the four lanes of a query) until the end of the kernel.
+            constexpr bool SM2 = !SPLIT && !P2 && !ALIBI && ATTN_PREFILL_SM2;
+            if constexpr (SM2) {
+    #pragma unroll
                 for (int u = 0; u < NQ; ++u) {
-                    o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[u][p], o[u][dt], 0, 0, 0);
-                    if (P2) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[u][p], o[u][dt], 0, 0, 0);
-                    if (SPLIT) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph[u][p], o[u][dt], 0, 0, 0);
+                    const int lim = past + wq0 + u * 16 + c;
+                    if (need_mask) {
+    #pragma unroll
+                        for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int key = key0 + sub_row(sub, 4 * g + r);
+                                if (key > lim || key >= total) st[u][sub][r] = -INFINITY;
+                            }
+                    }
+                    float mloc = fmaxf(fmaxf(st[u][0][0], st[u][0][1]), fmaxf(st[u][0][2], st[u][0][3]));
+    #pragma unroll
+                    for (int sub = 1; sub < 4; ++sub) mloc = fmaxf(fmaxf(fmaxf(st[u][sub][0], st[u][sub][1]), fmaxf(st[u][sub][2], st[u][sub][3])), mloc);
+                    {
+                        const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+                        mloc = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
+                        const auto b2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
+                        mloc = fmaxf(__builtin_bit_cast(float, b2[0]), __builtin_bit_cast(float, b2[1]));
+                    }
+                    const float mn = fmaxf(m_run[u], mloc * scale2);
+                    const bool dead = mn == -INFINITY;
+                    const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
+                    const float nmn = dead ? 0.0f : -mn;
+                    float rs = 0.0f;
+    #pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][sub][r], scale2, nmn));
+                            rs += pv;
+                            ph[u][sub >> 1][(sub & 1) * 4 + r] = (bf16_t)pv;
+                        }
+                    l_run[u] = l_run[u] * alpha + rs;                   // this lane's keys only: reduced over the lane groups after the last tile
+                    m_run[u] = mn;
+                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    #pragma unroll
+                        for (int dt = 0; dt < 8; ++dt)
+    #pragma unroll
+                            for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
+                    }
+                }
+            } else
+    #pragma unroll
+            for (int u = 0; u < NQ; ++u) {
+                const int lim = past + wq0 + u * 16 + c;                 // last visible key of this lane's query
+                float mloc = -INFINITY;
+                if (need_mask || alibi) {
+    #pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = key0 + sub_row(sub, 4 * g + r);
+                            float sv = st[u][sub][r] * scale2;
+                            if (alibi) sv += slope2 * (float)(key - (total - 1));
+                            if (key > lim || key >= total) sv = -INFINITY;
+                            st[u][sub][r] = sv;
+                            mloc = fmaxf(mloc, sv);
+                        }
+                } else {
+    #pragma unroll
+                    for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            st[u][sub][r] *= scale2;
+                            mloc = fmaxf(mloc, st[u][sub][r]);
+                        }
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mn = fmaxf(m_run[u], mloc);
+                const bool dead = mn == -INFINITY;
+                const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
+                float rs = 0.0f;
+    #pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(st[u][sub][r] - mn);
+                        rs += pv;
+                        const bf16_t pb = (bf16_t)pv;
+                        ph[u][sub >> 1][(sub & 1) * 4 + r] = pb;
+                        if (P2) pl[u][sub >> 1][(sub & 1) * 4 + r] = (bf16_t)(pv - (float)pb);
+                    }
+                rs += __shfl_xor(rs, 16, 64);
+                rs += __shfl_xor(rs, 32, 64);
+                l_run[u] = l_run[u] * alpha + rs;
+                m_run[u] = mn;
+                // once the running maxima have settled (after the first tiles of a row) no lane rescales: skip the 32 multiplies
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    #pragma unroll
+                    for (int dt = 0; dt < 8; ++dt)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
+                }
+            }
+            // ---- O^T += V^T P^T : 2 k-steps (32 keys) x 8 d-tiles ----
+            bf16x8_t vfb[PFV ? 8 : 1];
+            if constexpr (PFV) {                                         // the second 32 keys' fragments behind the first step's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int dt = 0; dt < 8; ++dt) vfb[dt] = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, 4 + g));
+            }
+    #pragma unroll
+            for (int p = 0; p < 2; ++p) {
+    #pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    bf16x8_t vf;
+                    if constexpr (PFV) vf = p == 0 ? vfa[dt] : vfb[dt];
+                    else vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, p * 4 + g));
+                    bf16x8_t vfl;
+                    if (SPLIT) vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, p * 4 + g));
+    #pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[u][p], o[u][dt], 0, 0, 0);
+                        if (P2) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[u][p], o[u][dt], 0, 0, 0);
+                        if (SPLIT) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfl, ph[u][p], o[u][dt], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
-    // ---- normalise and store: out[(b*S + q)][h*128 + d], 4 consecutive d per lane ----
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-        const int qi = wq0 + u * 16 + c;
-        if (qi >= S) continue;
-        const float inv = l_run[u] > 0.0f ? 1.0f / l_run[u] : 0.0f;
-        // natural-log log-sum-exp of the scaled, masked scores (attn_bwd.hip recomputes P from it)
-        if (lse && g == 0) lse[bh * S + qi] = (m_run[u] + log2f(l_run[u])) * 0.6931471805599453f;
-        const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            bf16x4_t hi4, lo4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = o[u][dt][r] * inv;
-                hi4[r] = (bf16_t)v;
-                lo4[r] = (bf16_t)(v - (float)hi4[r]);
+        // ---- normalise and store: out[(b*S + q)][h*128 + d], 4 consecutive d per lane ----
+    #pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const int qi = wq0 + u * 16 + c;
+            if (!SPLIT && !P2 && !ALIBI && ATTN_PREFILL_SM2) {                // SM2 kept the row sums per lane
+                l_run[u] += __shfl_xor(l_run[u], 16, 64);
+                l_run[u] += __shfl_xor(l_run[u], 32, 64);
             }
-            *(bf16x4_t*)(out + dst + dt * 16 + 4 * g) = hi4;
-            if (SPLIT) *(bf16x4_t*)(out_lo + dst + dt * 16 + 4 * g) = lo4;
+            if (qi >= S) continue;
+            const float inv = l_run[u] > 0.0f ? 1.0f / l_run[u] : 0.0f;
+            // natural-log log-sum-exp of the scaled, masked scores (attn_bwd.hip recomputes P from it)
+            if (lse && g == 0) lse[bh * S + qi] = (m_run[u] + log2f(l_run[u])) * 0.6931471805599453f;
+            const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
+    #pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                bf16x4_t hi4, lo4;
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o[u][dt][r] * inv;
+                    hi4[r] = (bf16_t)v;
+                    lo4[r] = (bf16_t)(v - (float)hi4[r]);
+                }
+                *(bf16x4_t*)(out + dst + dt * 16 + 4 * g) = hi4;
+                if (SPLIT) *(bf16x4_t*)(out_lo + dst + dt * 16 + 4 * g) = lo4;
+            }
         }
     }
 }
@@ -446,15 +567,25 @@ static void launch_attn_prefill(hipStream_t st, const bf16_t* q, const bf16_t* k
                                 int past, int smax, float scale, const float* alibi, float* lse) {
     const int lds = 65536;                                          // SPLIT: hi + lo planes, one stage; else two stages
     const int nbh = batch * nh;
-    if (!SPLIT && (long)cdiv(s, 128) * nbh >= 1024) {          // (hi+lo planes: two query sets per wave do not fit 256 registers)
-        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 2, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attn_prefill_kernel<SPLIT, 2, P2><<<cdiv(s, 128) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
-                                                                          past, smax, scale, alibi, lse);
-    } else {
-        (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attn_prefill_kernel<SPLIT, 1, P2><<<cdiv(s, 64) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
-                                                                         past, smax, scale, alibi, lse);
-    }
+    // query blocks in pairs (see the kernel) when the halved grid still fills the 512 workgroup slots of the chip evenly: at least four
+    // rounds, or exactly one or two; otherwise one block per workgroup, longest first within each head group
+    auto pairs_ok = [&](int nt) { const long wgs = (long)((nt + 1) / 2) * nbh; return nt >= 2 && (wgs >= 2048 || wgs == 512 || wgs == 1024); };
+    auto go = [&](auto alibi_c) {
+        constexpr bool AL = decltype(alibi_c)::value;
+        if (!SPLIT && (long)cdiv(s, 128) * nbh >= 1024) {          // (hi+lo planes: two query sets per wave do not fit 256 registers)
+            const int nt = cdiv(s, 128), pr = pairs_ok(nt);
+            (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, SPLIT ? 1 : 2, P2, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attn_prefill_kernel<SPLIT, SPLIT ? 1 : 2, P2, AL><<<(pr ? (nt + 1) / 2 : nt) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
+                                                                                                      past, smax, scale, alibi, lse, pr);
+        } else {
+            const int nt = cdiv(s, 64), pr = pairs_ok(nt);
+            (void)hipFuncSetAttribute((const void*)attn_prefill_kernel<SPLIT, 1, P2, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attn_prefill_kernel<SPLIT, 1, P2, AL><<<(pr ? (nt + 1) / 2 : nt) * nbh, 256, lds, st>>>(q, kc, vtc, q_lo, kc_lo, vtc_lo, out, out_lo, s, nh, nbh,
+                                                                                          past, smax, scale, alibi, lse, pr);
+        }
+    };
+    if (alibi) go(std::true_type{});
+    else go(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------
