@@ -635,6 +635,9 @@ __device__ __forceinline__ half8_t tr_frag(const char* tile, int row0, int col0,
 __device__ __forceinline__ f32x4_t mfma(half8_t a, half8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 }  // namespace a16
 
+#ifndef PRIOR_ATTN_P2_XCD
+#define PRIOR_ATTN_P2_XCD 1       // transposed pattern: the chunks of an in-block offset on one XCD (see the kernel)
+#endif
 template <int NK32>     // 32-wide head-dim steps: hd <= 32 NK32 (pad columns are zero)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prior_attn16_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -654,7 +657,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         nkeys = p.block_ctx; k0 = q0; ks = 1; coff = 0;
     } else if (p.pattern == 2) {
         const int chunks = p.blocks / p.qc;
-        const int off = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+        // The query chunks of one in-block offset read the same K / V rows (chunk ch: the first (ch + 1) qc of them).  Workgroups go to the
+        // XCDs round-robin by blockIdx.x (gridDim.x = block_ctx * chunks, a multiple of 8), so with off = x / chunks the chunks of an offset
+        // sat on DIFFERENT XCDs and each fetched those rows through its own L2.  Here: eight consecutive offsets, one per XCD, longest
+        // chunk first, then the same eight offsets' next chunk -- same XCD, eight workgroups later: the shorter chunks hit the L2.
+        int off, ch;
+        if (PRIOR_ATTN_P2_XCD && (p.block_ctx & 7) == 0) {
+            off = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * chunks));
+            ch = chunks - 1 - (blockIdx.x >> 3) % chunks;
+        } else {
+            off = blockIdx.x / chunks;
+            ch = blockIdx.x % chunks;
+        }
         nq = p.qc; q0 = ch * p.qc * p.block_ctx + off; qs = p.block_ctx;
         nkeys = (ch + 1) * p.qc; k0 = off; ks = p.block_ctx; coff = ch * p.qc;
     } else {
