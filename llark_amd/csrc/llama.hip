@@ -264,19 +264,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             }
         }
     };
+    // LDS-DMA sources as a wave-uniform base (the tile's first key) + a per-lane 32-bit byte offset computed once: 8 registers, no address
+    // arithmetic per tile (rebuilt per tile it was 77 VALU instructions; hoisted by hipcc as 64-bit pointers it was 32 registers and, with two
+    // query blocks per workgroup, spills)
+    unsigned dko[4], dvo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wv * 4 + i;                                    // this wave's 1 KiB pieces of each 16 KiB tile
+        const int krow = 4 * j + (lane >> 4);
+        dko[i] = (unsigned)(krow * 128 + (((lane & 15) ^ k_swz(krow)) << 3)) * 2u;
+        const int d = 8 * j + (lane >> 3);
+        dvo[i] = (unsigned)(d * smax + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2u;
+    }
     auto stage_dma = [&](char* dK, char* dV, int key0) __attribute__((always_inline)) {
-        int lane = threadIdx.x & 63;
-        asm volatile("" : "+v"(lane));
+        const char* kt_base = (const char*)(kb + (size_t)key0 * 128);
+        const char* vt_base = (const char*)(vb + key0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int j = wv * 4 + i;                                // this wave's 1 KiB pieces of each 16 KiB tile
-            const int krow = 4 * j + (lane >> 4);
-            const bf16_t* ks = kb + (size_t)(key0 + krow) * 128 + (((lane & 15) ^ k_swz(krow)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+            const int j = wv * 4 + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt_base + dko[i]),
                                              (__attribute__((address_space(3))) void*)(dK + j * 1024), 16, 0, 0);
-            const int d = 8 * j + (lane >> 3);
-            const bf16_t* vs = vb + (size_t)d * smax + key0 + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt_base + dvo[i]),
                                              (__attribute__((address_space(3))) void*)(dV + j * 1024), 16, 0, 0);
         }
     };
@@ -293,6 +301,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             }
         }
     };
+    // Per-lane LDS offsets of the fragment reads, once per kernel.  K: MFMA row c of score sub-tile `sub` is key 32 (sub / 2) + 4 (sub % 2) + krow0,
+    // krow0 = 8 (c / 4) + c % 4, and the row swizzle k_swz looks at key bits 0, 1, 3 only -- the same for every sub-tile: one offset per k-step
+    // (the XOR with the chunk index 4 ks + g), the sub-tile an immediate.  V^T: row d = 16 dt + c, swizzle (d >> 1) & 7 = (c >> 1) & 7: one offset
+    // per 32-key step, the d tile an immediate.  (Written as k_off(sub_row(sub, c), ..) / v_off(16 dt + c, ..) per read, hipcc rebuilt every
+    // address with VALU instructions: ~90 of the ~420 of a key tile, profiles/r06_pmc_attn_after.txt.)
+    int kaddr[4], vaddr[2];
+    {
+        const int krow0 = 8 * (c >> 2) + (c & 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kaddr[ks] = k_off(krow0, ks * 4 + g);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) vaddr[p] = v_off(c, p * 4 + g);
+    }
+    auto ksub = [](int sub) { return (32 * (sub >> 1) + 4 * (sub & 1)) * 256; };
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
         const int tile = pass == 0 ? nt - 1 - pidx : pidx;
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 bf16x8_t kfa[2][4];
     #pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
-                    kfa[0][sub] = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), g));
+                    kfa[0][sub] = *(const bf16x8_t*)(sK + kaddr[0] + ksub(sub));
     #pragma unroll
                     for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
@@ -363,7 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks < 3) {
     #pragma unroll
-                        for (int sub = 0; sub < 4; ++sub) kfa[(ks + 1) & 1][sub] = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), (ks + 1) * 4 + g));
+                        for (int sub = 0; sub < 4; ++sub) kfa[(ks + 1) & 1][sub] = *(const bf16x8_t*)(sK + kaddr[ks + 1] + ksub(sub));
                     }
                     __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
@@ -378,9 +400,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kf = *(const bf16x8_t*)(sK + k_off(sub_row(sub, c), ks * 4 + g));
+                    const bf16x8_t kf = *(const bf16x8_t*)(sK + kaddr[ks] + ksub(sub));
                     bf16x8_t kfl;
-                    if (SPLIT) kfl = *(const bf16x8_t*)(sKl + k_off(sub_row(sub, c), ks * 4 + g));
+                    if (SPLIT) kfl = *(const bf16x8_t*)(sKl + kaddr[ks] + ksub(sub));
     #pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][sub], 0, 0, 0);
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             if constexpr (PFV) {                                         // the first 32 keys' V^T fragments: in flight during the softmax
                 __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) vfa[dt] = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, g));
+                for (int dt = 0; dt < 8; ++dt) vfa[dt] = *(const bf16x8_t*)(sV + vaddr[0] + dt * 2048);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- mask + online softmax: this lane owns query c of each set; rows are keys sub_row(sub, 4g + r) ----
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             if constexpr (PFV) {                                         // the second 32 keys' fragments behind the first step's MFMAs
                 __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                for (int dt = 0; dt < 8; ++dt) vfb[dt] = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, 4 + g));
+                for (int dt = 0; dt < 8; ++dt) vfb[dt] = *(const bf16x8_t*)(sV + vaddr[1] + dt * 2048);
             }
     #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -518,9 +540,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 for (int dt = 0; dt < 8; ++dt) {
                     bf16x8_t vf;
                     if constexpr (PFV) vf = p == 0 ? vfa[dt] : vfb[dt];
-                    else vf = *(const bf16x8_t*)(sV + v_off(dt * 16 + c, p * 4 + g));
+                    else vf = *(const bf16x8_t*)(sV + vaddr[p] + dt * 2048);
                     bf16x8_t vfl;
-                    if (SPLIT) vfl = *(const bf16x8_t*)(sVl + v_off(dt * 16 + c, p * 4 + g));
+                    if (SPLIT) vfl = *(const bf16x8_t*)(sVl + vaddr[p] + dt * 2048);
     #pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[u][p], o[u][dt], 0, 0, 0);
