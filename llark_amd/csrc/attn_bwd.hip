@@ -217,20 +217,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int kb0 = tile * 64 * NK;
         const int wk0 = kb0 + wv * 16 * NK;                                  // the wave's first key
         bf16x8_t kf[NK][4], vf[NK][4];       // B operands: column = key c of set u, d = ks*32 + g*8 .. +8
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NK; ++u) {
             int kr = wk0 + u * 16 + c;
             kr = kr < S ? kr : S - 1;
-    #pragma unroll
+#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 kf[u][ks] = *(const bf16x8_t*)(kb + (size_t)kr * 128 + ks * 32 + g * 8);
                 vf[u][ks] = *(const bf16x8_t*)(vb + (size_t)kr * 128 + ks * 32 + g * 8);
             }
         }
         f32x4_t dka[NK][8], dva[NK][8];      // dK^T, dV^T: d = dt*16 + 4g + r, key c of set u
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NK; ++u)
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) dka[u][dt] = dva[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int nqt = (S + 63) / 64;
         const int qt0 = kb0 / 64;
@@ -276,18 +276,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // multiply -- the matrix pipe was busy 25 % of the time, profiles/r03_pmc_attn_swz.txt.)  A masked score becomes -inf
             // BEFORE the exponential: one select on the argument, no branch around v_exp_f32, one basic block per tile.
             auto load_s = [&](int sub, bf16x8_t* qfr, bf16x8_t* dfr) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     qfr[ks] = *(const bf16x8_t*)(sQ + bk_off(sub_row(sub, c), ks * 4 + g));
                     dfr[ks] = *(const bf16x8_t*)(sdO + bk_off(sub_row(sub, c), ks * 4 + g));
                 }
             };
             auto mma_s = [&](const bf16x8_t* qfr, const bf16x8_t* dfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NK; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NK; ++u) {
                         sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr[ks], kf[u][ks], sa[u], 0, 0, 0);
                         dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dfr[ks], vf[u][ks], dp[u], 0, 0, 0);
@@ -299,11 +299,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float4 l4 = *(const float4*)(sL + ql);
                 const float4 d4 = *(const float4*)(sD + ql);
                 const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NK; ++u) {
                     const int key = wk0 + u * 16 + c;
                     const float bias2 = slope2 * (float)(key - (S - 1));
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int qa = q0 + ql + r;
                         const bool ok = !need_mask || (qa < S && key <= qa);
@@ -315,16 +315,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             };
             auto load_t = [&](int p, int h, bf16x8_t* dof, bf16x8_t* qtf) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     dof[j] = tr_frag(sdO, 32 * p, (2 * h + j) * 16, g, c);     // dO^T rows d = dt*16 + c, queries 32p + 8g ..
                     qtf[j] = tr_frag(sQ, 32 * p, (2 * h + j) * 16, g, c);      // Q^T
                 }
             };
             auto mma_t = [&](int h, const bf16x8_t* dof, const bf16x8_t* qtf, const bf16x8_t* pf, const bf16x8_t* sf) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 2; ++j) {
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NK; ++u) {
                         dva[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof[j], pf[u], dva[u][2 * h + j], 0, 0, 0);
                         dka[u][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[j], sf[u], dka[u][2 * h + j], 0, 0, 0);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bf16x8_t qA[4], dA[4], qB[4], dB[4];
             load_s(0, qA, dA);
             __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
             for (int p = 0; p < 2; ++p) {
                 bf16x8_t pf[NK], sf[NK];
                 f32x4_t sa0[NK], dp0[NK], sa1[NK], dp1[NK];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
                 softmax(p, 1, sa1, dp1, pf, sf);
                 __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     if (h < 3) load_t(p, h + 1, tdo[(h + 1) & 1], tq[(h + 1) & 1]);
                     else if (p == 0) load_s(2, qA, dA);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NK; ++u) {
             const int key = wk0 + u * 16 + c;
             if (key >= S) continue;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             float* ko = dk + (bh * S + key) * 128 + 4 * g;
             float* vo = dv + (bh * S + key) * 128 + 4 * g;
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 *(f32x4_t*)(ko + dt * 16) = dka[u][dt];
                 *(f32x4_t*)(vo + dt * 16) = dva[u][dt];
@@ -416,11 +416,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int wq0 = q0 + wv * 16 * NQ;
         bf16x8_t qf[NQ][4], df[NQ][4];       // B operands: column = query c of set u
         float l2[NQ], dd[NQ];
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int qi = wq0 + u * 16 + c;
             const int qr = qi < S ? qi : S - 1;
-    #pragma unroll
+#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
                 df[u][ks] = *(const bf16x8_t*)(dob + (size_t)qr * ldo_ + ks * 32 + g * 8);
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
         }
         f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u)
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) dqa[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         int last_key = q0 + 64 * NQ - 1;
         if (last_key > S - 1) last_key = S - 1;
@@ -459,18 +459,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool need_mask = key0 + 63 > wq0 || wq0 + 16 * NQ - 1 >= S;    // else every (query, key) pair of the tile is visible
             // the same software pipeline as the dK / dV kernel: fragment reads one group of MFMAs ahead, pinned with scheduling barriers
             auto load_s = [&](int sub, bf16x8_t* kfr, bf16x8_t* vfr) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     kfr[ks] = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
                     vfr[ks] = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
                 }
             };
             auto mma_s = [&](const bf16x8_t* kfr, const bf16x8_t* vfr, f32x4_t* sa, f32x4_t* dp) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NQ; ++u) sa[u] = dp[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         sa[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[ks], qf[u][ks], sa[u], 0, 0, 0);
                         dp[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks], df[u][ks], dp[u], 0, 0, 0);
@@ -479,10 +479,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
             auto softmax = [&](int p, int hb, const f32x4_t* sa, const f32x4_t* dp, bf16x8_t* sf) __attribute__((always_inline)) {
                 const int kl = key0 + 32 * p + 8 * g + 4 * hb;               // this lane's 4 key rows: kl .. kl + 3
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NQ; ++u) {
                     const int qa = wq0 + u * 16 + c;
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = !need_mask || (qa < S && kl + r <= qa);
                         const float x = sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u];
@@ -492,20 +492,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             };
             auto load_t = [&](int p, int h, bf16x8_t* ktf) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 4; ++j) ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
             };
             auto mma_t = [&](int h, const bf16x8_t* ktf, const bf16x8_t* sf) __attribute__((always_inline)) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 4; ++j) {
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NQ; ++u) dqa[u][4 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[j], sf[u], dqa[u][4 * h + j], 0, 0, 0);
                 }
             };
             bf16x8_t kA[4], vA[4], kB[4], vB[4];
             load_s(0, kA, vA);
             __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
             for (int p = 0; p < 2; ++p) {
                 bf16x8_t sf[NQ];
                 f32x4_t sa0[NQ], dp0[NQ], sa1[NQ], dp1[NQ];
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int qi = wq0 + u * 16 + c;
             if (qi >= S) continue;
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 continue;
             }
             float* o = dq + (bh * S + qi) * 128 + 4 * g;
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) *(f32x4_t*)(o + dt * 16) = dqa[u][dt];
         }
     }

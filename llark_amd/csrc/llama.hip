@@ -324,11 +324,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
         const int wq0 = q0 + wv * 16 * NQ;                          // the wave's first query
         // Q fragments (B operand): column = query c of set u, d = ks*32 + g*8 .. +8
         bf16x8_t qf[NQ][4], ql[SPLIT ? NQ : 1][4];
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u) {
             int qr = wq0 + u * 16 + c;
             qr = qr < S ? qr : S - 1;
-    #pragma unroll
+#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 qf[u][ks] = *(const bf16x8_t*)(qb + (size_t)qr * 128 + ks * 32 + g * 8);
                 if (SPLIT) ql[u][ks] = *(const bf16x8_t*)(q_lo + bh * S * 128 + (size_t)qr * 128 + ks * 32 + g * 8);
@@ -336,9 +336,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
         }
         f32x4_t o[NQ][8];                                               // O^T: d = dt*16 + 4g + r, query c
         float m_run[NQ], l_run[NQ];
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u) {
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) o[u][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             m_run[u] = -INFINITY;
             l_run[u] = 0.0f;
@@ -374,36 +374,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 // k-step outermost: the 4 x NQ accumulators of a k-step are independent (the sub-tile-outermost order chains dependent MFMAs two
                 // apart and hipcc schedules three of them back to back), and the next k-step's four fragments are read under this one's MFMAs
                 bf16x8_t kfa[2][4];
-    #pragma unroll
+#pragma unroll
                 for (int sub = 0; sub < 4; ++sub) {
                     kfa[0][sub] = *(const bf16x8_t*)(sK + kaddr[0] + ksub(sub));
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (ks < 3) {
-    #pragma unroll
+#pragma unroll
                         for (int sub = 0; sub < 4; ++sub) kfa[(ks + 1) & 1][sub] = *(const bf16x8_t*)(sK + kaddr[ks + 1] + ksub(sub));
                     }
                     __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
                     for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                         for (int u = 0; u < NQ; ++u) st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfa[ks & 1][sub], qf[u][ks], st[u][sub], 0, 0, 0);
                 }
             } else {
-    #pragma unroll
+#pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NQ; ++u) st[u][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    #pragma unroll
+#pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + kaddr[ks] + ksub(sub));
                     bf16x8_t kfl;
                     if (SPLIT) kfl = *(const bf16x8_t*)(sKl + kaddr[ks] + ksub(sub));
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         st[u][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][sub], 0, 0, 0);
                         if (SPLIT) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             }
             if constexpr (PFV) {                                         // the first 32 keys' V^T fragments: in flight during the softmax
                 __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < 8; ++dt) vfa[dt] = *(const bf16x8_t*)(sV + vaddr[0] + dt * 2048);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -430,20 +430,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             // row sum stays PER LANE (alpha is common to the four lanes of a query) until the end of the kernel.
             constexpr bool SM2 = !SPLIT && !P2 && !ALIBI && ATTN_PREFILL_SM2;
             if constexpr (SM2) {
-    #pragma unroll
+#pragma unroll
                 for (int u = 0; u < NQ; ++u) {
                     const int lim = past + wq0 + u * 16 + c;
                     if (need_mask) {
-    #pragma unroll
+#pragma unroll
                         for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int key = key0 + sub_row(sub, 4 * g + r);
                                 if (key > lim || key >= total) st[u][sub][r] = -INFINITY;
                             }
                     }
                     float mloc = fmaxf(fmaxf(st[u][0][0], st[u][0][1]), fmaxf(st[u][0][2], st[u][0][3]));
-    #pragma unroll
+#pragma unroll
                     for (int sub = 1; sub < 4; ++sub) mloc = fmaxf(fmaxf(fmaxf(st[u][sub][0], st[u][sub][1]), fmaxf(st[u][sub][2], st[u][sub][3])), mloc);
                     {
                         const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                     const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
                     const float nmn = dead ? 0.0f : -mn;
                     float rs = 0.0f;
-    #pragma unroll
+#pragma unroll
                     for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][sub][r], scale2, nmn));
                             rs += pv;
@@ -467,21 +467,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                     l_run[u] = l_run[u] * alpha + rs;                   // this lane's keys only: reduced over the lane groups after the last tile
                     m_run[u] = mn;
                     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-    #pragma unroll
+#pragma unroll
                         for (int dt = 0; dt < 8; ++dt)
-    #pragma unroll
+#pragma unroll
                             for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
                     }
                 }
             } else
-    #pragma unroll
+#pragma unroll
             for (int u = 0; u < NQ; ++u) {
                 const int lim = past + wq0 + u * 16 + c;                 // last visible key of this lane's query
                 float mloc = -INFINITY;
                 if (need_mask || alibi) {
-    #pragma unroll
+#pragma unroll
                     for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = key0 + sub_row(sub, 4 * g + r);
                             float sv = st[u][sub][r] * scale2;
@@ -491,9 +491,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                             mloc = fmaxf(mloc, sv);
                         }
                 } else {
-    #pragma unroll
+#pragma unroll
                     for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             st[u][sub][r] *= scale2;
                             mloc = fmaxf(mloc, st[u][sub][r]);
@@ -505,9 +505,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 const bool dead = mn == -INFINITY;
                 const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_run[u] - mn);
                 float rs = 0.0f;
-    #pragma unroll
+#pragma unroll
                 for (int sub = 0; sub < 4; ++sub)
-    #pragma unroll
+#pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = dead ? 0.0f : __builtin_amdgcn_exp2f(st[u][sub][r] - mn);
                         rs += pv;
@@ -521,9 +521,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                 m_run[u] = mn;
                 // once the running maxima have settled (after the first tiles of a row) no lane rescales: skip the 32 multiplies
                 if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-    #pragma unroll
+#pragma unroll
                     for (int dt = 0; dt < 8; ++dt)
-    #pragma unroll
+#pragma unroll
                         for (int r = 0; r < 4; ++r) o[u][dt][r] *= alpha;
                 }
             }
@@ -531,19 +531,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             bf16x8_t vfb[PFV ? 8 : 1];
             if constexpr (PFV) {                                         // the second 32 keys' fragments behind the first step's MFMAs
                 __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < 8; ++dt) vfb[dt] = *(const bf16x8_t*)(sV + vaddr[1] + dt * 2048);
             }
-    #pragma unroll
+#pragma unroll
             for (int p = 0; p < 2; ++p) {
-    #pragma unroll
+#pragma unroll
                 for (int dt = 0; dt < 8; ++dt) {
                     bf16x8_t vf;
                     if constexpr (PFV) vf = p == 0 ? vfa[dt] : vfb[dt];
                     else vf = *(const bf16x8_t*)(sV + vaddr[p] + dt * 2048);
                     bf16x8_t vfl;
                     if (SPLIT) vfl = *(const bf16x8_t*)(sVl + vaddr[p] + dt * 2048);
-    #pragma unroll
+#pragma unroll
                     for (int u = 0; u < NQ; ++u) {
                         o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, ph[u][p], o[u][dt], 0, 0, 0);
                         if (P2) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pl[u][p], o[u][dt], 0, 0, 0);
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             }
         }
         // ---- normalise and store: out[(b*S + q)][h*128 + d], 4 consecutive d per lane ----
-    #pragma unroll
+#pragma unroll
         for (int u = 0; u < NQ; ++u) {
             const int qi = wq0 + u * 16 + c;
             if (!SPLIT && !P2 && !ALIBI && ATTN_PREFILL_SM2) {                // SM2 kept the row sums per lane
@@ -565,10 +565,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
             // natural-log log-sum-exp of the scaled, masked scores (attn_bwd.hip recomputes P from it)
             if (lse && g == 0) lse[bh * S + qi] = (m_run[u] + log2f(l_run[u])) * 0.6931471805599453f;
             const size_t dst = ((size_t)b * S + qi) * (size_t)(nh * 128) + h * 128;
-    #pragma unroll
+#pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 bf16x4_t hi4, lo4;
-    #pragma unroll
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = o[u][dt][r] * inv;
                     hi4[r] = (bf16_t)v;
