@@ -173,12 +173,15 @@ constexpr float kLog2e = 1.4426950408889634f;
 // query sets of 16 per wave in the dQ kernel: 1 (two sets: 256 registers with 16 spills at two waves per SIMD, 592 vs 546 us at
 // 2 x 32 x 2048)
 #define DQ_NQ 1
+#ifndef ATTN_BWD_DEBUG
+#define ATTN_BWD_DEBUG 0   // timing experiments on the dQ kernel only (results are garbage): 1 = no transposing LDS reads, 2 = no softmax arithmetic,
+#endif                     //   4 = no K / V fragment reads
 
 // One workgroup per 64 NK keys: wave wv owns keys kb0 + 16 NK wv .. as NK sets of 16 (B operands K, V in registers; dK^T, dV^T
 // [128 d][16 keys] x NK in accumulators).  Per 64-query tile: S = Q K^T and dP = dO V^T with the queries as MFMA rows (A from LDS),
 // so P and dS leave the MFMA as "column = key, 4 rows = queries" -- the B-operand layout of dV^T = dO^T P and dK^T = Q^T dS
 // (A = the sequence-contiguous tiles in LDS).  Nothing goes through an LDS scratch.
-template <int NK>
+template <int NK, bool ALIBI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ kc, const bf16_t* __restrict__ v_rm,
                                                            const bf16_t* __restrict__ dO,
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* db = dsum + bh * S;
     const float scale2 = scale * kLog2e;
     // ALiBi (MPT): the forward added slope_h * (key - (S - 1)) to the scaled scores; it has no gradient of its own
-    const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
+    const float slope2 = ALIBI ? alibi[bhid % nh] * kLog2e : 0.0f;     // (compile-time: the Llama instantiations carry no ALiBi arithmetic)
 
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -298,19 +301,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int ql = 32 * p + 8 * g + 4 * hb;                  // this lane's 4 query rows: ql .. ql + 3
                 const float4 l4 = *(const float4*)(sL + ql);
                 const float4 d4 = *(const float4*)(sD + ql);
-                const float lr[4] = {l4.x * kLog2e, l4.y * kLog2e, l4.z * kLog2e, l4.w * kLog2e}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+                // one fma per exponent and per dS factor: x = s scale2 + (bias - L log2 e),  dS = P (dP scale - D scale)
+                const float nlr[4] = {-l4.x * kLog2e, -l4.y * kLog2e, -l4.z * kLog2e, -l4.w * kLog2e};
+                const float nds[4] = {-d4.x * scale, -d4.y * scale, -d4.z * scale, -d4.w * scale};
 #pragma unroll
                 for (int u = 0; u < NK; ++u) {
                     const int key = wk0 + u * 16 + c;
-                    const float bias2 = slope2 * (float)(key - (S - 1));
+                    const float bias2 = ALIBI ? slope2 * (float)(key - (S - 1)) : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int qa = q0 + ql + r;
                         const bool ok = !need_mask || (qa < S && key <= qa);
-                        const float x = sa[u][r] * scale2 + bias2 - lr[r];
+                        const float x = __builtin_fmaf(sa[u][r], scale2, ALIBI ? bias2 + nlr[r] : nlr[r]);
                         const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
                         pf[u][hb * 4 + r] = pb;
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]) * scale);
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * __builtin_fmaf(dp[u][r], scale, nds[r]));
                     }
                 }
             };
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // One workgroup per 64 NQ queries: wave wv owns queries q0 + 16 NQ wv .. as NQ sets of 16 (B operands Q, dO in registers, dQ^T in
 // accumulators).  Per 64-key tile: S^T = K Q^T and dP^T = V dO^T with the keys as MFMA rows (A from LDS), dS^T leaves the MFMA in
 // the B-operand layout of dQ^T = K^T dS^T (A = the sequence-contiguous K tile in LDS).
-template <int NQ>
+template <int NQ, bool ALIBI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ v_rm,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse,
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* kb = kc + bh * (size_t)smax * 128;
     const bf16_t* vb = v_rm + bh * S * 128;
     const float scale2 = scale * kLog2e;
-    const float slope2 = alibi ? alibi[bhid % nh] * kLog2e : 0.0f;
+    const float slope2 = ALIBI ? alibi[bhid % nh] * kLog2e : 0.0f;     // (compile-time: the Llama instantiations carry no ALiBi arithmetic)
 
 #pragma nounroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -427,6 +432,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
             dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
+        }
+        float nl2[NQ], nds[NQ];             // one fma per exponent and per dS factor: x = s scale2 - L log2 e,  dS = P (dP scale - D scale)
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            nl2[u] = -l2[u];
+            nds[u] = -dd[u] * scale;
         }
         f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
 #pragma unroll
@@ -461,6 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             auto load_s = [&](int sub, bf16x8_t* kfr, bf16x8_t* vfr) __attribute__((always_inline)) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
+                    if constexpr (ATTN_BWD_DEBUG & 4) { kfr[ks] = qf[0][ks]; vfr[ks] = df[0][ks]; continue; }
                     kfr[ks] = *(const bf16x8_t*)(sK + bk_off(sub_row(sub, c), ks * 4 + g));
                     vfr[ks] = *(const bf16x8_t*)(sV + bk_off(sub_row(sub, c), ks * 4 + g));
                 }
@@ -484,16 +496,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int qa = wq0 + u * 16 + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        if constexpr (ATTN_BWD_DEBUG & 2) { sf[u][hb * 4 + r] = (bf16_t)(sa[u][r] + dp[u][r]); continue; }
                         const bool ok = !need_mask || (qa < S && kl + r <= qa);
-                        const float x = sa[u][r] * scale2 + slope2 * (float)(kl + r - (S - 1)) - l2[u];
+                        const float x = __builtin_fmaf(sa[u][r], scale2, ALIBI ? slope2 * (float)(kl + r - (S - 1)) + nl2[u] : nl2[u]);
                         const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]) * scale);
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * __builtin_fmaf(dp[u][r], scale, nds[u]));
                     }
                 }
             };
             auto load_t = [&](int p, int h, bf16x8_t* ktf) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ATTN_BWD_DEBUG & 1) { ktf[j] = qf[0][j]; continue; }
+                    ktf[j] = tr_frag(sK, 32 * p, (4 * h + j) * 16, g, c);     // K^T rows d = dt*16 + c, keys 32p + 8g ..
+                }
             };
             auto mma_t = [&](int h, const bf16x8_t* ktf, const bf16x8_t* sf) __attribute__((always_inline)) {
 #pragma unroll
@@ -570,12 +586,17 @@ static int attn_backward_impl(const void* q, const void* k_cache, const void* v_
     int pkv = 0, pq = 0;
     const int grid_kv = grid_of(cdiv(s, 64 * DKV_NK), pkv), grid_q = grid_of(cdiv(s, 64 * DQ_NQ), pq);
     const int lds_kv = 2 * (32768 + 512), lds_q = 2 * 32768;
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    attn_bwd_dkv_kernel<DKV_NK><<<grid_kv, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
-                                                           dk, dv, s, smax, nbh, nh, scale, alibi_slopes, f, pkv);
-    attn_bwd_dq_kernel<DQ_NQ><<<grid_q, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
-                                                       dq, s, smax, nbh, nh, scale, alibi_slopes, f, pq);
+    auto go = [&](auto alibi_c) {
+        constexpr bool AL = decltype(alibi_c)::value;
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<DKV_NK, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<DQ_NQ, AL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+        attn_bwd_dkv_kernel<DKV_NK, AL><<<grid_kv, 256, lds_kv, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse,
+                                                                   dsum, dk, dv, s, smax, nbh, nh, scale, alibi_slopes, f, pkv);
+        attn_bwd_dq_kernel<DQ_NQ, AL><<<grid_q, 256, lds_q, st>>>((const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_rm, (const bf16_t*)dO, lse, dsum,
+                                                               dq, s, smax, nbh, nh, scale, alibi_slopes, f, pq);
+    };
+    if (alibi_slopes) go(std::true_type{});
+    else go(std::false_type{});
     return check_launch("attn_backward");
 }
 
