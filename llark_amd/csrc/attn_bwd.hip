@@ -301,9 +301,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int ql = 32 * p + 8 * g + 4 * hb;                  // this lane's 4 query rows: ql .. ql + 3
                 const float4 l4 = *(const float4*)(sL + ql);
                 const float4 d4 = *(const float4*)(sD + ql);
-                // one fma per exponent and per dS factor: x = s scale2 + (bias - L log2 e),  dS = P (dP scale - D scale)
+                // one fma per exponent: x = s scale2 + (bias - L log2 e).  dS is formed WITHOUT its factor 1 / sqrt(d) -- dP - D stays an exact
+                // difference of nearly equal numbers (an fma dP scale - (D scale) would round D scale first and the cancellation amplify
+                // that) -- and dK is scaled once, in the epilogue: one multiply less per element
                 const float nlr[4] = {-l4.x * kLog2e, -l4.y * kLog2e, -l4.z * kLog2e, -l4.w * kLog2e};
-                const float nds[4] = {-d4.x * scale, -d4.y * scale, -d4.z * scale, -d4.w * scale};
+                const float dr[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int u = 0; u < NK; ++u) {
                     const int key = wk0 + u * 16 + c;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const float x = __builtin_fmaf(sa[u][r], scale2, ALIBI ? bias2 + nlr[r] : nlr[r]);
                         const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
                         pf[u][hb * 4 + r] = pb;
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * __builtin_fmaf(dp[u][r], scale, nds[r]));
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dr[r]));
                     }
                 }
             };
@@ -368,6 +370,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int u = 0; u < NK; ++u) {
             const int key = wk0 + u * 16 + c;
             if (key >= S) continue;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) dka[u][dt] *= scale;          // the factor dS was formed without
             if (f.dqkv != nullptr) {
                 store_dqkv_row(f, dka[u], 1, bhid / nh, bhid % nh, nh, S, key, g);
                 store_dqkv_row(f, dva[u], 2, bhid / nh, bhid % nh, nh, S, key, g);
@@ -433,12 +437,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             l2[u] = qi < S ? lse[bh * S + qi] * kLog2e : 0.0f;
             dd[u] = qi < S ? dsum[bh * S + qi] : 0.0f;
         }
-        float nl2[NQ], nds[NQ];             // one fma per exponent and per dS factor: x = s scale2 - L log2 e,  dS = P (dP scale - D scale)
+        float nl2[NQ];                      // one fma per exponent: x = s scale2 - L log2 e; dS without its factor 1 / sqrt(d) (see the dK / dV kernel)
 #pragma unroll
-        for (int u = 0; u < NQ; ++u) {
-            nl2[u] = -l2[u];
-            nds[u] = -dd[u] * scale;
-        }
+        for (int u = 0; u < NQ; ++u) nl2[u] = -l2[u];
         f32x4_t dqa[NQ][8];                 // dQ^T: d = dt*16 + 4g + r, query c of set u
 #pragma unroll
         for (int u = 0; u < NQ; ++u)
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const bool ok = !need_mask || (qa < S && kl + r <= qa);
                         const float x = __builtin_fmaf(sa[u][r], scale2, ALIBI ? slope2 * (float)(kl + r - (S - 1)) + nl2[u] : nl2[u]);
                         const bf16_t pb = (bf16_t)__builtin_amdgcn_exp2f(ok ? x : -INFINITY);
-                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * __builtin_fmaf(dp[u][r], scale, nds[u]));
+                        sf[u][hb * 4 + r] = (bf16_t)((float)pb * (dp[u][r] - dd[u]));
                     }
                 }
             };
@@ -548,6 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int u = 0; u < NQ; ++u) {
             const int qi = wq0 + u * 16 + c;
             if (qi >= S) continue;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) dqa[u][dt] *= scale;          // the factor dS was formed without
             if (f.dqkv != nullptr) {
                 store_dqkv_row(f, dqa[u], 0, bhid / nh, bhid % nh, nh, S, qi, g);
                 continue;

@@ -446,10 +446,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
 #pragma unroll
                     for (int sub = 1; sub < 4; ++sub) mloc = fmaxf(fmaxf(fmaxf(st[u][sub][0], st[u][sub][1]), fmaxf(st[u][sub][2], st[u][sub][3])), mloc);
                     {
-                        const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-                        mloc = fmaxf(__builtin_bit_cast(float, a[0]), __builtin_bit_cast(float, a[1]));
-                        const auto b2 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mloc), __builtin_bit_cast(unsigned, mloc), false, false);
-                        mloc = fmaxf(__builtin_bit_cast(float, b2[0]), __builtin_bit_cast(float, b2[1]));
+                        // all-reduce over the four lane groups of a query by two register swaps.  The swapped pair is copied into scalars before
+                        // the bit casts: __builtin_bit_cast(float, a[1]) on an element of the builtin's vector result reads element 0 with this
+                        // hipcc (both casts became the same register, max(a[0], a[0]) folded away: swap, move, swap, no v_max in the ISA), and
+                        // every lane ended up with lane group 0's maximum -- the same in all four groups, so still a softmax, but against a
+                        // reference below the row maximum: the output was ~1e-3 less accurate, found by the row-error bar of
+                        // tests/test_attn_bwd_gpu.py at 2 x 32 x 2000.  tests/test_attn_isa_cpu.py now looks for the two v_max in the ISA.
+                        const unsigned xm = __builtin_bit_cast(unsigned, mloc);
+                        const auto a = __builtin_amdgcn_permlane16_swap(xm, xm, false, false);
+                        const unsigned a0 = a[0], a1 = a[1];
+                        mloc = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+                        const unsigned ym = __builtin_bit_cast(unsigned, mloc);
+                        const auto b2 = __builtin_amdgcn_permlane32_swap(ym, ym, false, false);
+                        const unsigned b0 = b2[0], b1 = b2[1];
+                        mloc = fmaxf(__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1));
                     }
                     const float mn = fmaxf(m_run[u], mloc * scale2);
                     const bool dead = mn == -INFINITY;
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NQ == 1 &&
                             rs += pv;
                             ph[u][sub >> 1][(sub & 1) * 4 + r] = (bf16_t)pv;
                         }
-                    l_run[u] = l_run[u] * alpha + rs;                   // this lane's keys only: reduced over the lane groups after the last tile
+                l_run[u] = l_run[u] * alpha + rs;                   // this lane's keys only: reduced over the lane groups after the last tile
                     m_run[u] = mn;
                     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll

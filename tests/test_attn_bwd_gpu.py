@@ -65,7 +65,11 @@ def _run(q, k, v, dO, smax, slopes=None):
 
 @pytest.mark.parametrize("B,nh,S,smax,alibi", [(1, 2, 64, 64, False), (2, 3, 100, 128, False), (1, 2, 130, 256, False), (1, 4, 1024, 1024, False),
                                                (2, 2, 333, 512, False), (1, 1, 7, 64, False), (2, 8, 300, 320, False), (2, 4, 200, 256, True),
-                                               (1, 16, 515, 576, True)])
+                                               (1, 16, 515, 576, True),
+                                               # round 6: grids on which the kernels take TWO causal blocks per workgroup (64 heads x 16 / 15 blocks = 512
+                                               # workgroups of pairs): ragged last block, odd block count (the middle block alone), ALiBi, and the
+                                               # two-query-set forward (>= 1024 blocks of 128 queries)
+                                               (2, 32, 1000, 1024, False), (2, 32, 960, 1024, False), (2, 32, 960, 1024, True), (2, 32, 2000, 2048, False)])
 def test_attention_backward_vs_torch_fp32(B, nh, S, smax, alibi):
     q, k, v, dO = _case(B, nh, S, smax, seed=S)
     slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / nh) for i in range(nh)]) if alibi else None
