@@ -658,3 +658,72 @@ def test_decode_chained_launches_bit_identical(precision):
     # (in the bf16 flow an fp32-round-off difference flips single bf16 roundings of the following Linear inputs: bf16-ulp-sized logit changes)
     bar = 2e-5 if precision == "split" else 2e-2
     assert err <= bar * res[0].abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("mode", ["bf16", "split", "bf16_alibi", "lse", "lse_alibi"])
+def test_paired_query_blocks_equal_per_sequence_launches(mode):
+    """Round 6: on grids of the right size a workgroup of the causal attention kernels takes TWO query blocks (the p-th longest and the p-th
+    shortest of its head).  Every (sequence, head, block) is computed by the same arithmetic wherever it runs, so a batch of two sequences
+    at 32 heads x 1000 positions (16 ragged blocks of 64 -> 512 workgroups of pairs) must equal, bit for bit, the two sequences launched one
+    at a time (256 workgroups: one block each) -- for every instantiation of the kernel: bf16 and hi + lo operands, with and without ALiBi,
+    with the log-sum-exp output; and so must the backward's dQ / dK / dV."""
+    from llark_amd import ops
+    B, nh, S, smax, HD = 2, 32, 1000, 1024, 128
+    g = torch.Generator(device="cuda").manual_seed(41)
+    bf = dict(dtype=torch.bfloat16, device="cuda")
+    f32 = dict(dtype=torch.float32, device="cuda")
+
+    def planes(shape, scale=1.0):
+        x = torch.randn(shape, generator=g, **f32) * scale
+        hi = x.bfloat16()
+        return hi, (x - hi.float()).bfloat16()
+    q, ql = planes((B, nh, S, HD), 1.5)
+    k, kl = planes((B, nh, smax, HD), 1.5)
+    vt, vtl = planes((B, nh, HD, smax))
+    slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / nh) for i in range(nh)], **f32) if mode.endswith("alibi") else None
+
+    def run(b0, b1):
+        n = b1 - b0
+        sl = slice(b0, b1)
+        out = torch.empty((n * S, nh * HD), **bf)
+        extra = []
+        if mode == "split":
+            out_lo = torch.empty_like(out)
+            ops.attn_prefill(q[sl].contiguous(), k[sl].contiguous(), vt[sl].contiguous(), n, S, nh, HD, 0, out, ql[sl].contiguous(), kl[sl].contiguous(),
+                             vtl[sl].contiguous(), out_lo)
+            extra = [out_lo]
+        elif mode.startswith("bf16"):
+            ops.attn_prefill(q[sl].contiguous(), k[sl].contiguous(), vt[sl].contiguous(), n, S, nh, HD, 0, out, alibi_slopes=slopes)
+        else:
+            lse = torch.empty((n * nh, S), **f32)
+            ops.attn_prefill_lse(q[sl].contiguous(), k[sl].contiguous(), vt[sl].contiguous(), n, S, nh, HD, out, lse, alibi_slopes=slopes)
+            dO = (torch.randn((n * nh, S, HD), generator=torch.Generator(device="cuda").manual_seed(7 + b0), **f32) * 0.1).bfloat16()
+            v_rm = vt[sl, :, :, :S].transpose(-1, -2).contiguous().view(n * nh, S, HD)
+            dq, dk, dv = (torch.empty((n * nh, S, HD), **f32) for _ in range(3))
+            dsum = torch.empty((n * nh, S), **f32)
+            ops.attn_backward(q[sl].contiguous().view(n * nh, S, HD), k[sl].contiguous(), v_rm, dO, out, lse, dsum, n, S, nh, HD, dq, dk, dv, alibi_slopes=slopes)
+            extra = [lse, dq, dk, dv, dO]
+        torch.cuda.synchronize()
+        return [out] + extra
+
+    one = [run(0, 1), run(1, 2)]
+    if mode.startswith("lse"):                       # the batched launch must see the same dO as the per-sequence ones
+        dO_all = torch.cat([one[0][-1], one[1][-1]])
+        n = B
+        out = torch.empty((n * S, nh * HD), **bf)
+        lse = torch.empty((n * nh, S), **f32)
+        ops.attn_prefill_lse(q, k, vt, n, S, nh, HD, out, lse, alibi_slopes=slopes)
+        v_rm = vt[:, :, :, :S].transpose(-1, -2).contiguous().view(n * nh, S, HD)
+        dq, dk, dv = (torch.empty((n * nh, S, HD), **f32) for _ in range(3))
+        dsum = torch.empty((n * nh, S), **f32)
+        ops.attn_backward(q.view(n * nh, S, HD), k, v_rm, dO_all, out, lse, dsum, n, S, nh, HD, dq, dk, dv, alibi_slopes=slopes)
+        torch.cuda.synchronize()
+        both = [out, lse, dq, dk, dv]
+        for i, t in enumerate(both):
+            ref = torch.cat([one[0][i], one[1][i]])
+            assert torch.equal(t, ref), (mode, i, (t.float() - ref.float()).abs().max().item())
+    else:
+        both = run(0, 2)
+        for i, t in enumerate(both):
+            ref = torch.cat([one[0][i], one[1][i]])
+            assert torch.equal(t, ref), (mode, i, (t.float() - ref.float()).abs().max().item())
