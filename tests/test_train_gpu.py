@@ -631,16 +631,17 @@ def test_adamw_twins_equals_adamw_plus_packed_twins():
     assert torch.equal(wf, ops.pack_weight16_frag(pc, n))
 
 
-def test_swiglu_train_epilogues_match_the_two_launch_path():
+@pytest.mark.parametrize("m,H,I", [(300, 256, 384), (4096, 4096, 11008), (4100, 4096, 11008)])
+def test_swiglu_train_epilogues_match_the_two_launch_path(m, H, I):
     """llark_gemm16_fragw_swiglu_train: mode 0 = gate|up product + SwiGLU (act from the fp32 accumulators like llark_swiglu_fwd; gate | up
     left as bf16); mode 1 = d(act) product + SwiGLU backward on those bf16 values.  Compared with the separate kernels run on the same
     bf16-rounded gate | up: only the hardware exp2 / rcp of the epilogue (<= 1e-6 relative) and one bf16 rounding differ."""
     from llark_amd import ops
     g = torch.Generator(device="cuda").manual_seed(8)
-    m, H, I = 300, 256, 384
+    ws = 0.08 if H <= 256 else 0.02                                     # (the 7B shapes at a 7B-like weight scale; ragged row tile at m = 4100)
     x = torch.randn(m, H, generator=g, device="cuda").bfloat16()
-    wgu = (torch.randn(2 * I, H, generator=g, device="cuda") * 0.08).bfloat16()
-    wdown = (torch.randn(H, I, generator=g, device="cuda") * 0.08).bfloat16()
+    wgu = (torch.randn(2 * I, H, generator=g, device="cuda") * ws).bfloat16()
+    wdown = (torch.randn(H, I, generator=g, device="cuda") * ws).bfloat16()
     act = torch.empty(m, I, dtype=torch.bfloat16, device="cuda")
     gu16 = torch.empty(m, 2 * I, dtype=torch.bfloat16, device="cuda")
     assert ops.gemm16_fragw_swiglu_train(0, x, ops.pack_weight16_frag(wgu, 2 * I), 2 * I, H, act, gu16)
@@ -829,3 +830,69 @@ def test_fused_accumulation_equals_separate_micro_batches():
     glob = tr.forward_backward(ids.cuda(), segs, labels.cuda(), 1.0)          # one global token mean: a different gradient
     rel = max(((gf.float() - sep[name]).norm() / (sep[name].norm() + 1e-30)).item() for name, gf in tr.export_grads_hf().items())
     assert rel > 1e-2
+
+
+@pytest.mark.parametrize("n,k,rope_heads", [(12288, 4096, 32), (4096, 4096, 0), (22016, 4096, 0), (4096, 11008, 0)])
+def test_adamw_twins_at_the_7b_weight_shapes(n, k, rope_heads):
+    """The same equalities as the small-shape test on the four weight shapes of a Llama-2-7B layer (q|k|v with its RoPE row order over 2 x 32
+    heads, o_proj, gate|up, down_proj): 50-90 M elements each -- index arithmetic and tile edges at the sizes the step runs."""
+    from llark_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(n + k)
+    p0 = (torch.randn(n, k, generator=g, device="cuda") * 0.02).bfloat16()
+    grad = torch.randn(n * k, generator=g, device="cuda") * 1e-3
+    m0 = torch.randn(n * k, generator=g, device="cuda") * 1e-4
+    v0 = torch.rand(n * k, generator=g, device="cuda") * 1e-7
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    ops.adamw(pa.view(-1), grad, ma, va, 5e-5, 0.9, 0.999, 1e-8, 0.0, 2, 0.25)
+    wfrag = torch.empty((n * k,), dtype=torch.bfloat16, device="cuda")
+    wtfrag = torch.empty((n * k,), dtype=torch.bfloat16, device="cuda")
+    rope_rows = 2 * rope_heads * 128
+    ops.adamw_twins(pb, grad, mb, vb, 5e-5, 0.9, 0.999, 1e-8, 0.0, 2, 0.25, wfrag=wfrag, rope_rows=rope_rows, wtfrag=wtfrag)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and not torch.equal(pa, p0)
+    src = pb.index_select(0, ops.rope_qkv_row_order(rope_heads, 128).cuda()) if rope_heads else pb
+    assert torch.equal(wfrag, ops.pack_weight16_frag(src, n))
+    assert torch.equal(wtfrag, ops.pack_weight16_frag(ops.transposed16(pb), k))
+
+
+def test_round6_paths_agree_with_round5_paths_at_7b_width(monkeypatch):
+    """The whole micro-batch at the width and grid sizes the step runs -- hidden 4096, 32 heads, intermediate 11008, one decoder layer, 2 x 1024
+    tokens (the attention kernels on their paired-block grids: 64 heads x 16 blocks) -- through round 6's paths (twins, fused RoPE / SwiGLU /
+    attention glue, dW on the DMA loop) and through round 5's (every LLARK_TRAIN_* switch off): the gradients agree to the bf16-flow noise of
+    the small-width test.  Complements the autograd fixture above (one sequence of 1024: unpaired attention grids)."""
+    from llark_amd.m2t.engine import HipLlamaEngine, LlamaDims
+    from llark_amd.m2t.train_engine import HipLlamaTrainer
+    V, B, S, F = 32004, 2, 1024, 25
+    dims = LlamaDims(num_hidden_layers=1, vocab_size=V)
+    assert (dims.hidden_size, dims.intermediate_size, dims.num_attention_heads) == (4096, 11008, 32)
+    eng = HipLlamaEngine(dims, "cuda", B, S, precision="bf16")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    H, I = dims.hidden_size, dims.intermediate_size
+
+    def n(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g, device="cuda") * std).bfloat16()
+    ones = torch.ones(H, device="cuda")
+    eng.set_layer(0, n(H, H), n(H, H), n(H, H), n(H, H), n(I, H), n(I, H), n(H, I), ones, ones)
+    eng.set_globals(n(V, H), ones, n(V, H), n(H, dims.mm_hidden_size), torch.zeros(H, device="cuda"))
+    cg = torch.Generator().manual_seed(6)
+    ids = torch.randint(3, 32000, (B, S), generator=cg)
+    labels = ids.clone()
+    labels[:, :40] = -100
+    emb = torch.randn(B, F, dims.mm_hidden_size, generator=cg).cuda()
+    segs = [(b, 1, emb[b]) for b in range(B)]
+    tr = HipLlamaTrainer(eng, embed_grad_tokens=[32001, 32002])
+    assert tr.twins and tr.rope_fused and tr.swiglu_fused and tr.dw_fragw and tr.attn_glue_fused
+    la = tr.forward_backward(ids.cuda(), segs, labels.cuda()).item()
+    for k in ("LLARK_TRAIN_TWINS", "LLARK_TRAIN_DW_FRAGW", "LLARK_TRAIN_ATTN_GLUE_FUSED", "LLARK_TRAIN_NORM_BWD_OUT16"):
+        monkeypatch.setenv(k, "0")
+    tr0 = HipLlamaTrainer(eng, embed_grad_tokens=[32001, 32002])
+    assert not tr0.twins and not tr0.dw_fragw and not tr0.attn_glue_fused
+    lb = tr0.forward_backward(ids.cuda(), segs, labels.cuda()).item()
+    assert abs(la - lb) <= 2e-3 * abs(lb), (la, lb)
+    for name, prm in tr.params:
+        a, b = tr.grads[name].float(), tr0.grads[name].float()
+        if b.norm().item() == 0.0:
+            assert a.norm().item() == 0.0, name
+            continue
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel <= 2e-2, f"{name}: {rel:.3e}"
